@@ -1,0 +1,211 @@
+"""ctypes packing of the ``.Call``-level entry points onto a C ABI.
+
+``CAbiDispatcher(lib, prefix)`` turns ``dispatcher("C_colStats_SVT", ...)``
+into a call of ``<prefix>colStats_SVT`` in ``lib``.  The HIP library
+(``libsvt_hip.so``, prefix ``svt_``; include/svt_hip.h) and the CPU oracle
+(``libsvt_oracle.so``, prefix ``orc_``; oracle/svt_oracle.h) deliberately
+expose the same host-level signatures -- both restate the reference's
+``.Call`` entry points on plain pointers -- so one packer serves both and the
+parity tests drive them with identical arguments.
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import POINTER, byref, c_char_p, c_double, c_int, c_void_p
+
+import numpy as np
+
+from .api import OPCODES, SparseArrayError, naked_result
+from .svt import (INTSXP, LGLSXP, REALSXP, SVT_SparseArray, make_view,
+                  r_type_of, svt_view)
+
+_RT = {"logical": LGLSXP, "integer": INTSXP, "double": REALSXP}
+
+
+def _F(a: np.ndarray) -> np.ndarray:
+    return np.asfortranarray(a)
+
+
+def _ptr(a: np.ndarray):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+class CAbiDispatcher:
+    def __init__(self, lib: ctypes.CDLL, prefix: str):
+        self.lib = lib
+        self.prefix = prefix
+        self._declare()
+
+    # -- prototypes ----------------------------------------------------------
+    def _fn(self, name):
+        return getattr(self.lib, self.prefix + name)
+
+    def _declare(self):
+        V = POINTER(svt_view)
+        I = c_int
+        P = c_void_p
+        protos = {
+            "last_error": (c_char_p, []),
+            "crossprod2_SVT_mat": (I, [V, P, I, I, I, I, P]),
+            "crossprod2_mat_SVT": (I, [P, I, I, I, V, I, P]),
+            "crossprod2_SVT_SVT": (I, [V, V, P]),
+            "crossprod1_SVT": (I, [V, P]),
+            "summarize_SVT": (I, [V, I, I, c_double, P, P, POINTER(I), POINTER(I)]),
+            "colStats_out_Rtype": (I, [I, I]),
+            "colStats_SVT": (I, [V, I, I, c_double, I, P, POINTER(I)]),
+            "rowStats_SVT": (I, [V, I, I, P, I, P, POINTER(I)]),
+            "rowsum_SVT": (I, [V, P, I, I, P, POINTER(I)]),
+            "colsum_SVT": (I, [V, P, I, I, P, POINTER(I)]),
+            "rowsum_dgCMatrix": (I, [I, I, P, P, P, P, I, I, P]),
+            "colsum_dgCMatrix": (I, [I, I, P, P, P, P, I, I, P]),
+        }
+        for name, (res, args) in protos.items():
+            f = self._fn(name)
+            f.restype = res
+            f.argtypes = args
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = self._fn("last_error")()
+            raise SparseArrayError(msg.decode() if msg else f"error {rc}")
+
+    # -- dispatcher ------------------------------------------------------------
+    def __call__(self, name: str, *args):
+        if not name.startswith("C_"):
+            raise SparseArrayError(f"unknown entry point {name}")
+        return getattr(self, name)(*args)
+
+    # crossprod ---------------------------------------------------------------
+    def C_crossprod2_SVT_mat(self, x: SVT_SparseArray, y: np.ndarray, tr_y: bool):
+        y = _F(y)
+        ans_ncol = y.shape[0] if tr_y else y.shape[1]
+        out = np.zeros((x.dim[1], ans_ncol), dtype=np.float64, order="F")
+        xv = make_view(x)
+        self._check(self._fn("crossprod2_SVT_mat")(
+            byref(xv), _ptr(y), y.shape[0], y.shape[1], _RT[r_type_of(y)],
+            int(tr_y), _ptr(out)))
+        return out
+
+    def C_crossprod2_mat_SVT(self, x: np.ndarray, y: SVT_SparseArray, tr_x: bool):
+        x = _F(x)
+        ans_nrow = x.shape[0] if tr_x else x.shape[1]
+        out = np.zeros((ans_nrow, y.dim[1]), dtype=np.float64, order="F")
+        yv = make_view(y)
+        self._check(self._fn("crossprod2_mat_SVT")(
+            _ptr(x), x.shape[0], x.shape[1], _RT[r_type_of(x)], byref(yv),
+            int(tr_x), _ptr(out)))
+        return out
+
+    def C_crossprod2_SVT_SVT(self, x: SVT_SparseArray, y: SVT_SparseArray):
+        out = np.zeros((x.dim[1], y.dim[1]), dtype=np.float64, order="F")
+        xv, yv = make_view(x), make_view(y)
+        self._check(self._fn("crossprod2_SVT_SVT")(byref(xv), byref(yv), _ptr(out)))
+        return out
+
+    def C_crossprod1_SVT(self, x: SVT_SparseArray):
+        out = np.zeros((x.dim[1], x.dim[1]), dtype=np.float64, order="F")
+        xv = make_view(x)
+        self._check(self._fn("crossprod1_SVT")(byref(xv), _ptr(out)))
+        return out
+
+    # stats -------------------------------------------------------------------
+    def _opcode(self, op: str) -> int:
+        if op not in OPCODES:
+            raise SparseArrayError(
+                "'op' must be one of: " + ", ".join(f'"{k}"' for k in OPCODES))
+        return OPCODES[op]
+
+    def C_summarize_SVT(self, x, op, na_rm, center):
+        oc = self._opcode(op)
+        out_d = np.zeros(2, np.float64)
+        out_i = np.zeros(2, np.int32)
+        out_Rtype, warn = c_int(0), c_int(0)
+        xv = make_view(x)
+        self._check(self._fn("summarize_SVT")(
+            byref(xv), oc, int(na_rm), float(center), _ptr(out_d), _ptr(out_i),
+            byref(out_Rtype), byref(warn)))
+        return naked_result(op, x.type, out_d, out_i), bool(warn.value)
+
+    def _stat_out(self, op, x, shape):
+        oc = self._opcode(op)
+        rt = self._fn("colStats_out_Rtype")(oc, x.Rtype)
+        if rt < 0:
+            self._check(rt)
+        dtype = np.float64 if rt == REALSXP else np.int32
+        n = int(np.prod(shape, dtype=np.int64)) if len(shape) else 1
+        flat = np.zeros(max(n, 1), dtype=dtype)
+        return oc, flat, n
+
+    def C_colStats_SVT(self, x, op, na_rm, center, dims):
+        shape = tuple(x.dim[dims:])
+        oc, flat, n = self._stat_out(op, x, shape)
+        warn = c_int(0)
+        xv = make_view(x)
+        self._check(self._fn("colStats_SVT")(
+            byref(xv), oc, int(na_rm), float(center), int(dims), _ptr(flat),
+            byref(warn)))
+        flat = flat[:n]
+        ans = flat.reshape(shape, order="F") if len(shape) > 1 else flat
+        return ans, bool(warn.value)
+
+    def C_rowStats_SVT(self, x, op, na_rm, center, dims):
+        shape = tuple(x.dim[:dims])
+        oc, flat, n = self._stat_out(op, x, shape)
+        warn = c_int(0)
+        cptr = None
+        if center is not None:
+            center = np.ascontiguousarray(
+                np.reshape(np.asarray(center, np.float64), -1, order="F"))
+            if center.size != n:
+                raise SparseArrayError("unexpected 'center' length")
+            cptr = _ptr(center)
+        xv = make_view(x)
+        self._check(self._fn("rowStats_SVT")(
+            byref(xv), oc, int(na_rm), cptr, int(dims), _ptr(flat), byref(warn)))
+        flat = flat[:n]
+        ans = flat.reshape(shape, order="F") if len(shape) > 1 else flat
+        return ans, bool(warn.value)
+
+    # rowsum / colsum -----------------------------------------------------------
+    def _xsum(self, fname, x, group, ngroup, na_rm, shape):
+        dtype = np.float64 if x.type == "double" else np.int32
+        out = np.zeros(shape, dtype=dtype, order="F")
+        group = np.ascontiguousarray(group, dtype=np.int32)
+        ov = c_int(0)
+        xv = make_view(x)
+        self._check(self._fn(fname)(byref(xv), _ptr(group), int(ngroup),
+                                    int(na_rm), _ptr(out), byref(ov)))
+        return out, bool(ov.value)
+
+    def C_rowsum_SVT(self, x, group, ngroup, na_rm):
+        if x.ndim != 2:
+            raise SparseArrayError("input object must have 2 dimensions")
+        return self._xsum("rowsum_SVT", x, group, ngroup, na_rm,
+                          (ngroup, x.dim[1]))
+
+    def C_colsum_SVT(self, x, group, ngroup, na_rm):
+        if x.ndim != 2:
+            raise SparseArrayError("input object must have 2 dimensions")
+        return self._xsum("colsum_SVT", x, group, ngroup, na_rm,
+                          (x.dim[0], ngroup))
+
+    def _dgc(self, fname, x, group, ngroup, na_rm, shape):
+        (nrow, ncol), p, i, xx = x
+        p = np.ascontiguousarray(p, np.int32)
+        i = np.ascontiguousarray(i, np.int32)
+        xx = np.ascontiguousarray(xx, np.float64)
+        group = np.ascontiguousarray(group, dtype=np.int32)
+        out = np.zeros(shape, dtype=np.float64, order="F")
+        self._check(self._fn(fname)(int(nrow), int(ncol), _ptr(xx), _ptr(i),
+                                    _ptr(p), _ptr(group), int(ngroup),
+                                    int(na_rm), _ptr(out)))
+        return out
+
+    def C_rowsum_dgCMatrix(self, x, group, ngroup, na_rm):
+        """``x`` = ((nrow, ncol), p, i, x) -- the dgCMatrix slots."""
+        return self._dgc("rowsum_dgCMatrix", x, group, ngroup, na_rm,
+                         (ngroup, x[0][1]))
+
+    def C_colsum_dgCMatrix(self, x, group, ngroup, na_rm):
+        return self._dgc("colsum_dgCMatrix", x, group, ngroup, na_rm,
+                         (x[0][0], ngroup))

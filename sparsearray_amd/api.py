@@ -1,0 +1,422 @@
+"""R-level operator surface of the hot path, mirrored in Python.
+
+Each function restates the argument checking / dispatch of the reference's
+S4 method and then goes through ``SparseArray_Call(.NAME, ...)`` -- exactly
+one ``.Call`` entry point per operation, the same names and argument meaning
+as ``src/R_init_SparseArray.c:94,121-134``:
+
+    C_crossprod2_SVT_mat  C_crossprod2_mat_SVT  C_crossprod2_SVT_SVT
+    C_crossprod1_SVT      C_colStats_SVT        C_rowStats_SVT
+    C_summarize_SVT       C_rowsum_SVT          C_colsum_SVT
+    C_rowsum_dgCMatrix    C_colsum_dgCMatrix
+
+The product binds those names to the HIP library (``sparsearray_amd._hip``);
+there is no CPU implementation in this package.  A ``Session`` can be built
+around any other dispatcher with the same entry points -- the test-suite does
+that with the CPU oracle so both run through identical R-level logic.
+
+Conventions: dense inputs/outputs are numpy arrays with R index semantics;
+"logical" results are int32 with ``NA_integer`` for NA.
+"""
+from __future__ import annotations
+
+import warnings
+from typing import Callable, Optional
+
+import numpy as np
+
+from .svt import (NA_integer, NA_real, SVT_SparseArray, is_NA_real, r_type_of)
+
+
+class SparseArrayError(RuntimeError):
+    """R's error() raised by an entry point."""
+
+
+_SUPPORTED_MULT_TYPES = ("double", "integer")
+
+
+def _check_crossprod_input_type(type_: str):
+    # R/SparseMatrix-mult.R:13-20
+    if type_ not in _SUPPORTED_MULT_TYPES:
+        raise SparseArrayError(
+            "input objects must be of type() \"double\" or \"integer\"")
+
+
+def _common_type(t1: str, t2: str) -> str:
+    order = {"logical": 0, "integer": 1, "double": 2}
+    return t1 if order[t1] >= order[t2] else t2
+
+
+def _as_R_matrix(y) -> np.ndarray:
+    y = np.asarray(y)
+    if y.ndim != 2:
+        raise SparseArrayError("input objects must have 2 dimensions")
+    if y.dtype == np.bool_:
+        y = y.astype(np.int32)
+    if y.dtype not in (np.float64, np.int32):
+        raise TypeError("dense operands must be float64 or int32")
+    return y
+
+
+def _dense_to_double(y: np.ndarray) -> np.ndarray:
+    if y.dtype == np.float64:
+        return y
+    out = y.astype(np.float64)
+    out[y == NA_integer] = NA_real
+    return out
+
+
+class Session:
+    """All R-level generics of the hot path over one ``.Call`` dispatcher."""
+
+    def __init__(self, call: Callable):
+        self._call = call
+
+    # SparseArray.Call(), R/thread-control.R:87-92
+    def SparseArray_Call(self, name: str, *args):
+        return self._call(name, *args)
+
+    # ------------------------------------------------------------------
+    # crossprod / tcrossprod / %*%   (R/SparseMatrix-mult.R)
+    # ------------------------------------------------------------------
+    def _crossprod2_SparseMatrix_matrix(self, x, y, transpose_y=False):
+        y = _as_R_matrix(y)
+        if x.ndim != 2:
+            raise SparseArrayError("input objects must have 2 dimensions")
+        if transpose_y:
+            if x.dim[0] != y.shape[1]:
+                raise SparseArrayError("non-conformable arguments")
+        elif x.dim[0] != y.shape[0]:
+            raise SparseArrayError("non-conformable arguments")
+        ytype = r_type_of(y)
+        if x.type == ytype:
+            _check_crossprod_input_type(x.type)
+        else:
+            xy = _common_type(x.type, ytype)
+            _check_crossprod_input_type(xy)
+            x = x.with_type(xy)
+            y = _dense_to_double(y)
+        return self.SparseArray_Call("C_crossprod2_SVT_mat", x, y,
+                                     bool(transpose_y))
+
+    def _crossprod2_matrix_SparseMatrix(self, x, y, transpose_x=False):
+        x = _as_R_matrix(x)
+        if y.ndim != 2:
+            raise SparseArrayError("input objects must have 2 dimensions")
+        if transpose_x:
+            if x.shape[1] != y.dim[0]:
+                raise SparseArrayError("non-conformable arguments")
+        elif x.shape[0] != y.dim[0]:
+            raise SparseArrayError("non-conformable arguments")
+        xtype = r_type_of(x)
+        if xtype == y.type:
+            _check_crossprod_input_type(y.type)
+        else:
+            xy = _common_type(xtype, y.type)
+            _check_crossprod_input_type(xy)
+            y = y.with_type(xy)
+            x = _dense_to_double(x)
+        return self.SparseArray_Call("C_crossprod2_mat_SVT", x, y,
+                                     bool(transpose_x))
+
+    def _crossprod2_SparseMatrix_SparseMatrix(self, x, y):
+        if x.ndim != 2 or y.ndim != 2:
+            raise SparseArrayError("input objects must have 2 dimensions")
+        if x.dim[0] != y.dim[0]:
+            raise SparseArrayError("non-conformable arguments")
+        if x.type == y.type:
+            _check_crossprod_input_type(x.type)
+        else:
+            xy = _common_type(x.type, y.type)
+            _check_crossprod_input_type(xy)
+            x, y = x.with_type(xy), y.with_type(xy)
+        return self.SparseArray_Call("C_crossprod2_SVT_SVT", x, y)
+
+    def _crossprod1_SparseMatrix(self, x):
+        if x.ndim != 2:
+            raise SparseArrayError("'x' must have 2 dimensions")
+        _check_crossprod_input_type(x.type)
+        return self.SparseArray_Call("C_crossprod1_SVT", x)
+
+    def crossprod(self, x, y=None):
+        xs, ys = isinstance(x, SVT_SparseArray), isinstance(y, SVT_SparseArray)
+        if xs and y is None:
+            return self._crossprod1_SparseMatrix(x)
+        if xs and ys:
+            return self._crossprod2_SparseMatrix_SparseMatrix(x, y)
+        if xs:
+            return self._crossprod2_SparseMatrix_matrix(x, y)
+        if ys:
+            return self._crossprod2_matrix_SparseMatrix(x, y)
+        raise TypeError("crossprod() needs at least one SVT_SparseArray")
+
+    def tcrossprod(self, x, y=None):
+        xs, ys = isinstance(x, SVT_SparseArray), isinstance(y, SVT_SparseArray)
+        if xs and y is None:
+            return self._crossprod1_SparseMatrix(x.t())
+        if xs and ys:
+            return self._crossprod2_SparseMatrix_SparseMatrix(x.t(), y.t())
+        if xs:
+            return self._crossprod2_SparseMatrix_matrix(x.t(), y, True)
+        if ys:
+            return self._crossprod2_matrix_SparseMatrix(x, y.t(), True)
+        raise TypeError("tcrossprod() needs at least one SVT_SparseArray")
+
+    def matmul(self, x, y):
+        """``x %*% y`` (R/SparseMatrix-mult.R:195-215)."""
+        xs, ys = isinstance(x, SVT_SparseArray), isinstance(y, SVT_SparseArray)
+        if xs and ys:
+            return self._crossprod2_SparseMatrix_SparseMatrix(x.t(), y)
+        if xs:
+            return self._crossprod2_SparseMatrix_matrix(x.t(), y)
+        if ys:
+            return self._crossprod2_matrix_SparseMatrix(x, y, True)
+        raise TypeError("%*% needs at least one SVT_SparseArray")
+
+    # ------------------------------------------------------------------
+    # matrixStats  (R/SparseArray-matrixStats.R)
+    # ------------------------------------------------------------------
+    def _colStats(self, op, x, na_rm=False, center=None, dims=1):
+        # .colStats_SparseArray, R/SparseArray-matrixStats.R:68-107
+        dims = int(dims)
+        if dims <= 0 or dims > x.ndim:
+            raise SparseArrayError(
+                "'dims' must be a single integer that is > 0 and <= "
+                "length(dim(x)) for the col*() functions, and >= 0 and < "
+                "length(dim(x)) for the row*() functions")
+        if not isinstance(na_rm, (bool, np.bool_)):
+            raise SparseArrayError("'na.rm' must be TRUE or FALSE")
+        center = NA_real if center is None else float(center)
+        ans, warn = self.SparseArray_Call("C_colStats_SVT", x, op,
+                                          bool(na_rm), center, dims)
+        if warn:
+            warnings.warn("NAs introduced by coercion of "
+                          "infinite values to integers")
+        return ans
+
+    def _rowStats(self, op, x, na_rm=False, center=None, dims=1):
+        # .rowStats_SparseArray, R/SparseArray-matrixStats.R:197-259
+        dims = int(dims)
+        if dims < 0 or dims >= x.ndim:
+            raise SparseArrayError(
+                "'dims' must be a single integer that is > 0 and <= "
+                "length(dim(x)) for the col*() functions, and >= 0 and < "
+                "length(dim(x)) for the row*() functions")
+        if dims == 0:
+            return self._colStats(op, x, na_rm, center, x.ndim)
+        if op not in ("countNAs", "anyNA", "min", "max", "sum",
+                      "centered_X2_sum"):
+            return self._OLD_rowStats(op, x, na_rm, center, dims)
+        if center is not None:
+            ans_dim = x.dim[:dims]
+            center = np.asarray(center, dtype=np.float64)
+            n = int(np.prod(ans_dim))
+            if center.ndim >= 1 and center.shape == tuple(ans_dim):
+                pass
+            elif center.size in (1, n):
+                center = np.broadcast_to(center.reshape(-1, order="F"), (n,)) \
+                    if center.size == 1 else center
+                center = np.reshape(center, ans_dim, order="F")
+            else:
+                raise SparseArrayError("unexpected 'center' length")
+        ans, warn = self.SparseArray_Call("C_rowStats_SVT", x, op,
+                                          bool(na_rm), center, dims)
+        if warn:
+            warnings.warn("NAs introduced by coercion of "
+                          "infinite values to integers")
+        return ans
+
+    def _OLD_rowStats(self, op, x, na_rm, center, dims):
+        # .OLD_rowStats_SparseArray (:122-190): transpose then col stats.
+        if x.ndim > 2:
+            raise SparseArrayError(
+                f"row {op}() on >2-D objects goes through aperm() in the "
+                "reference; not on the device path")
+        tx = x.t()
+        return self._colStats(op, tx, na_rm, center, x.ndim - dims)
+
+    def _colCountVals(self, x, na_rm=False, dims=1):
+        ans = float(np.prod(x.dim[:dims], dtype=np.float64))
+        if na_rm:
+            ans = ans - self._colStats("countNAs", x, dims=dims)
+        return ans
+
+    def _rowCountVals(self, x, na_rm=False, dims=1):
+        ans = float(np.prod(x.dim[dims:], dtype=np.float64))
+        if na_rm:
+            ans = ans - self._rowStats("countNAs", x, dims=dims)
+        return ans
+
+    def colAnyNAs(self, x, dims=1): return self._colStats("anyNA", x, dims=dims)
+    def rowAnyNAs(self, x, dims=1): return self._rowStats("anyNA", x, dims=dims)
+    def colCountNAs(self, x, dims=1): return self._colStats("countNAs", x, dims=dims)
+    def rowCountNAs(self, x, dims=1): return self._rowStats("countNAs", x, dims=dims)
+    def colAnys(self, x, na_rm=False, dims=1): return self._colStats("any", x, na_rm, dims=dims)
+    def rowAnys(self, x, na_rm=False, dims=1): return self._rowStats("any", x, na_rm, dims=dims)
+    def colAlls(self, x, na_rm=False, dims=1): return self._colStats("all", x, na_rm, dims=dims)
+    def rowAlls(self, x, na_rm=False, dims=1): return self._rowStats("all", x, na_rm, dims=dims)
+    def colMins(self, x, na_rm=False, dims=1): return self._colStats("min", x, na_rm, dims=dims)
+    def rowMins(self, x, na_rm=False, dims=1): return self._rowStats("min", x, na_rm, dims=dims)
+    def colMaxs(self, x, na_rm=False, dims=1): return self._colStats("max", x, na_rm, dims=dims)
+    def rowMaxs(self, x, na_rm=False, dims=1): return self._rowStats("max", x, na_rm, dims=dims)
+
+    def colRanges(self, x, na_rm=False, dims=1):
+        mins = self.colMins(x, na_rm, dims)
+        maxs = self.colMaxs(x, na_rm, dims)
+        return np.stack([mins, maxs], axis=-1)
+
+    def rowRanges(self, x, na_rm=False, dims=1):
+        mins = self.rowMins(x, na_rm, dims)
+        maxs = self.rowMaxs(x, na_rm, dims)
+        return np.stack([mins, maxs], axis=-1)
+
+    def colSums(self, x, na_rm=False, dims=1): return self._colStats("sum", x, na_rm, dims=dims)
+    def rowSums(self, x, na_rm=False, dims=1): return self._rowStats("sum", x, na_rm, dims=dims)
+    def colProds(self, x, na_rm=False, dims=1): return self._colStats("prod", x, na_rm, dims=dims)
+    def rowProds(self, x, na_rm=False, dims=1): return self._rowStats("prod", x, na_rm, dims=dims)
+    def colMeans(self, x, na_rm=False, dims=1): return self._colStats("mean", x, na_rm, dims=dims)
+
+    def rowMeans(self, x, na_rm=False, dims=1):
+        # :511-516
+        sums = self.rowSums(x, na_rm, dims)
+        nvals = self._rowCountVals(x, na_rm, dims)
+        with np.errstate(all="ignore"):
+            return sums / nvals
+
+    colSums2, rowSums2, colMeans2, rowMeans2 = colSums, rowSums, colMeans, rowMeans
+
+    def colVars(self, x, na_rm=False, center=None, dims=1):
+        return self._colStats("var1", x, na_rm, center, dims)
+
+    def colSds(self, x, na_rm=False, center=None, dims=1):
+        return self._colStats("sd1", x, na_rm, center, dims)
+
+    def rowVars(self, x, na_rm=False, center=None, dims=1):
+        # :645-660
+        nvals = self._rowCountVals(x, na_rm, dims)
+        with np.errstate(all="ignore"):
+            if center is None:
+                center = self.rowSums(x, na_rm, dims) / nvals
+            cx2 = self._rowStats("centered_X2_sum", x, na_rm, center, dims)
+            return cx2 / (nvals - 1)
+
+    def rowSds(self, x, na_rm=False, center=None, dims=1):
+        with np.errstate(all="ignore"):
+            return np.sqrt(self.rowVars(x, na_rm, center, dims))
+
+    # ------------------------------------------------------------------
+    # whole-array summarization  (R/SparseArray-summarization.R)
+    # ------------------------------------------------------------------
+    def summarize_SVT(self, op, x, na_rm=False, center=None):
+        center = NA_real if center is None else float(center)
+        ans, warn = self.SparseArray_Call("C_summarize_SVT", x, op,
+                                          bool(na_rm), center)
+        if warn:
+            warnings.warn("NAs introduced by coercion of "
+                          "infinite values to integers")
+        return ans
+
+    def anyNA(self, x): return self.summarize_SVT("anyNA", x)
+    def countNAs(self, x): return self.summarize_SVT("countNAs", x)
+    def any(self, x, na_rm=False): return self.summarize_SVT("any", x, na_rm)
+    def all(self, x, na_rm=False): return self.summarize_SVT("all", x, na_rm)
+    def min(self, x, na_rm=False): return self.summarize_SVT("min", x, na_rm)
+    def max(self, x, na_rm=False): return self.summarize_SVT("max", x, na_rm)
+    def range(self, x, na_rm=False): return self.summarize_SVT("range", x, na_rm)
+    def sum(self, x, na_rm=False): return self.summarize_SVT("sum", x, na_rm)
+    def prod(self, x, na_rm=False): return self.summarize_SVT("prod", x, na_rm)
+    def mean(self, x, na_rm=False): return self.summarize_SVT("mean", x, na_rm)
+    def var(self, x, na_rm=False): return self.summarize_SVT("var1", x, na_rm)
+    def sd(self, x, na_rm=False): return self.summarize_SVT("sd1", x, na_rm)
+
+    # ------------------------------------------------------------------
+    # rowsum / colsum  (R/rowsum-methods.R)
+    # ------------------------------------------------------------------
+    @staticmethod
+    def _compute_ugroup(group, expected_len, reorder):
+        group = list(group)
+        if len(group) != expected_len:
+            raise SparseArrayError("incorrect length for 'group'")
+        ug = list(dict.fromkeys(group))
+        if reorder:
+            ug = sorted(ug, key=lambda g: (g is None, g))
+        return ug
+
+    @staticmethod
+    def _match(group, ugroup):
+        pos = {g: i + 1 for i, g in enumerate(ugroup)}
+        return np.asarray([pos[g] for g in group], dtype=np.int32)
+
+    def rowsum(self, x, group, reorder=True, na_rm=False):
+        """Returns (matrix ngroup x ncol, ugroup)."""
+        if isinstance(x, SVT_SparseArray):
+            nrow = x.dim[0]
+        else:
+            nrow = x[0][0]
+        ugroup = self._compute_ugroup(group, nrow, reorder)
+        g = self._match(group, ugroup)
+        if isinstance(x, SVT_SparseArray):
+            ans, ovflow = self.SparseArray_Call("C_rowsum_SVT", x, g,
+                                                len(ugroup), bool(na_rm))
+            if ovflow:
+                warnings.warn("NAs produced by integer overflow")
+        else:
+            ans = self.SparseArray_Call("C_rowsum_dgCMatrix", x, g,
+                                        len(ugroup), bool(na_rm))
+        return ans, ugroup
+
+    def colsum(self, x, group, reorder=True, na_rm=False):
+        """Returns (matrix nrow x ngroup, ugroup)."""
+        if isinstance(x, SVT_SparseArray):
+            ncol = x.dim[1]
+        else:
+            ncol = x[0][1]
+        ugroup = self._compute_ugroup(group, ncol, reorder)
+        g = self._match(group, ugroup)
+        if isinstance(x, SVT_SparseArray):
+            ans, ovflow = self.SparseArray_Call("C_colsum_SVT", x, g,
+                                                len(ugroup), bool(na_rm))
+            if ovflow:
+                warnings.warn("NAs produced by integer overflow")
+        else:
+            ans = self.SparseArray_Call("C_colsum_dgCMatrix", x, g,
+                                        len(ugroup), bool(na_rm))
+        return ans, ugroup
+
+
+# ---------------------------------------------------------------------------
+# Shared helpers for dispatchers (argument packing for the C ABIs)
+# ---------------------------------------------------------------------------
+OPCODES = {
+    "anyNA": 1, "countNAs": 2, "any": 3, "all": 4, "min": 5, "max": 6,
+    "range": 7, "sum": 8, "prod": 9, "mean": 10, "centered_X2_sum": 11,
+    "sum_X_X2": 12, "var1": 13, "var2": 14, "sd1": 15, "sd2": 16,
+}
+
+
+def back_to_int(x: float) -> int:
+    # BACK_TO_INT, src/Rvector_summarization.c:1199
+    return int(x + 0.5) if x >= 0 else int(x - 0.5)
+
+
+def naked_result(op: str, in_type: str, out_d, out_i):
+    """res2nakedSEXP(), src/Rvector_summarization.c:1239-1296."""
+    INT_MAX = 2 ** 31 - 1
+    if op in ("anyNA", "any", "all"):
+        return np.int32(out_i[0])
+    if op == "countNAs":
+        return np.float64(out_d[0]) if out_d[0] > INT_MAX else np.int32(back_to_int(out_d[0]))
+    if op in ("min", "max") and in_type != "double":
+        return np.int32(out_i[0])
+    if op == "range":
+        if in_type == "double":
+            return np.array([out_d[0], out_d[1]], dtype=np.float64)
+        return np.array([out_i[0], out_i[1]], dtype=np.int32)
+    if op in ("sum", "prod") and in_type in ("logical", "integer"):
+        v = out_d[0]
+        if np.isnan(v):
+            return NA_integer
+        if v < -INT_MAX or v > INT_MAX:
+            return np.float64(v)
+        return np.int32(back_to_int(v))
+    return np.float64(out_d[0])

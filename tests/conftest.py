@@ -1,0 +1,26 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle_session
+    return oracle_session()
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """The product session.  Fails loudly when libsvt_hip.so is missing or no
+    GPU is visible -- there is no fallback."""
+    import sparsearray_amd
+    return sparsearray_amd.hip_session()
