@@ -1,0 +1,221 @@
+/*
+ * svt_hip.h -- C ABI of libsvt_hip.so, the MI355X (gfx950) backend for
+ * SparseArray's SVT compute hot path.
+ *
+ * Plain C: pointers and sizes only, no R types, no torch types.  There are
+ * two levels:
+ *
+ *   1. Host level -- one function per `.Call` entry point of the reference
+ *      (src/R_init_SparseArray.c:94,121-134).  Arguments are host pointers.
+ *      The function marshals the SVT leaves into the CSC device layout,
+ *      runs the HIP kernels and copies the result back into the caller's
+ *      buffer.  This is what the R package's C glue binds.
+ *
+ *   2. Device level -- operands already resident in HBM (uploaded once with
+ *      svt_upload(), or wrapped around existing device buffers), kernels
+ *      launched asynchronously on a caller-supplied HIP stream, no
+ *      allocation and no synchronisation inside.  This is what bench.py and
+ *      the multi-GPU driver use.
+ *
+ * Return convention (all int-returning functions):
+ *     0   success
+ *    -1   error; message in svt_last_error().  The R glue turns it into
+ *         error(), like the reference's own error() calls
+ *         (e.g. src/SparseMatrix_mult.c:943-966).
+ * Warning conditions ("NAs introduced by coercion of infinite values to
+ * integers", src/SparseArray_matrixStats.c:278-280; "NAs produced by integer
+ * overflow", src/rowsum_methods.c:122-123) are reported through the
+ * `warn` / `ovflow` out-parameters so that the caller raises them on the R
+ * thread after the call.
+ *
+ * Element types use R's SEXPTYPE codes.  Dense matrices are column-major
+ * (R layout).  Missing values: NA_integer_ = INT_MIN, NA_real_ = the NaN with
+ * low word 1954.
+ */
+#ifndef SVT_HIP_H
+#define SVT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVT_LGLSXP 10
+#define SVT_INTSXP 13
+#define SVT_REALSXP 14
+
+/* Opcodes of src/Rvector_summarization.h:12-34 */
+#define SVT_OP_ANYNA            1
+#define SVT_OP_COUNTNAS         2
+#define SVT_OP_ANY              3
+#define SVT_OP_ALL              4
+#define SVT_OP_MIN              5
+#define SVT_OP_MAX              6
+#define SVT_OP_RANGE            7
+#define SVT_OP_SUM              8
+#define SVT_OP_PROD             9
+#define SVT_OP_MEAN            10
+#define SVT_OP_CENTERED_X2_SUM 11
+#define SVT_OP_SUM_X_X2        12
+#define SVT_OP_VAR1            13
+#define SVT_OP_VAR2            14
+#define SVT_OP_SD1             15
+#define SVT_OP_SD2             16
+
+/*
+ * Host view of an SVT (Sparse Vector Tree, src/leaf_utils.h:10-31): the
+ * tree flattened to its prod(dim[1..ndim-1]) leaves in depth-first order
+ * (outermost dim slowest).  nzcount[j] == 0 is a NULL leaf / NULL subtree;
+ * nzvals[j] == NULL with nzcount[j] > 0 is a lacunar leaf (all ones).
+ * Replaces the (x_dim, x_type, x_SVT) argument triple of the .Call entry
+ * points (src/SparseMatrix_mult.h:6-43, src/SparseArray_matrixStats.h:6-28,
+ * src/rowsum_methods.h:6-36).
+ */
+typedef struct svt_view {
+	int32_t Rtype;
+	int32_t ndim;
+	const int32_t *dim;
+	int32_t svt_is_null;          /* x@SVT is NULL */
+	int64_t nleaves;
+	const int32_t *nzcount;
+	const int32_t *const *nzoffs;
+	const void *const *nzvals;
+} svt_view;
+
+/* ---------------------------------------------------------------------- */
+/* Library state                                                          */
+/* ---------------------------------------------------------------------- */
+
+/* Selects the HIP device for the calling process (one process per GPU).
+   Returns 0, or -1 when no gfx950 device is usable.  Called implicitly with
+   device 0 by the first host-level call. */
+int svt_init(int device);
+const char *svt_last_error(void);
+/* "gfx950" etc. of the selected device, or "" before svt_init(). */
+const char *svt_device_arch(void);
+
+/* ---------------------------------------------------------------------- */
+/* 1. Host level: the .Call entry points                                   */
+/* ---------------------------------------------------------------------- */
+
+/* C_crossprod2_SVT_mat, src/SparseMatrix_mult.c:931-982.
+   out: ncol(x) x (tr_y ? y_nrow : y_ncol) doubles. */
+int svt_crossprod2_SVT_mat(const svt_view *x, const void *y, int y_nrow,
+			   int y_ncol, int y_Rtype, int tr_y, double *out);
+/* C_crossprod2_mat_SVT, src/SparseMatrix_mult.c:985-1034.
+   out: (tr_x ? x_nrow : x_ncol) x ncol(y) doubles. */
+int svt_crossprod2_mat_SVT(const void *x, int x_nrow, int x_ncol, int x_Rtype,
+			   const svt_view *y, int tr_x, double *out);
+/* C_crossprod2_SVT_SVT, src/SparseMatrix_mult.c:1037-1101. */
+int svt_crossprod2_SVT_SVT(const svt_view *x, const svt_view *y, double *out);
+/* C_crossprod1_SVT, src/SparseMatrix_mult.c:1104-1140. */
+int svt_crossprod1_SVT(const svt_view *x, double *out);
+
+/* C_summarize_SVT, src/SparseArray_summarization.c:112-142.  The result is
+   left in out_d[0..1] or out_i[0..1] according to *out_Rtype. */
+int svt_summarize_SVT(const svt_view *x, int opcode, int na_rm, double center,
+		      double *out_d, int *out_i, int *out_Rtype, int *warn);
+
+/* Result element type of a col/row stat (src/Rvector_summarization.c:97-165):
+   SVT_LGLSXP/SVT_INTSXP -> int32 buffer, SVT_REALSXP -> double buffer. */
+int svt_colStats_out_Rtype(int opcode, int in_Rtype);
+/* C_colStats_SVT, src/SparseArray_matrixStats.c:234-284.
+   out: prod(dim[dims..]) elements. */
+int svt_colStats_SVT(const svt_view *x, int opcode, int na_rm, double center,
+		     int dims, void *out, int *warn);
+/* C_rowStats_SVT, src/SparseArray_matrixStats.c:1121-1205.
+   center: NULL or prod(dim[0..dims-1]) doubles.  out: same length. */
+int svt_rowStats_SVT(const svt_view *x, int opcode, int na_rm,
+		     const double *center, int dims, void *out, int *warn);
+
+/* C_rowsum_SVT / C_colsum_SVT, src/rowsum_methods.c:281-325, 363-401.
+   group: 1-based, NA allowed.  out: ngroup x ncol (rowsum) or nrow x ngroup
+   (colsum); int32 for SVT_INTSXP input, else double. */
+int svt_rowsum_SVT(const svt_view *x, const int *group, int ngroup, int na_rm,
+		   void *out, int *ovflow);
+int svt_colsum_SVT(const svt_view *x, const int *group, int ngroup, int na_rm,
+		   void *out, int *ovflow);
+/* C_rowsum_dgCMatrix / C_colsum_dgCMatrix, src/rowsum_methods.c:328-356,
+   404-439: the (x, i, p) slots of a dgCMatrix. */
+int svt_rowsum_dgCMatrix(int nrow, int ncol, const double *xx, const int *xi,
+			 const int *xp, const int *group, int ngroup,
+			 int na_rm, double *out);
+int svt_colsum_dgCMatrix(int nrow, int ncol, const double *xx, const int *xi,
+			 const int *xp, const int *group, int ngroup,
+			 int na_rm, double *out);
+
+/* ---------------------------------------------------------------------- */
+/* 2. Device level                                                         */
+/* ---------------------------------------------------------------------- */
+
+/*
+ * CSC-like device layout of an SVT (the device-side analogue of
+ * dump_SVT_to_CsparseMatrix_slots(), src/SVT_SparseArray_class.c:598-633):
+ *   col_ptr int64[ncol+1], row_idx int32[nnz], val f64|i32[nnz]
+ * with ncol = number of leaves, nrow = dim[0]; lacunar leaves are expanded
+ * to explicit ones.  All pointers are device pointers.
+ */
+typedef struct svt_dev_csc {
+	int32_t Rtype;
+	int32_t owned;        /* buffers were allocated by svt_upload() */
+	int64_t nrow;
+	int64_t ncol;
+	int64_t nnz;
+	int64_t *col_ptr;
+	int32_t *row_idx;
+	void *val;
+} svt_dev_csc;
+
+/* Marshal + H2D.  Returns NULL on error. */
+svt_dev_csc *svt_upload(const svt_view *x);
+/* Wrap device buffers owned by the caller (e.g. a torch allocation). */
+svt_dev_csc *svt_wrap_device_csc(int Rtype, int64_t nrow, int64_t ncol,
+				 int64_t nnz, int64_t *col_ptr,
+				 int32_t *row_idx, void *val);
+void svt_release(svt_dev_csc *h);
+
+/*
+ * crossprod(A, Y): out[c, k] = sum_r A[r, c] * Y[r, k], the kernel family
+ * K1-K8 of the reference (src/SparseMatrix_mult.c:131-239) for all K dense
+ * columns in one pass over A.
+ *   Y      in_nrow x K, column-major with leading dimension ldY (doubles for
+ *          a REALSXP A, int32 for an INTSXP A); or, with tr_y != 0, K x
+ *          in_nrow column-major (ldY >= K), i.e. rows of Y are contiguous.
+ *   out    element (c, k) is written at out[c * out_stride_c + k *
+ *          out_stride_k]: (1, ncol) gives the column-major ncol x K result
+ *          of C_crossprod2_SVT_mat, (K, 1) gives the K x ncol result of
+ *          C_crossprod2_mat_SVT.
+ *   ws     workspace of at least svt_dev_crossprod_ws_bytes() bytes.
+ * Asynchronous on `stream` (a hipStream_t).
+ */
+size_t svt_dev_crossprod_ws_bytes(int64_t nrow, int64_t ncol, int K);
+int svt_dev_crossprod_csc_dense(const svt_dev_csc *A, const void *Y,
+				int64_t ldY, int K, int tr_y, double *out,
+				int64_t out_stride_c, int64_t out_stride_k,
+				void *ws, size_t ws_bytes, void *stream);
+
+/* col stats over segments of `inner` consecutive leaves each
+   (dims > 1 => inner = prod(dim[1..dims-1])); out has ncol/inner elements of
+   svt_colStats_out_Rtype().  warn_flag: device int, set to 1 on the
+   "NAs introduced" condition (may be NULL). */
+int svt_dev_colstats(const svt_dev_csc *A, int opcode, int na_rm,
+		     double center, int64_t inner, void *out, int *warn_flag,
+		     void *stream);
+
+/* row sums: out[(j % inner) * nrow + r] += A[r, j]; `out` (doubles) must be
+   zeroed by the caller. */
+int svt_dev_rowsums(const svt_dev_csc *A, int na_rm, int64_t inner,
+		    double *out, void *stream);
+
+/* rowsum(): out (ngroup x ncol, zeroed by the callee); group is a device
+   array of nrow 1-based group ids (NA -> last group).  f64 input only at
+   this level. */
+int svt_dev_rowsum(const svt_dev_csc *A, const int *group, int ngroup,
+		   int na_rm, double *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVT_HIP_H */

@@ -1,12 +1,12 @@
 """ctypes packing of the ``.Call``-level entry points onto a C ABI.
 
 ``CAbiDispatcher(lib, prefix)`` turns ``dispatcher("C_colStats_SVT", ...)``
-into a call of ``<prefix>colStats_SVT`` in ``lib``.  The HIP library
-(``libsvt_hip.so``, prefix ``svt_``; include/svt_hip.h) and the CPU oracle
-(``libsvt_oracle.so``, prefix ``orc_``; oracle/svt_oracle.h) deliberately
-expose the same host-level signatures -- both restate the reference's
-``.Call`` entry points on plain pointers -- so one packer serves both and the
-parity tests drive them with identical arguments.
+into a call of ``<prefix>colStats_SVT`` in ``lib``.  The product instantiates
+it once, for the HIP library (``libsvt_hip.so``, prefix ``svt_``;
+include/svt_hip.h).  The packer is parameterised by (library, prefix) so that
+the test-suite can drive its CPU checker -- which exposes the same host-level
+signatures under another prefix -- with byte-identical arguments; nothing in
+this package loads or names that checker.
 """
 from __future__ import annotations
 

@@ -1,0 +1,68 @@
+"""ctypes binding of libsvt_hip.so (include/svt_hip.h).
+
+There is deliberately no fallback here: a missing library, a missing symbol or
+a box without an MI355X raises ``HipBackendError`` at first use.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsvt_hip.so")
+
+# Every symbol include/svt_hip.h declares (checked by tests/test_abi.py).
+EXPORTS = [
+    "svt_init", "svt_last_error", "svt_device_arch",
+    "svt_crossprod2_SVT_mat", "svt_crossprod2_mat_SVT",
+    "svt_crossprod2_SVT_SVT", "svt_crossprod1_SVT",
+    "svt_summarize_SVT", "svt_colStats_out_Rtype", "svt_colStats_SVT",
+    "svt_rowStats_SVT", "svt_rowsum_SVT", "svt_colsum_SVT",
+    "svt_rowsum_dgCMatrix", "svt_colsum_dgCMatrix",
+    "svt_upload", "svt_wrap_device_csc", "svt_release",
+    "svt_dev_crossprod_ws_bytes", "svt_dev_crossprod_csc_dense",
+    "svt_dev_colstats", "svt_dev_rowsums", "svt_dev_rowsum",
+]
+
+
+class HipBackendError(RuntimeError):
+    pass
+
+
+_lib = None
+_ready = False
+
+
+def load_library() -> ctypes.CDLL:
+    """dlopen only -- no GPU needed (used by the ABI tests on CPU boxes)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipBackendError(
+                f"{LIB_PATH} is missing: build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  sparsearray_amd has no CPU path.")
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.svt_last_error.restype = ctypes.c_char_p
+        _lib.svt_device_arch.restype = ctypes.c_char_p
+        _lib.svt_init.argtypes = [ctypes.c_int]
+        _lib.svt_init.restype = ctypes.c_int
+    return _lib
+
+
+def init(device: int | None = None) -> ctypes.CDLL:
+    """Load the library and bind this process to one GPU (LOCAL_RANK by default)."""
+    global _ready
+    lib = load_library()
+    if not _ready:
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        if lib.svt_init(device) != 0:
+            raise HipBackendError(lib.svt_last_error().decode())
+        _ready = True
+    return lib
+
+
+def hip_dispatcher():
+    from ._dispatch import CAbiDispatcher
+    return CAbiDispatcher(init(), "svt_")

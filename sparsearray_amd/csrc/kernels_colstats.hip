@@ -1,0 +1,273 @@
+// col* matrixStats and whole-array summarization on the CSC device layout.
+//
+// Reference: C_colStats_SVT / REC_colStats_SVT (src/SparseArray_matrixStats.c:
+// 200-284) call _summarize_SVT() (src/SparseArray_summarization.c:89-109) once
+// per "generalized column".  On the device a generalized column is a run of
+// `inner` consecutive leaves, i.e. one contiguous slice of val[]; the op is a
+// streaming segmented reduction over that slice (row_idx is never read).
+//
+// Two launch shapes share one body:
+//   NT = 64  : one wavefront per segment, 4 segments per 256-thread workgroup
+//              (short leaves: config 1 / config 5, ~100 nz per leaf)
+//   NT = 256 : one workgroup per segment (long leaves: config 2, ~1e4 nz)
+//
+// Sequential NA/NaN rules of src/Rvector_summarization.c:177-734 restated as
+// order-independent predicates (valid because every rule is of the form "any
+// NA anywhere wins, else any NaN wins, else the plain IEEE reduction"):
+//   flags & F_NA   some value is R's NA (payload 1954 / INT_MIN)
+//   flags & F_NAN  some value is a NaN that is not NA
+// Roofline: HBM; algorithmic bytes = 8 (f64) or 4 (i32) per nonzero.
+#include "svt_common.h"
+
+#define F_NA    1
+#define F_NAN   2
+#define F_TRUE  4   // a non-NA value != 0
+#define F_ZERO  8   // a stored value == 0 (not expected in a valid SVT)
+#define F_HAVE 16   // at least one non-NA value went into min/max
+
+template <int NT>
+__device__ inline double red_sum(double v, double *sm)
+{
+	v = wave_sum(v);
+	if (NT == SVT_WAVE)
+		return __shfl(v, 0, SVT_WAVE);
+	const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+	__syncthreads();
+	if (l == 0) sm[w] = v;
+	__syncthreads();
+	double t = 0.0;
+	for (int i = 0; i < NT / SVT_WAVE; i++) t += sm[i];
+	return t;
+}
+template <int NT>
+__device__ inline double red_prod(double v, double *sm)
+{
+	v = wave_prod(v);
+	if (NT == SVT_WAVE)
+		return __shfl(v, 0, SVT_WAVE);
+	const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+	__syncthreads();
+	if (l == 0) sm[w] = v;
+	__syncthreads();
+	double t = 1.0;
+	for (int i = 0; i < NT / SVT_WAVE; i++) t *= sm[i];
+	return t;
+}
+template <int NT>
+__device__ inline double red_min(double v, double *sm, bool is_min)
+{
+	v = is_min ? wave_min(v) : wave_max(v);
+	if (NT == SVT_WAVE)
+		return __shfl(v, 0, SVT_WAVE);
+	const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+	__syncthreads();
+	if (l == 0) sm[w] = v;
+	__syncthreads();
+	double t = sm[0];
+	for (int i = 1; i < NT / SVT_WAVE; i++)
+		t = is_min ? (sm[i] < t ? sm[i] : t) : (sm[i] > t ? sm[i] : t);
+	return t;
+}
+template <int NT>
+__device__ inline long long red_sum_ll(long long v, double *sm)
+{
+	v = wave_sum_ll(v);
+	if (NT == SVT_WAVE)
+		return __shfl(v, 0, SVT_WAVE);
+	long long *s = (long long *) sm;
+	const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+	__syncthreads();
+	if (l == 0) s[w] = v;
+	__syncthreads();
+	long long t = 0;
+	for (int i = 0; i < NT / SVT_WAVE; i++) t += s[i];
+	return t;
+}
+template <int NT>
+__device__ inline int red_or(int v, double *sm)
+{
+	v = wave_or(v);
+	if (NT == SVT_WAVE)
+		return __shfl(v, 0, SVT_WAVE);
+	int *s = (int *) sm;
+	const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+	__syncthreads();
+	if (l == 0) s[w] = v;
+	__syncthreads();
+	int t = 0;
+	for (int i = 0; i < NT / SVT_WAVE; i++) t |= s[i];
+	return t;
+}
+
+template <typename T> struct ValTraits;
+template <> struct ValTraits<double> {
+	static __device__ inline bool is_missing(double v) { return v != v; }
+	static __device__ inline bool is_na(double v) { return svt_is_na(v); }
+	static __device__ inline double as_double(double v) { return v; }
+};
+template <> struct ValTraits<int> {
+	static __device__ inline bool is_missing(int v) { return v == NA_INT; }
+	static __device__ inline bool is_na(int v) { return v == NA_INT; }
+	static __device__ inline double as_double(int v) { return (double) v; }
+};
+
+template <typename T, int NT>
+__global__ void __launch_bounds__(256)
+colstats_kernel(StatsArgs a)
+{
+	__shared__ double sm[4 * (256 / SVT_WAVE)];
+	const int per_block = 256 / NT;
+	const int sub = NT == 256 ? 0 : (threadIdx.x >> 6);
+	const int tid = NT == 256 ? threadIdx.x : (threadIdx.x & 63);
+	const int64_t g = (int64_t) blockIdx.x * per_block + sub;
+	if (NT == SVT_WAVE && g >= a.nseg)
+		return;   // whole wave exits together; no barriers on this path
+	double *my_sm = sm + sub * 4;
+	(void) my_sm;
+	const T *__restrict__ val = (const T *) a.val;
+	const int64_t beg = a.col_ptr[g * a.inner];
+	const int64_t end = a.col_ptr[(g + 1) * a.inner];
+	const int64_t nz = end - beg;
+	const int64_t zerocount = a.seg_len - nz;
+	const int oc = a.opcode;
+	const bool narm = a.na_rm != 0;
+	const bool is_dbl = sizeof(T) == 8;
+	typedef ValTraits<T> VT;
+
+	int flags = 0;
+	long long nacnt = 0;
+	double acc = (oc == SVT_OP_PROD) ? 1.0 : 0.0;
+	const bool is_minmax = oc == SVT_OP_MIN || oc == SVT_OP_MAX;
+	const bool is_min = oc == SVT_OP_MIN;
+	double mm = is_min ? INFINITY : -INFINITY;
+
+	// ---- pass 1: flags, NA count, sum / product / extremum -------------
+	for (int64_t k = beg + tid; k < end; k += NT) {
+		const T v = val[k];
+		if (VT::is_missing(v)) {
+			nacnt++;
+			flags |= VT::is_na(v) ? F_NA : F_NAN;
+			if (narm)
+				continue;
+			// fall through: NaN/NA take part in the IEEE reduction
+			// (ints: the value is never used once F_NA is set)
+			if (!is_dbl)
+				continue;
+		} else {
+			if (v != (T) 0) flags |= F_TRUE; else flags |= F_ZERO;
+			flags |= F_HAVE;
+		}
+		const double d = VT::as_double(v);
+		if (oc == SVT_OP_PROD) acc *= d;
+		else if (is_minmax) { if (d == d) mm = is_min ? (d < mm ? d : mm) : (d > mm ? d : mm); }
+		else acc += d;
+	}
+	flags = red_or<NT>(flags, my_sm);
+	nacnt = red_sum_ll<NT>(nacnt, my_sm);
+	if (oc == SVT_OP_PROD) acc = red_prod<NT>(acc, my_sm);
+	else if (is_minmax) mm = red_min<NT>(mm, my_sm, is_min);
+	else acc = red_sum<NT>(acc, my_sm);
+
+	const bool brk_na = (flags & F_NA) && !narm;   // "breaking value" NA
+	const double n_eff = (double) (a.seg_len - (narm ? nacnt : 0));
+	const double NAr = svt_na_real();
+	double rd = 0.0;
+	int ri = 0;
+	int warn = 0;
+
+	switch (oc) {
+	case SVT_OP_ANYNA:
+		ri = (flags & (F_NA | F_NAN)) ? 1 : 0;
+		break;
+	case SVT_OP_COUNTNAS:
+		rd = (double) nacnt;
+		break;
+	case SVT_OP_ANY:      // src/Rvector_summarization.c:260-284
+		ri = (flags & F_TRUE) ? 1 : (brk_na ? NA_INT : 0);
+		break;
+	case SVT_OP_ALL:      // :289-313 plus the implicit zero of :1100-1106
+		ri = ((flags & F_ZERO) || zerocount > 0) ? 0 : (brk_na ? NA_INT : 1);
+		break;
+	case SVT_OP_SUM:
+		rd = brk_na ? NAr : acc;
+		break;
+	case SVT_OP_MEAN:
+		rd = brk_na ? NAr : acc / n_eff;
+		break;
+	case SVT_OP_PROD:
+		if (brk_na) rd = NAr;
+		else rd = zerocount > 0 ? acc * 0.0 : acc;
+		break;
+	case SVT_OP_MIN: case SVT_OP_MAX:
+		if (is_dbl) {
+			if (brk_na) { rd = NAr; break; }
+			if ((flags & F_NAN) && !narm) { rd = NAN; break; }
+			if (zerocount > 0)
+				mm = is_min ? (0.0 < mm ? 0.0 : mm) : (0.0 > mm ? 0.0 : mm);
+			rd = mm;
+		} else {
+			if (brk_na) { ri = NA_INT; break; }
+			bool have = (flags & F_HAVE) != 0;
+			if (zerocount > 0) {
+				mm = have ? (is_min ? (0.0 < mm ? 0.0 : mm) : (0.0 > mm ? 0.0 : mm)) : 0.0;
+				have = true;
+			}
+			if (!have) { ri = NA_INT; warn = 1; }   // :1108-1128
+			else ri = (int) mm;
+		}
+		break;
+	case SVT_OP_CENTERED_X2_SUM: case SVT_OP_VAR1: case SVT_OP_SD1: {
+		// src/SparseArray_summarization.c:70-109: without a center the
+		// mean comes from a first full pass (done above: acc, nacnt).
+		double c = a.center;
+		if (c != c)
+			c = brk_na ? NAr : acc / n_eff;
+		double acc2 = 0.0;
+		for (int64_t k = beg + tid; k < end; k += NT) {
+			const T v = val[k];
+			if (VT::is_missing(v) && (narm || !is_dbl))
+				continue;
+			const double d = VT::as_double(v) - c;
+			acc2 += d * d;
+		}
+		acc2 = red_sum<NT>(acc2, my_sm);
+		if (brk_na) { rd = NAr; break; }
+		rd = acc2 + c * c * (double) zerocount;
+		if (oc == SVT_OP_CENTERED_X2_SUM) break;
+		if (n_eff <= 1.0) { rd = NAr; break; }
+		rd /= (n_eff - 1.0);
+		if (oc == SVT_OP_SD1) rd = sqrt(rd);
+		break;
+	}
+	default:
+		break;
+	}
+	if (tid == 0) {
+		const bool out_is_int = oc == SVT_OP_ANYNA || oc == SVT_OP_ANY ||
+			oc == SVT_OP_ALL || (is_minmax && !is_dbl);
+		if (out_is_int) ((int *) a.out)[g] = ri;
+		else ((double *) a.out)[g] = rd;
+		if (warn && a.warn_flag) *a.warn_flag = 1;
+	}
+}
+
+int launch_colstats(const StatsArgs &a, int64_t nnz, hipStream_t s)
+{
+	if (a.nseg <= 0)
+		return 0;
+	if (a.nseg > 0x7FFFFFFFLL)
+		return svt_set_error("too many generalized columns");
+	const int64_t avg = nnz / a.nseg;
+	const bool is_dbl = a.Rtype == SVT_REALSXP;
+	if (avg >= 1024) {
+		dim3 grid((unsigned) a.nseg), block(256);
+		if (is_dbl) hipLaunchKernelGGL((colstats_kernel<double, 256>), grid, block, 0, s, a);
+		else hipLaunchKernelGGL((colstats_kernel<int, 256>), grid, block, 0, s, a);
+	} else {
+		dim3 grid((unsigned) ((a.nseg + 3) / 4)), block(256);
+		if (is_dbl) hipLaunchKernelGGL((colstats_kernel<double, 64>), grid, block, 0, s, a);
+		else hipLaunchKernelGGL((colstats_kernel<int, 64>), grid, block, 0, s, a);
+	}
+	HIP_TRY(hipGetLastError());
+	return 0;
+}

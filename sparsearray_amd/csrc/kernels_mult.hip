@@ -1,0 +1,251 @@
+// crossprod(): sparse (CSC leaves) x dense, all K dense columns in one pass.
+//
+// Reference: the 13 OpenMP loops of src/SparseMatrix_mult.c:131-296 call one
+// of the per-leaf dot products of src/SparseVec_dotprod.c once per (leaf,
+// dense column) pair, with the dense columns in the OUTER loop
+// (crossprod2_SVT_mat_double :385-431), so the sparse operand is streamed K
+// times.  Here A is streamed once per 64-column tile of Y and every nonzero is
+// applied to 64 dense columns at a time (lane = dense column).
+//
+// Pipeline of one call:
+//   1. prep:   Y (column-major, R layout) -> Yt[r][k] row-major, K padded to
+//              a multiple of 64, so that the 64 lanes of a wavefront read one
+//              contiguous 512-byte run per nonzero.  The same pass evaluates
+//              the reference's prescan predicates per dense column
+//              (has_no_NaN_or_Inf / has_no_NA, :23-36): a count of non-finite
+//              entries and an "R NA present" bit.
+//   2. gather: one wavefront per (leaf, 64-column tile); (row, value) of the
+//              leaf are wave-uniform scalar loads; acc[lane] += v * Yt[row][lane]
+//              in ascending offset order -- the summation order of
+//              _dotprod_doubleSV_finite_doubles (SparseVec_dotprod.c:28-43).
+//
+// NA / NaN / Inf semantics without a second code path.  The reference switches
+// to _dotprod_doubleSV_doubles (:48-65) when the dense column is not finite;
+// that routine also multiplies the implicit zeros of the leaf, so a non-finite
+// y at a zero row turns the result into NaN, and any R NA (in the column or in
+// the leaf) gives NA_real_.  Equivalently, per (leaf, column):
+//     column has NA                      -> NA_real_
+//     column not finite and leaf has NA  -> NA_real_
+//     #non-finite y gathered < #non-finite in the column -> sum + NaN
+// which only needs the per-column counters from step 1.  Integer operands
+// (:73-114): NA in the column or in the leaf -> NA_real_.
+//
+// Roofline: HBM.  Algorithmic bytes = 12 per nonzero + 8*nrow*K (Y) +
+// 8*ncol*K (out).
+#include "svt_common.h"
+
+#define KT 64   // dense columns per wavefront tile
+
+struct ColFlags {
+	int *nonfinite;   // [Kp] count of NaN/Inf/NA entries (double) or NA (int)
+	int *has_na;      // [Kp]
+};
+
+static inline int64_t pad_k(int K) { return ((int64_t) K + KT - 1) / KT * KT; }
+
+size_t crossprod_ws_bytes(int64_t nrow, int64_t ncol, int K)
+{
+	(void) ncol;
+	const int64_t Kp = pad_k(K);
+	return (size_t) (nrow > 0 ? nrow : 1) * Kp * 8 + (size_t) Kp * 8 + 256;
+}
+
+// ---- step 1 -------------------------------------------------------------------
+// Tiled transpose through LDS: a 64x64 tile, read along rows of Y's storage
+// (consecutive r), written along k.
+template <typename T>
+__global__ void __launch_bounds__(256)
+prep_dense_kernel(const T *__restrict__ Y, int64_t ldY, int64_t nrow, int K,
+		  int tr_y, double *__restrict__ Yt, int64_t Kp, ColFlags fl)
+{
+	__shared__ double tile[64][65];
+	const int64_t r0 = (int64_t) blockIdx.x * 64;
+	const int k0 = blockIdx.y * 64;
+	const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
+	const bool is_dbl = sizeof(T) == 8;
+	if (!tr_y) {
+		// element (r, k) at Y[r + k*ldY]: lanes run along r
+		for (int kk = ty; kk < 64; kk += 4) {
+			const int64_t r = r0 + tx;
+			const int k = k0 + kk;
+			double d = 0.0;
+			if (r < nrow && k < K) {
+				const T v = Y[r + (int64_t) k * ldY];
+				bool na, nf;
+				if (is_dbl) { d = (double) v; nf = !svt_is_finite(d); na = svt_is_na(d); }
+				else { na = nf = ((int) v == NA_INT); d = na ? svt_na_real() : (double) v; }
+				if (nf) atomicAdd(fl.nonfinite + k, 1);
+				if (na) fl.has_na[k] = 1;
+			}
+			tile[kk][tx] = d;
+		}
+		__syncthreads();
+		for (int rr = ty; rr < 64; rr += 4) {
+			const int64_t r = r0 + rr;
+			if (r < nrow)
+				Yt[r * Kp + k0 + tx] = tile[tx][rr];
+		}
+	} else {
+		// element (r, k) at Y[k + r*ldY]: already row-contiguous
+		for (int rr = ty; rr < 64; rr += 4) {
+			const int64_t r = r0 + rr;
+			const int k = k0 + tx;
+			double d = 0.0;
+			if (r < nrow && k < K) {
+				const T v = Y[k + r * ldY];
+				bool na, nf;
+				if (is_dbl) { d = (double) v; nf = !svt_is_finite(d); na = svt_is_na(d); }
+				else { na = nf = ((int) v == NA_INT); d = na ? svt_na_real() : (double) v; }
+				if (nf) atomicAdd(fl.nonfinite + k, 1);
+				if (na) fl.has_na[k] = 1;
+			}
+			if (r < nrow)
+				Yt[r * Kp + k] = d;
+		}
+	}
+}
+
+// ---- step 2 -------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+crossprod_gather_kernel(const int64_t *__restrict__ col_ptr,
+			const int32_t *__restrict__ row_idx,
+			const T *__restrict__ val, int64_t ncol,
+			const double *__restrict__ Yt, int64_t Kp, int K,
+			ColFlags fl, double *__restrict__ out,
+			int64_t sc, int64_t sk)
+{
+	const int lane = threadIdx.x & 63;
+	const int64_t c = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (c >= ncol)
+		return;
+	const int k = blockIdx.y * KT + lane;
+	const bool is_dbl = sizeof(T) == 8;
+	const int64_t beg = col_ptr[c], end = col_ptr[c + 1];
+	const double *__restrict__ ycol = Yt + blockIdx.y * KT + lane;
+	double acc = 0.0;
+	int nf_hit = 0;
+	bool leaf_na = false;
+	for (int64_t i = beg; i < end; i++) {
+		const int32_t r = row_idx[i];   // wave-uniform -> scalar load
+		const T v = val[i];
+		const double y = ycol[(int64_t) r * Kp];
+		double dv;
+		if (is_dbl) {
+			dv = (double) v;
+			leaf_na |= svt_is_na(dv);
+		} else {
+			leaf_na |= ((int) v == NA_INT);
+			dv = (double) v;
+		}
+		nf_hit += svt_is_finite(y) ? 0 : 1;
+		acc = __dadd_rn(acc, __dmul_rn(dv, y));
+	}
+	if (k >= K)
+		return;
+	const int col_nf = fl.nonfinite[k];
+	double res = acc;
+	if (is_dbl) {
+		if (col_nf > 0) {
+			if (fl.has_na[k] || leaf_na) res = svt_na_real();
+			else if (nf_hit < col_nf) res = acc + NAN;
+		} else if (leaf_na) {
+			res = svt_na_real();
+		}
+	} else {
+		if (col_nf > 0 || leaf_na) res = svt_na_real();
+	}
+	out[c * sc + (int64_t) k * sk] = res;
+}
+
+int launch_crossprod_csc_dense(const CrossprodArgs &a, hipStream_t s)
+{
+	if (a.ncol <= 0 || a.K <= 0)
+		return 0;
+	const int64_t Kp = pad_k(a.K);
+	if (a.ws_bytes < crossprod_ws_bytes(a.nrow, a.ncol, a.K))
+		return svt_set_error("crossprod workspace too small");
+	double *Yt = (double *) a.ws;
+	const int64_t nrow1 = a.nrow > 0 ? a.nrow : 1;
+	ColFlags fl;
+	fl.nonfinite = (int *) (Yt + nrow1 * Kp);
+	fl.has_na = fl.nonfinite + Kp;
+	HIP_TRY(hipMemsetAsync(fl.nonfinite, 0, (size_t) Kp * 8, s));
+	const bool is_dbl = a.Rtype == SVT_REALSXP;
+	if (a.nrow > 0) {
+		dim3 grid((unsigned) ((a.nrow + 63) / 64), (unsigned) (Kp / 64));
+		if (is_dbl)
+			hipLaunchKernelGGL(prep_dense_kernel<double>, grid, dim3(256), 0, s,
+					   (const double *) a.Y, a.ldY, a.nrow, a.K, a.tr_y, Yt, Kp, fl);
+		else
+			hipLaunchKernelGGL(prep_dense_kernel<int>, grid, dim3(256), 0, s,
+					   (const int *) a.Y, a.ldY, a.nrow, a.K, a.tr_y, Yt, Kp, fl);
+	}
+	dim3 grid((unsigned) ((a.ncol + 3) / 4), (unsigned) (Kp / KT));
+	if (is_dbl)
+		hipLaunchKernelGGL(crossprod_gather_kernel<double>, grid, dim3(256), 0, s,
+				   a.col_ptr, a.row_idx, (const double *) a.val, a.ncol,
+				   Yt, Kp, a.K, fl, a.out, a.out_stride_c, a.out_stride_k);
+	else
+		hipLaunchKernelGGL(crossprod_gather_kernel<int>, grid, dim3(256), 0, s,
+				   a.col_ptr, a.row_idx, (const int *) a.val, a.ncol,
+				   Yt, Kp, a.K, fl, a.out, a.out_stride_c, a.out_stride_k);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+// ---- "preprocessing": leaves -> dense columns (src/SparseVec.c:9-47) ------------
+template <typename T>
+__global__ void densify_kernel(const int64_t *__restrict__ col_ptr,
+			       const int32_t *__restrict__ row_idx,
+			       const T *__restrict__ val, int64_t nrow, int64_t c0,
+			       int64_t nc, T *__restrict__ dense)
+{
+	const int lane = threadIdx.x & 63;
+	const int64_t j = (int64_t) blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	if (j >= nc)
+		return;
+	const int64_t beg = col_ptr[c0 + j], end = col_ptr[c0 + j + 1];
+	for (int64_t k = beg + lane; k < end; k += SVT_WAVE)
+		dense[j * nrow + row_idx[k]] = val[k];
+}
+
+int launch_densify(const int64_t *col_ptr, const int32_t *row_idx,
+		   const void *val, int Rtype, int64_t nrow, int64_t c0,
+		   int64_t nc, void *dense, hipStream_t s)
+{
+	if (nc <= 0 || nrow <= 0)
+		return 0;
+	const size_t esz = Rtype == SVT_REALSXP ? 8 : 4;
+	HIP_TRY(hipMemsetAsync(dense, 0, (size_t) nrow * nc * esz, s));
+	const unsigned nb = (unsigned) ((nc + 3) / 4);
+	if (Rtype == SVT_REALSXP)
+		hipLaunchKernelGGL(densify_kernel<double>, dim3(nb), dim3(256), 0, s, col_ptr,
+				   row_idx, (const double *) val, nrow, c0, nc, (double *) dense);
+	else
+		hipLaunchKernelGGL(densify_kernel<int>, dim3(nb), dim3(256), 0, s, col_ptr,
+				   row_idx, (const int *) val, nrow, c0, nc, (int *) dense);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+// compute_sym_dotprods_* write out[k] and out[k*n] from one dot product
+// (src/SparseMatrix_mult.c:263-296): keep the (i > j) value, mirror it.
+__global__ void mirror_lower_kernel(double *out, int64_t n)
+{
+	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n)
+		return;
+	for (int64_t j = blockIdx.y; j < i; j += gridDim.y)
+		out[j + i * n] = out[i + j * n];
+}
+
+int launch_mirror_lower(double *out, int64_t n, hipStream_t s)
+{
+	if (n <= 1)
+		return 0;
+	dim3 grid((unsigned) ((n + 255) / 256), (unsigned) (n < 1024 ? n : 1024));
+	hipLaunchKernelGGL(mirror_lower_kernel, grid, dim3(256), 0, s, out, n);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}

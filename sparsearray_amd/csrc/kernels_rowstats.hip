@@ -1,0 +1,369 @@
+// row* matrixStats, rowsum() and colsum() on the CSC device layout.
+//
+// Reference: C_rowStats_SVT (src/SparseArray_matrixStats.c:1121-1205) walks
+// the tree serially and scatters every leaf into a dense `out`
+// (update_out_for_rowSums :599-634 etc.); rowsum_SVT_double/int and
+// colsum_SVT_double/int (src/rowsum_methods.c:86-125, 204-255) do the same
+// into group-indexed outputs.  On the device each leaf is owned by one
+// wavefront and the scatter is done with memory-side atomics (or LDS atomics
+// when the per-column target fits in LDS), which is legal because every
+// update rule of the reference reduces to an order-independent form:
+//   sum-like ops : IEEE addition (NA/NaN propagate by themselves)
+//   min / max    : "any NA wins, else any NaN wins, else the extremum", plus
+//                  the implicit zero when a cell is covered fewer than
+//                  nstrata times (:914-961)
+// Roofline: HBM (12 B per nonzero + the dense output); the atomic rate of the
+// memory side is the practical bound for scattered 8-byte adds.
+#include "svt_common.h"
+
+#define RF_NA   1
+#define RF_NAN  2
+#define RF_HAVE 4
+
+// --------------------------------------------------------------------------
+// row stats
+// --------------------------------------------------------------------------
+struct MinMaxScratch {
+	unsigned long long *best;   // ordered-double or sign-extended int
+	int *flags;
+	unsigned int *cov;
+};
+
+__host__ __device__ inline MinMaxScratch split_scratch(void *p, int64_t n)
+{
+	MinMaxScratch s;
+	s.best = (unsigned long long *) p;
+	s.flags = (int *) (s.best + n);
+	s.cov = (unsigned int *) (s.flags + n);
+	return s;
+}
+
+size_t rowstats_scratch_bytes(int opcode, int out_Rtype, int64_t out_len)
+{
+	(void) out_Rtype;
+	if (opcode != SVT_OP_MIN && opcode != SVT_OP_MAX)
+		return 16;
+	return (size_t) out_len * 16 + 16;
+}
+
+__global__ void rowstats_init_kernel(RowStatsArgs a)
+{
+	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= a.out_len)
+		return;
+	switch (a.opcode) {
+	case SVT_OP_ANYNA:
+		((int *) a.out)[i] = 0;
+		break;
+	case SVT_OP_COUNTNAS: case SVT_OP_SUM:
+		((double *) a.out)[i] = 0.0;
+		break;
+	case SVT_OP_CENTERED_X2_SUM: {   // :1044-1066
+		const double c = a.center ? a.center[i] : 0.0;
+		((double *) a.out)[i] = a.center ? c * c * (double) a.nstrata : 0.0;
+		break;
+	}
+	default: {
+		MinMaxScratch s = split_scratch(a.scratch, a.out_len);
+		s.best[i] = a.opcode == SVT_OP_MIN ? ~0ULL : 0ULL;
+		s.flags[i] = 0;
+		s.cov[i] = 0;
+	}
+	}
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+rowstats_scatter_kernel(RowStatsArgs a)
+{
+	const int lane = threadIdx.x & 63;
+	const int64_t j = (int64_t) blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	if (j >= a.ncol)
+		return;
+	const T *__restrict__ val = (const T *) a.val;
+	const int32_t *__restrict__ row = a.row_idx;
+	const int64_t beg = a.col_ptr[j], end = a.col_ptr[j + 1];
+	const int64_t base = (j % a.inner) * a.nrow;
+	const bool is_dbl = sizeof(T) == 8;
+	const bool narm = a.na_rm != 0;
+	const double NAr = svt_na_real();
+	MinMaxScratch ms = split_scratch(a.scratch, a.out_len);
+
+	for (int64_t k = beg + lane; k < end; k += SVT_WAVE) {
+		const T v = val[k];
+		const int64_t i = base + row[k];
+		const bool miss = is_dbl ? (v != v) : ((int) v == NA_INT);
+		const bool isna = is_dbl ? svt_is_na((double) v) : miss;
+		switch (a.opcode) {
+		case SVT_OP_ANYNA:       // :498-514
+			if (miss) ((int *) a.out)[i] = 1;
+			break;
+		case SVT_OP_COUNTNAS:    // :516-535
+			if (miss) atomicAdd((double *) a.out + i, 1.0);
+			break;
+		case SVT_OP_SUM: {       // :599-634 with :412-433
+			if (miss && narm) break;
+			const double x = (!is_dbl && miss) ? NAr : (double) v;
+			atomicAdd((double *) a.out + i, x);
+			break;
+		}
+		case SVT_OP_CENTERED_X2_SUM: {   // :636-696
+			const double c = a.center ? a.center[i] : 0.0;
+			if (miss && narm) {
+				atomicAdd((double *) a.out + i, -(c * c));
+				break;
+			}
+			const double x = (!is_dbl && miss) ? NAr : (double) v;
+			atomicAdd((double *) a.out + i, x * (x - 2 * c));
+			break;
+		}
+		default: {               // min / max, :537-597
+			atomicAdd(ms.cov + i, 1u);
+			if (miss) {
+				atomicOr(ms.flags + i, isna ? RF_NA : RF_NAN);
+				break;
+			}
+			atomicOr(ms.flags + i, RF_HAVE);
+			unsigned long long key = is_dbl ?
+				f64_to_ordered((double) v) :
+				(unsigned long long) ((long long) (int) v + 0x80000000LL);
+			if (a.opcode == SVT_OP_MIN) atomicMin(ms.best + i, key);
+			else atomicMax(ms.best + i, key);
+		}
+		}
+	}
+}
+
+template <typename T>
+__global__ void rowstats_minmax_finish_kernel(RowStatsArgs a)
+{
+	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= a.out_len)
+		return;
+	MinMaxScratch ms = split_scratch(a.scratch, a.out_len);
+	const bool is_dbl = sizeof(T) == 8;
+	const bool is_min = a.opcode == SVT_OP_MIN;
+	const bool narm = a.na_rm != 0;
+	const int fl = ms.flags[i];
+	const bool partial = (int64_t) ms.cov[i] < a.nstrata;   // implicit zeros
+	bool have = (fl & RF_HAVE) != 0;
+	if (is_dbl) {
+		double m = have ? ordered_to_f64(ms.best[i]) : 0.0;
+		double r;
+		if (!narm && (fl & RF_NA)) r = svt_na_real();
+		else if (!narm && (fl & RF_NAN)) r = NAN;
+		else {
+			if (partial) {
+				m = have ? (is_min ? (0.0 < m ? 0.0 : m) : (0.0 > m ? 0.0 : m)) : 0.0;
+				have = true;
+			}
+			r = have ? m : (is_min ? INFINITY : -INFINITY);   // :956-957
+		}
+		((double *) a.out)[i] = r;
+	} else {
+		int m = have ? (int) ((long long) ms.best[i] - 0x80000000LL) : 0;
+		int r;
+		if (!narm && (fl & RF_NA)) r = NA_INT;
+		else {
+			if (partial) {
+				m = have ? (is_min ? (0 < m ? 0 : m) : (0 > m ? 0 : m)) : 0;
+				have = true;
+			}
+			if (have) r = m;
+			else { r = NA_INT; if (a.warn_flag) *a.warn_flag = 1; }   // :930-931
+		}
+		((int *) a.out)[i] = r;
+	}
+}
+
+int launch_rowstats(const RowStatsArgs &a, int64_t nnz, hipStream_t s)
+{
+	(void) nnz;
+	if (a.out_len <= 0)
+		return 0;
+	const bool is_dbl = a.Rtype == SVT_REALSXP;
+	const unsigned nb_out = (unsigned) ((a.out_len + 255) / 256);
+	hipLaunchKernelGGL(rowstats_init_kernel, dim3(nb_out), dim3(256), 0, s, a);
+	if (a.ncol > 0 && a.nstrata > 0) {
+		const unsigned nb = (unsigned) ((a.ncol + 3) / 4);
+		if (is_dbl) hipLaunchKernelGGL(rowstats_scatter_kernel<double>, dim3(nb), dim3(256), 0, s, a);
+		else hipLaunchKernelGGL(rowstats_scatter_kernel<int>, dim3(nb), dim3(256), 0, s, a);
+	}
+	if (a.opcode == SVT_OP_MIN || a.opcode == SVT_OP_MAX) {
+		if (is_dbl) hipLaunchKernelGGL(rowstats_minmax_finish_kernel<double>, dim3(nb_out), dim3(256), 0, s, a);
+		else hipLaunchKernelGGL(rowstats_minmax_finish_kernel<int>, dim3(nb_out), dim3(256), 0, s, a);
+	}
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+// --------------------------------------------------------------------------
+// rowsum / colsum
+// --------------------------------------------------------------------------
+struct IntSumScratch {
+	long long *sum;
+	int *na;
+};
+__host__ __device__ inline IntSumScratch split_int_scratch(void *p, int64_t n)
+{
+	IntSumScratch s;
+	s.sum = (long long *) p;
+	s.na = (int *) (s.sum + n);
+	return s;
+}
+size_t groupsum_scratch_bytes(int Rtype, int64_t out_len)
+{
+	return Rtype == SVT_REALSXP ? 16 : (size_t) out_len * 12 + 16;
+}
+
+__device__ inline int64_t col_beg(const GroupSumArgs &a, int64_t j)
+{
+	return a.col_ptr64 ? a.col_ptr64[j] : (int64_t) a.col_ptr32[j];
+}
+
+// One workgroup per column, group accumulators in LDS (ds_add_f64), one
+// coalesced store of the finished column: compute_rowsum_doubles,
+// src/rowsum_methods.c:44-64.
+__global__ void __launch_bounds__(256)
+rowsum_f64_lds_kernel(GroupSumArgs a)
+{
+	extern __shared__ double acc[];
+	const int64_t j = blockIdx.x;
+	for (int g = threadIdx.x; g < a.ngroup; g += blockDim.x)
+		acc[g] = 0.0;
+	__syncthreads();
+	const double *__restrict__ val = (const double *) a.val;
+	const int64_t beg = col_beg(a, j), end = col_beg(a, j + 1);
+	for (int64_t k = beg + threadIdx.x; k < end; k += blockDim.x) {
+		const double v = val[k];
+		if (a.na_rm && v != v)
+			continue;
+		int g = a.group[a.row_idx[k]];
+		if (g == NA_INT) g = a.ngroup;
+		atomicAdd(&acc[g - 1], v);
+	}
+	__syncthreads();
+	double *out = (double *) a.out + j * (int64_t) a.ngroup;
+	for (int g = threadIdx.x; g < a.ngroup; g += blockDim.x)
+		out[g] = acc[g];
+}
+
+// One wavefront per column, memory-side atomics (short columns or too many
+// groups for LDS).  TARGET 0: rowsum -> out[g-1 + j*ngroup];
+// TARGET 1: colsum -> out[row + (group[j]-1)*nrow]  (:141-199, :204-255)
+template <typename T, int TARGET>
+__global__ void __launch_bounds__(256)
+groupsum_atomic_kernel(GroupSumArgs a, int64_t out_len)
+{
+	const int lane = threadIdx.x & 63;
+	const int64_t j = (int64_t) blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	if (j >= a.ncol)
+		return;
+	const T *__restrict__ val = (const T *) a.val;
+	const bool is_dbl = sizeof(T) == 8;
+	const int64_t beg = col_beg(a, j), end = col_beg(a, j + 1);
+	int64_t colbase = 0;
+	if (TARGET == 1) {
+		int g = a.group[j];
+		if (g == NA_INT) g = a.ngroup;
+		colbase = (int64_t) (g - 1) * a.nrow;
+	} else {
+		colbase = j * (int64_t) a.ngroup;
+	}
+	IntSumScratch is = split_int_scratch(a.scratch, out_len);
+	for (int64_t k = beg + lane; k < end; k += SVT_WAVE) {
+		const T v = val[k];
+		const bool miss = is_dbl ? (v != v) : ((int) v == NA_INT);
+		if (miss && a.na_rm)
+			continue;
+		int64_t i;
+		if (TARGET == 1) {
+			i = colbase + a.row_idx[k];
+		} else {
+			int g = a.group[a.row_idx[k]];
+			if (g == NA_INT) g = a.ngroup;
+			i = colbase + g - 1;
+		}
+		if (is_dbl) {
+			atomicAdd((double *) a.out + i, (double) v);
+		} else if (miss) {
+			atomicOr(is.na + i, 1);
+		} else {
+			atomicAdd((unsigned long long *) is.sum + i,
+				  (unsigned long long) (long long) (int) v);
+		}
+	}
+}
+
+// int32 results: NA is sticky, a sum outside [-INT_MAX, INT_MAX] becomes NA
+// and raises the overflow flag (safe_int_add semantics applied to the total;
+// src/rowsum_methods.c:66-84, 166-199).
+__global__ void groupsum_int_finish_kernel(GroupSumArgs a, int64_t out_len)
+{
+	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= out_len)
+		return;
+	IntSumScratch is = split_int_scratch(a.scratch, out_len);
+	const long long sum = is.sum[i];
+	int r;
+	if (is.na[i]) {
+		r = NA_INT;
+	} else if (sum > 2147483647LL || sum < -2147483647LL) {
+		r = NA_INT;
+		if (a.ovflow_flag) *a.ovflow_flag = 1;
+	} else {
+		r = (int) sum;
+	}
+	((int *) a.out)[i] = r;
+}
+
+static int groupsum_common(const GroupSumArgs &a, int64_t out_len, bool colsum,
+			   hipStream_t s)
+{
+	const bool is_dbl = a.Rtype == SVT_REALSXP;
+	if (out_len <= 0)
+		return 0;
+	if (is_dbl)
+		HIP_TRY(hipMemsetAsync(a.out, 0, (size_t) out_len * 8, s));
+	else
+		HIP_TRY(hipMemsetAsync(a.scratch, 0, (size_t) out_len * 12, s));
+	if (a.ncol > 0) {
+		const unsigned nb = (unsigned) ((a.ncol + 3) / 4);
+		if (colsum) {
+			if (is_dbl) hipLaunchKernelGGL((groupsum_atomic_kernel<double, 1>), dim3(nb), dim3(256), 0, s, a, out_len);
+			else hipLaunchKernelGGL((groupsum_atomic_kernel<int, 1>), dim3(nb), dim3(256), 0, s, a, out_len);
+		} else {
+			if (is_dbl) hipLaunchKernelGGL((groupsum_atomic_kernel<double, 0>), dim3(nb), dim3(256), 0, s, a, out_len);
+			else hipLaunchKernelGGL((groupsum_atomic_kernel<int, 0>), dim3(nb), dim3(256), 0, s, a, out_len);
+		}
+	}
+	if (!is_dbl) {
+		const unsigned nbo = (unsigned) ((out_len + 255) / 256);
+		hipLaunchKernelGGL(groupsum_int_finish_kernel, dim3(nbo), dim3(256), 0, s, a, out_len);
+	}
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+int launch_rowsum(const GroupSumArgs &a, hipStream_t s)
+{
+	const int64_t out_len = (int64_t) a.ngroup * a.ncol;
+	return groupsum_common(a, out_len, false, s);
+}
+
+// Long f64 columns with few groups: LDS accumulators, no memory atomics.
+int launch_rowsum_lds(const GroupSumArgs &a, hipStream_t s)
+{
+	if (a.ncol <= 0 || a.ngroup <= 0)
+		return 0;
+	hipLaunchKernelGGL(rowsum_f64_lds_kernel, dim3((unsigned) a.ncol), dim3(256),
+			   (size_t) a.ngroup * 8, s, a);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+int launch_colsum(const GroupSumArgs &a, hipStream_t s)
+{
+	const int64_t out_len = (int64_t) a.ngroup * a.nrow;
+	return groupsum_common(a, out_len, true, s);
+}

@@ -1,0 +1,830 @@
+// Host side of libsvt_hip.so: the C ABI of include/svt_hip.h.
+//
+// Host-level functions restate the argument checks and dispatch of the
+// reference's .Call entry points (file:line at each function), marshal the
+// SVT leaves into the CSC device layout (model:
+// dump_SVT_to_CsparseMatrix_slots, src/SVT_SparseArray_class.c:598-633),
+// launch the kernels and copy the result back.  No arithmetic of the hot path
+// happens on the host.
+#include "svt_common.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+static thread_local char g_err[1024];
+static int g_device = -1;
+static char g_arch[64] = "";
+
+int svt_set_error(const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof(g_err), fmt, ap);
+	va_end(ap);
+	return -1;
+}
+
+extern "C" const char *svt_last_error(void) { return g_err; }
+extern "C" const char *svt_device_arch(void) { return g_arch; }
+
+extern "C" int svt_init(int device)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+		return svt_set_error("libsvt_hip: no HIP device visible -- the SVT "
+				     "backend has no CPU fallback");
+	if (device < 0 || device >= n)
+		return svt_set_error("libsvt_hip: device %d out of range (0..%d)",
+				     device, n - 1);
+	HIP_TRY(hipSetDevice(device));
+	hipDeviceProp_t prop;
+	HIP_TRY(hipGetDeviceProperties(&prop, device));
+	snprintf(g_arch, sizeof(g_arch), "%s", prop.gcnArchName);
+	if (strncmp(g_arch, "gfx950", 6) != 0)
+		return svt_set_error("libsvt_hip: device %d is %s; this library "
+				     "carries gfx950 (MI355X) code only", device, g_arch);
+	g_device = device;
+	return 0;
+}
+
+static int ensure_init()
+{
+	if (g_device >= 0)
+		return 0;
+	return svt_init(0);
+}
+
+// ---- small RAII device buffer --------------------------------------------------
+struct DevBuf {
+	void *p = nullptr;
+	size_t bytes = 0;
+	DevBuf() {}
+	DevBuf(const DevBuf &) = delete;
+	~DevBuf() { if (p) (void) hipFree(p); }
+	int alloc(size_t n)
+	{
+		if (n == 0) n = 16;
+		HIP_TRY(hipMalloc(&p, n));
+		bytes = n;
+		return 0;
+	}
+	int upload(const void *src, size_t n)
+	{
+		if (alloc(n)) return -1;
+		if (n) HIP_TRY(hipMemcpy(p, src, n, hipMemcpyHostToDevice));
+		return 0;
+	}
+	int zero()
+	{
+		HIP_TRY(hipMemset(p, 0, bytes));
+		return 0;
+	}
+	template <typename T> T *as() { return (T *) p; }
+};
+
+// ---- SVT -> CSC marshal ----------------------------------------------------------
+static size_t elt_size(int Rtype) { return Rtype == SVT_REALSXP ? 8 : 4; }
+
+static int check_view(const svt_view *x)
+{
+	if (x == NULL || x->ndim < 1 || x->dim == NULL)
+		return svt_set_error("invalid svt_view");
+	if (x->Rtype != SVT_REALSXP && x->Rtype != SVT_INTSXP &&
+	    x->Rtype != SVT_LGLSXP)
+		return svt_set_error("does not support SparseArray objects of "
+				     "type code %d", x->Rtype);
+	int64_t n = 1;
+	for (int a = 1; a < x->ndim; a++) n *= x->dim[a];
+	if (n != x->nleaves)
+		return svt_set_error("svt_view: nleaves does not match dim");
+	return 0;
+}
+
+struct HostCSC {
+	std::vector<int64_t> col_ptr;
+	std::vector<int32_t> row_idx;
+	std::vector<char> val;
+};
+
+static int marshal(const svt_view *x, HostCSC &h)
+{
+	const int64_t n = x->nleaves;
+	const size_t esz = elt_size(x->Rtype);
+	const int dim0 = x->dim[0];
+	h.col_ptr.assign((size_t) n + 1, 0);
+	for (int64_t j = 0; j < n; j++) {
+		int c = x->svt_is_null ? 0 : x->nzcount[j];
+		if (c < 0 || c > dim0)
+			return svt_set_error("invalid SVT leaf (nzcount %d, dim %d)", c, dim0);
+		h.col_ptr[j + 1] = h.col_ptr[j] + c;
+	}
+	const int64_t nnz = h.col_ptr[n];
+	h.row_idx.resize((size_t) nnz);
+	h.val.resize((size_t) nnz * esz);
+	for (int64_t j = 0; j < n; j++) {
+		const int64_t s = h.col_ptr[j], c = h.col_ptr[j + 1] - s;
+		if (c == 0) continue;
+		const int32_t *offs = x->nzoffs[j];
+		if (offs == NULL)
+			return svt_set_error("invalid SVT leaf (NULL nzoffs)");
+		memcpy(&h.row_idx[(size_t) s], offs, (size_t) c * 4);
+		const void *v = x->nzvals[j];
+		if (v != NULL) {
+			memcpy(&h.val[(size_t) s * esz], v, (size_t) c * esz);
+		} else if (esz == 8) {     // lacunar leaf: all ones
+			double *d = (double *) &h.val[(size_t) s * esz];
+			for (int64_t k = 0; k < c; k++) d[k] = 1.0;
+		} else {
+			int *d = (int *) &h.val[(size_t) s * esz];
+			for (int64_t k = 0; k < c; k++) d[k] = 1;
+		}
+	}
+	return 0;
+}
+
+extern "C" svt_dev_csc *svt_upload(const svt_view *x)
+{
+	if (ensure_init() || check_view(x))
+		return NULL;
+	HostCSC h;
+	if (marshal(x, h))
+		return NULL;
+	svt_dev_csc *d = (svt_dev_csc *) calloc(1, sizeof(*d));
+	d->Rtype = x->Rtype;
+	d->owned = 1;
+	d->nrow = x->dim[0];
+	d->ncol = x->nleaves;
+	d->nnz = h.col_ptr[(size_t) x->nleaves];
+	const size_t esz = elt_size(x->Rtype);
+	const size_t nn = (size_t) (d->nnz > 0 ? d->nnz : 1);
+	if (hipMalloc((void **) &d->col_ptr, (size_t) (d->ncol + 1) * 8) != hipSuccess ||
+	    hipMalloc((void **) &d->row_idx, nn * 4) != hipSuccess ||
+	    hipMalloc(&d->val, nn * esz) != hipSuccess) {
+		svt_set_error("hipMalloc failed while uploading an SVT (%lld nnz)",
+			      (long long) d->nnz);
+		svt_release(d);
+		return NULL;
+	}
+	hipError_t e = hipMemcpy(d->col_ptr, h.col_ptr.data(), (size_t) (d->ncol + 1) * 8,
+				 hipMemcpyHostToDevice);
+	if (e == hipSuccess && d->nnz)
+		e = hipMemcpy(d->row_idx, h.row_idx.data(), (size_t) d->nnz * 4,
+			      hipMemcpyHostToDevice);
+	if (e == hipSuccess && d->nnz)
+		e = hipMemcpy(d->val, h.val.data(), (size_t) d->nnz * esz,
+			      hipMemcpyHostToDevice);
+	if (e != hipSuccess) {
+		svt_set_error("H2D copy failed: %s", hipGetErrorString(e));
+		svt_release(d);
+		return NULL;
+	}
+	return d;
+}
+
+extern "C" svt_dev_csc *svt_wrap_device_csc(int Rtype, int64_t nrow, int64_t ncol,
+					    int64_t nnz, int64_t *col_ptr,
+					    int32_t *row_idx, void *val)
+{
+	svt_dev_csc *d = (svt_dev_csc *) calloc(1, sizeof(*d));
+	d->Rtype = Rtype;
+	d->owned = 0;
+	d->nrow = nrow;
+	d->ncol = ncol;
+	d->nnz = nnz;
+	d->col_ptr = col_ptr;
+	d->row_idx = row_idx;
+	d->val = val;
+	return d;
+}
+
+extern "C" void svt_release(svt_dev_csc *h)
+{
+	if (h == NULL)
+		return;
+	if (h->owned) {
+		if (h->col_ptr) (void) hipFree(h->col_ptr);
+		if (h->row_idx) (void) hipFree(h->row_idx);
+		if (h->val) (void) hipFree(h->val);
+	}
+	free(h);
+}
+
+struct CscGuard {
+	svt_dev_csc *h;
+	explicit CscGuard(svt_dev_csc *p) : h(p) {}
+	~CscGuard() { svt_release(h); }
+};
+
+// ==================================================================================
+// Device level
+// ==================================================================================
+extern "C" size_t svt_dev_crossprod_ws_bytes(int64_t nrow, int64_t ncol, int K)
+{
+	return crossprod_ws_bytes(nrow, ncol, K);
+}
+
+extern "C" int svt_dev_crossprod_csc_dense(const svt_dev_csc *A, const void *Y,
+					   int64_t ldY, int K, int tr_y, double *out,
+					   int64_t out_stride_c, int64_t out_stride_k,
+					   void *ws, size_t ws_bytes, void *stream)
+{
+	CrossprodArgs a;
+	a.col_ptr = A->col_ptr; a.row_idx = A->row_idx; a.val = A->val;
+	a.Rtype = A->Rtype == SVT_REALSXP ? SVT_REALSXP : SVT_INTSXP;
+	a.nrow = A->nrow; a.ncol = A->ncol;
+	a.Y = Y; a.ldY = ldY; a.K = K; a.tr_y = tr_y;
+	a.out = out; a.out_stride_c = out_stride_c; a.out_stride_k = out_stride_k;
+	a.ws = ws; a.ws_bytes = ws_bytes;
+	return launch_crossprod_csc_dense(a, (hipStream_t) stream);
+}
+
+static int check_stat_op(int opcode, int Rtype)
+{
+	// _get_summarize_opcode(), src/Rvector_summarization.c:19-78
+	if (opcode < SVT_OP_ANYNA || opcode > SVT_OP_SD2)
+		return svt_set_error("'op' must be one of: \"anyNA\", \"countNAs\", "
+				     "\"any\", \"all\", \"min\", \"max\", \"range\", \"sum\", "
+				     "\"prod\", \"mean\", \"centered_X2_sum\", \"sum_X_X2\", "
+				     "\"var1\", \"var2\", \"sd1\", \"sd2\"");
+	if ((opcode == SVT_OP_ANY || opcode == SVT_OP_ALL) && Rtype == SVT_REALSXP)
+		return svt_set_error("%s() does not support SparseArray objects of "
+				     "type() \"double\"", opcode == SVT_OP_ANY ? "any" : "all");
+	return 0;
+}
+
+extern "C" int svt_colStats_out_Rtype(int opcode, int in_Rtype)
+{
+	// _init_SummarizeResult(), src/Rvector_summarization.c:97-165
+	switch (opcode) {
+	case SVT_OP_ANYNA: case SVT_OP_ANY: case SVT_OP_ALL:
+		return SVT_LGLSXP;
+	case SVT_OP_MIN: case SVT_OP_MAX: case SVT_OP_RANGE:
+		return in_Rtype == SVT_REALSXP ? SVT_REALSXP : SVT_INTSXP;
+	default:
+		if (opcode < SVT_OP_ANYNA || opcode > SVT_OP_SD2)
+			return svt_set_error("unknown opcode %d", opcode);
+		return SVT_REALSXP;
+	}
+}
+
+static int device_op_supported(int opcode)
+{
+	if (opcode == SVT_OP_RANGE || opcode == SVT_OP_SUM_X_X2 ||
+	    opcode == SVT_OP_VAR2 || opcode == SVT_OP_SD2)
+		return svt_set_error("op code %d is not reachable from the R API for "
+				     "col/row stats and is not implemented on the device",
+				     opcode);
+	return 0;
+}
+
+extern "C" int svt_dev_colstats(const svt_dev_csc *A, int opcode, int na_rm,
+				double center, int64_t inner, void *out,
+				int *warn_flag, void *stream)
+{
+	if (check_stat_op(opcode, A->Rtype) || device_op_supported(opcode))
+		return -1;
+	if (inner <= 0 || A->ncol % inner != 0)
+		return svt_set_error("'inner' must divide the number of leaves");
+	StatsArgs a;
+	a.col_ptr = A->col_ptr; a.val = A->val; a.Rtype = A->Rtype;
+	a.nseg = A->ncol / inner; a.inner = inner; a.seg_len = inner * A->nrow;
+	a.opcode = opcode; a.na_rm = na_rm; a.center = center;
+	a.out = out; a.warn_flag = warn_flag;
+	return launch_colstats(a, A->nnz, (hipStream_t) stream);
+}
+
+extern "C" int svt_dev_rowsums(const svt_dev_csc *A, int na_rm, int64_t inner,
+			       double *out, void *stream)
+{
+	RowStatsArgs a;
+	memset(&a, 0, sizeof(a));
+	a.col_ptr = A->col_ptr; a.row_idx = A->row_idx; a.val = A->val;
+	a.Rtype = A->Rtype; a.ncol = A->ncol; a.nrow = A->nrow;
+	a.inner = inner; a.nstrata = inner > 0 ? A->ncol / inner : 0;
+	a.out_len = inner * A->nrow;
+	a.opcode = SVT_OP_SUM; a.na_rm = na_rm; a.out = out;
+	return launch_rowstats(a, A->nnz, (hipStream_t) stream);
+}
+
+extern "C" int svt_dev_rowsum(const svt_dev_csc *A, const int *group, int ngroup,
+			      int na_rm, double *out, void *stream)
+{
+	if (A->Rtype != SVT_REALSXP)
+		return svt_set_error("svt_dev_rowsum: f64 input only");
+	GroupSumArgs a;
+	memset(&a, 0, sizeof(a));
+	a.col_ptr64 = A->col_ptr; a.row_idx = A->row_idx; a.val = A->val;
+	a.Rtype = A->Rtype; a.nrow = A->nrow; a.ncol = A->ncol;
+	a.group = group; a.ngroup = ngroup; a.na_rm = na_rm; a.out = out;
+	if (ngroup <= 8192 && A->ncol > 0 && A->nnz / A->ncol >= ngroup / 4)
+		return launch_rowsum_lds(a, (hipStream_t) stream);
+	return launch_rowsum(a, (hipStream_t) stream);
+}
+
+// ==================================================================================
+// Host level: crossprod
+// ==================================================================================
+static int check_mult_view(const svt_view *x, const char *what)
+{
+	if (check_view(x))
+		return -1;
+	if (x->ndim != 2)
+		return svt_set_error("%s must have 2 dimensions", what);
+	// get_and_check_input_Rtype(), src/SparseMatrix_mult.c:915-928
+	if (x->Rtype != SVT_REALSXP && x->Rtype != SVT_INTSXP)
+		return svt_set_error("input type is not supported yet");
+	return 0;
+}
+
+// Largest number of dense columns handled per launch so that the row-major
+// staging copy of the dense operand stays below ~1 GiB.
+static int chunk_K(int64_t nrow, int64_t K)
+{
+	const int64_t budget = (int64_t) 1 << 30;
+	int64_t kc = budget / (8 * (nrow > 0 ? nrow : 1));
+	kc = kc / 64 * 64;
+	if (kc < 64) kc = 64;
+	if (kc > K) kc = K;
+	return (int) kc;
+}
+
+// out (device) receives all K columns; the dense operand is already on the device.
+static int dev_crossprod_chunked(const svt_dev_csc *A, const void *Y_dev, int64_t ldY,
+				 int64_t K, int tr_y, double *out_dev,
+				 int64_t sc, int64_t sk)
+{
+	if (K <= 0 || A->ncol <= 0)
+		return 0;
+	const int kc = chunk_K(A->nrow, K);
+	DevBuf ws;
+	if (ws.alloc(crossprod_ws_bytes(A->nrow, A->ncol, kc)))
+		return -1;
+	const size_t esz = elt_size(A->Rtype);
+	for (int64_t k0 = 0; k0 < K; k0 += kc) {
+		const int kn = (int) (K - k0 < kc ? K - k0 : kc);
+		const char *Yc = (const char *) Y_dev +
+			(tr_y ? (size_t) k0 : (size_t) k0 * (size_t) ldY) * esz;
+		if (svt_dev_crossprod_csc_dense(A, Yc, ldY, kn, tr_y,
+						out_dev + k0 * sk, sc, sk,
+						ws.p, ws.bytes, 0))
+			return -1;
+	}
+	HIP_TRY(hipDeviceSynchronize());
+	return 0;
+}
+
+// C_crossprod2_SVT_mat, src/SparseMatrix_mult.c:931-982
+extern "C" int svt_crossprod2_SVT_mat(const svt_view *x, const void *y, int y_nrow,
+				      int y_ncol, int y_Rtype, int tr_y, double *out)
+{
+	if (ensure_init() || check_mult_view(x, "input objects"))
+		return -1;
+	const int in_nrow = x->dim[0], out_nrow = x->dim[1];
+	if (in_nrow != (tr_y ? y_ncol : y_nrow))
+		return svt_set_error("input objects are non-conformable");
+	if (y_Rtype == SVT_LGLSXP) y_Rtype = SVT_INTSXP;
+	if (x->Rtype != y_Rtype)
+		return svt_set_error("SparseArray internal error in "
+				     "C_crossprod2_SVT_mat():\n"
+				     "    'x_Rtype != TYPEOF(y)' not supported yet");
+	const int out_ncol = tr_y ? y_nrow : y_ncol;
+	const size_t out_n = (size_t) out_nrow * out_ncol;
+	memset(out, 0, out_n * sizeof(double));
+	if (x->svt_is_null || out_n == 0)     // :389-390
+		return 0;
+	CscGuard A(svt_upload(x));
+	if (A.h == NULL) return -1;
+	DevBuf Y, O;
+	if (Y.upload(y, (size_t) y_nrow * y_ncol * elt_size(y_Rtype)) ||
+	    O.alloc(out_n * 8) || O.zero())
+		return -1;
+	if (dev_crossprod_chunked(A.h, Y.p, y_nrow, out_ncol, tr_y, O.as<double>(),
+				  1, out_nrow))
+		return -1;
+	HIP_TRY(hipMemcpy(out, O.p, out_n * 8, hipMemcpyDeviceToHost));
+	return 0;
+}
+
+// C_crossprod2_mat_SVT, src/SparseMatrix_mult.c:985-1034
+extern "C" int svt_crossprod2_mat_SVT(const void *x, int x_nrow, int x_ncol,
+				      int x_Rtype, const svt_view *y, int tr_x,
+				      double *out)
+{
+	if (ensure_init() || check_mult_view(y, "input objects"))
+		return -1;
+	const int in_nrow = y->dim[0], out_ncol = y->dim[1];
+	if ((tr_x ? x_ncol : x_nrow) != in_nrow)
+		return svt_set_error("input objects are non-conformable");
+	if (x_Rtype == SVT_LGLSXP) x_Rtype = SVT_INTSXP;
+	if (x_Rtype != y->Rtype)
+		return svt_set_error("input objects must have the same type() for now");
+	const int out_nrow = tr_x ? x_nrow : x_ncol;
+	const size_t out_n = (size_t) out_nrow * out_ncol;
+	memset(out, 0, out_n * sizeof(double));
+	if (y->svt_is_null || out_n == 0)     // :439-440
+		return 0;
+	CscGuard A(svt_upload(y));
+	if (A.h == NULL) return -1;
+	DevBuf X, O;
+	if (X.upload(x, (size_t) x_nrow * x_ncol * elt_size(x_Rtype)) ||
+	    O.alloc(out_n * 8) || O.zero())
+		return -1;
+	// result cell (i = dense vector, j = leaf) lives at out[i + j*out_nrow]
+	if (dev_crossprod_chunked(A.h, X.p, x_nrow, out_nrow, tr_x, O.as<double>(),
+				  out_nrow, 1))
+		return -1;
+	HIP_TRY(hipMemcpy(out, O.p, out_n * 8, hipMemcpyDeviceToHost));
+	return 0;
+}
+
+// Densify columns of `pp` chunk by chunk and multiply every chunk with the
+// leaves of `other`: crossprod2_Lpp_* / crossprod2_Rpp_*,
+// src/SparseMatrix_mult.c:728-820.
+static int dev_crossprod_pp(const svt_dev_csc *other, const svt_dev_csc *pp,
+			    double *out_dev, int64_t sc, int64_t sk)
+{
+	const int64_t K = pp->ncol, nrow = pp->nrow;
+	if (K <= 0 || other->ncol <= 0)
+		return 0;
+	const int kc = chunk_K(nrow, K);
+	const size_t esz = elt_size(pp->Rtype);
+	DevBuf dense, ws;
+	if (dense.alloc((size_t) (nrow > 0 ? nrow : 1) * kc * esz) ||
+	    ws.alloc(crossprod_ws_bytes(nrow, other->ncol, kc)))
+		return -1;
+	for (int64_t k0 = 0; k0 < K; k0 += kc) {
+		const int kn = (int) (K - k0 < kc ? K - k0 : kc);
+		if (launch_densify(pp->col_ptr, pp->row_idx, pp->val, pp->Rtype, nrow,
+				   k0, kn, dense.p, 0))
+			return -1;
+		if (svt_dev_crossprod_csc_dense(other, dense.p, nrow, kn, 0,
+						out_dev + k0 * sk, sc, sk,
+						ws.p, ws.bytes, 0))
+			return -1;
+	}
+	HIP_TRY(hipDeviceSynchronize());
+	return 0;
+}
+
+static int64_t view_nzcount(const svt_view *x)   // _REC_nzcount_SVT, SVT_SparseArray_class.c:200-218
+{
+	int64_t t = 0;
+	if (x->svt_is_null) return 0;
+	for (int64_t j = 0; j < x->nleaves; j++) t += x->nzcount[j];
+	return t;
+}
+
+// C_crossprod2_SVT_SVT, src/SparseMatrix_mult.c:1037-1101
+extern "C" int svt_crossprod2_SVT_SVT(const svt_view *x, const svt_view *y, double *out)
+{
+	if (ensure_init() || check_mult_view(x, "input objects") ||
+	    check_mult_view(y, "input objects"))
+		return -1;
+	const int in_nrow = x->dim[0];
+	if (in_nrow != y->dim[0])
+		return svt_set_error("input SVT_SparseMatrix objects are non-conformable");
+	if (x->Rtype != y->Rtype)
+		return svt_set_error("input SVT_SparseMatrix objects must have the "
+				     "same type() for now");
+	const int out_nrow = x->dim[1], out_ncol = y->dim[1];
+	const size_t out_n = (size_t) out_nrow * out_ncol;
+	memset(out, 0, out_n * sizeof(double));
+	if (out_n == 0)
+		return 0;
+	const int64_t Lpp_nops = view_nzcount(y) * out_nrow;   // :1077-1078
+	const int64_t Rpp_nops = view_nzcount(x) * out_ncol;
+	CscGuard X(svt_upload(x)), Y(svt_upload(y));
+	if (X.h == NULL || Y.h == NULL) return -1;
+	DevBuf O;
+	if (O.alloc(out_n * 8) || O.zero())
+		return -1;
+	int rc;
+	if (Lpp_nops < Rpp_nops)   // expand the columns of x, walk the leaves of y
+		rc = dev_crossprod_pp(Y.h, X.h, O.as<double>(), out_nrow, 1);
+	else                       // expand the columns of y, walk the leaves of x
+		rc = dev_crossprod_pp(X.h, Y.h, O.as<double>(), 1, out_nrow);
+	if (rc) return -1;
+	HIP_TRY(hipMemcpy(out, O.p, out_n * 8, hipMemcpyDeviceToHost));
+	return 0;
+}
+
+// C_crossprod1_SVT, src/SparseMatrix_mult.c:1104-1140
+extern "C" int svt_crossprod1_SVT(const svt_view *x, double *out)
+{
+	if (ensure_init() || check_mult_view(x, "'x'"))
+		return -1;
+	const int n = x->dim[1];
+	const size_t out_n = (size_t) n * n;
+	memset(out, 0, out_n * sizeof(double));
+	if (x->svt_is_null || out_n == 0)      // :880-881
+		return 0;
+	CscGuard X(svt_upload(x));
+	if (X.h == NULL) return -1;
+	DevBuf O;
+	if (O.alloc(out_n * 8) || O.zero())
+		return -1;
+	if (dev_crossprod_pp(X.h, X.h, O.as<double>(), 1, n))
+		return -1;
+	if (launch_mirror_lower(O.as<double>(), n, 0))
+		return -1;
+	HIP_TRY(hipMemcpy(out, O.p, out_n * 8, hipMemcpyDeviceToHost));
+	return 0;
+}
+
+// ==================================================================================
+// Host level: stats
+// ==================================================================================
+static int run_colstats(const svt_dev_csc *A, int opcode, int na_rm, double center,
+			int64_t inner, void *out_host, int out_Rtype, int *warn)
+{
+	const int64_t nseg = A->ncol / inner;
+	const size_t osz = out_Rtype == SVT_REALSXP ? 8 : 4;
+	DevBuf O, W;
+	if (O.alloc((size_t) nseg * osz) || W.alloc(16) || W.zero())
+		return -1;
+	if (svt_dev_colstats(A, opcode, na_rm, center, inner, O.p, W.as<int>(), 0))
+		return -1;
+	int w = 0;
+	HIP_TRY(hipMemcpy(out_host, O.p, (size_t) nseg * osz, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(&w, W.p, 4, hipMemcpyDeviceToHost));
+	if (w) *warn = 1;
+	return 0;
+}
+
+// C_colStats_SVT, src/SparseArray_matrixStats.c:234-284
+extern "C" int svt_colStats_SVT(const svt_view *x, int opcode, int na_rm, double center,
+				int dims, void *out, int *warn)
+{
+	*warn = 0;
+	if (ensure_init() || check_view(x) || check_stat_op(opcode, x->Rtype))
+		return -1;
+	if (dims < 1 || dims > x->ndim)
+		return svt_set_error("'dims' must be >= 1 and <= %d", x->ndim);
+	if (device_op_supported(opcode))
+		return -1;
+	int64_t inner = 1, nout = 1;
+	for (int a = 1; a < dims; a++) inner *= x->dim[a];
+	for (int a = dims; a < x->ndim; a++) nout *= x->dim[a];
+	if (nout == 0)
+		return 0;
+	const int out_Rtype = svt_colStats_out_Rtype(opcode, x->Rtype);
+	CscGuard A(svt_upload(x));
+	if (A.h == NULL) return -1;
+	if (inner == 0) {
+		// zero-extent inner dims: every result summarizes an empty vector.
+		// One empty leaf per result gives exactly that.
+		std::vector<int64_t> cp((size_t) nout + 1, 0);
+		DevBuf P;
+		if (P.upload(cp.data(), cp.size() * 8)) return -1;
+		svt_dev_csc E = *A.h;
+		E.owned = 0; E.ncol = nout; E.nnz = 0; E.nrow = 0; E.col_ptr = P.as<int64_t>();
+		return run_colstats(&E, opcode, na_rm, center, 1, out, out_Rtype, warn);
+	}
+	return run_colstats(A.h, opcode, na_rm, center, inner, out, out_Rtype, warn);
+}
+
+// C_summarize_SVT, src/SparseArray_summarization.c:112-142
+extern "C" int svt_summarize_SVT(const svt_view *x, int opcode, int na_rm, double center,
+				 double *out_d, int *out_i, int *out_Rtype, int *warn)
+{
+	*warn = 0;
+	if (ensure_init() || check_view(x) || check_stat_op(opcode, x->Rtype))
+		return -1;
+	if (opcode == SVT_OP_SUM_X_X2 || opcode == SVT_OP_VAR2 || opcode == SVT_OP_SD2)
+		return device_op_supported(opcode);
+	const int rt = svt_colStats_out_Rtype(opcode, x->Rtype);
+	*out_Rtype = rt;
+	out_d[0] = out_d[1] = 0.0;
+	out_i[0] = out_i[1] = 0;
+	CscGuard A(svt_upload(x));
+	if (A.h == NULL) return -1;
+	svt_dev_csc V = *A.h;      // the whole array as one generalized column
+	V.owned = 0;
+	int64_t inner = V.ncol;
+	DevBuf P;
+	if (inner == 0) {          // some outer dim is 0: one empty segment
+		int64_t cp[2] = {0, 0};
+		if (P.upload(cp, sizeof(cp))) return -1;
+		V.ncol = 1; V.nrow = 0; V.nnz = 0; V.col_ptr = P.as<int64_t>();
+		inner = 1;
+	}
+	const int ops[2] = { opcode == SVT_OP_RANGE ? SVT_OP_MIN : opcode, SVT_OP_MAX };
+	const int nops = opcode == SVT_OP_RANGE ? 2 : 1;
+	for (int t = 0; t < nops; t++) {
+		double d = 0.0;
+		int i = 0;
+		void *dst = rt == SVT_REALSXP ? (void *) &d : (void *) &i;
+		if (run_colstats(&V, ops[t], na_rm, center, inner, dst, rt, warn))
+			return -1;
+		out_d[t] = d;
+		out_i[t] = i;
+	}
+	return 0;
+}
+
+// C_rowStats_SVT, src/SparseArray_matrixStats.c:1121-1205
+extern "C" int svt_rowStats_SVT(const svt_view *x, int opcode, int na_rm,
+				const double *center, int dims, void *out, int *warn)
+{
+	*warn = 0;
+	if (ensure_init() || check_view(x) || check_stat_op(opcode, x->Rtype))
+		return -1;
+	if (dims < 1 || dims > x->ndim - 1)
+		return svt_set_error("'dims' must be >= 1 and <= %d", x->ndim - 1);
+	if (opcode != SVT_OP_COUNTNAS && opcode != SVT_OP_ANYNA &&
+	    opcode != SVT_OP_MIN && opcode != SVT_OP_MAX &&
+	    opcode != SVT_OP_SUM && opcode != SVT_OP_CENTERED_X2_SUM)
+		return svt_set_error("SparseArray internal error in C_rowStats_SVT():\n"
+				     "    operation not supported");
+	const int out_Rtype = svt_colStats_out_Rtype(opcode, x->Rtype);
+	const size_t osz = out_Rtype == SVT_REALSXP ? 8 : 4;
+	int64_t inner = 1, nstrata = 1;
+	for (int a = 1; a < dims; a++) inner *= x->dim[a];
+	for (int a = dims; a < x->ndim; a++) nstrata *= x->dim[a];
+	const int64_t out_len = inner * x->dim[0];
+	if (out_len == 0)
+		return 0;
+	if ((opcode == SVT_OP_MIN || opcode == SVT_OP_MAX) && nstrata == 0) {
+		// constant fill, :970-982
+		for (int64_t i = 0; i < out_len; i++) {
+			if (out_Rtype == SVT_REALSXP)
+				((double *) out)[i] = opcode == SVT_OP_MIN ? INFINITY : -INFINITY;
+			else
+				((int *) out)[i] = NA_INT;
+		}
+		if (out_Rtype != SVT_REALSXP) *warn = 1;
+		return 0;
+	}
+	if (nstrata > 0xFFFFFFFFLL)
+		return svt_set_error("too many strata for the device coverage counters");
+	CscGuard A(svt_upload(x));
+	if (A.h == NULL) return -1;
+	DevBuf O, C, S, W;
+	if (O.alloc((size_t) out_len * osz) ||
+	    S.alloc(rowstats_scratch_bytes(opcode, out_Rtype, out_len)) ||
+	    W.alloc(16) || W.zero())
+		return -1;
+	if (center != NULL && C.upload(center, (size_t) out_len * 8))
+		return -1;
+	RowStatsArgs a;
+	a.col_ptr = A.h->col_ptr; a.row_idx = A.h->row_idx; a.val = A.h->val;
+	a.Rtype = A.h->Rtype; a.ncol = A.h->ncol; a.nrow = A.h->nrow;
+	a.inner = inner; a.nstrata = nstrata; a.out_len = out_len;
+	a.opcode = opcode; a.na_rm = na_rm;
+	a.center = center ? C.as<double>() : NULL;
+	a.out = O.p; a.scratch = S.p; a.warn_flag = W.as<int>();
+	if (launch_rowstats(a, A.h->nnz, 0))
+		return -1;
+	int w = 0;
+	HIP_TRY(hipMemcpy(out, O.p, (size_t) out_len * osz, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(&w, W.p, 4, hipMemcpyDeviceToHost));
+	if (w) *warn = 1;
+	return 0;
+}
+
+// ==================================================================================
+// Host level: rowsum / colsum
+// ==================================================================================
+static int check_group(const int *group, int n, int ngroup)   // rowsum_methods.c:15-37
+{
+	for (int i = 0; i < n; i++) {
+		const int g = group[i];
+		if (g == NA_INT) {
+			if (ngroup < 1)
+				return svt_set_error("'ngroup' must be >= 1 when 'group' "
+						     "contains missing values");
+		} else if (g < 1 || g > ngroup) {
+			return svt_set_error("all non-NA values in 'group' must "
+					     "be >= 1 and <= 'ngroup'");
+		}
+	}
+	return 0;
+}
+
+static int groupsum_host(const svt_dev_csc *A, const int32_t *col_ptr32,
+			 const int *group, int ngroup, int na_rm, bool colsum,
+			 void *out, int *ovflow)
+{
+	const int64_t glen = colsum ? A->ncol : A->nrow;
+	const int64_t out_len = colsum ? A->nrow * (int64_t) ngroup
+				       : (int64_t) ngroup * A->ncol;
+	if (out_len > 0x7FFFFFFFLL)   // safe_int_mult() guard, :296-301
+		return svt_set_error("too many groups (matrix of sums will be too big)");
+	const size_t osz = elt_size(A->Rtype);
+	if (out_len == 0)
+		return 0;
+	DevBuf G, O, S, W;
+	if (G.upload(group, (size_t) glen * 4) || O.alloc((size_t) out_len * osz) ||
+	    S.alloc(groupsum_scratch_bytes(A->Rtype, out_len)) || W.alloc(16) || W.zero())
+		return -1;
+	GroupSumArgs a;
+	memset(&a, 0, sizeof(a));
+	a.col_ptr64 = col_ptr32 ? NULL : A->col_ptr;
+	a.col_ptr32 = col_ptr32;
+	a.row_idx = A->row_idx; a.val = A->val; a.Rtype = A->Rtype;
+	a.nrow = A->nrow; a.ncol = A->ncol;
+	a.group = G.as<int>(); a.ngroup = ngroup; a.na_rm = na_rm;
+	a.out = O.p; a.scratch = S.p; a.ovflow_flag = W.as<int>();
+	int rc;
+	if (colsum)
+		rc = launch_colsum(a, 0);
+	else if (A->Rtype == SVT_REALSXP && ngroup <= 8192 && A->ncol > 0 &&
+		 A->nnz / A->ncol >= ngroup / 4)
+		rc = launch_rowsum_lds(a, 0);
+	else
+		rc = launch_rowsum(a, 0);
+	if (rc) return -1;
+	int w = 0;
+	HIP_TRY(hipMemcpy(out, O.p, (size_t) out_len * osz, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(&w, W.p, 4, hipMemcpyDeviceToHost));
+	if (ovflow && w) *ovflow = 1;
+	return 0;
+}
+
+static int xsum_SVT(const svt_view *x, const int *group, int ngroup, int na_rm,
+		    bool colsum, void *out, int *ovflow)
+{
+	*ovflow = 0;
+	if (ensure_init() || check_view(x))
+		return -1;
+	if (x->ndim != 2)
+		return svt_set_error("input object must have 2 dimensions");
+	if (x->Rtype != SVT_REALSXP && x->Rtype != SVT_INTSXP)
+		return svt_set_error("rowsum() and colsum() do not support "
+				     "SVT_SparseMatrix objects of this type at the moment");
+	if (check_group(group, colsum ? x->dim[1] : x->dim[0], ngroup))
+		return -1;
+	CscGuard A(svt_upload(x));
+	if (A.h == NULL) return -1;
+	return groupsum_host(A.h, NULL, group, ngroup, na_rm, colsum, out, ovflow);
+}
+
+// C_rowsum_SVT, src/rowsum_methods.c:281-325
+extern "C" int svt_rowsum_SVT(const svt_view *x, const int *group, int ngroup,
+			      int na_rm, void *out, int *ovflow)
+{
+	return xsum_SVT(x, group, ngroup, na_rm, false, out, ovflow);
+}
+
+// C_colsum_SVT, src/rowsum_methods.c:363-401
+extern "C" int svt_colsum_SVT(const svt_view *x, const int *group, int ngroup,
+			      int na_rm, void *out, int *ovflow)
+{
+	return xsum_SVT(x, group, ngroup, na_rm, true, out, ovflow);
+}
+
+static int xsum_dgC(int nrow, int ncol, const double *xx, const int *xi, const int *xp,
+		    const int *group, int ngroup, int na_rm, bool colsum, double *out)
+{
+	if (ensure_init() || check_group(group, colsum ? ncol : nrow, ngroup))
+		return -1;
+	const int64_t nnz = ncol > 0 ? xp[ncol] : 0;
+	DevBuf P, I, X;
+	if (P.upload(xp, (size_t) (ncol + 1) * 4) || I.upload(xi, (size_t) nnz * 4) ||
+	    X.upload(xx, (size_t) nnz * 8))
+		return -1;
+	svt_dev_csc A;
+	memset(&A, 0, sizeof(A));
+	A.Rtype = SVT_REALSXP; A.nrow = nrow; A.ncol = ncol; A.nnz = nnz;
+	A.row_idx = I.as<int32_t>(); A.val = X.p;
+	int ov = 0;
+	// the LDS path reads col_ptr64; keep the int32 'p' slot on the atomic path
+	const int64_t out_len = colsum ? (int64_t) nrow * ngroup : (int64_t) ngroup * ncol;
+	if (out_len > 0x7FFFFFFFLL)
+		return svt_set_error("too many groups (matrix of sums will be too big)");
+	if (out_len == 0)
+		return 0;
+	DevBuf G, O, S;
+	if (G.upload(group, (size_t) (colsum ? ncol : nrow) * 4) ||
+	    O.alloc((size_t) out_len * 8) || S.alloc(16))
+		return -1;
+	GroupSumArgs a;
+	memset(&a, 0, sizeof(a));
+	a.col_ptr32 = P.as<int32_t>();
+	a.row_idx = A.row_idx; a.val = A.val; a.Rtype = SVT_REALSXP;
+	a.nrow = nrow; a.ncol = ncol; a.group = G.as<int>(); a.ngroup = ngroup;
+	a.na_rm = na_rm; a.out = O.p; a.scratch = S.p;
+	if (colsum ? launch_colsum(a, 0) : launch_rowsum(a, 0))
+		return -1;
+	(void) ov;
+	HIP_TRY(hipMemcpy(out, O.p, (size_t) out_len * 8, hipMemcpyDeviceToHost));
+	return 0;
+}
+
+// C_rowsum_dgCMatrix / C_colsum_dgCMatrix, src/rowsum_methods.c:328-356, 404-439
+extern "C" int svt_rowsum_dgCMatrix(int nrow, int ncol, const double *xx, const int *xi,
+				    const int *xp, const int *group, int ngroup,
+				    int na_rm, double *out)
+{
+	return xsum_dgC(nrow, ncol, xx, xi, xp, group, ngroup, na_rm, false, out);
+}
+extern "C" int svt_colsum_dgCMatrix(int nrow, int ncol, const double *xx, const int *xi,
+				    const int *xp, const int *group, int ngroup,
+				    int na_rm, double *out)
+{
+	return xsum_dgC(nrow, ncol, xx, xi, xp, group, ngroup, na_rm, true, out);
+}

@@ -1,0 +1,47 @@
+"""The C-ABI library loads and exports every symbol include/svt_hip.h declares
+(no compute calls: runs without a GPU)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "svt_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(svt_[A-Za-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_export_list_agree():
+    from sparsearray_amd._hip import EXPORTS
+    assert sorted(EXPORTS) == _declared_symbols()
+
+
+def test_library_exports_every_declared_symbol():
+    from sparsearray_amd._hip import load_library
+    lib = load_library()
+    for sym in _declared_symbols():
+        assert hasattr(lib, sym), f"libsvt_hip.so does not export {sym}"
+
+
+def test_product_fails_loudly_without_gpu():
+    """On a box without an MI355X the product path must raise, not fall back."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import sparsearray_amd
+    from sparsearray_amd._hip import HipBackendError
+    with pytest.raises(HipBackendError, match="no HIP device|gfx950"):
+        sparsearray_amd.hip_session()
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "sparsearray_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                for needle in ("import oracle", "from oracle", "svt_oracle", "orc_"):
+                    assert needle not in src, f"{f} references the oracle ({needle})"

@@ -1,0 +1,165 @@
+"""HIP path vs the CPU oracle on the same seeded inputs, at sizes the oracle
+finishes in seconds (randomSparseArray()-style inputs plus special values)."""
+import numpy as np
+import pytest
+
+from helpers import assert_equal, assert_identical, random_csc
+from sparsearray_amd import NA_integer, NA_real, SVT_SparseArray
+
+pytestmark = pytest.mark.gpu
+
+
+def _svt(nrow, ncol, density, seed, dtype="double"):
+    cp, ri, v = random_csc(nrow, ncol, density, seed, dtype)
+    t = "double" if dtype == "double" else "integer"
+    return SVT_SparseArray.from_csc((nrow, ncol), t, cp, ri, v)
+
+
+def _sprinkle(x, seed, what):
+    """Plant special values into some leaves (copies the value arrays)."""
+    rng = np.random.default_rng(seed)
+    leaves = []
+    for lf in x.leaves:
+        if lf is None or rng.random() > 0.3:
+            leaves.append(lf)
+            continue
+        offs, vals = lf
+        vals = vals.copy()
+        vals[rng.integers(0, len(vals))] = what[rng.integers(0, len(what))]
+        leaves.append((offs, vals))
+    return SVT_SparseArray(x.dim, x.type, leaves)
+
+
+SPECIAL_D = [NA_real, np.nan, np.inf, -np.inf]
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+@pytest.mark.parametrize("K", [1, 7, 64, 130])
+def test_crossprod_svt_dense(hip, oracle, seed, K):
+    x = _svt(3000, 257, 0.01, seed)
+    y = np.random.default_rng(seed + 10).uniform(-1, 1, (3000, K))
+    assert_identical(hip.crossprod(x, y), oracle.crossprod(x, y))
+    assert_identical(hip.crossprod(y, x), oracle.crossprod(y, x))
+    yt = np.asfortranarray(y.T)
+    assert_identical(hip.tcrossprod(x.t(), yt), oracle.tcrossprod(x.t(), yt))
+
+
+@pytest.mark.parametrize("seed", [3, 4])
+def test_crossprod_special_values(hip, oracle, seed):
+    x = _sprinkle(_svt(500, 40, 0.05, seed), seed, SPECIAL_D)
+    rng = np.random.default_rng(seed)
+    y = rng.uniform(-1, 1, (500, 9))
+    y[rng.integers(0, 500, 6), rng.integers(0, 9, 6)] = [np.inf, -np.inf, np.nan, NA_real, np.inf, np.nan]
+    for a, b in ((x, y), (y, x)):
+        assert_equal(hip.crossprod(a, b), oracle.crossprod(a, b), tol=1e-12, strict_na=True)
+    assert_equal(hip.crossprod(x, x), oracle.crossprod(x, x), tol=1e-12, strict_na=True)
+    assert_equal(hip.crossprod(x), oracle.crossprod(x), tol=1e-12, strict_na=True)
+
+
+@pytest.mark.parametrize("seed", [5])
+def test_crossprod_int(hip, oracle, seed):
+    x = _svt(800, 33, 0.03, seed, "int")
+    xn = _sprinkle(x, seed, [NA_integer])
+    rng = np.random.default_rng(seed)
+    y = rng.integers(-9, 9, (800, 5)).astype(np.int32)
+    yn = y.copy()
+    yn[3, 2] = NA_integer
+    for a in (x, xn):
+        for b in (y, yn):
+            assert_identical(hip.crossprod(a, b), oracle.crossprod(a, b))
+            assert_identical(hip.crossprod(b, a), oracle.crossprod(b, a))
+        assert_identical(hip.crossprod(a), oracle.crossprod(a))
+        assert_identical(hip.crossprod(a, xn), oracle.crossprod(a, xn))
+
+
+@pytest.mark.parametrize("seed", [6, 7])
+def test_sparse_sparse_and_matmul(hip, oracle, seed):
+    a = _svt(2500, 40, 0.07, seed)
+    b = _svt(2500, 65, 0.2, seed + 1)
+    assert_identical(hip.crossprod(a, b), oracle.crossprod(a, b))
+    assert_identical(hip.crossprod(b, a), oracle.crossprod(b, a))
+    got, want = hip.crossprod(a), oracle.crossprod(a)
+    assert_identical(got, want)
+    assert np.array_equal(got, got.T)
+    c = _svt(40, 12, 0.3, seed + 2)
+    assert_identical(hip.matmul(a, c), oracle.matmul(a, c))
+
+
+OPS_COL = ["colSums", "colMeans", "colVars", "colSds", "colMins", "colMaxs",
+           "colProds", "colAnyNAs", "colCountNAs"]
+OPS_ROW = ["rowSums", "rowMeans", "rowVars", "rowSds", "rowMins", "rowMaxs",
+           "rowAnyNAs", "rowCountNAs"]
+
+
+@pytest.mark.parametrize("na_rm", [False, True])
+@pytest.mark.parametrize("shape,density", [((1000, 300), 0.01), ((20000, 12), 0.2),
+                                           ((60, 50, 8), 0.05)])
+def test_matrixstats_double(hip, oracle, shape, density, na_rm):
+    ncol = int(np.prod(shape[1:]))
+    x2 = _sprinkle(_svt(shape[0], ncol, density, 11), 11, SPECIAL_D[:2] + [3.5, -2.0])
+    x = SVT_SparseArray(shape, "double", x2.leaves)
+    for dims in range(1, len(shape)):
+        for op in OPS_COL + OPS_ROW:
+            kw = {} if "AnyNAs" in op or "CountNAs" in op else {"na_rm": na_rm}
+            got = getattr(hip, op)(x, dims=dims, **kw)
+            want = getattr(oracle, op)(x, dims=dims, **kw)
+            if got.dtype == np.int32:
+                assert_identical(got, want, op)
+            else:
+                assert_equal(got, want, tol=1e-6, what=f"{op} dims={dims}", strict_na="M" in op[3:4])
+
+
+@pytest.mark.parametrize("na_rm", [False, True])
+def test_matrixstats_int_exact(hip, oracle, na_rm):
+    x = _sprinkle(_svt(5000, 64, 0.05, 12, "int"), 12, [NA_integer, -7])
+    for op in ["colSums", "colMeans", "colMins", "colMaxs", "colAnys", "colAlls",
+               "rowSums", "rowMins", "rowMaxs", "rowAnys", "rowAlls", "colVars"]:
+        got = getattr(hip, op)(x, na_rm=na_rm)
+        want = getattr(oracle, op)(x, na_rm=na_rm)
+        if op == "colVars":
+            assert_equal(got, want, tol=1e-9, what=op, strict_na=True)
+        else:
+            assert_identical(got, want, op)   # integer work: bit-exact
+
+
+@pytest.mark.parametrize("ngroup", [3, 1000])
+@pytest.mark.parametrize("na_rm", [False, True])
+def test_rowsum_colsum(hip, oracle, ngroup, na_rm):
+    rng = np.random.default_rng(13)
+    x = _sprinkle(_svt(6000, 50, 0.05, 13), 13, SPECIAL_D)
+    grp = list(rng.integers(0, ngroup, 6000))
+    got, ug1 = hip.rowsum(x, grp, na_rm=na_rm)
+    want, ug2 = oracle.rowsum(x, grp, na_rm=na_rm)
+    assert ug1 == ug2
+    assert_equal(got, want, tol=1e-9)
+    xt = x.t()
+    got, _ = hip.colsum(xt, grp, na_rm=na_rm)
+    want, _ = oracle.colsum(xt, grp, na_rm=na_rm)
+    assert_equal(got, want, tol=1e-9)
+    xi = _sprinkle(_svt(6000, 50, 0.05, 14, "int"), 14, [NA_integer])
+    got, _ = hip.rowsum(xi, grp, na_rm=na_rm)
+    want, _ = oracle.rowsum(xi, grp, na_rm=na_rm)
+    assert_identical(got, want)
+    got, _ = hip.colsum(xi.t(), grp, na_rm=na_rm)
+    want, _ = oracle.colsum(xi.t(), grp, na_rm=na_rm)
+    assert_identical(got, want)
+
+
+def test_summarize(hip, oracle):
+    x = _svt(4000, 100, 0.02, 15)
+    for op in ["sum", "mean", "var", "sd", "min", "max", "range", "prod", "anyNA"]:
+        assert_equal(getattr(hip, op)(x), getattr(oracle, op)(x), tol=1e-6, what=op)
+    xi = _svt(4000, 100, 0.02, 16, "int")
+    for op in ["sum", "min", "max", "range", "any", "all", "anyNA"]:
+        assert_identical(getattr(hip, op)(xi), getattr(oracle, op)(xi), op)
+
+
+def test_error_behaviour(hip):
+    from sparsearray_amd import SparseArrayError
+    x = _svt(100, 10, 0.1, 17)
+    with pytest.raises(SparseArrayError, match="non-conformable"):
+        hip.crossprod(x, np.zeros((99, 3)))
+    with pytest.raises(SparseArrayError, match="does not support"):
+        hip.any(x)
+    with pytest.raises(SparseArrayError, match="group"):
+        hip.SparseArray_Call("C_rowsum_SVT", x, np.full(100, 7, np.int32), 3, False)
