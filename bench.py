@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline benchmark of BASELINE.json on MI355X.
+
+Workload (BASELINE.json configs[1], reading 2a of SURVEY.md section 8d):
+    A = SVT_SparseMatrix 1e6 x 1e4 @ 1% density (randomSparseArray()-style),
+    Y = dense double 1e6 x 128,  step = crossprod(A, Y) -> 1e4 x 128.
+One step = one pass of the hot path (stage Y + sparse x dense product) over
+operands already resident in HBM.  Metric: GNZ/s = nonzeros of A streamed per
+second (whole job, all ranks).
+
+    python bench.py --gpus N --steps K --warmup W
+N > 1 is launched by torch.distributed.run (one rank per GPU): A and Y are
+row-sharded (every rank owns a full-size row block, weak scaling) and the
+small ncol x K result is all-reduced over RCCL inside the timed step.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--nrow", type=int, default=1_000_000)
+    p.add_argument("--ncol", type=int, default=10_000)
+    p.add_argument("--density", type=float, default=0.01)
+    p.add_argument("--K", type=int, default=128)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-extras", action="store_true")
+    return p.parse_args()
+
+
+def cpu_baseline(col_ptr, row_idx, val, Y, nrow, K, nleaves_sample):
+    """The oracle (CPU restatement of the reference's C/OpenMP path) timed on
+    the host cores of this box, on the first `nleaves_sample` leaves of A
+    against all K dense columns."""
+    import ctypes
+    from oracle import load_oracle
+    from sparsearray_amd.svt import make_view_from_csc
+    lib = load_oracle()
+    ns = min(nleaves_sample, col_ptr.numel() - 1)
+    cp = col_ptr[: ns + 1].cpu().numpy()
+    nz = int(cp[-1])
+    ri = row_idx[:nz].cpu().numpy()
+    vv = val[:nz].cpu().numpy()
+    yh = np.ascontiguousarray(Y.cpu().numpy())          # (K, nrow) == col-major nrow x K
+    view = make_view_from_csc((nrow, ns), "double", cp, ri, vv)
+    out = np.zeros((K, ns), dtype=np.float64)
+    ncores = len(os.sched_getaffinity(0))
+    lib.orc_set_max_threads(ncores)
+    fn = lib.orc_crossprod2_SVT_mat
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                   ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    t0 = time.perf_counter()
+    rc = fn(ctypes.addressof(view), yh.ctypes.data, nrow, K, 14, 0, out.ctypes.data)
+    dt = time.perf_counter() - t0
+    assert rc == 0
+    return {"value": nz / dt / 1e9, "unit": "GNZ/s", "cores": ncores, "kind": "port",
+            "sample": f"first {ns} leaves of A ({nz} nnz) x all {K} dense columns, "
+                      f"oracle C/OpenMP path, {dt:.2f} s wall"}, out, ns
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from sparsearray_amd import synth
+    from sparsearray_amd.device import CrossprodPlan, DeviceCSC, colstats, rowsum, rowsums
+
+    nrow, ncol, K = a.nrow, a.ncol, a.K
+    # row-sharded global matrix: every rank owns an nrow x ncol block
+    col_ptr, row_idx, val = synth.random_device_csc(nrow, ncol, a.density, seed=1 + rank, device=dev)
+    Y = synth.random_dense(nrow, K, seed=101 + rank, device=dev)
+    A = DeviceCSC(nrow, col_ptr, row_idx, val)
+    nnz = A.nnz
+    plan = CrossprodPlan(A, K)
+    out = torch.zeros((K, ncol), dtype=torch.float64, device=dev)
+
+    def step(ev=None):
+        plan.prepare(Y, nrow)
+        if ev is not None:
+            ev[0].record()
+        plan.multiply(out, 1, ncol)
+        if ev is not None:
+            ev[1].record()
+        if world > 1:
+            dist.all_reduce(out)
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+           for _ in range(a.steps)]
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(evs[i])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tn = torch.tensor([nnz], dtype=torch.int64, device=dev)
+        dist.all_reduce(tn)
+        total_nnz = int(tn.item())
+    else:
+        total_nnz = nnz
+    kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs]))
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # roofline of the dominant kernel (the sparse x dense product), per launch
+    alg_bytes = nnz * 12 + 8 * (ncol + 1) + nrow * K * 8 + ncol * K * 8
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tfile):
+        try:
+            tj = json.load(open(tfile))
+            if tj.get("nnz") == nnz or tj.get("workload_nnz_nominal") == int(nrow * ncol * a.density):
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    res = {
+        "metric": "GNZ/s, SVT crossprod(svt, dense) 1e6x1e4 @1% nnz",
+        "value": total_nnz * a.steps / elapsed / 1e9,
+        "unit": "GNZ/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": elapsed / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"crossprod(A[{nrow}x{ncol} SVT @{a.density}], Y[{nrow}x{K} dense f64]) "
+                               f"-> {ncol}x{K}; BASELINE.json configs[1] (reading 2a)",
+                   "nnz_per_gpu": nnz, "parallelism": "rows sharded, all-reduce of out" if world > 1 else "1 GPU"},
+        "roofline": {"bound": "hbm", "kernel": "crossprod_gather_kernel<double>",
+                     "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                     "frac": achieved / 8000.0, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": alg_bytes,
+                     "kernel_ms": kern_ms},
+    }
+    if world == 1 and not a.no_extras:
+        def timed(fn, reps=5):
+            fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+        grp = torch.randint(1, 1001, (nrow,), device=dev, dtype=torch.int32)
+        ex = {}
+        for name, fn, nbytes in (
+            ("colSums", lambda: colstats(A, "sum"), nnz * 8 + ncol * 16),
+            ("colVars", lambda: colstats(A, "var1"), nnz * 8 + ncol * 16),
+            ("rowSums", lambda: rowsums(A), nnz * 12 + nrow * 8),
+            ("rowsum_1e3_groups", lambda: rowsum(A, grp, 1000), nnz * 12 + nrow * 4 + 1000 * ncol * 8),
+        ):
+            ms = timed(fn)
+            ex[name] = {"ms": ms, "GNZ/s": nnz / ms / 1e6, "GB/s": nbytes / ms / 1e6}
+        res["extras"] = ex
+    if world == 1 and not a.no_cpu_baseline:
+        ns = max(1, min(ncol, int(2e7 / max(nnz / ncol, 1))))
+        cb, ref_out, ns = cpu_baseline(col_ptr, row_idx, val, Y, nrow, K, ns)
+        # the timed GPU result must agree with the CPU oracle on the sample
+        got = out[:, :ns].cpu().numpy()
+        err = np.max(np.abs(got - ref_out) / np.maximum(np.abs(ref_out), 1e-12))
+        cb["max_rel_err_vs_gpu"] = float(err)
+        res["cpu_baseline"] = cb
+    print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

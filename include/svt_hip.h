@@ -191,6 +191,17 @@ void svt_release(svt_dev_csc *h);
  * Asynchronous on `stream` (a hipStream_t).
  */
 size_t svt_dev_crossprod_ws_bytes(int64_t nrow, int64_t ncol, int K);
+/* The two phases of svt_dev_crossprod_csc_dense(), callable separately so a
+   dense operand can be prepared once and multiplied several times (and so
+   that each phase can be timed): (1) stage Y into `ws` and evaluate the
+   reference's per-column prescan predicates (src/SparseMatrix_mult.c:23-36);
+   (2) the sparse x dense product proper, reading `ws`. */
+int svt_dev_dense_prepare(const void *Y, int64_t ldY, int64_t nrow, int K,
+			  int tr_y, int Rtype, void *ws, size_t ws_bytes,
+			  void *stream);
+int svt_dev_crossprod_prepared(const svt_dev_csc *A, const void *ws, int K,
+			       double *out, int64_t out_stride_c,
+			       int64_t out_stride_k, void *stream);
 int svt_dev_crossprod_csc_dense(const svt_dev_csc *A, const void *Y,
 				int64_t ldY, int K, int tr_y, double *out,
 				int64_t out_stride_c, int64_t out_stride_k,

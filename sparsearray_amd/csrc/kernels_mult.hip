@@ -158,31 +158,46 @@ crossprod_gather_kernel(const int64_t *__restrict__ col_ptr,
 	out[c * sc + (int64_t) k * sk] = res;
 }
 
-int launch_crossprod_csc_dense(const CrossprodArgs &a, hipStream_t s)
+static ColFlags flags_of(void *ws, int64_t nrow, int64_t Kp)
 {
-	if (a.ncol <= 0 || a.K <= 0)
+	ColFlags fl;
+	fl.nonfinite = (int *) ((double *) ws + (nrow > 0 ? nrow : 1) * Kp);
+	fl.has_na = fl.nonfinite + Kp;
+	return fl;
+}
+
+int launch_dense_prepare(const CrossprodArgs &a, hipStream_t s)
+{
+	if (a.K <= 0)
 		return 0;
 	const int64_t Kp = pad_k(a.K);
 	if (a.ws_bytes < crossprod_ws_bytes(a.nrow, a.ncol, a.K))
 		return svt_set_error("crossprod workspace too small");
 	double *Yt = (double *) a.ws;
-	const int64_t nrow1 = a.nrow > 0 ? a.nrow : 1;
-	ColFlags fl;
-	fl.nonfinite = (int *) (Yt + nrow1 * Kp);
-	fl.has_na = fl.nonfinite + Kp;
+	ColFlags fl = flags_of(a.ws, a.nrow, Kp);
 	HIP_TRY(hipMemsetAsync(fl.nonfinite, 0, (size_t) Kp * 8, s));
-	const bool is_dbl = a.Rtype == SVT_REALSXP;
 	if (a.nrow > 0) {
 		dim3 grid((unsigned) ((a.nrow + 63) / 64), (unsigned) (Kp / 64));
-		if (is_dbl)
+		if (a.Rtype == SVT_REALSXP)
 			hipLaunchKernelGGL(prep_dense_kernel<double>, grid, dim3(256), 0, s,
 					   (const double *) a.Y, a.ldY, a.nrow, a.K, a.tr_y, Yt, Kp, fl);
 		else
 			hipLaunchKernelGGL(prep_dense_kernel<int>, grid, dim3(256), 0, s,
 					   (const int *) a.Y, a.ldY, a.nrow, a.K, a.tr_y, Yt, Kp, fl);
 	}
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+int launch_crossprod_prepared(const CrossprodArgs &a, hipStream_t s)
+{
+	if (a.ncol <= 0 || a.K <= 0)
+		return 0;
+	const int64_t Kp = pad_k(a.K);
+	const double *Yt = (const double *) a.ws;
+	ColFlags fl = flags_of(a.ws, a.nrow, Kp);
 	dim3 grid((unsigned) ((a.ncol + 3) / 4), (unsigned) (Kp / KT));
-	if (is_dbl)
+	if (a.Rtype == SVT_REALSXP)
 		hipLaunchKernelGGL(crossprod_gather_kernel<double>, grid, dim3(256), 0, s,
 				   a.col_ptr, a.row_idx, (const double *) a.val, a.ncol,
 				   Yt, Kp, a.K, fl, a.out, a.out_stride_c, a.out_stride_k);
@@ -192,6 +207,15 @@ int launch_crossprod_csc_dense(const CrossprodArgs &a, hipStream_t s)
 				   Yt, Kp, a.K, fl, a.out, a.out_stride_c, a.out_stride_k);
 	HIP_TRY(hipGetLastError());
 	return 0;
+}
+
+int launch_crossprod_csc_dense(const CrossprodArgs &a, hipStream_t s)
+{
+	if (a.ncol <= 0 || a.K <= 0)
+		return 0;
+	if (launch_dense_prepare(a, s))
+		return -1;
+	return launch_crossprod_prepared(a, s);
 }
 
 // ---- "preprocessing": leaves -> dense columns (src/SparseVec.c:9-47) ------------

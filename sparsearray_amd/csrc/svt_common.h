@@ -183,6 +183,8 @@ struct CrossprodArgs {
 	size_t ws_bytes;
 };
 size_t crossprod_ws_bytes(int64_t nrow, int64_t ncol, int K);
+int launch_dense_prepare(const CrossprodArgs &a, hipStream_t s);
+int launch_crossprod_prepared(const CrossprodArgs &a, hipStream_t s);
 int launch_crossprod_csc_dense(const CrossprodArgs &a, hipStream_t s);
 // Scatter leaves [c0, c0+nc) of a CSC into a dense column-major nrow x nc
 // matrix (the "preprocessing" of src/SparseMatrix_mult.c:632-724).

@@ -242,6 +242,32 @@ extern "C" int svt_dev_crossprod_csc_dense(const svt_dev_csc *A, const void *Y,
 	return launch_crossprod_csc_dense(a, (hipStream_t) stream);
 }
 
+extern "C" int svt_dev_dense_prepare(const void *Y, int64_t ldY, int64_t nrow, int K,
+				     int tr_y, int Rtype, void *ws, size_t ws_bytes,
+				     void *stream)
+{
+	CrossprodArgs a;
+	memset(&a, 0, sizeof(a));
+	a.Rtype = Rtype == SVT_REALSXP ? SVT_REALSXP : SVT_INTSXP;
+	a.nrow = nrow; a.Y = Y; a.ldY = ldY; a.K = K; a.tr_y = tr_y;
+	a.ws = ws; a.ws_bytes = ws_bytes;
+	return launch_dense_prepare(a, (hipStream_t) stream);
+}
+
+extern "C" int svt_dev_crossprod_prepared(const svt_dev_csc *A, const void *ws, int K,
+					  double *out, int64_t out_stride_c,
+					  int64_t out_stride_k, void *stream)
+{
+	CrossprodArgs a;
+	memset(&a, 0, sizeof(a));
+	a.col_ptr = A->col_ptr; a.row_idx = A->row_idx; a.val = A->val;
+	a.Rtype = A->Rtype == SVT_REALSXP ? SVT_REALSXP : SVT_INTSXP;
+	a.nrow = A->nrow; a.ncol = A->ncol; a.K = K;
+	a.out = out; a.out_stride_c = out_stride_c; a.out_stride_k = out_stride_k;
+	a.ws = (void *) ws;
+	return launch_crossprod_prepared(a, (hipStream_t) stream);
+}
+
 static int check_stat_op(int opcode, int Rtype)
 {
 	// _get_summarize_opcode(), src/Rvector_summarization.c:19-78

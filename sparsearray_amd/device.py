@@ -1,0 +1,156 @@
+"""Device-resident operands (HBM) and the device-level entry points.
+
+torch is used here as plumbing only: it owns the device allocations and the
+HIP stream the kernels are launched on.  Every computation is a call into
+libsvt_hip.so (include/svt_hip.h, "device level").
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import c_double, c_int, c_int64, c_size_t, c_void_p
+
+import numpy as np
+import torch
+
+from . import _hip
+from .api import OPCODES, SparseArrayError
+from .svt import INTSXP, LGLSXP, REALSXP
+
+_protos_done = False
+
+
+def _lib():
+    global _protos_done
+    lib = _hip.init()
+    if not _protos_done:
+        lib.svt_wrap_device_csc.restype = c_void_p
+        lib.svt_wrap_device_csc.argtypes = [c_int, c_int64, c_int64, c_int64,
+                                            c_void_p, c_void_p, c_void_p]
+        lib.svt_release.argtypes = [c_void_p]
+        lib.svt_release.restype = None
+        lib.svt_dev_crossprod_ws_bytes.restype = c_size_t
+        lib.svt_dev_crossprod_ws_bytes.argtypes = [c_int64, c_int64, c_int]
+        lib.svt_dev_dense_prepare.argtypes = [c_void_p, c_int64, c_int64, c_int, c_int,
+                                              c_int, c_void_p, c_size_t, c_void_p]
+        lib.svt_dev_crossprod_prepared.argtypes = [c_void_p, c_void_p, c_int, c_void_p,
+                                                   c_int64, c_int64, c_void_p]
+        lib.svt_dev_crossprod_csc_dense.argtypes = [c_void_p, c_void_p, c_int64, c_int,
+                                                    c_int, c_void_p, c_int64, c_int64,
+                                                    c_void_p, c_size_t, c_void_p]
+        lib.svt_dev_colstats.argtypes = [c_void_p, c_int, c_int, c_double, c_int64,
+                                         c_void_p, c_void_p, c_void_p]
+        lib.svt_dev_rowsums.argtypes = [c_void_p, c_int, c_int64, c_void_p, c_void_p]
+        lib.svt_dev_rowsum.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]
+        lib.svt_colStats_out_Rtype.argtypes = [c_int, c_int]
+        _protos_done = True
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise SparseArrayError(_lib().svt_last_error().decode())
+
+
+def _stream() -> c_void_p:
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class DeviceCSC:
+    """An SVT in its device layout: col_ptr int64[ncol+1], row_idx int32[nnz],
+    val f64|i32[nnz] (struct svt_dev_csc).  ``ncol`` counts leaves."""
+
+    def __init__(self, nrow: int, col_ptr: torch.Tensor, row_idx: torch.Tensor,
+                 val: torch.Tensor, logical: bool = False):
+        assert col_ptr.dtype == torch.int64 and row_idx.dtype == torch.int32
+        assert val.dtype in (torch.float64, torch.int32)
+        assert col_ptr.is_cuda and row_idx.is_cuda and val.is_cuda
+        self.nrow = int(nrow)
+        self.ncol = int(col_ptr.numel() - 1)
+        self.nnz = int(row_idx.numel())
+        self.col_ptr, self.row_idx, self.val = col_ptr.contiguous(), row_idx.contiguous(), val.contiguous()
+        self.Rtype = REALSXP if val.dtype == torch.float64 else (LGLSXP if logical else INTSXP)
+        self._h = _lib().svt_wrap_device_csc(self.Rtype, self.nrow, self.ncol, self.nnz,
+                                             self.col_ptr.data_ptr(), self.row_idx.data_ptr(),
+                                             self.val.data_ptr())
+
+    @classmethod
+    def from_host(cls, nrow, col_ptr, row_idx, val, device="cuda"):
+        return cls(nrow, torch.as_tensor(np.asarray(col_ptr, np.int64), device=device),
+                   torch.as_tensor(np.asarray(row_idx, np.int32), device=device),
+                   torch.as_tensor(np.asarray(val), device=device))
+
+    @property
+    def handle(self):
+        return c_void_p(self._h)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _lib().svt_release(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class CrossprodPlan:
+    """Reusable workspace for crossprod(A, Y) with K dense columns."""
+
+    def __init__(self, A: DeviceCSC, K: int):
+        self.A, self.K = A, int(K)
+        n = _lib().svt_dev_crossprod_ws_bytes(A.nrow, A.ncol, self.K)
+        self.ws = torch.empty(n, dtype=torch.uint8, device=A.val.device)
+
+    def prepare(self, Y: torch.Tensor, ldY: int, tr_y: bool = False):
+        """Y: device buffer holding the dense operand in R (column-major) layout."""
+        _check(_lib().svt_dev_dense_prepare(Y.data_ptr(), ldY, self.A.nrow, self.K,
+                                            int(tr_y), self.A.Rtype, self.ws.data_ptr(),
+                                            self.ws.numel(), _stream()))
+
+    def multiply(self, out: torch.Tensor, stride_c: int, stride_k: int):
+        _check(_lib().svt_dev_crossprod_prepared(self.A.handle, self.ws.data_ptr(), self.K,
+                                                 out.data_ptr(), stride_c, stride_k, _stream()))
+
+    def run(self, Y, ldY, out, stride_c=1, stride_k=None, tr_y=False):
+        if stride_k is None:
+            stride_k = self.A.ncol
+        self.prepare(Y, ldY, tr_y)
+        self.multiply(out, stride_c, stride_k)
+
+
+def crossprod_csc_dense(A: DeviceCSC, Y: torch.Tensor) -> torch.Tensor:
+    """crossprod(A, Y) for a dense Y given as a (K, nrow) C-contiguous tensor,
+    i.e. the column-major nrow x K matrix R would hand over.  Returns the
+    (K, ncol) C-contiguous tensor that is the column-major ncol x K result."""
+    K, nrow = Y.shape
+    assert nrow == A.nrow and Y.is_contiguous()
+    out = torch.zeros((K, A.ncol), dtype=torch.float64, device=Y.device)
+    CrossprodPlan(A, K).run(Y, nrow, out)
+    return out
+
+
+def colstats(A: DeviceCSC, op: str, na_rm=False, center=float("nan"), inner=1):
+    oc = OPCODES[op]
+    rt = _lib().svt_colStats_out_Rtype(oc, A.Rtype)
+    nseg = A.ncol // inner
+    out = torch.empty(nseg, dtype=torch.float64 if rt == REALSXP else torch.int32,
+                      device=A.val.device)
+    warn = torch.zeros(4, dtype=torch.int32, device=A.val.device)
+    _check(_lib().svt_dev_colstats(A.handle, oc, int(na_rm), float(center), inner,
+                                   out.data_ptr(), warn.data_ptr(), _stream()))
+    return out, warn
+
+
+def rowsums(A: DeviceCSC, na_rm=False, inner=1, out=None):
+    if out is None:
+        out = torch.empty(inner * A.nrow, dtype=torch.float64, device=A.val.device)
+    _check(_lib().svt_dev_rowsums(A.handle, int(na_rm), inner, out.data_ptr(), _stream()))
+    return out
+
+
+def rowsum(A: DeviceCSC, group: torch.Tensor, ngroup: int, na_rm=False, out=None):
+    assert group.dtype == torch.int32 and group.numel() == A.nrow
+    if out is None:
+        out = torch.empty((A.ncol, ngroup), dtype=torch.float64, device=A.val.device)
+    _check(_lib().svt_dev_rowsum(A.handle, group.data_ptr(), int(ngroup), int(na_rm),
+                                 out.data_ptr(), _stream()))
+    return out

@@ -106,7 +106,8 @@ def test_matrixstats_double(hip, oracle, shape, density, na_rm):
             if got.dtype == np.int32:
                 assert_identical(got, want, op)
             else:
-                assert_equal(got, want, tol=1e-6, what=f"{op} dims={dims}", strict_na="M" in op[3:4])
+                assert_equal(got, want, tol=1e-6, what=f"{op} dims={dims}",
+                             strict_na="M" in op[3:4], atol=1e-9)
 
 
 @pytest.mark.parametrize("na_rm", [False, True])
@@ -131,11 +132,11 @@ def test_rowsum_colsum(hip, oracle, ngroup, na_rm):
     got, ug1 = hip.rowsum(x, grp, na_rm=na_rm)
     want, ug2 = oracle.rowsum(x, grp, na_rm=na_rm)
     assert ug1 == ug2
-    assert_equal(got, want, tol=1e-9)
+    assert_equal(got, want, tol=1e-9, atol=1e-10)
     xt = x.t()
     got, _ = hip.colsum(xt, grp, na_rm=na_rm)
     want, _ = oracle.colsum(xt, grp, na_rm=na_rm)
-    assert_equal(got, want, tol=1e-9)
+    assert_equal(got, want, tol=1e-9, atol=1e-10)
     xi = _sprinkle(_svt(6000, 50, 0.05, 14, "int"), 14, [NA_integer])
     got, _ = hip.rowsum(xi, grp, na_rm=na_rm)
     want, _ = oracle.rowsum(xi, grp, na_rm=na_rm)
@@ -148,7 +149,7 @@ def test_rowsum_colsum(hip, oracle, ngroup, na_rm):
 def test_summarize(hip, oracle):
     x = _svt(4000, 100, 0.02, 15)
     for op in ["sum", "mean", "var", "sd", "min", "max", "range", "prod", "anyNA"]:
-        assert_equal(getattr(hip, op)(x), getattr(oracle, op)(x), tol=1e-6, what=op)
+        assert_equal(getattr(hip, op)(x), getattr(oracle, op)(x), tol=1e-6, what=op, atol=1e-9)
     xi = _svt(4000, 100, 0.02, 16, "int")
     for op in ["sum", "min", "max", "range", "any", "all", "anyNA"]:
         assert_identical(getattr(hip, op)(xi), getattr(oracle, op)(xi), op)
