@@ -42,6 +42,19 @@ def parse():
     return p.parse_args()
 
 
+def host_cores() -> int:
+    """CPU cores this process may really use: the cgroup quota when there is
+    one (a GPU box hands each job a share of a big host), else the affinity."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return min(n, int(os.environ.get("SVT_BENCH_CPU_THREADS", "16")))
+
+
 def cpu_baseline(col_ptr, row_idx, val, Y, nrow, K, nleaves_sample):
     """The oracle (CPU restatement of the reference's C/OpenMP path) timed on
     the host cores of this box, on the first `nleaves_sample` leaves of A
@@ -58,7 +71,7 @@ def cpu_baseline(col_ptr, row_idx, val, Y, nrow, K, nleaves_sample):
     yh = np.ascontiguousarray(Y.cpu().numpy())          # (K, nrow) == col-major nrow x K
     view = make_view_from_csc((nrow, ns), "double", cp, ri, vv)
     out = np.zeros((K, ns), dtype=np.float64)
-    ncores = len(os.sched_getaffinity(0))
+    ncores = host_cores()
     lib.orc_set_max_threads(ncores)
     fn = lib.orc_crossprod2_SVT_mat
     fn.restype = ctypes.c_int
