@@ -1,6 +1,6 @@
 #!/bin/bash
 # Profiling recipe for the headline step (run on the GPU box from the repo root):
-#   bash tools_profile.sh <tag>
+#   bash tools/profile.sh <tag>
 # Writes rocprofv3 kernel-trace stats and (separate passes) the FETCH_SIZE /
 # WRITE_SIZE counters under gpurun_out/prof_<tag>/.
 set -u
