@@ -1,0 +1,83 @@
+"""World-size-2 tests of the multi-GPU sharding logic on CPU (gloo).  The local
+compute is the CPU oracle here; on the GPU box bench.py plugs the HIP path into
+the same functions."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from helpers import random_csc
+        from oracle import oracle_session
+        from sparsearray_amd import SVT_SparseArray
+        from sparsearray_amd import parallel as par
+        S = oracle_session()
+        nrow, ncol, K = 5000, 37, 9
+        cp, ri, v = random_csc(nrow, ncol, 0.02, seed=5)
+        Y = np.random.default_rng(6).uniform(-1, 1, (nrow, K))
+        full = SVT_SparseArray.from_csc((nrow, ncol), "double", cp, ri, v)
+
+        # crossprod: rows sharded, partials all-reduced
+        r0, r1 = par.row_block(nrow, rank, world)
+        scp, sri, sv = par.row_shard_csc(cp, ri, v, r0, r1)
+        shard = SVT_SparseArray.from_csc((r1 - r0, ncol), "double", scp, sri, sv)
+        got = par.sharded_crossprod(
+            lambda: torch.from_numpy(np.ascontiguousarray(S.crossprod(shard, Y[r0:r1]))))
+        want = S.crossprod(full, Y)
+        ok1 = np.allclose(got.numpy(), want, rtol=1e-12, atol=1e-12)
+
+        # colSums: leaves sharded by nnz, scalars gathered
+        blocks = par.col_blocks_by_nnz(cp, world)
+        c0, c1 = blocks[rank]
+        sub = SVT_SparseArray((nrow, c1 - c0), "double", full.leaves[c0:c1])
+        loc = torch.from_numpy(np.asarray(S.colSums(sub), dtype=np.float64))
+        allc = par.gather_columns(loc, [b[1] - b[0] for b in blocks])
+        ok2 = np.array_equal(allc.numpy(), S.colSums(full))
+        # torch-tensor flavour of the row filter agrees with the numpy one
+        tcp, tri, tv = par.row_shard_csc(torch.from_numpy(cp), torch.from_numpy(ri),
+                                         torch.from_numpy(v), r0, r1)
+        ok3 = np.array_equal(tcp.numpy(), scp) and np.array_equal(tri.numpy(), sri) \
+            and np.array_equal(tv.numpy(), sv)
+        q.put((rank, ok1, ok2, ok3))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_row_sharded_crossprod_and_column_sharded_colsums_gloo():
+    world = 2
+    port = 29500 + os.getpid() % 2000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok1, ok2, ok3 in res:
+        assert ok1, f"rank {rank}: sharded crossprod differs"
+        assert ok2, f"rank {rank}: sharded colSums differs"
+        assert ok3, f"rank {rank}: torch/numpy row filter differ"
+
+
+def test_row_blocks_cover():
+    sys.path.insert(0, ROOT)
+    from sparsearray_amd.parallel import row_block
+    for n, w in ((10, 3), (7, 8), (1_000_000, 8)):
+        blocks = [row_block(n, r, w) for r in range(w)]
+        assert blocks[0][0] == 0 and blocks[-1][1] == n
+        assert all(blocks[i][1] == blocks[i + 1][0] for i in range(w - 1))
