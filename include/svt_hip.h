@@ -207,6 +207,29 @@ int svt_dev_crossprod_csc_dense(const svt_dev_csc *A, const void *Y,
 				int64_t out_stride_c, int64_t out_stride_k,
 				void *ws, size_t ws_bytes, void *stream);
 
+/*
+ * Fast path of crossprod(A, Y) for f64 operands: a panel-blocked copy of A
+ * ("PBC", see sparsearray_amd/csrc/kernels_mult_pbc.hip) built once per
+ * sparse operand -- the device analogue of the reference's per-call leaf
+ * "preprocessing" (src/SparseMatrix_mult.c:632-724) -- and a kernel that keeps
+ * row panels of Y in LDS and per-column partial sums in registers.
+ *   CBW   columns per wavefront (16, 32, 48 or 64), WPB wavefronts per
+ *         workgroup, logR = log2(rows per panel).
+ * svt_dev_pbc_build() allocates and synchronises (not for the launch path).
+ * svt_dev_crossprod_pbc() has the semantics and the out-indexing of
+ * svt_dev_crossprod_csc_dense() (A is needed for the general path that
+ * takes over when Y holds NaN/Inf/NA); Y is f64.
+ */
+typedef struct svt_dev_pbc svt_dev_pbc;
+svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB, int logR);
+void svt_dev_pbc_release(svt_dev_pbc *P);
+size_t svt_dev_crossprod_pbc_ws_bytes(const svt_dev_pbc *P, int K);
+int svt_dev_crossprod_pbc(const svt_dev_pbc *P, const svt_dev_csc *A,
+			  const double *Y, int64_t ldY, int K, int tr_y,
+			  double *out, int64_t out_stride_c,
+			  int64_t out_stride_k, void *ws, size_t ws_bytes,
+			  void *stream);
+
 /* col stats over segments of `inner` consecutive leaves each
    (dims > 1 => inner = prod(dim[1..dims-1])); out has ncol/inner elements of
    svt_colStats_out_Rtype().  warn_flag: device int, set to 1 on the

@@ -56,9 +56,12 @@ size_t crossprod_ws_bytes(int64_t nrow, int64_t ncol, int K)
 template <typename T>
 __global__ void __launch_bounds__(256)
 prep_dense_kernel(const T *__restrict__ Y, int64_t ldY, int64_t nrow, int K,
-		  int tr_y, double *__restrict__ Yt, int64_t Kp, ColFlags fl)
+		  int tr_y, double *__restrict__ Yt, int64_t Kp, ColFlags fl,
+		  const int *__restrict__ run_flag)
 {
 	__shared__ double tile[64][65];
+	if (run_flag != NULL && *run_flag == 0)
+		return;   // fast path already produced the result
 	const int64_t r0 = (int64_t) blockIdx.x * 64;
 	const int k0 = blockIdx.y * 64;
 	const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
@@ -113,8 +116,10 @@ crossprod_gather_kernel(const int64_t *__restrict__ col_ptr,
 			const T *__restrict__ val, int64_t ncol,
 			const double *__restrict__ Yt, int64_t Kp, int K,
 			ColFlags fl, double *__restrict__ out,
-			int64_t sc, int64_t sk)
+			int64_t sc, int64_t sk, const int *__restrict__ run_flag)
 {
+	if (run_flag != NULL && *run_flag == 0)
+		return;
 	const int lane = threadIdx.x & 63;
 	const int64_t c = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
 	if (c >= ncol)
@@ -166,7 +171,23 @@ static ColFlags flags_of(void *ws, int64_t nrow, int64_t Kp)
 	return fl;
 }
 
-int launch_dense_prepare(const CrossprodArgs &a, hipStream_t s)
+static int dense_prepare(const CrossprodArgs &a, const int *run_flag, hipStream_t s);
+static int crossprod_prepared(const CrossprodArgs &a, const int *run_flag, hipStream_t s);
+
+int launch_dense_prepare(const CrossprodArgs &a, hipStream_t s) { return dense_prepare(a, NULL, s); }
+int launch_crossprod_prepared(const CrossprodArgs &a, hipStream_t s) { return crossprod_prepared(a, NULL, s); }
+
+// Both phases, skipped on the device when *flag == 0 (see kernels_mult_pbc.hip).
+int launch_crossprod_general_if(const CrossprodArgs &a, const int *flag, hipStream_t s)
+{
+	if (a.ncol <= 0 || a.K <= 0)
+		return 0;
+	if (dense_prepare(a, flag, s))
+		return -1;
+	return crossprod_prepared(a, flag, s);
+}
+
+static int dense_prepare(const CrossprodArgs &a, const int *run_flag, hipStream_t s)
 {
 	if (a.K <= 0)
 		return 0;
@@ -180,16 +201,16 @@ int launch_dense_prepare(const CrossprodArgs &a, hipStream_t s)
 		dim3 grid((unsigned) ((a.nrow + 63) / 64), (unsigned) (Kp / 64));
 		if (a.Rtype == SVT_REALSXP)
 			hipLaunchKernelGGL(prep_dense_kernel<double>, grid, dim3(256), 0, s,
-					   (const double *) a.Y, a.ldY, a.nrow, a.K, a.tr_y, Yt, Kp, fl);
+					   (const double *) a.Y, a.ldY, a.nrow, a.K, a.tr_y, Yt, Kp, fl, run_flag);
 		else
 			hipLaunchKernelGGL(prep_dense_kernel<int>, grid, dim3(256), 0, s,
-					   (const int *) a.Y, a.ldY, a.nrow, a.K, a.tr_y, Yt, Kp, fl);
+					   (const int *) a.Y, a.ldY, a.nrow, a.K, a.tr_y, Yt, Kp, fl, run_flag);
 	}
 	HIP_TRY(hipGetLastError());
 	return 0;
 }
 
-int launch_crossprod_prepared(const CrossprodArgs &a, hipStream_t s)
+static int crossprod_prepared(const CrossprodArgs &a, const int *run_flag, hipStream_t s)
 {
 	if (a.ncol <= 0 || a.K <= 0)
 		return 0;
@@ -200,11 +221,11 @@ int launch_crossprod_prepared(const CrossprodArgs &a, hipStream_t s)
 	if (a.Rtype == SVT_REALSXP)
 		hipLaunchKernelGGL(crossprod_gather_kernel<double>, grid, dim3(256), 0, s,
 				   a.col_ptr, a.row_idx, (const double *) a.val, a.ncol,
-				   Yt, Kp, a.K, fl, a.out, a.out_stride_c, a.out_stride_k);
+				   Yt, Kp, a.K, fl, a.out, a.out_stride_c, a.out_stride_k, run_flag);
 	else
 		hipLaunchKernelGGL(crossprod_gather_kernel<int>, grid, dim3(256), 0, s,
 				   a.col_ptr, a.row_idx, (const int *) a.val, a.ncol,
-				   Yt, Kp, a.K, fl, a.out, a.out_stride_c, a.out_stride_k);
+				   Yt, Kp, a.K, fl, a.out, a.out_stride_c, a.out_stride_k, run_flag);
 	HIP_TRY(hipGetLastError());
 	return 0;
 }

@@ -37,6 +37,15 @@ def _lib():
         lib.svt_dev_crossprod_csc_dense.argtypes = [c_void_p, c_void_p, c_int64, c_int,
                                                     c_int, c_void_p, c_int64, c_int64,
                                                     c_void_p, c_size_t, c_void_p]
+        lib.svt_dev_pbc_build.restype = c_void_p
+        lib.svt_dev_pbc_build.argtypes = [c_void_p, c_int, c_int, c_int]
+        lib.svt_dev_pbc_release.argtypes = [c_void_p]
+        lib.svt_dev_pbc_release.restype = None
+        lib.svt_dev_crossprod_pbc_ws_bytes.restype = c_size_t
+        lib.svt_dev_crossprod_pbc_ws_bytes.argtypes = [c_void_p, c_int]
+        lib.svt_dev_crossprod_pbc.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int,
+                                              c_int, c_void_p, c_int64, c_int64, c_void_p,
+                                              c_size_t, c_void_p]
         lib.svt_dev_colstats.argtypes = [c_void_p, c_int, c_int, c_double, c_int64,
                                          c_void_p, c_void_p, c_void_p]
         lib.svt_dev_rowsums.argtypes = [c_void_p, c_int, c_int64, c_void_p, c_void_p]
@@ -115,6 +124,35 @@ class CrossprodPlan:
             stride_k = self.A.ncol
         self.prepare(Y, ldY, tr_y)
         self.multiply(out, stride_c, stride_k)
+
+
+class PbcPlan:
+    """Fast path of crossprod(A, Y) for f64: panel-blocked copy of A (built
+    once, here) + workspace for K dense columns."""
+
+    def __init__(self, A: DeviceCSC, K: int, CBW: int = 32, WPB: int = 16, logR: int = 8):
+        assert A.Rtype == REALSXP
+        self.A, self.K = A, int(K)
+        self._p = _lib().svt_dev_pbc_build(A.handle, CBW, WPB, logR)
+        if not self._p:
+            raise SparseArrayError(_lib().svt_last_error().decode())
+        n = _lib().svt_dev_crossprod_pbc_ws_bytes(self._p, self.K)
+        self.ws = torch.empty(n, dtype=torch.uint8, device=A.val.device)
+
+    def run(self, Y, ldY, out, stride_c=1, stride_k=None, tr_y=False):
+        if stride_k is None:
+            stride_k = self.A.ncol
+        _check(_lib().svt_dev_crossprod_pbc(self._p, self.A.handle, Y.data_ptr(), ldY, self.K,
+                                            int(tr_y), out.data_ptr(), stride_c, stride_k,
+                                            self.ws.data_ptr(), self.ws.numel(), _stream()))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_p", None):
+                _lib().svt_dev_pbc_release(self._p)
+                self._p = None
+        except Exception:
+            pass
 
 
 def crossprod_csc_dense(A: DeviceCSC, Y: torch.Tensor) -> torch.Tensor:

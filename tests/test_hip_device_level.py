@@ -1,0 +1,81 @@
+"""Device-level entry points (operands resident in HBM, torch owns the memory):
+the panel-blocked crossprod fast path and the stats kernels against the CPU
+oracle."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_equal, random_csc
+from sparsearray_amd import NA_real, SVT_SparseArray
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(cp, ri, v, nrow):
+    from sparsearray_amd.device import DeviceCSC
+    return DeviceCSC.from_host(nrow, cp, ri, v)
+
+
+@pytest.mark.parametrize("cfg", [(32, 16, 8), (16, 16, 7), (48, 16, 6), (64, 8, 8), (64, 4, 5)])
+@pytest.mark.parametrize("shape", [(5000, 300, 70), (70000, 1100, 128), (300, 17, 5)])
+def test_pbc_crossprod_matches_oracle(hip, oracle, cfg, shape):
+    from sparsearray_amd.device import PbcPlan
+    nrow, ncol, K = shape
+    CBW, WPB, logR = cfg
+    cp, ri, v = random_csc(nrow, ncol, 0.01 if nrow > 1000 else 0.2, seed=21)
+    x = SVT_SparseArray.from_csc((nrow, ncol), "double", cp, ri, v)
+    y = np.random.default_rng(22).uniform(-1, 1, (nrow, K))
+    want = oracle.crossprod(x, y)
+    A = _dev(cp, ri, v, nrow)
+    Yd = torch.as_tensor(np.ascontiguousarray(y.T), device="cuda")      # (K, nrow) == col-major
+    out = torch.zeros((K, ncol), dtype=torch.float64, device="cuda")
+    plan = PbcPlan(A, K, CBW, WPB, logR)
+    plan.run(Yd, nrow, out)
+    torch.cuda.synchronize()
+    assert_equal(out.cpu().numpy().T, want, tol=1e-9, atol=1e-11, what="pbc crossprod")
+    # mat_SVT orientation: out[k, c] with strides (K, 1) and transposed dense operand
+    out2 = torch.zeros((ncol, K), dtype=torch.float64, device="cuda")
+    Yr = torch.as_tensor(np.ascontiguousarray(y), device="cuda")        # (nrow, K): K x nrow col-major
+    plan.run(Yr, K, out2, stride_c=K, stride_k=1, tr_y=True)
+    torch.cuda.synchronize()
+    assert_equal(out2.cpu().numpy(), want, tol=1e-9, atol=1e-11, what="pbc crossprod tr")
+
+
+def test_pbc_special_values_take_general_path(hip, oracle):
+    from sparsearray_amd.device import PbcPlan
+    nrow, ncol, K = 4000, 150, 20
+    cp, ri, v = random_csc(nrow, ncol, 0.02, seed=23)
+    v = v.copy()
+    v[5] = NA_real
+    v[100] = np.inf
+    x = SVT_SparseArray.from_csc((nrow, ncol), "double", cp, ri, v)
+    A = _dev(cp, ri, v, nrow)
+    plan = PbcPlan(A, K)
+    rng = np.random.default_rng(24)
+    for poison in ([], [np.nan], [np.inf, NA_real]):
+        y = rng.uniform(-1, 1, (nrow, K))
+        for t, val in enumerate(poison):
+            y[17 + 31 * t, 3 + t] = val
+        want = oracle.crossprod(x, y)
+        Yd = torch.as_tensor(np.ascontiguousarray(y.T), device="cuda")
+        out = torch.zeros((K, ncol), dtype=torch.float64, device="cuda")
+        plan.run(Yd, nrow, out)
+        torch.cuda.synchronize()
+        assert_equal(out.cpu().numpy().T, want, tol=1e-9, atol=1e-11, strict_na=True,
+                     what=f"poison={poison}")
+
+
+def test_device_stats(hip, oracle):
+    from sparsearray_amd.device import colstats, rowsum, rowsums
+    nrow, ncol = 30000, 64
+    cp, ri, v = random_csc(nrow, ncol, 0.05, seed=25)
+    x = SVT_SparseArray.from_csc((nrow, ncol), "double", cp, ri, v)
+    A = _dev(cp, ri, v, nrow)
+    for op, fn in (("sum", oracle.colSums), ("mean", oracle.colMeans), ("var1", oracle.colVars)):
+        got, _ = colstats(A, op)
+        assert_equal(got.cpu().numpy(), fn(x), tol=1e-6, atol=1e-9, what=op)
+    assert_equal(rowsums(A).cpu().numpy(), oracle.rowSums(x), tol=1e-6, atol=1e-9)
+    grp = np.random.default_rng(26).integers(1, 11, nrow).astype(np.int32)
+    got = rowsum(A, torch.as_tensor(grp, device="cuda"), 10).cpu().numpy().T
+    want, _ = oracle.SparseArray_Call("C_rowsum_SVT", x, grp, 10, False)
+    assert_equal(got, want, tol=1e-6, atol=1e-9)
