@@ -41,7 +41,7 @@ def parse():
                    help="pbc: panel-blocked LDS kernel (default); v1: gather kernel")
     p.add_argument("--cbw", type=int, default=32)
     p.add_argument("--wpb", type=int, default=16)
-    p.add_argument("--logr", type=int, default=8)
+    p.add_argument("--logr", type=int, default=7)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extras", action="store_true")
     return p.parse_args()

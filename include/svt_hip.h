@@ -230,6 +230,11 @@ int svt_dev_crossprod_pbc(const svt_dev_pbc *P, const svt_dev_csc *A,
 			  int64_t out_stride_k, void *ws, size_t ws_bytes,
 			  void *stream);
 
+/* Diagnostic only (tools/tune_pbc.py): 0 = normal; 1 / 2 = timing-only builds of
+   the PBC kernel without the Y staging / without the record loop (results are
+   wrong by construction). */
+void svt_dev_pbc_set_debug(int mode);
+
 /* col stats over segments of `inner` consecutive leaves each
    (dims > 1 => inner = prod(dim[1..dims-1])); out has ncol/inner elements of
    svt_colStats_out_Rtype().  warn_flag: device int, set to 1 on the

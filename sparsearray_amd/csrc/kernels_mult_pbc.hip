@@ -16,8 +16,13 @@
 //                partial sums; a wavefront owns NV = CBW/16 consecutive slabs
 //   tile(s, p) = the nonzeros of slab s in row panel p, in CSC order
 //                (column-major, rows ascending), stored contiguously and
-//                zero-padded to a multiple of PBC_BATCH records:
-//                rc[i] = (local column << 16) | (row - p*R),  v[i] = value
+//                zero-padded to a multiple of PBC_BATCH records of 16 bytes:
+//                { u32 8*(row - p*R)   byte offset of the row in an LDS column,
+//                  u32 2*(local column) VGPR index of the partial sum,
+//                  f64 value }
+//                (pre-scaled so that the product loop spends no scalar ALU
+//                work on decoding: the scalar unit is shared by the 4 SIMDs of
+//                a CU and is the first thing that saturates)
 //   tile order = (wavefront, panel, slab-within-wavefront): everything one
 //                wavefront reads is one sequential stream
 //   tile_ptr[t] = first record of tile t
@@ -48,8 +53,7 @@ struct svt_dev_pbc {
 	int64_t nrow, ncol, nnz, nrec;
 	int CBW, WPB, logR;
 	int64_t ngroups, nblocks, npanels;
-	uint32_t *rc;
-	double *v;
+	uint4 *rec;            // [nrec] 16-byte records
 	int64_t *tile_ptr;     // [ngroups*npanels + 1]
 	int *col_has_na;       // [ncol]
 };
@@ -69,7 +73,8 @@ __device__ inline int64_t lower_bound_row(const int32_t *__restrict__ row, int64
 	return lo;
 }
 
-#define PBC_BATCH 8        // records per scalar-load batch; tiles are padded to it
+#define PBC_BATCH 4        // records per scalar-load batch; tiles are padded to it
+#define PBC_AHEAD 2        // panels of look-ahead of the record prefetch into L2
 
 // One wavefront per (slab of 16 columns, chunk of PCH panels).  MODE 0: count
 // the records of each tile (rounded up to PBC_BATCH).  MODE 1: write records to
@@ -79,7 +84,7 @@ __global__ void __launch_bounds__(64)
 pbc_pass_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__ row_idx,
 		const double *__restrict__ val, int64_t ncol, int NV, int logR,
 		int64_t npanels, int64_t *__restrict__ counts_or_ptr,
-		uint32_t *__restrict__ rc, double *__restrict__ v, int *__restrict__ col_has_na)
+		uint4 *__restrict__ rec, int *__restrict__ col_has_na)
 {
 	__shared__ int64_t fill[PCH];
 	const int lane = threadIdx.x;
@@ -117,8 +122,12 @@ pbc_pass_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__
 			__syncthreads();
 			if (MODE == 1 && active) {
 				const double x = val[k];
-				rc[pos] = ((uint32_t) (c - c0) << 16) | (uint32_t) (r - (int32_t) ((p + p0) << logR));
-				v[pos] = x;
+				uint4 t;
+				t.x = (uint32_t) (r - (int32_t) ((p + p0) << logR)) * 8u;
+				t.y = (uint32_t) (c - c0) * 2u;
+				t.z = (uint32_t) __double2loint(x);
+				t.w = (uint32_t) __double2hiint(x);
+				rec[pos] = t;
 				if (svt_is_na(x)) saw_na = 1;
 			}
 			if (is_last) fill[p] += rank + 1;
@@ -134,7 +143,7 @@ pbc_pass_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__
 		} else {
 			// fill[i] = one past the last real record; pad up to the next tile
 			const int64_t stop = counts_or_ptr[TILE_OF(p0 + i) + 1];
-			for (int64_t q = fill[i]; q < stop; q++) { rc[q] = 0; v[q] = 0.0; }
+			for (int64_t q = fill[i]; q < stop; q++) rec[q] = make_uint4(0, 0, 0, 0);
 		}
 	}
 #undef TILE_OF
@@ -143,8 +152,7 @@ pbc_pass_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__
 extern "C" void svt_dev_pbc_release(svt_dev_pbc *h)
 {
 	if (h == NULL) return;
-	if (h->rc) (void) hipFree(h->rc);
-	if (h->v) (void) hipFree(h->v);
+	if (h->rec) (void) hipFree(h->rec);
 	if (h->tile_ptr) (void) hipFree(h->tile_ptr);
 	if (h->col_has_na) (void) hipFree(h->col_has_na);
 	free(h);
@@ -180,7 +188,7 @@ extern "C" svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB
 		dim3 grid((unsigned) h->ngroups, (unsigned) ((h->npanels + PCH - 1) / PCH));
 		hipLaunchKernelGGL(pbc_pass_kernel<0>, grid, dim3(64), 0, 0, A->col_ptr, A->row_idx,
 				   (const double *) A->val, A->ncol, CBW / 16, logR, h->npanels,
-				   h->tile_ptr, (uint32_t *) NULL, (double *) NULL, h->col_has_na);
+				   h->tile_ptr, (uint4 *) NULL, h->col_has_na);
 		// exclusive scan in place over ntiles+1 entries (last entry = total)
 		ok = hipcub::DeviceScan::ExclusiveSum(NULL, tmp_bytes, h->tile_ptr, h->tile_ptr,
 						      (int) (ntiles + 1)) == hipSuccess &&
@@ -190,12 +198,17 @@ extern "C" svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB
 		int64_t nrec = 0;
 		if (ok) ok = hipMemcpy(&nrec, h->tile_ptr + ntiles, 8, hipMemcpyDeviceToHost) == hipSuccess;
 		h->nrec = nrec;
-		if (ok) ok = hipMalloc((void **) &h->rc, (size_t) (nrec + PBC_BATCH) * 4) == hipSuccess &&
-			     hipMalloc((void **) &h->v, (size_t) (nrec + PBC_BATCH) * 8) == hipSuccess;
+		if (ok && (nrec + 2 * PBC_BATCH) * 16 >= ((int64_t) 1 << 32)) {
+			svt_set_error("svt_dev_pbc_build: operand too large for 32-bit record offsets");
+			if (tmp) (void) hipFree(tmp);
+			svt_dev_pbc_release(h);
+			return NULL;
+		}
+		if (ok) ok = hipMalloc((void **) &h->rec, (size_t) (nrec + 2 * PBC_BATCH) * 16) == hipSuccess;
 		if (ok) {
 			hipLaunchKernelGGL(pbc_pass_kernel<1>, grid, dim3(64), 0, 0, A->col_ptr,
 					   A->row_idx, (const double *) A->val, A->ncol, CBW / 16, logR,
-					   h->npanels, h->tile_ptr, h->rc, h->v, h->col_has_na);
+					   h->npanels, h->tile_ptr, h->rec, h->col_has_na);
 			ok = hipDeviceSynchronize() == hipSuccess;
 		}
 	}
@@ -211,39 +224,192 @@ extern "C" svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB
 // ---------------------------------------------------------------------------
 // main kernel
 // ---------------------------------------------------------------------------
+static int g_pbc_debug = 0;
+extern "C" void svt_dev_pbc_set_debug(int mode) { g_pbc_debug = mode; }
+
 struct PbcFlags {
 	int *y_nonfinite;    // [1] any NaN/Inf/NA in the dense operand
 };
 
-// One batch of PBC_BATCH records applied to one slab's partial sums.  All
-// record fields are wave-uniform (SGPRs); `acc[c]` with a uniform c compiles to
-// s_set_gpr_idx + v_mov (register-indexed access, no scratch).
-__device__ inline void apply_batch(d16 &acc, const uint32_t (&r)[PBC_BATCH],
-				   const double (&a)[PBC_BATCH],
-				   const double *__restrict__ ycol)
-{
-	double y[PBC_BATCH];
-#pragma unroll
-	for (int q = 0; q < PBC_BATCH; q++)
-		y[q] = ycol[r[q] & 0xFFFFu];
-#pragma unroll
-	for (int q = 0; q < PBC_BATCH; q++) {
-		const int c = (int) (r[q] >> 16);
-		acc[c] = __builtin_fma(a[q], y[q], acc[c]);
-	}
-}
+// A batch of PBC_BATCH (= 4) records = 16 dwords, held in a block of 16 SGPRs
+// that is pinned to fixed physical registers (s[32:47] / s[48:63]) so that the
+// hand-written step below can name the fields directly: no decoding, no copies.
+typedef uint32_t batch_t __attribute__((ext_vector_type(16)));
 
-template <int NV, int WPB>
+// Staging of one Y panel through registers: NPF 16-byte pieces per thread,
+// fetched while the previous panel is being consumed, written to LDS between
+// two barriers.  LDS layout ylds[k][r], row stride RS = R + 1 doubles (odd, so
+// that the lane = k reads of the product loop are bank-conflict free).
+// Piece e (0 .. 32R-1) of a panel: column-major Y -> rows 2*(e % (R/2)), +1 of
+// dense column e / (R/2); row-contiguous Y (TRY) -> dense columns 2*(e % 32),
+// +1 of row e / 32.  Thread (w, lane) owns pieces (w*NPF + q)*64 + lane.
+// Panels that stick out of Y (last rows, K not a multiple of 64) or that are
+// not 16-byte aligned take the element-wise path in commit().
+template <int NPF, int WPB, int LOGR, bool TRY>
+struct Stager {
+	double2 pf[NPF];
+	bool fast = false;
+
+	__device__ static inline void piece(int e, int &kk, int &rr)
+	{
+		constexpr int R = 1 << LOGR;
+		if (!TRY) { kk = e / (R / 2); rr = (e % (R / 2)) * 2; }
+		else { kk = (e % 32) * 2; rr = e / 32; }
+	}
+
+	__device__ inline void fetch(const double *__restrict__ Y, int64_t ldY, int64_t nrow,
+				     int K, int k0, int64_t p, int w, int lane)
+	{
+		constexpr int R = 1 << LOGR;
+		const int64_t r0 = p << LOGR;
+		fast = (r0 + R <= nrow) && (k0 + 64 <= K) && ((ldY & 1) == 0) &&
+		       ((((uintptr_t) Y) & 15) == 0);          // wave-uniform
+		if (!fast)
+			return;
+#pragma unroll
+		for (int q = 0; q < NPF; q++) {
+			int kk, rr;
+			piece((w * NPF + q) * 64 + lane, kk, rr);
+			const double *src = TRY ? Y + (k0 + kk) + (r0 + rr) * ldY
+						: Y + (r0 + rr) + (int64_t) (k0 + kk) * ldY;
+			pf[q] = *(const double2 *) src;
+		}
+	}
+
+	__device__ inline void commit(double *__restrict__ ylds, const double *__restrict__ Y,
+				      int64_t ldY, int64_t nrow, int K, int k0, int64_t p,
+				      int w, int lane, int &bad)
+	{
+		constexpr int R = 1 << LOGR, RS = R + 1;
+		if (fast) {
+#pragma unroll
+			for (int q = 0; q < NPF; q++) {
+				int kk, rr;
+				piece((w * NPF + q) * 64 + lane, kk, rr);
+				if (!svt_is_finite(pf[q].x) || !svt_is_finite(pf[q].y)) bad = 1;
+				ylds[kk * RS + rr] = pf[q].x;
+				if (!TRY) ylds[kk * RS + rr + 1] = pf[q].y;
+				else ylds[(kk + 1) * RS + rr] = pf[q].y;
+			}
+			return;
+		}
+		const int64_t r0 = p << LOGR;
+		for (int idx = w * 64 + lane; idx < 64 * R; idx += WPB * 64) {
+			const int kk = TRY ? (idx & 63) : (idx >> LOGR);
+			const int rr = TRY ? (idx >> 6) : (idx & (R - 1));
+			const int64_t r = r0 + rr;
+			double y = 0.0;
+			if (r < nrow && k0 + kk < K)
+				y = TRY ? Y[(k0 + kk) + r * ldY] : Y[r + (int64_t) (k0 + kk) * ldY];
+			if (!svt_is_finite(y)) bad = 1;
+			ylds[kk * RS + rr] = y;
+		}
+	}
+};
+
+// The record loop of one tile (one slab of the wavefront, one panel), written
+// by hand: the scalar unit is shared by the 4 SIMDs of a CU, so every SALU
+// instruction per record counts, and the compiler's lowering of a
+// register-indexed accumulator costs 2 mode switches + 4 v_mov per record
+// (tools/micro/idx_bench.hip).  Per batch of 4 records:
+//   wait for the CURRENT batch (scalar load issued one step earlier)
+//   4 x LDS address = lane base + row offset; 4 x ds_read_b64 (lane = dense
+//     column: bank-conflict free); wait for them
+//   issue the 64-byte scalar load of the NEXT batch (lands under the FMAs)
+//   4 x acc[c_q] += a_q * y_q in VGPR-index mode: the 16 partial sums of the
+//     slab are pinned to 32 VGPRs; each v_fma_f64 addresses source-2 and
+//     destination relative to M0 = 2*c_q  ->  1 SALU + 1 VALU per record.
+// Two batches live in s[32:47] ("A") and s[48:63] ("B") and swap roles every
+// step.  Contract: on entry the batch at byte offset `off` is in A (loaded or
+// in flight); on exit the same holds for the new `off`.  A wavefront's stream
+// is contiguous across slabs and panels, so the look-ahead never needs to know
+// where a tile ends (the array has 2 batches of slack at its end).
+// Record = {s+0: LDS byte offset of the row, s+1: 2*column, s[+2:+3]: value}.
+#define PBC_HALF_STEP(V0, V1, NB, NLO, NHI, R0, I0, A0L, A0H, R1, I1, A1L, A1H,        \
+		      R2, I2, A2L, A2H, R3, I3, A3L, A3H)                              \
+	"s_waitcnt lgkmcnt(0)\n\t"                                                     \
+	"v_add_u32 %[t0], s" #R0 ", %[lb]\n\t"                                          \
+	"v_add_u32 %[t1], s" #R1 ", %[lb]\n\t"                                          \
+	"v_add_u32 %[t2], s" #R2 ", %[lb]\n\t"                                          \
+	"v_add_u32 %[t3], s" #R3 ", %[lb]\n\t"                                          \
+	"ds_read_b64 %[y0], %[t0]\n\t"                                                \
+	"ds_read_b64 %[y1], %[t1]\n\t"                                                \
+	"ds_read_b64 %[y2], %[t2]\n\t"                                                \
+	"ds_read_b64 %[y3], %[t3]\n\t"                                                \
+	"s_waitcnt lgkmcnt(0)\n\t"                                                     \
+	"s_add_u32 %[off], %[off], 64\n\t"                                             \
+	"s_load_dwordx16 s[" #NLO ":" #NHI "], %[base], %[off]\n\t"                     \
+	"s_set_gpr_idx_on s" #I0 ", gpr_idx(SRC2,DST)\n\t"                              \
+	"v_fma_f64 v[" #V0 ":" #V1 "], s[" #A0L ":" #A0H "], %[y0], v[" #V0 ":" #V1 "]\n\t" \
+	"s_set_gpr_idx_idx s" #I1 "\n\t"                                                \
+	"v_fma_f64 v[" #V0 ":" #V1 "], s[" #A1L ":" #A1H "], %[y1], v[" #V0 ":" #V1 "]\n\t" \
+	"s_set_gpr_idx_idx s" #I2 "\n\t"                                                \
+	"v_fma_f64 v[" #V0 ":" #V1 "], s[" #A2L ":" #A2H "], %[y2], v[" #V0 ":" #V1 "]\n\t" \
+	"s_set_gpr_idx_idx s" #I3 "\n\t"                                                \
+	"v_fma_f64 v[" #V0 ":" #V1 "], s[" #A3L ":" #A3H "], %[y3], v[" #V0 ":" #V1 "]\n\t" \
+	"s_set_gpr_idx_off\n\t"                                                        \
+	"s_sub_u32 %[" #NB "], %[" #NB "], 1\n\t"
+
+// All batches of one tile: two half steps per loop trip (A -> B, B -> A); if
+// the tile has an odd number of batches the look-ahead batch ends up in B and
+// is moved to A, so that every tile starts with its first batch in A.
+#define PBC_TILE_TXT(V0, V1, NB)                                                       \
+	"s_cmp_eq_u32 %[" #NB "], 0\n\t"                                               \
+	"s_cbranch_scc1 3f\n"                                                          \
+	"1:\n\t"                                                                       \
+	PBC_HALF_STEP(V0, V1, NB, 48, 63, 32, 33, 34, 35, 36, 37, 38, 39,              \
+		      40, 41, 42, 43, 44, 45, 46, 47)                                  \
+	"s_cmp_eq_u32 %[" #NB "], 0\n\t"                                               \
+	"s_cbranch_scc1 2f\n\t"                                                        \
+	PBC_HALF_STEP(V0, V1, NB, 32, 47, 48, 49, 50, 51, 52, 53, 54, 55,              \
+		      56, 57, 58, 59, 60, 61, 62, 63)                                  \
+	"s_cmp_lg_u32 %[" #NB "], 0\n\t"                                               \
+	"s_cbranch_scc1 1b\n\t"                                                        \
+	"s_branch 3f\n"                                                                \
+	"2:\n\t"                                                                       \
+	"s_waitcnt lgkmcnt(0)\n\t"                                                     \
+	"s_mov_b64 s[32:33], s[48:49]\n\t"                                             \
+	"s_mov_b64 s[34:35], s[50:51]\n\t"                                             \
+	"s_mov_b64 s[36:37], s[52:53]\n\t"                                             \
+	"s_mov_b64 s[38:39], s[54:55]\n\t"                                             \
+	"s_mov_b64 s[40:41], s[56:57]\n\t"                                             \
+	"s_mov_b64 s[42:43], s[58:59]\n\t"                                             \
+	"s_mov_b64 s[44:45], s[60:61]\n\t"                                             \
+	"s_mov_b64 s[46:47], s[62:63]\n"                                               \
+	"3:\n\t"
+
+// Operand lists shared by the per-NV panel blocks.  s[32:63] belong to the
+// block from its first to its last instruction (nothing is live in them across
+// blocks: the look-ahead load still in flight at the end is drained and simply
+// leaves the next panel's first batch warm in the scalar cache).
+#define PBC_PANEL_HEAD "s_load_dwordx16 s[32:47], %[base], %[off]\n\t"
+#define PBC_PANEL_TAIL "s_waitcnt lgkmcnt(0)"
+#define PBC_PANEL_TMP_OUTS                                                             \
+	[t0] "=&v"(t0_), [t1] "=&v"(t1_), [t2] "=&v"(t2_), [t3] "=&v"(t3_),              \
+	[y0] "=&v"(y0_), [y1] "=&v"(y1_), [y2] "=&v"(y2_), [y3] "=&v"(y3_)
+#define PBC_PANEL_CLOBBERS                                                             \
+	"m0", "scc", "memory", "s32", "s33", "s34", "s35", "s36", "s37", "s38", "s39",   \
+	"s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50",     \
+	"s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61",     \
+	"s62", "s63"
+
+// DBG: 0 = product build; 1 = skip staging of Y (timing only); 2 = skip the
+// record loop (timing only).  Selected with svt_dev_pbc_set_debug().
+template <int NV, int WPB, int LOGR, bool TRY, int DBG>
 __global__ void __launch_bounds__(WPB * 64)
-crossprod_pbc_kernel(const uint32_t *__restrict__ rc, const double *__restrict__ v,
-		     const int64_t *__restrict__ tile_ptr, int64_t npanels, int logR,
-		     const double *__restrict__ Y, int64_t ldY, int tr_y, int64_t nrow, int K,
+crossprod_pbc_kernel(const uint4 *__restrict__ rec,
+		     const int64_t *__restrict__ tile_ptr, int64_t npanels,
+		     const double *__restrict__ Y, int64_t ldY, int64_t nrow, int K,
 		     int64_t ncol, int64_t panels_per_split, double *__restrict__ part,
 		     int64_t Kp, PbcFlags fl)
 {
+	// The only LDS object of this kernel: its byte offset is 0, which
+	// lds_read_batch() relies on.
 	extern __shared__ double ylds[];            // [64][R + 1]
-	const int R = 1 << logR;
-	const int RS = R + 1;                       // odd stride (in doubles): conflict-free lane=k reads
+	constexpr int R = 1 << LOGR;
+	constexpr int RS = R + 1;
+	constexpr int NPF = R / (2 * WPB);          // 16-byte pieces per thread per panel
+	static_assert(NPF >= 1 && NPF * 2 * WPB == R, "panel must split evenly over the workgroup");
 	const int tid = threadIdx.x, lane = tid & 63;
 	// the wavefront id is wave-uniform; tell the compiler so that everything
 	// derived from it (tile bounds, records) lives in SGPRs / scalar loads
@@ -254,69 +420,124 @@ crossprod_pbc_kernel(const uint32_t *__restrict__ rc, const double *__restrict__
 	const int64_t pa = (int64_t) split * panels_per_split;
 	const int64_t pb = pa + panels_per_split < npanels ? pa + panels_per_split : npanels;
 	const int k0 = kt * 64;
+	if (pa >= pb)
+		return;                                 // whole workgroup: no barrier crossed yet
 
 	d16 acc[NV];
 #pragma unroll
 	for (int i = 0; i < NV; i++) acc[i] = 0.0;
 	int bad = 0;
-	const double *__restrict__ ycol = ylds + lane * RS;
+	uint32_t touch = 0, tv = 0;
+	const uint32_t lane_base = (uint32_t) lane * (RS * 8);
+	Stager<NPF, WPB, LOGR, TRY> st;
 
-	for (int64_t p = pa; p < pb; p++) {
-		// tile bounds of this wavefront for panel p: NV+1 consecutive words
-		const int64_t *__restrict__ tb = tile_ptr + (wv * npanels + p) * NV;
+	// prologue: panel pa straight into LDS
+	if (DBG != 1) {
+		st.fetch(Y, ldY, nrow, K, k0, pa, w, lane);
+		st.commit(ylds, Y, ldY, nrow, K, k0, pa, w, lane, bad);
+	}
+	__syncthreads();
+	const int64_t *__restrict__ tb = tile_ptr + (wv * npanels + pa) * NV;
+	// byte offset of the wavefront's current batch (32-bit: svt_dev_pbc_build
+	// refuses layouts of 4 GiB or more)
+	uint32_t off = (uint32_t) tb[0] * 16u;
+
+	for (int64_t p = pa; p < pb; p++, tb += NV) {
 		int64_t bounds[NV + 1];
 #pragma unroll
 		for (int j = 0; j <= NV; j++) bounds[j] = tb[j];
-
-		__syncthreads();                        // previous panel fully consumed
-		// ---- stage Y[p*R .. p*R+R) x [k0 .. k0+64) into LDS -----------
-		const int64_t r0 = p << logR;
-		if (!tr_y) {
-			// column-major Y: for one k, R consecutive rows are contiguous
-			for (int idx = tid; idx < 64 * R; idx += WPB * 64) {
-				const int kk = idx >> logR, rr = idx & (R - 1);
-				const int64_t r = r0 + rr;
-				double y = 0.0;
-				if (r < nrow && k0 + kk < K) y = Y[r + (int64_t) (k0 + kk) * ldY];
-				if (!svt_is_finite(y)) bad = 1;
-				ylds[kk * RS + rr] = y;
-			}
-		} else {
-			// Y given as K x nrow (rows of the product's dense operand contiguous)
-			for (int idx = tid; idx < 64 * R; idx += WPB * 64) {
-				const int rr = idx >> 6, kk = idx & 63;
-				const int64_t r = r0 + rr;
-				double y = 0.0;
-				if (r < nrow && k0 + kk < K) y = Y[(k0 + kk) + r * ldY];
-				if (!svt_is_finite(y)) bad = 1;
-				ylds[kk * RS + rr] = y;
-			}
+		// next panel of Y starts its trip from L2/HBM now, lands in registers
+		if (DBG != 1 && p + 1 < pb) st.fetch(Y, ldY, nrow, K, k0, p + 1, w, lane);
+		// Pull this wavefront's records of panel p + PBC_AHEAD towards L2: one
+		// dword per 128-byte line.  The loaded word is only consumed one panel
+		// later, so nothing waits for it here.
+		touch ^= tv;
+		tv = 0;
+		if (DBG != 2 && p + PBC_AHEAD < npanels) {
+			const int64_t ta = tb[NV * PBC_AHEAD], te = tb[NV * (PBC_AHEAD + 1)];
+			const uint32_t off = lane * 128u;
+			const uint32_t len = (uint32_t) (te - ta) * 16u;
+			if (off < len)
+				tv = *(const uint32_t *) ((const char *) (rec + ta) + off);
 		}
-		__syncthreads();
+
 		// ---- this wavefront's records, slab by slab ----------------------
+		if (DBG == 2) {
 #pragma unroll
-		for (int j = 0; j < NV; j++) {
-			for (int64_t i = bounds[j]; i < bounds[j + 1]; i += PBC_BATCH) {
-				uint32_t r[PBC_BATCH];
-				double a[PBC_BATCH];
-#pragma unroll
-				for (int q = 0; q < PBC_BATCH; q++) { r[q] = rc[i + q]; a[q] = v[i + q]; }
-				apply_batch(acc[j], r, a, ycol);
+			for (int j = 0; j < NV; j++) acc[j][0] += (double) bounds[j];
+		} else {
+#define NB(J) ((uint32_t) ((bounds[(J) + 1] - bounds[J]) / PBC_BATCH))
+			uint32_t t0_, t1_, t2_, t3_;
+			double y0_, y1_, y2_, y3_;
+			uint32_t nb0 = NB(0);
+			if constexpr (NV == 1) {
+				asm volatile(PBC_PANEL_HEAD PBC_TILE_TXT(64, 65, nb0) PBC_PANEL_TAIL
+					     : "+{v[64:95]}"(acc[0]), [off] "+s"(off), [nb0] "+s"(nb0),
+					       PBC_PANEL_TMP_OUTS
+					     : [base] "s"(rec), [lb] "v"(lane_base)
+					     : PBC_PANEL_CLOBBERS);
+			} else if constexpr (NV == 2) {
+				uint32_t nb1 = NB(1);
+				asm volatile(PBC_PANEL_HEAD PBC_TILE_TXT(64, 65, nb0)
+					     PBC_TILE_TXT(96, 97, nb1) PBC_PANEL_TAIL
+					     : "+{v[64:95]}"(acc[0]), "+{v[96:127]}"(acc[NV > 1 ? 1 : 0]),
+					       [off] "+s"(off), [nb0] "+s"(nb0), [nb1] "+s"(nb1),
+					       PBC_PANEL_TMP_OUTS
+					     : [base] "s"(rec), [lb] "v"(lane_base)
+					     : PBC_PANEL_CLOBBERS);
+			} else if constexpr (NV == 3) {
+				uint32_t nb1 = NB(1), nb2 = NB(2);
+				asm volatile(PBC_PANEL_HEAD PBC_TILE_TXT(64, 65, nb0)
+					     PBC_TILE_TXT(96, 97, nb1) PBC_TILE_TXT(128, 129, nb2)
+					     PBC_PANEL_TAIL
+					     : "+{v[64:95]}"(acc[0]), "+{v[96:127]}"(acc[NV > 1 ? 1 : 0]),
+					       "+{v[128:159]}"(acc[NV > 2 ? 2 : 0]),
+					       [off] "+s"(off), [nb0] "+s"(nb0), [nb1] "+s"(nb1),
+					       [nb2] "+s"(nb2), PBC_PANEL_TMP_OUTS
+					     : [base] "s"(rec), [lb] "v"(lane_base)
+					     : PBC_PANEL_CLOBBERS);
+			} else {
+				uint32_t nb1 = NB(1), nb2 = NB(2), nb3 = NB(3);
+				asm volatile(PBC_PANEL_HEAD PBC_TILE_TXT(64, 65, nb0)
+					     PBC_TILE_TXT(96, 97, nb1) PBC_TILE_TXT(128, 129, nb2)
+					     PBC_TILE_TXT(160, 161, nb3) PBC_PANEL_TAIL
+					     : "+{v[64:95]}"(acc[0]), "+{v[96:127]}"(acc[NV > 1 ? 1 : 0]),
+					       "+{v[128:159]}"(acc[NV > 2 ? 2 : 0]),
+					       "+{v[160:191]}"(acc[NV > 3 ? 3 : 0]),
+					       [off] "+s"(off), [nb0] "+s"(nb0), [nb1] "+s"(nb1),
+					       [nb2] "+s"(nb2), [nb3] "+s"(nb3), PBC_PANEL_TMP_OUTS
+					     : [base] "s"(rec), [lb] "v"(lane_base)
+					     : PBC_PANEL_CLOBBERS);
 			}
+#undef NB
+		}
+		if (p + 1 < pb) {
+			__syncthreads();                    // panel p fully consumed
+			if (DBG != 1) st.commit(ylds, Y, ldY, nrow, K, k0, p + 1, w, lane, bad);
+			__syncthreads();
 		}
 	}
 	if (b == 0 && __any(bad) && lane == 0)
 		*fl.y_nonfinite = 1;
+	touch ^= tv;
+	if (touch == 0x9E3779B9u && K < 0)      // never true: keeps the prefetch loads alive
+		fl.y_nonfinite[1] = 1;
 	// ---- partial results: part[(split*Kp + k) * ncol + c] -----------------
 	const int64_t c0 = wv * (16 * NV);
-	double *__restrict__ dst = part + ((int64_t) split * Kp + k0 + lane) * ncol;
+	double *__restrict__ dst = part + ((int64_t) split * Kp + k0 + lane) * ncol + c0;
+	if (c0 + 16 * NV <= ncol) {                 // wave-uniform: whole slabs inside
 #pragma unroll
-	for (int i = 0; i < NV; i++)
+		for (int ii = 0; ii < NV; ii++)
 #pragma unroll
-		for (int j = 0; j < 16; j++) {
-			const int64_t c = c0 + i * 16 + j;
-			if (c < ncol) dst[c] = acc[i][j];
-		}
+			for (int jj = 0; jj < 16; jj++)
+				dst[ii * 16 + jj] = acc[ii][jj];
+	} else {
+#pragma unroll
+		for (int ii = 0; ii < NV; ii++)
+#pragma unroll
+			for (int jj = 0; jj < 16; jj++)
+				if (c0 + ii * 16 + jj < ncol) dst[ii * 16 + jj] = acc[ii][jj];
+	}
 }
 
 // out[c, k] = sum over splits (fixed order) ; NA_real_ for leaves holding an NA
@@ -337,37 +558,48 @@ __global__ void pbc_reduce_kernel(const double *__restrict__ part, int nsplit, i
 // ---------------------------------------------------------------------------
 // launch
 // ---------------------------------------------------------------------------
-static int pick_nsplit(const svt_dev_pbc *P, int K)
+// Row splits: enough workgroups to fill the chip, every split non-empty.
+static int pick_nsplit(const svt_dev_pbc *P, int K, int64_t *pps_out)
 {
 	const int64_t kt = ((int64_t) K + 63) / 64;
 	int64_t s = (512 + P->nblocks * kt - 1) / (P->nblocks * kt);   // aim for >= 512 workgroups
 	s = (s + 7) / 8 * 8;                                           // whole XCD rounds
 	if (s > P->npanels) s = P->npanels;
 	if (s < 1) s = 1;
+	const int64_t pps = (P->npanels + s - 1) / s;
+	s = (P->npanels + pps - 1) / pps;                              // drop empty splits
+	if (pps_out) *pps_out = pps;
 	return (int) s;
 }
 
 extern "C" size_t svt_dev_crossprod_pbc_ws_bytes(const svt_dev_pbc *P, int K)
 {
 	const int64_t Kp = ((int64_t) K + 63) / 64 * 64;
-	const int ns = pick_nsplit(P, K);
+	const int ns = pick_nsplit(P, K, NULL);
 	// [flags 256 B][partials][general-path workspace]
 	return 256 + (size_t) ns * Kp * (P->ncol > 0 ? P->ncol : 1) * 8 +
 	       crossprod_ws_bytes(P->nrow, P->ncol, K);
 }
 
-template <int NV, int WPB>
+template <int NV, int WPB, int LOGR>
 static void launch_main(const svt_dev_pbc *P, const double *Y, int64_t ldY, int tr_y, int K,
 			int nsplit, int64_t pps, double *part, int64_t Kp, PbcFlags fl,
 			hipStream_t s)
 {
-	const int R = 1 << P->logR;
+	const int R = 1 << LOGR;
 	const size_t lds = (size_t) 64 * (R + 1) * 8;
 	dim3 grid((unsigned) nsplit, (unsigned) (Kp / 64), (unsigned) P->nblocks);
-	auto kern = crossprod_pbc_kernel<NV, WPB>;
+	void (*kern)(const uint4 *, const int64_t *, int64_t, const double *,
+		     int64_t, int64_t, int, int64_t, int64_t, double *, int64_t, PbcFlags);
+	if (tr_y)
+		kern = g_pbc_debug == 2 ? crossprod_pbc_kernel<NV, WPB, LOGR, true, 2> :
+					  crossprod_pbc_kernel<NV, WPB, LOGR, true, 0>;
+	else
+		kern = g_pbc_debug == 2 ? crossprod_pbc_kernel<NV, WPB, LOGR, false, 2> :
+					  crossprod_pbc_kernel<NV, WPB, LOGR, false, 0>;
 	(void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-	hipLaunchKernelGGL(kern, grid, dim3(WPB * 64), lds, s, P->rc, P->v, P->tile_ptr, P->npanels,
-			   P->logR, Y, ldY, tr_y, P->nrow, K, P->ncol, pps, part, Kp, fl);
+	hipLaunchKernelGGL(kern, grid, dim3(WPB * 64), lds, s, P->rec, P->tile_ptr, P->npanels,
+			   Y, ldY, P->nrow, K, P->ncol, pps, part, Kp, fl);
 }
 
 int launch_crossprod_general_if(const CrossprodArgs &a, const int *flag, hipStream_t s);
@@ -383,25 +615,27 @@ extern "C" int svt_dev_crossprod_pbc(const svt_dev_pbc *P, const svt_dev_csc *A,
 	if (ws_bytes < svt_dev_crossprod_pbc_ws_bytes(P, K))
 		return svt_set_error("svt_dev_crossprod_pbc: workspace too small");
 	const int64_t Kp = ((int64_t) K + 63) / 64 * 64;
-	const int nsplit = pick_nsplit(P, K);
-	const int64_t pps = (P->npanels + nsplit - 1) / nsplit;
+	int64_t pps = 1;
+	const int nsplit = pick_nsplit(P, K, &pps);
 	PbcFlags fl;
 	fl.y_nonfinite = (int *) ws;
 	double *part = (double *) ((char *) ws + 256);
 	void *gen_ws = (char *) part + (size_t) nsplit * Kp * P->ncol * 8;
 	HIP_TRY(hipMemsetAsync(ws, 0, 256, s));
-	const int key = P->CBW / 16 * 100 + P->WPB;
+	const int key = (P->CBW / 16) * 10000 + P->WPB * 100 + P->logR;
+#define PBC_CASE(NV, WPB, LOGR) \
+	case (NV) * 10000 + (WPB) * 100 + (LOGR): \
+		launch_main<NV, WPB, LOGR>(P, Y, ldY, tr_y, K, nsplit, pps, part, Kp, fl, s); break;
 	switch (key) {
-	case 116: launch_main<1, 16>(P, Y, ldY, tr_y, K, nsplit, pps, part, Kp, fl, s); break;
-	case 216: launch_main<2, 16>(P, Y, ldY, tr_y, K, nsplit, pps, part, Kp, fl, s); break;
-	case 316: launch_main<3, 16>(P, Y, ldY, tr_y, K, nsplit, pps, part, Kp, fl, s); break;
-	case 208: launch_main<2, 8>(P, Y, ldY, tr_y, K, nsplit, pps, part, Kp, fl, s); break;
-	case 308: launch_main<3, 8>(P, Y, ldY, tr_y, K, nsplit, pps, part, Kp, fl, s); break;
-	case 408: launch_main<4, 8>(P, Y, ldY, tr_y, K, nsplit, pps, part, Kp, fl, s); break;
-	case 404: launch_main<4, 4>(P, Y, ldY, tr_y, K, nsplit, pps, part, Kp, fl, s); break;
+	PBC_CASE(1, 16, 7) PBC_CASE(2, 16, 7)
+	PBC_CASE(1, 16, 8) PBC_CASE(2, 16, 8)
+	PBC_CASE(2, 8, 7) PBC_CASE(3, 8, 7) PBC_CASE(4, 8, 7)
+	PBC_CASE(2, 8, 6) PBC_CASE(4, 4, 5)
 	default:
-		return svt_set_error("svt_dev_crossprod_pbc: unsupported (CBW=%d, WPB=%d)", P->CBW, P->WPB);
+		return svt_set_error("svt_dev_crossprod_pbc: unsupported (CBW=%d, WPB=%d, logR=%d)",
+				     P->CBW, P->WPB, P->logR);
 	}
+#undef PBC_CASE
 	dim3 rgrid((unsigned) ((P->ncol + 255) / 256), (unsigned) K);
 	hipLaunchKernelGGL(pbc_reduce_kernel, rgrid, dim3(256), 0, s, part, nsplit, Kp, K, P->ncol,
 			   P->col_has_na, out, out_stride_c, out_stride_k);

@@ -16,7 +16,7 @@ def _dev(cp, ri, v, nrow):
     return DeviceCSC.from_host(nrow, cp, ri, v)
 
 
-@pytest.mark.parametrize("cfg", [(32, 16, 8), (16, 16, 7), (48, 16, 6), (64, 8, 8), (64, 4, 5)])
+@pytest.mark.parametrize("cfg", [(32, 16, 7), (16, 16, 7), (48, 8, 7), (64, 8, 7), (32, 8, 6), (64, 4, 5), (32, 16, 8)])
 @pytest.mark.parametrize("shape", [(5000, 300, 70), (70000, 1100, 128), (300, 17, 5)])
 def test_pbc_crossprod_matches_oracle(hip, oracle, cfg, shape):
     from sparsearray_amd.device import PbcPlan

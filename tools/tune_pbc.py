@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Tuning harness for the PBC crossprod kernel (run on the GPU box):
+times the kernel for several (CBW, WPB, logR) and, with --ablate, the
+timing-only builds (no staging / no record loop)."""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sparsearray_amd import synth  # noqa: E402
+from sparsearray_amd.device import DeviceCSC, PbcPlan, _lib  # noqa: E402
+
+p = argparse.ArgumentParser()
+p.add_argument("--nrow", type=int, default=1_000_000)
+p.add_argument("--ncol", type=int, default=10_000)
+p.add_argument("--density", type=float, default=0.01)
+p.add_argument("--K", type=int, default=128)
+p.add_argument("--cfgs", default="32,16,8")
+p.add_argument("--ablate", action="store_true")
+p.add_argument("--reps", type=int, default=5)
+a = p.parse_args()
+
+dev = torch.device("cuda", 0)
+cp, ri, v = synth.random_device_csc(a.nrow, a.ncol, a.density, seed=1, device=dev)
+Y = synth.random_dense(a.nrow, a.K, seed=101, device=dev)
+A = DeviceCSC(a.nrow, cp, ri, v)
+out = torch.zeros((a.K, a.ncol), dtype=torch.float64, device=dev)
+lib = _lib()
+
+
+def timed(fn, reps):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+for cfg in a.cfgs.split(";"):
+    cbw, wpb, logr = (int(x) for x in cfg.split(","))
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    plan = PbcPlan(A, a.K, cbw, wpb, logr)
+    torch.cuda.synchronize(); build = (time.perf_counter() - t0) * 1e3
+    row = [f"cfg cbw={cbw} wpb={wpb} logR={logr}: build {build:.1f} ms"]
+    for mode, name in ((0, "full"), (2, "no-compute")):
+        if mode and not a.ablate:
+            continue
+        lib.svt_dev_pbc_set_debug(mode)
+        ms = timed(lambda: plan.run(Y, a.nrow, out), a.reps)
+        row.append(f"{name} {ms:.3f} ms ({A.nnz / ms / 1e6:.1f} GNZ/s)")
+    lib.svt_dev_pbc_set_debug(0)
+    print("  ".join(row), flush=True)
+    del plan
