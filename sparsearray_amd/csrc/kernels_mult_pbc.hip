@@ -12,9 +12,9 @@
 // from the CSC layout (svt_dev_pbc_build), the device analogue of the
 // reference's per-call "preprocessing" of leaves (src/SparseMatrix_mult.c:
 // 632-724):
-//   slab       = 16 consecutive columns = one register-indexable vector of
-//                partial sums; a wavefront owns NV = CBW/16 consecutive slabs
-//   tile(s, p) = the nonzeros of slab s in row panel p, in CSC order
+//   group      = CBW consecutive columns = the partial sums one wavefront keeps
+//                in registers (CBW/16 register-indexable vectors, contiguous)
+//   tile(g, p) = the nonzeros of group g in row panel p, in CSC order
 //                (column-major, rows ascending), stored contiguously and
 //                zero-padded to a multiple of PBC_BATCH records of 16 bytes:
 //                { u32 8*(row - p*R)   byte offset of the row in an LDS column,
@@ -23,9 +23,9 @@
 //                (pre-scaled so that the product loop spends no scalar ALU
 //                work on decoding: the scalar unit is shared by the 4 SIMDs of
 //                a CU and is the first thing that saturates)
-//   tile order = (wavefront, panel, slab-within-wavefront): everything one
-//                wavefront reads is one sequential stream
-//   tile_ptr[t] = first record of tile t
+//   tile order = (group, panel): everything one wavefront reads is one
+//                sequential stream
+//   tile_ptr[g*npanels + p] = first record of tile (g, p)
 // A workgroup = WPB wavefronts; grid = (row split, 64-wide tile of dense
 // columns, column block).  Row splits give >= 256
 // workgroups; their partial results are summed in a fixed order by
@@ -76,29 +76,27 @@ __device__ inline int64_t lower_bound_row(const int32_t *__restrict__ row, int64
 #define PBC_BATCH 4        // records per scalar-load batch; tiles are padded to it
 #define PBC_AHEAD 2        // panels of look-ahead of the record prefetch into L2
 
-// One wavefront per (slab of 16 columns, chunk of PCH panels).  MODE 0: count
+// One wavefront per (group of CBW columns, chunk of PCH panels).  MODE 0: count
 // the records of each tile (rounded up to PBC_BATCH).  MODE 1: write records to
 // their final position and zero-fill the padding.
 template <int MODE>
 __global__ void __launch_bounds__(64)
 pbc_pass_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__ row_idx,
-		const double *__restrict__ val, int64_t ncol, int NV, int logR,
+		const double *__restrict__ val, int64_t ncol, int CBW, int logR,
 		int64_t npanels, int64_t *__restrict__ counts_or_ptr,
 		uint4 *__restrict__ rec, int *__restrict__ col_has_na)
 {
 	__shared__ int64_t fill[PCH];
 	const int lane = threadIdx.x;
-	const int64_t slab = blockIdx.x;
-	const int64_t wv = slab / NV;
-	const int j = (int) (slab % NV);
+	const int64_t wv = blockIdx.x;
 	const int64_t p0 = (int64_t) blockIdx.y * PCH;
 	const int64_t p1 = p0 + PCH < npanels ? p0 + PCH : npanels;
-#define TILE_OF(P) ((wv * npanels + (P)) * NV + j)
+#define TILE_OF(P) (wv * npanels + (P))
 	for (int i = lane; i < PCH; i += 64)
 		fill[i] = (MODE == 1 && p0 + i < npanels) ? counts_or_ptr[TILE_OF(p0 + i)] : 0;
 	__syncthreads();
-	const int64_t c0 = slab * 16;
-	const int64_t c1 = c0 + 16 < ncol ? c0 + 16 : ncol;
+	const int64_t c0 = wv * CBW;
+	const int64_t c1 = c0 + CBW < ncol ? c0 + CBW : ncol;
 	for (int64_t c = c0; c < c1; c++) {
 		const int64_t beg = col_ptr[c], end = col_ptr[c + 1];
 		const int64_t lo = lower_bound_row(row_idx, beg, end, p0 << logR);
@@ -174,7 +172,7 @@ extern "C" svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB
 	h->CBW = CBW; h->WPB = WPB; h->logR = logR;
 	const int64_t CB = (int64_t) CBW * WPB;
 	h->nblocks = (A->ncol + CB - 1) / CB;
-	h->ngroups = h->nblocks * WPB * (CBW / 16);   // slabs of 16 columns
+	h->ngroups = h->nblocks * WPB;                // one group per wavefront
 	h->npanels = (A->nrow + (1LL << logR) - 1) >> logR;
 	if (h->npanels < 1) h->npanels = 1;
 	const int64_t ntiles = h->ngroups * h->npanels;
@@ -187,7 +185,7 @@ extern "C" svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB
 	if (ok && A->ncol > 0 && A->nnz > 0) {
 		dim3 grid((unsigned) h->ngroups, (unsigned) ((h->npanels + PCH - 1) / PCH));
 		hipLaunchKernelGGL(pbc_pass_kernel<0>, grid, dim3(64), 0, 0, A->col_ptr, A->row_idx,
-				   (const double *) A->val, A->ncol, CBW / 16, logR, h->npanels,
+				   (const double *) A->val, A->ncol, CBW, logR, h->npanels,
 				   h->tile_ptr, (uint4 *) NULL, h->col_has_na);
 		// exclusive scan in place over ntiles+1 entries (last entry = total)
 		ok = hipcub::DeviceScan::ExclusiveSum(NULL, tmp_bytes, h->tile_ptr, h->tile_ptr,
@@ -198,16 +196,18 @@ extern "C" svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB
 		int64_t nrec = 0;
 		if (ok) ok = hipMemcpy(&nrec, h->tile_ptr + ntiles, 8, hipMemcpyDeviceToHost) == hipSuccess;
 		h->nrec = nrec;
-		if (ok && (nrec + 2 * PBC_BATCH) * 16 >= ((int64_t) 1 << 32)) {
+		if (ok && (nrec + 4 * PBC_BATCH) * 16 >= ((int64_t) 1 << 32)) {
 			svt_set_error("svt_dev_pbc_build: operand too large for 32-bit record offsets");
 			if (tmp) (void) hipFree(tmp);
 			svt_dev_pbc_release(h);
 			return NULL;
 		}
-		if (ok) ok = hipMalloc((void **) &h->rec, (size_t) (nrec + 2 * PBC_BATCH) * 16) == hipSuccess;
+		if (ok) ok = hipMalloc((void **) &h->rec, (size_t) (nrec + 4 * PBC_BATCH) * 16) == hipSuccess &&
+			     // the look-ahead stages of the kernel read up to 3 batches past the end
+			     hipMemset(h->rec + nrec, 0, (size_t) 4 * PBC_BATCH * 16) == hipSuccess;
 		if (ok) {
 			hipLaunchKernelGGL(pbc_pass_kernel<1>, grid, dim3(64), 0, 0, A->col_ptr,
-					   A->row_idx, (const double *) A->val, A->ncol, CBW / 16, logR,
+					   A->row_idx, (const double *) A->val, A->ncol, CBW, logR,
 					   h->npanels, h->tile_ptr, h->rec, h->col_has_na);
 			ok = hipDeviceSynchronize() == hipSuccess;
 		}
@@ -225,7 +225,12 @@ extern "C" svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB
 // main kernel
 // ---------------------------------------------------------------------------
 static int g_pbc_debug = 0;
-extern "C" void svt_dev_pbc_set_debug(int mode) { g_pbc_debug = mode; }
+static int g_pbc_nsplit = 0;
+extern "C" void svt_dev_pbc_set_debug(int mode)
+{
+	if (mode >= 100) g_pbc_nsplit = mode - 100;   // 100 + n: force n row splits (tuning)
+	else g_pbc_debug = mode;
+}
 
 struct PbcFlags {
 	int *y_nonfinite;    // [1] any NaN/Inf/NA in the dense operand
@@ -307,91 +312,99 @@ struct Stager {
 	}
 };
 
-// The record loop of one tile (one slab of the wavefront, one panel), written
-// by hand: the scalar unit is shared by the 4 SIMDs of a CU, so every SALU
-// instruction per record counts, and the compiler's lowering of a
+// The record loop of one tile (the records of one wavefront in one panel),
+// written by hand: the scalar unit is shared by the 4 SIMDs of a CU, so every
+// SALU instruction per record counts, and the compiler's lowering of a
 // register-indexed accumulator costs 2 mode switches + 4 v_mov per record
-// (tools/micro/idx_bench.hip).  Per batch of 4 records:
-//   wait for the CURRENT batch (scalar load issued one step earlier)
-//   4 x LDS address = lane base + row offset; 4 x ds_read_b64 (lane = dense
-//     column: bank-conflict free); wait for them
-//   issue the 64-byte scalar load of the NEXT batch (lands under the FMAs)
-//   4 x acc[c_q] += a_q * y_q in VGPR-index mode: the 16 partial sums of the
-//     slab are pinned to 32 VGPRs; each v_fma_f64 addresses source-2 and
-//     destination relative to M0 = 2*c_q  ->  1 SALU + 1 VALU per record.
-// Two batches live in s[32:47] ("A") and s[48:63] ("B") and swap roles every
-// step.  Contract: on entry the batch at byte offset `off` is in A (loaded or
-// in flight); on exit the same holds for the new `off`.  A wavefront's stream
-// is contiguous across slabs and panels, so the look-ahead never needs to know
-// where a tile ends (the array has 2 batches of slack at its end).
+// (tools/micro/idx_bench.hip).
+//
+// Software pipeline over batches of 4 records, 3 stages:
+//   L(k+2)  one 64-byte scalar load                       -> SGPR block
+//   D(k+1)  4 x (LDS address = lane base + row offset), 4 x ds_read_b64
+//           (lane = dense column: bank-conflict free)      -> y set
+//   F(k)    4 x acc[c_q] += a_q * y_q in VGPR-index mode: all partial sums of
+//           the wavefront are pinned to v[64 ...]; each v_fma_f64 addresses
+//           source-2 and destination relative to M0 = 2*c_q
+//           (1 SALU + 1 VALU per record)
+// and ONE `s_waitcnt lgkmcnt(0)` per step, after the FMAs: the scalar load and
+// the LDS reads of the step complete under them.  Three SGPR blocks (s[32:47],
+// s[48:63], s[64:79]) and two y sets rotate, hence 6 phases per loop trip.
+// The stream of a wavefront is contiguous (and has 3 batches of slack at the
+// end of the array), so the look-ahead stages never need to know where the
+// tile ends; row offsets of look-ahead records are valid LDS addresses.
 // Record = {s+0: LDS byte offset of the row, s+1: 2*column, s[+2:+3]: value}.
-#define PBC_HALF_STEP(V0, V1, NB, NLO, NHI, R0, I0, A0L, A0H, R1, I1, A1L, A1H,        \
-		      R2, I2, A2L, A2H, R3, I3, A3L, A3H)                              \
-	"s_waitcnt lgkmcnt(0)\n\t"                                                     \
-	"v_add_u32 %[t0], s" #R0 ", %[lb]\n\t"                                          \
-	"v_add_u32 %[t1], s" #R1 ", %[lb]\n\t"                                          \
-	"v_add_u32 %[t2], s" #R2 ", %[lb]\n\t"                                          \
-	"v_add_u32 %[t3], s" #R3 ", %[lb]\n\t"                                          \
-	"ds_read_b64 %[y0], %[t0]\n\t"                                                \
-	"ds_read_b64 %[y1], %[t1]\n\t"                                                \
-	"ds_read_b64 %[y2], %[t2]\n\t"                                                \
-	"ds_read_b64 %[y3], %[t3]\n\t"                                                \
-	"s_waitcnt lgkmcnt(0)\n\t"                                                     \
-	"s_add_u32 %[off], %[off], 64\n\t"                                             \
-	"s_load_dwordx16 s[" #NLO ":" #NHI "], %[base], %[off]\n\t"                     \
+#define PBC_D4(B0, B1, B2, B3, YS)                                                    \
+	"v_add_u32 %[t0], s" #B0 ", %[lb]\n\t"                                          \
+	"v_add_u32 %[t1], s" #B1 ", %[lb]\n\t"                                          \
+	"v_add_u32 %[t2], s" #B2 ", %[lb]\n\t"                                          \
+	"v_add_u32 %[t3], s" #B3 ", %[lb]\n\t"                                          \
+	"ds_read_b64 %[" #YS "0], %[t0]\n\t"                                           \
+	"ds_read_b64 %[" #YS "1], %[t1]\n\t"                                           \
+	"ds_read_b64 %[" #YS "2], %[t2]\n\t"                                           \
+	"ds_read_b64 %[" #YS "3], %[t3]\n\t"
+#define PBC_F4(I0, A0L, A0H, I1, A1L, A1H, I2, A2L, A2H, I3, A3L, A3H, YS)              \
 	"s_set_gpr_idx_on s" #I0 ", gpr_idx(SRC2,DST)\n\t"                              \
-	"v_fma_f64 v[" #V0 ":" #V1 "], s[" #A0L ":" #A0H "], %[y0], v[" #V0 ":" #V1 "]\n\t" \
+	"v_fma_f64 v[64:65], s[" #A0L ":" #A0H "], %[" #YS "0], v[64:65]\n\t"            \
 	"s_set_gpr_idx_idx s" #I1 "\n\t"                                                \
-	"v_fma_f64 v[" #V0 ":" #V1 "], s[" #A1L ":" #A1H "], %[y1], v[" #V0 ":" #V1 "]\n\t" \
+	"v_fma_f64 v[64:65], s[" #A1L ":" #A1H "], %[" #YS "1], v[64:65]\n\t"            \
 	"s_set_gpr_idx_idx s" #I2 "\n\t"                                                \
-	"v_fma_f64 v[" #V0 ":" #V1 "], s[" #A2L ":" #A2H "], %[y2], v[" #V0 ":" #V1 "]\n\t" \
+	"v_fma_f64 v[64:65], s[" #A2L ":" #A2H "], %[" #YS "2], v[64:65]\n\t"            \
 	"s_set_gpr_idx_idx s" #I3 "\n\t"                                                \
-	"v_fma_f64 v[" #V0 ":" #V1 "], s[" #A3L ":" #A3H "], %[y3], v[" #V0 ":" #V1 "]\n\t" \
-	"s_set_gpr_idx_off\n\t"                                                        \
-	"s_sub_u32 %[" #NB "], %[" #NB "], 1\n\t"
-
-// All batches of one tile: two half steps per loop trip (A -> B, B -> A); if
-// the tile has an odd number of batches the look-ahead batch ends up in B and
-// is moved to A, so that every tile starts with its first batch in A.
-#define PBC_TILE_TXT(V0, V1, NB)                                                       \
-	"s_cmp_eq_u32 %[" #NB "], 0\n\t"                                               \
-	"s_cbranch_scc1 3f\n"                                                          \
-	"1:\n\t"                                                                       \
-	PBC_HALF_STEP(V0, V1, NB, 48, 63, 32, 33, 34, 35, 36, 37, 38, 39,              \
-		      40, 41, 42, 43, 44, 45, 46, 47)                                  \
-	"s_cmp_eq_u32 %[" #NB "], 0\n\t"                                               \
-	"s_cbranch_scc1 2f\n\t"                                                        \
-	PBC_HALF_STEP(V0, V1, NB, 32, 47, 48, 49, 50, 51, 52, 53, 54, 55,              \
-		      56, 57, 58, 59, 60, 61, 62, 63)                                  \
-	"s_cmp_lg_u32 %[" #NB "], 0\n\t"                                               \
-	"s_cbranch_scc1 1b\n\t"                                                        \
-	"s_branch 3f\n"                                                                \
-	"2:\n\t"                                                                       \
+	"v_fma_f64 v[64:65], s[" #A3L ":" #A3H "], %[" #YS "3], v[64:65]\n\t"            \
+	"s_set_gpr_idx_off\n\t"
+// block A = s[32:47], B = s[48:63], C = s[64:79]
+#ifdef PBC_EXPERIMENT_CACHED   /* timing experiment only: every load hits a 1 KB window */
+#define PBC_LOAD_A "s_and_b32 s80, %[lo], 0x3c0\n\ts_load_dwordx16 s[32:47], %[base], s80\n\t"
+#define PBC_LOAD_B "s_and_b32 s80, %[lo], 0x3c0\n\ts_load_dwordx16 s[48:63], %[base], s80\n\t"
+#define PBC_LOAD_C "s_and_b32 s80, %[lo], 0x3c0\n\ts_load_dwordx16 s[64:79], %[base], s80\n\t"
+#else
+#define PBC_LOAD_A "s_load_dwordx16 s[32:47], %[base], %[lo]\n\t"
+#define PBC_LOAD_B "s_load_dwordx16 s[48:63], %[base], %[lo]\n\t"
+#define PBC_LOAD_C "s_load_dwordx16 s[64:79], %[base], %[lo]\n\t"
+#endif
+#define PBC_D_A(YS) PBC_D4(32, 36, 40, 44, YS)
+#define PBC_D_B(YS) PBC_D4(48, 52, 56, 60, YS)
+#define PBC_D_C(YS) PBC_D4(64, 68, 72, 76, YS)
+#define PBC_F_A(YS) PBC_F4(33, 34, 35, 37, 38, 39, 41, 42, 43, 45, 46, 47, YS)
+#define PBC_F_B(YS) PBC_F4(49, 50, 51, 53, 54, 55, 57, 58, 59, 61, 62, 63, YS)
+#define PBC_F_C(YS) PBC_F4(65, 66, 67, 69, 70, 71, 73, 74, 75, 77, 78, 79, YS)
+// one phase: load into LB, LDS reads for DB into set YD, FMAs of FB with set YF
+#define PBC_PHASE(LOADTXT, DTXT, FTXT)                                                 \
+	"s_add_u32 %[lo], %[lo], 64\n\t"                                               \
+	LOADTXT DTXT FTXT                                                              \
 	"s_waitcnt lgkmcnt(0)\n\t"                                                     \
-	"s_mov_b64 s[32:33], s[48:49]\n\t"                                             \
-	"s_mov_b64 s[34:35], s[50:51]\n\t"                                             \
-	"s_mov_b64 s[36:37], s[52:53]\n\t"                                             \
-	"s_mov_b64 s[38:39], s[54:55]\n\t"                                             \
-	"s_mov_b64 s[40:41], s[56:57]\n\t"                                             \
-	"s_mov_b64 s[42:43], s[58:59]\n\t"                                             \
-	"s_mov_b64 s[44:45], s[60:61]\n\t"                                             \
-	"s_mov_b64 s[46:47], s[62:63]\n"                                               \
-	"3:\n\t"
-
-// Operand lists shared by the per-NV panel blocks.  s[32:63] belong to the
-// block from its first to its last instruction (nothing is live in them across
-// blocks: the look-ahead load still in flight at the end is drained and simply
-// leaves the next panel's first batch warm in the scalar cache).
-#define PBC_PANEL_HEAD "s_load_dwordx16 s[32:47], %[base], %[off]\n\t"
-#define PBC_PANEL_TAIL "s_waitcnt lgkmcnt(0)"
-#define PBC_PANEL_TMP_OUTS                                                             \
+	"s_sub_u32 %[nb], %[nb], 1\n\t"                                                \
+	"s_cmp_eq_u32 %[nb], 0\n\t"                                                    \
+	"s_cbranch_scc1 9f\n\t"
+#define PBC_PANEL_TXT                                                                  \
+	"s_cmp_eq_u32 %[nb], 0\n\t"                                                    \
+	"s_cbranch_scc1 9f\n\t"                                                        \
+	/* prologue: batch 0 -> A, then its LDS reads + batch 1 -> B */                \
+	PBC_LOAD_A                                                                     \
+	"s_waitcnt lgkmcnt(0)\n\t"                                                     \
+	"s_add_u32 %[lo], %[lo], 64\n\t"                                               \
+	PBC_LOAD_B PBC_D_A(ya)                                                         \
+	"s_waitcnt lgkmcnt(0)\n"                                                       \
+	"1:\n\t"                                                                       \
+	PBC_PHASE(PBC_LOAD_C, PBC_D_B(yb), PBC_F_A(ya))                                \
+	PBC_PHASE(PBC_LOAD_A, PBC_D_C(ya), PBC_F_B(yb))                                \
+	PBC_PHASE(PBC_LOAD_B, PBC_D_A(yb), PBC_F_C(ya))                                \
+	PBC_PHASE(PBC_LOAD_C, PBC_D_B(ya), PBC_F_A(yb))                                \
+	PBC_PHASE(PBC_LOAD_A, PBC_D_C(yb), PBC_F_B(ya))                                \
+	PBC_PHASE(PBC_LOAD_B, PBC_D_A(ya), PBC_F_C(yb))                                \
+	"s_branch 1b\n"                                                                \
+	"9:\n\t"
+#define PBC_PANEL_OPS                                                                  \
+	[lo] "+s"(lo_), [nb] "+s"(nb_),                                                \
 	[t0] "=&v"(t0_), [t1] "=&v"(t1_), [t2] "=&v"(t2_), [t3] "=&v"(t3_),              \
-	[y0] "=&v"(y0_), [y1] "=&v"(y1_), [y2] "=&v"(y2_), [y3] "=&v"(y3_)
+	[ya0] "=&v"(ya0_), [ya1] "=&v"(ya1_), [ya2] "=&v"(ya2_), [ya3] "=&v"(ya3_),      \
+	[yb0] "=&v"(yb0_), [yb1] "=&v"(yb1_), [yb2] "=&v"(yb2_), [yb3] "=&v"(yb3_)
 #define PBC_PANEL_CLOBBERS                                                             \
 	"m0", "scc", "memory", "s32", "s33", "s34", "s35", "s36", "s37", "s38", "s39",   \
 	"s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50",     \
 	"s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61",     \
-	"s62", "s63"
+	"s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72",     \
+	"s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80"
 
 // DBG: 0 = product build; 1 = skip staging of Y (timing only); 2 = skip the
 // record loop (timing only).  Selected with svt_dev_pbc_set_debug().
@@ -437,15 +450,13 @@ crossprod_pbc_kernel(const uint4 *__restrict__ rec,
 		st.commit(ylds, Y, ldY, nrow, K, k0, pa, w, lane, bad);
 	}
 	__syncthreads();
-	const int64_t *__restrict__ tb = tile_ptr + (wv * npanels + pa) * NV;
+	const int64_t *__restrict__ tb = tile_ptr + (wv * npanels + pa);
 	// byte offset of the wavefront's current batch (32-bit: svt_dev_pbc_build
 	// refuses layouts of 4 GiB or more)
 	uint32_t off = (uint32_t) tb[0] * 16u;
 
-	for (int64_t p = pa; p < pb; p++, tb += NV) {
-		int64_t bounds[NV + 1];
-#pragma unroll
-		for (int j = 0; j <= NV; j++) bounds[j] = tb[j];
+	for (int64_t p = pa; p < pb; p++, tb += 1) {
+		const int64_t tbeg = tb[0], tend = tb[1];
 		// next panel of Y starts its trip from L2/HBM now, lands in registers
 		if (DBG != 1 && p + 1 < pb) st.fetch(Y, ldY, nrow, K, k0, p + 1, w, lane);
 		// Pull this wavefront's records of panel p + PBC_AHEAD towards L2: one
@@ -454,62 +465,47 @@ crossprod_pbc_kernel(const uint4 *__restrict__ rec,
 		touch ^= tv;
 		tv = 0;
 		if (DBG != 2 && p + PBC_AHEAD < npanels) {
-			const int64_t ta = tb[NV * PBC_AHEAD], te = tb[NV * (PBC_AHEAD + 1)];
-			const uint32_t off = lane * 128u;
+			const int64_t ta = tb[PBC_AHEAD], te = tb[PBC_AHEAD + 1];
+			const uint32_t toff = lane * 128u;
 			const uint32_t len = (uint32_t) (te - ta) * 16u;
-			if (off < len)
-				tv = *(const uint32_t *) ((const char *) (rec + ta) + off);
+			if (toff < len)
+				tv = *(const uint32_t *) ((const char *) (rec + ta) + toff);
 		}
 
-		// ---- this wavefront's records, slab by slab ----------------------
+		// ---- this wavefront's records of the panel --------------------------
 		if (DBG == 2) {
-#pragma unroll
-			for (int j = 0; j < NV; j++) acc[j][0] += (double) bounds[j];
+			acc[0][0] += (double) tbeg;
 		} else {
-#define NB(J) ((uint32_t) ((bounds[(J) + 1] - bounds[J]) / PBC_BATCH))
+			uint32_t nb_ = (uint32_t) ((tend - tbeg) / PBC_BATCH);
+			uint32_t lo_ = off;                 // byte offset of the stream cursor
+			off += nb_ * (PBC_BATCH * 16u);
 			uint32_t t0_, t1_, t2_, t3_;
-			double y0_, y1_, y2_, y3_;
-			uint32_t nb0 = NB(0);
+			double ya0_, ya1_, ya2_, ya3_, yb0_, yb1_, yb2_, yb3_;
 			if constexpr (NV == 1) {
-				asm volatile(PBC_PANEL_HEAD PBC_TILE_TXT(64, 65, nb0) PBC_PANEL_TAIL
-					     : "+{v[64:95]}"(acc[0]), [off] "+s"(off), [nb0] "+s"(nb0),
-					       PBC_PANEL_TMP_OUTS
+				asm volatile(PBC_PANEL_TXT
+					     : "+{v[64:95]}"(acc[0]), PBC_PANEL_OPS
 					     : [base] "s"(rec), [lb] "v"(lane_base)
 					     : PBC_PANEL_CLOBBERS);
 			} else if constexpr (NV == 2) {
-				uint32_t nb1 = NB(1);
-				asm volatile(PBC_PANEL_HEAD PBC_TILE_TXT(64, 65, nb0)
-					     PBC_TILE_TXT(96, 97, nb1) PBC_PANEL_TAIL
+				asm volatile(PBC_PANEL_TXT
 					     : "+{v[64:95]}"(acc[0]), "+{v[96:127]}"(acc[NV > 1 ? 1 : 0]),
-					       [off] "+s"(off), [nb0] "+s"(nb0), [nb1] "+s"(nb1),
-					       PBC_PANEL_TMP_OUTS
+					       PBC_PANEL_OPS
 					     : [base] "s"(rec), [lb] "v"(lane_base)
 					     : PBC_PANEL_CLOBBERS);
 			} else if constexpr (NV == 3) {
-				uint32_t nb1 = NB(1), nb2 = NB(2);
-				asm volatile(PBC_PANEL_HEAD PBC_TILE_TXT(64, 65, nb0)
-					     PBC_TILE_TXT(96, 97, nb1) PBC_TILE_TXT(128, 129, nb2)
-					     PBC_PANEL_TAIL
+				asm volatile(PBC_PANEL_TXT
 					     : "+{v[64:95]}"(acc[0]), "+{v[96:127]}"(acc[NV > 1 ? 1 : 0]),
-					       "+{v[128:159]}"(acc[NV > 2 ? 2 : 0]),
-					       [off] "+s"(off), [nb0] "+s"(nb0), [nb1] "+s"(nb1),
-					       [nb2] "+s"(nb2), PBC_PANEL_TMP_OUTS
+					       "+{v[128:159]}"(acc[NV > 2 ? 2 : 0]), PBC_PANEL_OPS
 					     : [base] "s"(rec), [lb] "v"(lane_base)
 					     : PBC_PANEL_CLOBBERS);
 			} else {
-				uint32_t nb1 = NB(1), nb2 = NB(2), nb3 = NB(3);
-				asm volatile(PBC_PANEL_HEAD PBC_TILE_TXT(64, 65, nb0)
-					     PBC_TILE_TXT(96, 97, nb1) PBC_TILE_TXT(128, 129, nb2)
-					     PBC_TILE_TXT(160, 161, nb3) PBC_PANEL_TAIL
+				asm volatile(PBC_PANEL_TXT
 					     : "+{v[64:95]}"(acc[0]), "+{v[96:127]}"(acc[NV > 1 ? 1 : 0]),
 					       "+{v[128:159]}"(acc[NV > 2 ? 2 : 0]),
-					       "+{v[160:191]}"(acc[NV > 3 ? 3 : 0]),
-					       [off] "+s"(off), [nb0] "+s"(nb0), [nb1] "+s"(nb1),
-					       [nb2] "+s"(nb2), [nb3] "+s"(nb3), PBC_PANEL_TMP_OUTS
+					       "+{v[160:191]}"(acc[NV > 3 ? 3 : 0]), PBC_PANEL_OPS
 					     : [base] "s"(rec), [lb] "v"(lane_base)
 					     : PBC_PANEL_CLOBBERS);
 			}
-#undef NB
 		}
 		if (p + 1 < pb) {
 			__syncthreads();                    // panel p fully consumed
@@ -564,6 +560,7 @@ static int pick_nsplit(const svt_dev_pbc *P, int K, int64_t *pps_out)
 	const int64_t kt = ((int64_t) K + 63) / 64;
 	int64_t s = (512 + P->nblocks * kt - 1) / (P->nblocks * kt);   // aim for >= 512 workgroups
 	s = (s + 7) / 8 * 8;                                           // whole XCD rounds
+	if (g_pbc_nsplit > 0) s = g_pbc_nsplit;                        // tuning override
 	if (s > P->npanels) s = P->npanels;
 	if (s < 1) s = 1;
 	const int64_t pps = (P->npanels + s - 1) / s;

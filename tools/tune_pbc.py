@@ -21,6 +21,7 @@ p.add_argument("--K", type=int, default=128)
 p.add_argument("--cfgs", default="32,16,8")
 p.add_argument("--ablate", action="store_true")
 p.add_argument("--reps", type=int, default=5)
+p.add_argument("--nsplits", default="0")
 a = p.parse_args()
 
 dev = torch.device("cuda", 0)
@@ -47,12 +48,17 @@ for cfg in a.cfgs.split(";"):
     plan = PbcPlan(A, a.K, cbw, wpb, logr)
     torch.cuda.synchronize(); build = (time.perf_counter() - t0) * 1e3
     row = [f"cfg cbw={cbw} wpb={wpb} logR={logr}: build {build:.1f} ms"]
-    for mode, name in ((0, "full"), (2, "no-compute")):
-        if mode and not a.ablate:
-            continue
-        lib.svt_dev_pbc_set_debug(mode)
-        ms = timed(lambda: plan.run(Y, a.nrow, out), a.reps)
-        row.append(f"{name} {ms:.3f} ms ({A.nnz / ms / 1e6:.1f} GNZ/s)")
-    lib.svt_dev_pbc_set_debug(0)
+    for ns in (int(x) for x in a.nsplits.split(",")):
+        lib.svt_dev_pbc_set_debug(100 + ns)
+        del plan
+        plan = PbcPlan(A, a.K, cbw, wpb, logr)      # workspace depends on the split count
+        for mode, name in ((0, "full"), (2, "no-compute")):
+            if mode and not a.ablate:
+                continue
+            lib.svt_dev_pbc_set_debug(mode)
+            ms = timed(lambda: plan.run(Y, a.nrow, out), a.reps)
+            row.append(f"[nsplit {ns}] {name} {ms:.3f} ms ({A.nnz / ms / 1e6:.1f} GNZ/s)")
+        lib.svt_dev_pbc_set_debug(0)
+    lib.svt_dev_pbc_set_debug(100)
     print("  ".join(row), flush=True)
     del plan
