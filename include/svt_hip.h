@@ -230,6 +230,16 @@ int svt_dev_crossprod_pbc(const svt_dev_pbc *P, const svt_dev_csc *A,
 			  int64_t out_stride_k, void *ws, size_t ws_bytes,
 			  void *stream);
 
+/* The two phases of svt_dev_crossprod_pbc() separately (so that each can be
+   timed): phase 1 = the LDS-panel product kernel (partial sums into ws),
+   phase 2 = deterministic sum of the partials into `out` + the general path
+   when Y is not finite. */
+int svt_dev_crossprod_pbc_phase(const svt_dev_pbc *P, const svt_dev_csc *A,
+				const double *Y, int64_t ldY, int K, int tr_y,
+				double *out, int64_t out_stride_c,
+				int64_t out_stride_k, void *ws, size_t ws_bytes,
+				void *stream, int phase);
+
 /* Diagnostic only (tools/tune_pbc.py): 0 = normal; 1 / 2 = timing-only builds of
    the PBC kernel without the Y staging / without the record loop (results are
    wrong by construction). */

@@ -601,10 +601,13 @@ static void launch_main(const svt_dev_pbc *P, const double *Y, int64_t ldY, int 
 
 int launch_crossprod_general_if(const CrossprodArgs &a, const int *flag, hipStream_t s);
 
-extern "C" int svt_dev_crossprod_pbc(const svt_dev_pbc *P, const svt_dev_csc *A, const double *Y,
-				     int64_t ldY, int K, int tr_y, double *out,
-				     int64_t out_stride_c, int64_t out_stride_k, void *ws,
-				     size_t ws_bytes, void *stream)
+// phase 1: the LDS-panel product kernel (partials into ws); phase 2: sum the
+// partials into `out`, then the general kernels if Y was not finite.
+extern "C" int svt_dev_crossprod_pbc_phase(const svt_dev_pbc *P, const svt_dev_csc *A,
+					   const double *Y, int64_t ldY, int K, int tr_y,
+					   double *out, int64_t out_stride_c,
+					   int64_t out_stride_k, void *ws, size_t ws_bytes,
+					   void *stream, int phase)
 {
 	hipStream_t s = (hipStream_t) stream;
 	if (P->ncol <= 0 || K <= 0)
@@ -618,21 +621,25 @@ extern "C" int svt_dev_crossprod_pbc(const svt_dev_pbc *P, const svt_dev_csc *A,
 	fl.y_nonfinite = (int *) ws;
 	double *part = (double *) ((char *) ws + 256);
 	void *gen_ws = (char *) part + (size_t) nsplit * Kp * P->ncol * 8;
-	HIP_TRY(hipMemsetAsync(ws, 0, 256, s));
-	const int key = (P->CBW / 16) * 10000 + P->WPB * 100 + P->logR;
+	if (phase == 1) {
+		HIP_TRY(hipMemsetAsync(ws, 0, 256, s));
+		const int key = (P->CBW / 16) * 10000 + P->WPB * 100 + P->logR;
 #define PBC_CASE(NV, WPB, LOGR) \
-	case (NV) * 10000 + (WPB) * 100 + (LOGR): \
-		launch_main<NV, WPB, LOGR>(P, Y, ldY, tr_y, K, nsplit, pps, part, Kp, fl, s); break;
-	switch (key) {
-	PBC_CASE(1, 16, 7) PBC_CASE(2, 16, 7)
-	PBC_CASE(1, 16, 8) PBC_CASE(2, 16, 8)
-	PBC_CASE(2, 8, 7) PBC_CASE(3, 8, 7) PBC_CASE(4, 8, 7)
-	PBC_CASE(2, 8, 6) PBC_CASE(4, 4, 5)
-	default:
-		return svt_set_error("svt_dev_crossprod_pbc: unsupported (CBW=%d, WPB=%d, logR=%d)",
-				     P->CBW, P->WPB, P->logR);
-	}
+		case (NV) * 10000 + (WPB) * 100 + (LOGR): \
+			launch_main<NV, WPB, LOGR>(P, Y, ldY, tr_y, K, nsplit, pps, part, Kp, fl, s); break;
+		switch (key) {
+		PBC_CASE(1, 16, 7) PBC_CASE(2, 16, 7)
+		PBC_CASE(1, 16, 8) PBC_CASE(2, 16, 8)
+		PBC_CASE(2, 8, 7) PBC_CASE(3, 8, 7) PBC_CASE(4, 8, 7)
+		PBC_CASE(2, 8, 6) PBC_CASE(4, 4, 5)
+		default:
+			return svt_set_error("svt_dev_crossprod_pbc: unsupported (CBW=%d, WPB=%d, logR=%d)",
+					     P->CBW, P->WPB, P->logR);
+		}
 #undef PBC_CASE
+		HIP_TRY(hipGetLastError());
+		return 0;
+	}
 	dim3 rgrid((unsigned) ((P->ncol + 255) / 256), (unsigned) K);
 	hipLaunchKernelGGL(pbc_reduce_kernel, rgrid, dim3(256), 0, s, part, nsplit, Kp, K, P->ncol,
 			   P->col_has_na, out, out_stride_c, out_stride_k);
@@ -645,4 +652,16 @@ extern "C" int svt_dev_crossprod_pbc(const svt_dev_pbc *P, const svt_dev_csc *A,
 	a.out = out; a.out_stride_c = out_stride_c; a.out_stride_k = out_stride_k;
 	a.ws = gen_ws; a.ws_bytes = crossprod_ws_bytes(P->nrow, P->ncol, K);
 	return launch_crossprod_general_if(a, fl.y_nonfinite, s);
+}
+
+extern "C" int svt_dev_crossprod_pbc(const svt_dev_pbc *P, const svt_dev_csc *A, const double *Y,
+				     int64_t ldY, int K, int tr_y, double *out,
+				     int64_t out_stride_c, int64_t out_stride_k, void *ws,
+				     size_t ws_bytes, void *stream)
+{
+	if (svt_dev_crossprod_pbc_phase(P, A, Y, ldY, K, tr_y, out, out_stride_c, out_stride_k,
+					ws, ws_bytes, stream, 1))
+		return -1;
+	return svt_dev_crossprod_pbc_phase(P, A, Y, ldY, K, tr_y, out, out_stride_c, out_stride_k,
+					   ws, ws_bytes, stream, 2);
 }

@@ -46,6 +46,9 @@ def _lib():
         lib.svt_dev_crossprod_pbc.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int,
                                               c_int, c_void_p, c_int64, c_int64, c_void_p,
                                               c_size_t, c_void_p]
+        lib.svt_dev_crossprod_pbc_phase.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int,
+                                                    c_int, c_void_p, c_int64, c_int64, c_void_p,
+                                                    c_size_t, c_void_p, c_int]
         lib.svt_dev_colstats.argtypes = [c_void_p, c_int, c_int, c_double, c_int64,
                                          c_void_p, c_void_p, c_void_p]
         lib.svt_dev_rowsums.argtypes = [c_void_p, c_int, c_int64, c_void_p, c_void_p]
@@ -145,6 +148,14 @@ class PbcPlan:
         _check(_lib().svt_dev_crossprod_pbc(self._p, self.A.handle, Y.data_ptr(), ldY, self.K,
                                             int(tr_y), out.data_ptr(), stride_c, stride_k,
                                             self.ws.data_ptr(), self.ws.numel(), _stream()))
+
+    def run_phase(self, phase, Y, ldY, out, stride_c=1, stride_k=None, tr_y=False):
+        if stride_k is None:
+            stride_k = self.A.ncol
+        _check(_lib().svt_dev_crossprod_pbc_phase(self._p, self.A.handle, Y.data_ptr(), ldY,
+                                                  self.K, int(tr_y), out.data_ptr(), stride_c,
+                                                  stride_k, self.ws.data_ptr(), self.ws.numel(),
+                                                  _stream(), phase))
 
     def __del__(self):
         try:
