@@ -226,18 +226,21 @@ def main():
             e1.record(); torch.cuda.synchronize()
             return e0.elapsed_time(e1) / reps
         grp = torch.randint(1, 1001, (nrow,), device=dev, dtype=torch.int32)
+        from sparsearray_amd.device import _lib as _devlib
+        rs_out = torch.empty(nrow, dtype=torch.float64, device=dev)
+        rs_ws = torch.empty(_devlib().svt_dev_rowstats_ws_bytes(nrow, ncol), dtype=torch.uint8, device=dev)
         ex = {}
         for name, fn, nbytes in (
             ("colSums", lambda: colstats(A, "sum"), nnz * 8 + ncol * 16),
             ("colVars", lambda: colstats(A, "var1"), nnz * 8 + ncol * 16),
-            ("rowSums", lambda: rowsums(A), nnz * 12 + nrow * 8),
+            ("rowSums", lambda: rowsums(A, out=rs_out, ws=rs_ws), nnz * 12 + nrow * 8),
             ("rowsum_1e3_groups", lambda: rowsum(A, grp, 1000), nnz * 12 + nrow * 4 + 1000 * ncol * 8),
         ):
             ms = timed(fn)
             ex[name] = {"ms": ms, "GNZ/s": nnz / ms / 1e6, "GB/s": nbytes / ms / 1e6}
         res["extras"] = ex
     if world == 1 and not a.no_cpu_baseline:
-        ns = max(1, min(ncol, int(8e7 / max(nnz / ncol, 1))))   # ~1e10 nz*K: 10-30 s of CPU work
+        ns = max(1, min(ncol, int(1e8 / max(nnz / ncol, 1))))   # <= 1e8 nz x K: 10-30 core-seconds
         cb, ref_out, ns = cpu_baseline(col_ptr, row_idx, val, Y, nrow, K, ns)
         # the timed GPU result must agree with the CPU oracle on the sample
         got = out[:, :ns].cpu().numpy()

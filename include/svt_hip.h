@@ -253,10 +253,12 @@ int svt_dev_colstats(const svt_dev_csc *A, int opcode, int na_rm,
 		     double center, int64_t inner, void *out, int *warn_flag,
 		     void *stream);
 
-/* row sums: out[(j % inner) * nrow + r] += A[r, j]; `out` (doubles) must be
-   zeroed by the caller. */
+/* row sums: out[(j % inner) * nrow + r] = sum over the leaves j that map to
+   that cell.  Every output cell is owned by one workgroup (LDS row panels, no
+   memory atomics); ws: svt_dev_rowstats_ws_bytes() bytes. */
+size_t svt_dev_rowstats_ws_bytes(int64_t nrow, int64_t ncol);
 int svt_dev_rowsums(const svt_dev_csc *A, int na_rm, int64_t inner,
-		    double *out, void *stream);
+		    double *out, void *ws, size_t ws_bytes, void *stream);
 
 /* rowsum(): out (ngroup x ncol, zeroed by the callee); group is a device
    array of nrow 1-based group ids (NA -> last group).  f64 input only at

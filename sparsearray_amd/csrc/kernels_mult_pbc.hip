@@ -327,8 +327,8 @@ struct Stager {
 //           source-2 and destination relative to M0 = 2*c_q
 //           (1 SALU + 1 VALU per record)
 // and ONE `s_waitcnt lgkmcnt(0)` per step, after the FMAs: the scalar load and
-// the LDS reads of the step complete under them.  Three SGPR blocks (s[32:47],
-// s[48:63], s[64:79]) and two y sets rotate, hence 6 phases per loop trip.
+// the LDS reads of the step complete under them.  Three SGPR blocks (s[36:51],
+// s[52:67], s[68:83]) and two y sets rotate, hence 6 phases per loop trip.
 // The stream of a wavefront is contiguous (and has 3 batches of slack at the
 // end of the array), so the look-ahead stages never need to know where the
 // tile ends; row offsets of look-ahead records are valid LDS addresses.
@@ -352,22 +352,23 @@ struct Stager {
 	"s_set_gpr_idx_idx s" #I3 "\n\t"                                                \
 	"v_fma_f64 v[64:65], s[" #A3L ":" #A3H "], %[" #YS "3], v[64:65]\n\t"            \
 	"s_set_gpr_idx_off\n\t"
-// block A = s[32:47], B = s[48:63], C = s[64:79]
+// block A = s[36:51], B = s[52:67], C = s[68:83]  (s32-s35 are the stack/frame
+// pointer registers of the calling convention and are left alone)
 #ifdef PBC_EXPERIMENT_CACHED   /* timing experiment only: every load hits a 1 KB window */
-#define PBC_LOAD_A "s_and_b32 s80, %[lo], 0x3c0\n\ts_load_dwordx16 s[32:47], %[base], s80\n\t"
-#define PBC_LOAD_B "s_and_b32 s80, %[lo], 0x3c0\n\ts_load_dwordx16 s[48:63], %[base], s80\n\t"
-#define PBC_LOAD_C "s_and_b32 s80, %[lo], 0x3c0\n\ts_load_dwordx16 s[64:79], %[base], s80\n\t"
+#define PBC_LOAD_A "s_and_b32 s84, %[lo], 0x3c0\n\ts_load_dwordx16 s[36:51], %[base], s84\n\t"
+#define PBC_LOAD_B "s_and_b32 s84, %[lo], 0x3c0\n\ts_load_dwordx16 s[52:67], %[base], s84\n\t"
+#define PBC_LOAD_C "s_and_b32 s84, %[lo], 0x3c0\n\ts_load_dwordx16 s[68:83], %[base], s84\n\t"
 #else
-#define PBC_LOAD_A "s_load_dwordx16 s[32:47], %[base], %[lo]\n\t"
-#define PBC_LOAD_B "s_load_dwordx16 s[48:63], %[base], %[lo]\n\t"
-#define PBC_LOAD_C "s_load_dwordx16 s[64:79], %[base], %[lo]\n\t"
+#define PBC_LOAD_A "s_load_dwordx16 s[36:51], %[base], %[lo]\n\t"
+#define PBC_LOAD_B "s_load_dwordx16 s[52:67], %[base], %[lo]\n\t"
+#define PBC_LOAD_C "s_load_dwordx16 s[68:83], %[base], %[lo]\n\t"
 #endif
-#define PBC_D_A(YS) PBC_D4(32, 36, 40, 44, YS)
-#define PBC_D_B(YS) PBC_D4(48, 52, 56, 60, YS)
-#define PBC_D_C(YS) PBC_D4(64, 68, 72, 76, YS)
-#define PBC_F_A(YS) PBC_F4(33, 34, 35, 37, 38, 39, 41, 42, 43, 45, 46, 47, YS)
-#define PBC_F_B(YS) PBC_F4(49, 50, 51, 53, 54, 55, 57, 58, 59, 61, 62, 63, YS)
-#define PBC_F_C(YS) PBC_F4(65, 66, 67, 69, 70, 71, 73, 74, 75, 77, 78, 79, YS)
+#define PBC_D_A(YS) PBC_D4(36, 40, 44, 48, YS)
+#define PBC_D_B(YS) PBC_D4(52, 56, 60, 64, YS)
+#define PBC_D_C(YS) PBC_D4(68, 72, 76, 80, YS)
+#define PBC_F_A(YS) PBC_F4(37, 38, 39, 41, 42, 43, 45, 46, 47, 49, 50, 51, YS)
+#define PBC_F_B(YS) PBC_F4(53, 54, 55, 57, 58, 59, 61, 62, 63, 65, 66, 67, YS)
+#define PBC_F_C(YS) PBC_F4(69, 70, 71, 73, 74, 75, 77, 78, 79, 81, 82, 83, YS)
 // one phase: load into LB, LDS reads for DB into set YD, FMAs of FB with set YF
 #define PBC_PHASE(LOADTXT, DTXT, FTXT)                                                 \
 	"s_add_u32 %[lo], %[lo], 64\n\t"                                               \
@@ -377,6 +378,7 @@ struct Stager {
 	"s_cmp_eq_u32 %[nb], 0\n\t"                                                    \
 	"s_cbranch_scc1 9f\n\t"
 #define PBC_PANEL_TXT                                                                  \
+	"s_mov_b32 s85, m0\n\t"             /* VGPR-index mode rewrites M0 */           \
 	"s_cmp_eq_u32 %[nb], 0\n\t"                                                    \
 	"s_cbranch_scc1 9f\n\t"                                                        \
 	/* prologue: batch 0 -> A, then its LDS reads + batch 1 -> B */                \
@@ -393,18 +395,14 @@ struct Stager {
 	PBC_PHASE(PBC_LOAD_A, PBC_D_C(yb), PBC_F_B(ya))                                \
 	PBC_PHASE(PBC_LOAD_B, PBC_D_A(ya), PBC_F_C(yb))                                \
 	"s_branch 1b\n"                                                                \
-	"9:\n\t"
+	"9:\n\t"                                                                       \
+	"s_mov_b32 m0, s85\n\t"
 #define PBC_PANEL_OPS                                                                  \
 	[lo] "+s"(lo_), [nb] "+s"(nb_),                                                \
 	[t0] "=&v"(t0_), [t1] "=&v"(t1_), [t2] "=&v"(t2_), [t3] "=&v"(t3_),              \
 	[ya0] "=&v"(ya0_), [ya1] "=&v"(ya1_), [ya2] "=&v"(ya2_), [ya3] "=&v"(ya3_),      \
 	[yb0] "=&v"(yb0_), [yb1] "=&v"(yb1_), [yb2] "=&v"(yb2_), [yb3] "=&v"(yb3_)
-#define PBC_PANEL_CLOBBERS                                                             \
-	"m0", "scc", "memory", "s32", "s33", "s34", "s35", "s36", "s37", "s38", "s39",   \
-	"s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50",     \
-	"s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61",     \
-	"s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72",     \
-	"s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80"
+#define PBC_PANEL_CLOBBERS "scc", "memory", "s85", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84"
 
 // DBG: 0 = product build; 1 = skip staging of Y (timing only); 2 = skip the
 // record loop (timing only).  Selected with svt_dev_pbc_set_debug().

@@ -176,6 +176,215 @@ __global__ void rowstats_minmax_finish_kernel(RowStatsArgs a)
 	}
 }
 
+// --------------------------------------------------------------------------
+// Row-panel variant: no memory-side atomics.
+//
+// The output (inner x nrow cells) is cut into panels of ROWPANEL rows; one
+// workgroup owns one (output column i, panel q) pair, keeps its cells in LDS
+// (ds_add_f64 / ds_min_u64 ...), walks the nstrata leaves j = i + s*inner that
+// land on it and stores the finished cells once, coalesced.  The part of leaf j
+// inside panel q is a contiguous run of its (sorted) offsets; the run bounds
+// come from a table built by one binary search per (leaf, panel boundary)
+// (rowpanel_table_kernel).  Traffic: A once (12 B/nz) + the table + out once.
+// --------------------------------------------------------------------------
+#define ROWPANEL 2048
+#define ROWPANEL_NT 1024
+
+size_t rowstats_panel_ws_bytes(int64_t nrow, int64_t ncol)
+{
+	const int64_t npan = (nrow + ROWPANEL - 1) / ROWPANEL;
+	return (size_t) (ncol > 0 ? ncol : 1) * (size_t) (npan + 1) * 4 + 64;
+}
+
+// pt[q*ncol + j] = number of offsets of leaf j that are < q*ROWPANEL, q = 0..npan.
+// One wavefront per leaf streams its offsets once; the element that is the
+// first of its leaf at or past a panel boundary writes that boundary's entry.
+__global__ void __launch_bounds__(256)
+rowpanel_table_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__ row_idx,
+		      int64_t ncol, int64_t npan, int32_t *__restrict__ pt)
+{
+	const int64_t j = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
+	const int lane = threadIdx.x & 63;
+	if (j >= ncol)
+		return;
+	const int64_t beg = col_ptr[j], end = col_ptr[j + 1];
+	for (int64_t k = beg + lane; k < end; k += SVT_WAVE) {
+		const int64_t p = row_idx[k] / ROWPANEL;
+		const int64_t pp = k == beg ? -1 : row_idx[k - 1] / ROWPANEL;
+		for (int64_t q = pp + 1; q <= p; q++)
+			pt[q * ncol + j] = (int32_t) (k - beg);
+	}
+	// boundaries past the last offset (all of them for an empty leaf)
+	const int64_t pl = end > beg ? row_idx[end - 1] / ROWPANEL : -1;
+	for (int64_t q = pl + 1 + lane; q <= npan; q += SVT_WAVE)
+		pt[q * ncol + j] = (int32_t) (end - beg);
+}
+
+// G = lanes that share one leaf segment (power of two <= 64): the host picks
+// it from the mean segment length so that short segments still fill the wave.
+template <typename T>
+__global__ void __launch_bounds__(ROWPANEL_NT)
+rowstats_panel_kernel(RowStatsArgs a, const int32_t *__restrict__ pt, int64_t npan, int G)
+{
+	extern __shared__ unsigned long long lds64[];   // ROWPANEL cells
+	const int64_t q = blockIdx.x, i = blockIdx.y;
+	const int tid = threadIdx.x;
+	const int64_t r0 = q * ROWPANEL;
+	const int np = (int) (a.nrow - r0 < ROWPANEL ? a.nrow - r0 : ROWPANEL);   // rows in this panel
+	const int64_t cell0 = i * a.nrow + r0;
+	const bool is_dbl = sizeof(T) == 8;
+	const bool narm = a.na_rm != 0;
+	const int oc = a.opcode;
+	const bool is_minmax = oc == SVT_OP_MIN || oc == SVT_OP_MAX;
+	double *accd = (double *) lds64;
+	double *cen = accd + ROWPANEL;                       // centered_X2_sum only
+	int *flg = (int *) (lds64 + ROWPANEL);               // min/max only
+	unsigned int *cov = (unsigned int *) (flg + ROWPANEL);
+	const T *__restrict__ val = (const T *) a.val;
+	const int32_t *__restrict__ row = a.row_idx;
+	const double NAr = svt_na_real();
+
+	for (int r = tid; r < np; r += ROWPANEL_NT) {
+		if (is_minmax) {
+			lds64[r] = oc == SVT_OP_MIN ? ~0ULL : 0ULL;
+			flg[r] = 0;
+			cov[r] = 0;
+		} else if (oc == SVT_OP_CENTERED_X2_SUM) {
+			const double c = a.center ? a.center[cell0 + r] : 0.0;
+			cen[r] = c;
+			accd[r] = a.center ? c * c * (double) a.nstrata : 0.0;
+		} else if (oc == SVT_OP_ANYNA) {
+			((int *) lds64)[r] = 0;
+		} else {
+			accd[r] = 0.0;
+		}
+	}
+	__syncthreads();
+	const int sub = tid / G, sl = tid % G, nsub = ROWPANEL_NT / G;
+	const int32_t *__restrict__ pt0 = pt + q * a.ncol, *__restrict__ pt1 = pt0 + a.ncol;
+	int64_t nbeg = 0, nend = 0;
+	if (sub < a.nstrata) {
+		const int64_t j = i + (int64_t) sub * a.inner;
+		const int64_t base = a.col_ptr[j];
+		nbeg = base + pt0[j]; nend = base + pt1[j];
+	}
+	for (int64_t s = sub; s < a.nstrata; s += nsub) {
+		const int64_t beg = nbeg, end = nend;
+		if (s + nsub < a.nstrata) {                  // next segment's bounds, ahead of use
+			const int64_t j = i + (s + nsub) * a.inner;
+			const int64_t base = a.col_ptr[j];
+			nbeg = base + pt0[j]; nend = base + pt1[j];
+		}
+		for (int64_t k = beg + sl; k < end; k += G) {
+			const T v = val[k];
+			const int r = (int) (row[k] - r0);
+			const bool miss = is_dbl ? (v != v) : ((int) v == NA_INT);
+			switch (oc) {
+			case SVT_OP_ANYNA:
+				if (miss) ((int *) lds64)[r] = 1;
+				break;
+			case SVT_OP_COUNTNAS:
+				if (miss) atomicAdd(accd + r, 1.0);
+				break;
+			case SVT_OP_SUM:
+				if (miss && narm) break;
+				atomicAdd(accd + r, (!is_dbl && miss) ? NAr : (double) v);
+				break;
+			case SVT_OP_CENTERED_X2_SUM: {
+				const double c = cen[r];
+				if (miss && narm) { atomicAdd(accd + r, -(c * c)); break; }
+				const double x = (!is_dbl && miss) ? NAr : (double) v;
+				atomicAdd(accd + r, x * (x - 2 * c));
+				break;
+			}
+			default: {
+				atomicAdd(cov + r, 1u);
+				if (miss) {
+					const bool isna = is_dbl ? svt_is_na((double) v) : true;
+					atomicOr(flg + r, isna ? RF_NA : RF_NAN);
+					break;
+				}
+				atomicOr(flg + r, RF_HAVE);
+				const unsigned long long key = is_dbl ?
+					f64_to_ordered((double) v) :
+					(unsigned long long) ((long long) (int) v + 0x80000000LL);
+				if (oc == SVT_OP_MIN) atomicMin(lds64 + r, key);
+				else atomicMax(lds64 + r, key);
+			}
+			}
+		}
+	}
+	__syncthreads();
+	for (int r = tid; r < np; r += ROWPANEL_NT) {
+		const int64_t cell = cell0 + r;
+		if (!is_minmax) {
+			if (oc == SVT_OP_ANYNA) ((int *) a.out)[cell] = ((int *) lds64)[r];
+			else ((double *) a.out)[cell] = accd[r];
+			continue;
+		}
+		// NA > NaN > extremum; the implicit zero joins when the cell was
+		// covered fewer than nstrata times (:914-961)
+		const bool is_min = oc == SVT_OP_MIN;
+		const int fl = flg[r];
+		const bool partial = (int64_t) cov[r] < a.nstrata;
+		bool have = (fl & RF_HAVE) != 0;
+		if (is_dbl) {
+			double m = have ? ordered_to_f64(lds64[r]) : 0.0, res;
+			if (!narm && (fl & RF_NA)) res = NAr;
+			else if (!narm && (fl & RF_NAN)) res = NAN;
+			else {
+				if (partial) {
+					m = have ? (is_min ? (0.0 < m ? 0.0 : m) : (0.0 > m ? 0.0 : m)) : 0.0;
+					have = true;
+				}
+				res = have ? m : (is_min ? INFINITY : -INFINITY);
+			}
+			((double *) a.out)[cell] = res;
+		} else {
+			int m = have ? (int) ((long long) lds64[r] - 0x80000000LL) : 0, res;
+			if (!narm && (fl & RF_NA)) res = NA_INT;
+			else {
+				if (partial) {
+					m = have ? (is_min ? (0 < m ? 0 : m) : (0 > m ? 0 : m)) : 0;
+					have = true;
+				}
+				if (have) res = m;
+				else { res = NA_INT; if (a.warn_flag) *a.warn_flag = 1; }
+			}
+			((int *) a.out)[cell] = res;
+		}
+	}
+}
+
+// `ws`: rowstats_panel_ws_bytes() bytes.
+int launch_rowstats_panel(const RowStatsArgs &a, void *ws, hipStream_t s)
+{
+	if (a.out_len <= 0)
+		return 0;
+	const int64_t npan = (a.nrow + ROWPANEL - 1) / ROWPANEL;
+	int32_t *pt = (int32_t *) ws;
+	if (a.inner > 65535)
+		return svt_set_error("row stats: more than 65535 output columns per panel row");
+	if (a.ncol > 0)
+		hipLaunchKernelGGL(rowpanel_table_kernel, dim3((unsigned) ((a.ncol + 3) / 4)), dim3(256),
+				   0, s, a.col_ptr, a.row_idx, a.ncol, npan, pt);
+	// lanes per leaf segment ~ mean segment length (nnz unknown here: the
+	// caller passes it in a.nnz_hint, 0 = assume long segments)
+	int G = 64;
+	if (a.nnz_hint > 0 && a.ncol > 0) {
+		const double seg = (double) a.nnz_hint / ((double) a.ncol * (double) npan);
+		while (G > 8 && seg <= G / 2) G >>= 1;
+	}
+	const size_t lds = (size_t) ROWPANEL * 16;
+	dim3 grid((unsigned) npan, (unsigned) a.inner);
+	if (a.Rtype == SVT_REALSXP)
+		hipLaunchKernelGGL(rowstats_panel_kernel<double>, grid, dim3(ROWPANEL_NT), lds, s, a, pt, npan, G);
+	else
+		hipLaunchKernelGGL(rowstats_panel_kernel<int>, grid, dim3(ROWPANEL_NT), lds, s, a, pt, npan, G);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
 int launch_rowstats(const RowStatsArgs &a, int64_t nnz, hipStream_t s)
 {
 	(void) nnz;

@@ -144,9 +144,12 @@ struct RowStatsArgs {
 	void *out;              // device, out_len elements
 	void *scratch;          // device scratch (see rowstats_scratch_bytes)
 	int *warn_flag;
+	int64_t nnz_hint;       // nonzeros of the operand (launch tuning only), 0 = unknown
 };
 size_t rowstats_scratch_bytes(int opcode, int out_Rtype, int64_t out_len);
-int launch_rowstats(const RowStatsArgs &a, int64_t nnz, hipStream_t s);
+int launch_rowstats(const RowStatsArgs &a, int64_t nnz, hipStream_t s);      // memory atomics
+size_t rowstats_panel_ws_bytes(int64_t nrow, int64_t ncol);
+int launch_rowstats_panel(const RowStatsArgs &a, void *ws, hipStream_t s);      // LDS row panels
 
 struct GroupSumArgs {
 	const int64_t *col_ptr64;   // one of the two col_ptr flavours is set

@@ -323,17 +323,26 @@ extern "C" int svt_dev_colstats(const svt_dev_csc *A, int opcode, int na_rm,
 	return launch_colstats(a, A->nnz, (hipStream_t) stream);
 }
 
-extern "C" int svt_dev_rowsums(const svt_dev_csc *A, int na_rm, int64_t inner,
-			       double *out, void *stream)
+extern "C" size_t svt_dev_rowstats_ws_bytes(int64_t nrow, int64_t ncol)
 {
+	return rowstats_panel_ws_bytes(nrow, ncol);
+}
+
+extern "C" int svt_dev_rowsums(const svt_dev_csc *A, int na_rm, int64_t inner,
+			       double *out, void *ws, size_t ws_bytes, void *stream)
+{
+	if (inner <= 0 || A->ncol % inner != 0)
+		return svt_set_error("'inner' must divide the number of leaves");
+	if (ws_bytes < rowstats_panel_ws_bytes(A->nrow, A->ncol))
+		return svt_set_error("svt_dev_rowsums: workspace too small");
 	RowStatsArgs a;
 	memset(&a, 0, sizeof(a));
 	a.col_ptr = A->col_ptr; a.row_idx = A->row_idx; a.val = A->val;
 	a.Rtype = A->Rtype; a.ncol = A->ncol; a.nrow = A->nrow;
-	a.inner = inner; a.nstrata = inner > 0 ? A->ncol / inner : 0;
+	a.inner = inner; a.nstrata = A->ncol / inner;
 	a.out_len = inner * A->nrow;
-	a.opcode = SVT_OP_SUM; a.na_rm = na_rm; a.out = out;
-	return launch_rowstats(a, A->nnz, (hipStream_t) stream);
+	a.opcode = SVT_OP_SUM; a.na_rm = na_rm; a.out = out; a.nnz_hint = A->nnz;
+	return launch_rowstats_panel(a, ws, (hipStream_t) stream);
 }
 
 extern "C" int svt_dev_rowsum(const svt_dev_csc *A, const int *group, int ngroup,
@@ -702,9 +711,15 @@ extern "C" int svt_rowStats_SVT(const svt_view *x, int opcode, int na_rm,
 	a.inner = inner; a.nstrata = nstrata; a.out_len = out_len;
 	a.opcode = opcode; a.na_rm = na_rm;
 	a.center = center ? C.as<double>() : NULL;
-	a.out = O.p; a.scratch = S.p; a.warn_flag = W.as<int>();
-	if (launch_rowstats(a, A.h->nnz, 0))
+	a.out = O.p; a.scratch = S.p; a.warn_flag = W.as<int>(); a.nnz_hint = A.h->nnz;
+	if (inner <= 65535) {
+		DevBuf T;
+		if (T.alloc(rowstats_panel_ws_bytes(a.nrow, a.ncol)) || launch_rowstats_panel(a, T.p, 0))
+			return -1;
+		HIP_TRY(hipDeviceSynchronize());
+	} else if (launch_rowstats(a, A.h->nnz, 0)) {
 		return -1;
+	}
 	int w = 0;
 	HIP_TRY(hipMemcpy(out, O.p, (size_t) out_len * osz, hipMemcpyDeviceToHost));
 	HIP_TRY(hipMemcpy(&w, W.p, 4, hipMemcpyDeviceToHost));

@@ -51,7 +51,9 @@ def _lib():
                                                     c_size_t, c_void_p, c_int]
         lib.svt_dev_colstats.argtypes = [c_void_p, c_int, c_int, c_double, c_int64,
                                          c_void_p, c_void_p, c_void_p]
-        lib.svt_dev_rowsums.argtypes = [c_void_p, c_int, c_int64, c_void_p, c_void_p]
+        lib.svt_dev_rowstats_ws_bytes.restype = c_size_t
+        lib.svt_dev_rowstats_ws_bytes.argtypes = [c_int64, c_int64]
+        lib.svt_dev_rowsums.argtypes = [c_void_p, c_int, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]
         lib.svt_dev_rowsum.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]
         lib.svt_colStats_out_Rtype.argtypes = [c_int, c_int]
         _protos_done = True
@@ -189,10 +191,14 @@ def colstats(A: DeviceCSC, op: str, na_rm=False, center=float("nan"), inner=1):
     return out, warn
 
 
-def rowsums(A: DeviceCSC, na_rm=False, inner=1, out=None):
+def rowsums(A: DeviceCSC, na_rm=False, inner=1, out=None, ws=None):
     if out is None:
         out = torch.empty(inner * A.nrow, dtype=torch.float64, device=A.val.device)
-    _check(_lib().svt_dev_rowsums(A.handle, int(na_rm), inner, out.data_ptr(), _stream()))
+    if ws is None:
+        ws = torch.empty(_lib().svt_dev_rowstats_ws_bytes(A.nrow, A.ncol), dtype=torch.uint8,
+                         device=A.val.device)
+    _check(_lib().svt_dev_rowsums(A.handle, int(na_rm), inner, out.data_ptr(), ws.data_ptr(),
+                                  ws.numel(), _stream()))
     return out
 
 
