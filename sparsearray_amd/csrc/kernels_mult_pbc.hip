@@ -48,6 +48,7 @@
 #include <hipcub/hipcub.hpp>
 
 typedef double d16 __attribute__((ext_vector_type(16)));
+typedef double d8 __attribute__((ext_vector_type(8)));
 
 struct svt_dev_pbc {
 	int64_t nrow, ncol, nnz, nrec;
@@ -75,6 +76,8 @@ __device__ inline int64_t lower_bound_row(const int32_t *__restrict__ row, int64
 
 #define PBC_BATCH 4        // records per scalar-load batch; tiles are padded to it
 #define PBC_AHEAD 2        // panels of look-ahead of the record prefetch into L2
+#define PBC_SLACK 320       // zeroed records past the end: look-ahead loads and L2 touches land here
+#define PBC_TP_PAD 8        // tile_ptr entries past the end (= nrec): the kernels read up to [p + 3]
 
 // One wavefront per (group of CBW columns, chunk of PCH panels).  MODE 0: count
 // the records of each tile (rounded up to PBC_BATCH).  MODE 1: write records to
@@ -163,7 +166,7 @@ extern "C" svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB
 		svt_set_error("svt_dev_pbc_build: f64 operands only");
 		return NULL;
 	}
-	if (CBW <= 0 || CBW > 64 || (CBW & 15) || WPB <= 0 || WPB > 16 || logR < 4 || logR > 15) {
+	if (CBW <= 0 || CBW > 64 || WPB <= 0 || WPB > 16 || logR < 4 || logR > 15) {
 		svt_set_error("svt_dev_pbc_build: bad parameters");
 		return NULL;
 	}
@@ -178,9 +181,9 @@ extern "C" svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB
 	const int64_t ntiles = h->ngroups * h->npanels;
 	void *tmp = NULL;
 	size_t tmp_bytes = 0;
-	bool ok = hipMalloc((void **) &h->tile_ptr, (size_t) (ntiles + 1) * 8) == hipSuccess &&
+	bool ok = hipMalloc((void **) &h->tile_ptr, (size_t) (ntiles + 1 + PBC_TP_PAD) * 8) == hipSuccess &&
 		  hipMalloc((void **) &h->col_has_na, (size_t) (A->ncol > 0 ? A->ncol : 1) * 4) == hipSuccess;
-	if (ok) ok = hipMemset(h->tile_ptr, 0, (size_t) (ntiles + 1) * 8) == hipSuccess &&
+	if (ok) ok = hipMemset(h->tile_ptr, 0, (size_t) (ntiles + 1 + PBC_TP_PAD) * 8) == hipSuccess &&
 		     hipMemset(h->col_has_na, 0, (size_t) (A->ncol > 0 ? A->ncol : 1) * 4) == hipSuccess;
 	if (ok && A->ncol > 0 && A->nnz > 0) {
 		dim3 grid((unsigned) h->ngroups, (unsigned) ((h->npanels + PCH - 1) / PCH));
@@ -196,15 +199,20 @@ extern "C" svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB
 		int64_t nrec = 0;
 		if (ok) ok = hipMemcpy(&nrec, h->tile_ptr + ntiles, 8, hipMemcpyDeviceToHost) == hipSuccess;
 		h->nrec = nrec;
-		if (ok && (nrec + 4 * PBC_BATCH) * 16 >= ((int64_t) 1 << 32)) {
+		if (ok) {
+			int64_t pad[PBC_TP_PAD];
+			for (int i = 0; i < PBC_TP_PAD; i++) pad[i] = nrec;
+			ok = hipMemcpy(h->tile_ptr + ntiles + 1, pad, sizeof(pad), hipMemcpyHostToDevice) == hipSuccess;
+		}
+		if (ok && (nrec + PBC_SLACK) * 16 >= ((int64_t) 1 << 32)) {
 			svt_set_error("svt_dev_pbc_build: operand too large for 32-bit record offsets");
 			if (tmp) (void) hipFree(tmp);
 			svt_dev_pbc_release(h);
 			return NULL;
 		}
-		if (ok) ok = hipMalloc((void **) &h->rec, (size_t) (nrec + 4 * PBC_BATCH) * 16) == hipSuccess &&
-			     // the look-ahead stages of the kernel read up to 3 batches past the end
-			     hipMemset(h->rec + nrec, 0, (size_t) 4 * PBC_BATCH * 16) == hipSuccess;
+		if (ok) ok = hipMalloc((void **) &h->rec, (size_t) (nrec + PBC_SLACK) * 16) == hipSuccess &&
+			     // the look-ahead stages of the kernels read up to 3 batches past the end
+			     hipMemset(h->rec + nrec, 0, (size_t) PBC_SLACK * 16) == hipSuccess;
 		if (ok) {
 			hipLaunchKernelGGL(pbc_pass_kernel<1>, grid, dim3(64), 0, 0, A->col_ptr,
 					   A->row_idx, (const double *) A->val, A->ncol, CBW, logR,
@@ -235,6 +243,18 @@ extern "C" void svt_dev_pbc_set_debug(int mode)
 struct PbcFlags {
 	int *y_nonfinite;    // [1] any NaN/Inf/NA in the dense operand
 };
+
+// DBG == 3 (tuning only): cycles per section, per wavefront of workgroup (0,0,0):
+// [w][0] fetch issue, [1] record loop, [2] barrier after the loop, [3] commit,
+// [4] barrier after commit, [5] panels
+// (kept in the flag block at the head of the workspace, bytes 256 .. 1279)
+#define PBC_FLAG_BYTES 2048
+extern "C" int svt_dev_pbc_read_prof(const void *ws, unsigned long long *out)
+{
+	HIP_TRY(hipDeviceSynchronize());
+	HIP_TRY(hipMemcpy(out, (const char *) ws + 256, 16 * 8 * 8, hipMemcpyDeviceToHost));
+	return 0;
+}
 
 // A batch of PBC_BATCH (= 4) records = 16 dwords, held in a block of 16 SGPRs
 // that is pinned to fixed physical registers (s[32:47] / s[48:63]) so that the
@@ -412,7 +432,7 @@ crossprod_pbc_kernel(const uint4 *__restrict__ rec,
 		     const int64_t *__restrict__ tile_ptr, int64_t npanels,
 		     const double *__restrict__ Y, int64_t ldY, int64_t nrow, int K,
 		     int64_t ncol, int64_t panels_per_split, double *__restrict__ part,
-		     int64_t Kp, PbcFlags fl)
+		     int64_t Kp, PbcFlags fl, int CBW)
 {
 	// The only LDS object of this kernel: its byte offset is 0, which
 	// lds_read_batch() relies on.
@@ -453,6 +473,9 @@ crossprod_pbc_kernel(const uint4 *__restrict__ rec,
 	// refuses layouts of 4 GiB or more)
 	uint32_t off = (uint32_t) tb[0] * 16u;
 
+	unsigned long long pr[6] = {0, 0, 0, 0, 0, 0}, tq = 0;
+#define PBC_PROF(i) if (DBG == 3) { const unsigned long long t_ = __builtin_readcyclecounter(); pr[i] += t_ - tq; tq = t_; }
+	if (DBG == 3) tq = __builtin_readcyclecounter();
 	for (int64_t p = pa; p < pb; p++, tb += 1) {
 		const int64_t tbeg = tb[0], tend = tb[1];
 		// next panel of Y starts its trip from L2/HBM now, lands in registers
@@ -470,6 +493,7 @@ crossprod_pbc_kernel(const uint4 *__restrict__ rec,
 				tv = *(const uint32_t *) ((const char *) (rec + ta) + toff);
 		}
 
+		PBC_PROF(0)
 		// ---- this wavefront's records of the panel --------------------------
 		if (DBG == 2) {
 			acc[0][0] += (double) tbeg;
@@ -505,21 +529,28 @@ crossprod_pbc_kernel(const uint4 *__restrict__ rec,
 					     : PBC_PANEL_CLOBBERS);
 			}
 		}
+		PBC_PROF(1)
 		if (p + 1 < pb) {
 			__syncthreads();                    // panel p fully consumed
+			PBC_PROF(2)
 			if (DBG != 1) st.commit(ylds, Y, ldY, nrow, K, k0, p + 1, w, lane, bad);
+			PBC_PROF(3)
 			__syncthreads();
+			PBC_PROF(4)
 		}
+		if (DBG == 3) pr[5]++;
 	}
+	if (DBG == 3 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0)
+		for (int i = 0; i < 6; i++) ((unsigned long long *) (fl.y_nonfinite + 64))[w * 8 + i] = pr[i];
 	if (b == 0 && __any(bad) && lane == 0)
 		*fl.y_nonfinite = 1;
 	touch ^= tv;
 	if (touch == 0x9E3779B9u && K < 0)      // never true: keeps the prefetch loads alive
 		fl.y_nonfinite[1] = 1;
 	// ---- partial results: part[(split*Kp + k) * ncol + c] -----------------
-	const int64_t c0 = wv * (16 * NV);
+	const int64_t c0 = wv * CBW;
 	double *__restrict__ dst = part + ((int64_t) split * Kp + k0 + lane) * ncol + c0;
-	if (c0 + 16 * NV <= ncol) {                 // wave-uniform: whole slabs inside
+	if (CBW == 16 * NV && c0 + 16 * NV <= ncol) {   // wave-uniform: whole slabs inside
 #pragma unroll
 		for (int ii = 0; ii < NV; ii++)
 #pragma unroll
@@ -530,7 +561,202 @@ crossprod_pbc_kernel(const uint4 *__restrict__ rec,
 		for (int ii = 0; ii < NV; ii++)
 #pragma unroll
 			for (int jj = 0; jj < 16; jj++)
-				if (c0 + ii * 16 + jj < ncol) dst[ii * 16 + jj] = acc[ii][jj];
+				if (ii * 16 + jj < CBW && c0 + ii * 16 + jj < ncol) dst[ii * 16 + jj] = acc[ii][jj];
+	}
+}
+
+// ---------------------------------------------------------------------------
+// DMA kernel: the same product on the same layout, restructured around the three
+// things the register-staged kernel above spends its time on (measured with
+// s_memtime per section, tools/tune_pbc.py --prof: per 128-row panel ~3000
+// cycles in the record loop and ~4000 in fetch issue, two barriers and the
+// LDS write pass):
+//   * the Y panel goes global -> LDS by LDS-DMA (global_load_lds_dwordx4, one
+//     1 KiB piece = 128 rows of one dense column), double-buffered: the pieces of
+//     panel p+1 fly while panel p is consumed, ONE barrier per panel, no VGPRs
+//     and no ds_write pass.  LDS image: [dense column][128 rows + 1 pad], i.e.
+//     odd columns start 8 mod 16 bytes (tools/micro/stage_bench.hip checks that
+//     the DMA accepts that) so the lane = dense-column reads stay conflict-free.
+//   * L2 touches (one dword per 128-byte line) of this wavefront's records two
+//     panels ahead and of this workgroup's share of the Y panel three panels
+//     ahead, issued AFTER the DMA pieces so that the in-order vmcnt wait for the
+//     pieces does not wait for them: each touch gets two panel periods to land
+//     and the DMA / scalar loads that follow hit L2.
+//   * the whole panel loop is one asm statement (pbc_dma_asm.inc, generated by
+//     tools/gen_pbc_asm.py): the scalar-load pipeline of the record stream runs
+//     on across panel boundaries (only the LDS reads restart), loads use
+//     immediate offsets, the loop counter borrows instead of comparing.
+// The finiteness prescan of Y (src/SparseMatrix_mult.c:23-28) reads this
+// workgroup's 1/nblocks share of every landed panel back from LDS.
+// Grid: 1-D; when the number of row splits is a multiple of 8 the decode keeps
+// all column blocks of one (row split, dense tile) on one XCD, next to each
+// other in launch order, so that they pull the same Y panels through one L2 at
+// about the same time.
+// Preconditions (checked by the launcher, else the kernel above runs):
+// column-major Y, WPB = 16, logR = 7, nrow >= 256.
+// ---------------------------------------------------------------------------
+#include "pbc_dma_asm.inc"
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+#define PBC_DMA_YAHEAD 3
+#define PBC_DMA_CLOBBERS "memory", "scc", "vcc", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83"
+
+template <int NV, bool PROF>
+__global__ void __launch_bounds__(1024)
+crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restrict__ tile_ptr,
+			 int64_t npanels, const double *__restrict__ Y, int64_t ldY, int64_t nrow,
+			 int K, int64_t ncol, int CBW, int nsplit, int nblocks,
+			 int64_t panels_per_split, double *__restrict__ part, int64_t Kp,
+			 PbcFlags fl, int rt_lines)
+{
+	extern __shared__ double ylds[];            // 2 buffers x [64][129]
+	const int tid = threadIdx.x;
+	const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int kt = (int) (Kp / 64);
+	const int L = blockIdx.x;
+	int b, kh, split;
+	if ((nsplit & 7) == 0) {
+		const int xcd = L & 7, j = L >> 3, u = j / nblocks;
+		b = j % nblocks; kh = u % kt; split = (u / kt) * 8 + xcd;
+	} else {
+		const int u = L / nblocks;
+		b = L % nblocks; kh = u % kt; split = u / kt;
+	}
+	const int64_t pa = (int64_t) split * panels_per_split;
+	const int64_t pb = pa + panels_per_split < npanels ? pa + panels_per_split : npanels;
+	if (pa >= pb)
+		return;
+	const int k0 = kh * 64;
+	const int64_t wv = (int64_t) b * 16 + w;
+	const int64_t *__restrict__ tb = tile_ptr + (wv * npanels + pa);
+	const int64_t lastfull = nrow / 128 - 1;    // >= 1 (nrow >= 256)
+	const bool partial = (nrow & 127) != 0;
+
+	// NV == 3 keeps 40 columns (16 + 16 + 8): all 128 VGPRs are spoken for
+	// otherwise and the compiler needs a few for itself
+	d16 acc[NV > 2 ? 2 : NV];
+	d8 acc8 = 0.0;
+#pragma unroll
+	for (int i = 0; i < (NV > 2 ? 2 : NV); i++) acc[i] = 0.0;
+
+	// ---- wave-uniform state (SGPR vectors pinned to s[84:99], s[20:35]) ----------
+	u32x16 P0, P1;
+	{
+		const uint64_t recp = (uint64_t) (uintptr_t) rec, tpp = (uint64_t) (uintptr_t) (tb + 3);
+		P0[0] = (uint32_t) recp; P0[1] = (uint32_t) (recp >> 32);
+		P0[2] = (uint32_t) tpp; P0[3] = (uint32_t) (tpp >> 32);
+		P0[4] = (uint32_t) tb[0] * 16u;                 // stream cursor (bytes)
+		P0[5] = (uint32_t) pa; P0[6] = (uint32_t) pb;
+		P0[7] = 0;
+		P0[8] = (uint32_t) tb[0]; P0[9] = (uint32_t) tb[1]; P0[10] = (uint32_t) tb[2];
+		P0[11] = PBC_DMA_BUF;                           // toggles to 0 for the first panel
+		P0[12] = (uint32_t) (w * 4 * PBC_DMA_ROW + PBC_DMA_BUF);
+		// finiteness prescan: this block's share of the 8192 doubles of a panel
+		const int chunk = (8192 + nblocks - 1) / nblocks;
+		const int nit = (chunk + 1023) / 1024;
+		P0[13] = (uint32_t) nit;
+		P0[14] = partial ? (uint32_t) (npanels - 1) : 0xFFFFFFFFu;
+		P0[15] = partial ? (uint32_t) ((128 - (nrow & 127)) * 8) : 0u;
+#pragma unroll
+		for (int q = 0; q < 4; q++) {
+			int kk = k0 + w * 4 + q;
+			if (kk > K - 1) kk = K - 1;                 // tail of K: a valid column, never stored
+			const uint64_t src = (uint64_t) (uintptr_t) (Y + (int64_t) kk * ldY + (pa + 1) * 128);
+			P1[2 * q] = (uint32_t) src; P1[2 * q + 1] = (uint32_t) (src >> 32);
+		}
+		const int64_t ty = pa + PBC_DMA_YAHEAD < lastfull ? pa + PBC_DMA_YAHEAD : lastfull;
+		const uint64_t ytb = (uint64_t) (uintptr_t) (Y + (int64_t) k0 * ldY + ty * 128);
+		P1[8] = (uint32_t) ytb; P1[9] = (uint32_t) (ytb >> 32);
+		P1[10] = lastfull > PBC_DMA_YAHEAD ? (uint32_t) (lastfull - PBC_DMA_YAHEAD) : 0u;
+		P1[11] = 0; P1[12] = 0; P1[13] = 0; P1[14] = 0; P1[15] = 0;
+	}
+	// ---- per-lane constants (VGPR vector pinned to v[0:15]) -----------------------
+	u32x16 V0 = 0, V1 = 0;
+	{
+		const int lane = tid & 63;
+		V0[0] = (uint32_t) lane * PBC_DMA_ROW;
+		V0[1] = (uint32_t) lane * 16u;
+		V0[2] = lane < rt_lines ? (uint32_t) lane * 128u : 0u;
+		// dense touch: lanes 32.. take this wavefront's lines of the block's share
+		const int lines_blk = (512 + nblocks - 1) / nblocks;
+		const int nl = (lines_blk + 15) / 16;           // <= 32
+		uint32_t yto = 0;
+		if (lane >= 32 && lane - 32 < nl && (uint64_t) ldY * 8 * 64 < 0xFFFFFFFFull) {
+			int ln = (b * lines_blk + w * nl + (lane - 32)) % 512;
+			int kr = ln >> 3;
+			if (k0 + kr > K - 1) kr = K - 1 - k0;
+			yto = (uint32_t) ((int64_t) kr * ldY * 8 + (ln & 7) * 128);
+		}
+		V0[3] = yto;
+		const int chunk = (8192 + nblocks - 1) / nblocks;
+		const int nit = (chunk + 1023) / 1024;
+		int e0 = b * chunk;
+		if (e0 > 8192 - nit * 1024) e0 = 8192 - nit * 1024;
+		const int e = e0 + tid;
+		V0[4] = (uint32_t) ((e >> 7) * PBC_DMA_ROW + (e & 127) * 8);
+	}
+	// ---- first panel: straight into buffer 0 ---------------------------------------
+	{
+		const int lane = tid & 63;
+		const bool clampme = partial && pa == npanels - 1;
+#pragma unroll
+		for (int q = 0; q < 4; q++) {
+			int kk = k0 + w * 4 + q;
+			if (kk > K - 1) kk = K - 1;
+			// a partial last panel is staged as rows nrow-128 .. nrow-1
+			const int64_t r0 = clampme ? nrow - 128 : pa * 128;
+			const double *src = Y + (int64_t) kk * ldY + r0 + lane * 2;
+			double *dst = ylds + (w * 4 + q) * 129;
+			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) src,
+							 (__attribute__((address_space(3))) void *) dst, 16, 0, 0);
+		}
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	}
+	if constexpr (PROF) {
+		// tuning build (NV <= 2): cycles per section in v[96:100], see gen_pbc_asm.py
+		u32x16 PV = 0;
+		asm volatile(PBC_DMA_ASM_TEXT_PROF
+			     : "+{v[32:63]}"(acc[0]), "+{v[64:95]}"(acc[NV > 1 ? 1 : 0]),
+			       "+{v[0:15]}"(V0), "+{v[16:31]}"(V1), "+{s[84:99]}"(P0), "+{s[20:35]}"(P1),
+			       "+{v[96:111]}"(PV)
+			     : : PBC_DMA_CLOBBERS, "v112", "v113");
+		if (blockIdx.x == 0 && (tid & 63) == 0) {
+			unsigned long long *o = (unsigned long long *) (fl.y_nonfinite + 64) + w * 8;
+			// [rec, dma wait, barrier, issue, prescan, panels]
+			for (int i = 0; i < 5; i++) o[i] = PV[i];
+			o[5] = (unsigned long long) (pb - pa);
+		}
+	} else if constexpr (NV == 1) {
+		asm volatile(PBC_DMA_ASM_TEXT
+			     : "+{v[32:63]}"(acc[0]), "+{v[0:15]}"(V0), "+{v[16:31]}"(V1),
+			       "+{s[84:99]}"(P0), "+{s[20:35]}"(P1)
+			     : : PBC_DMA_CLOBBERS);
+	} else if constexpr (NV == 2) {
+		asm volatile(PBC_DMA_ASM_TEXT
+			     : "+{v[32:63]}"(acc[0]), "+{v[64:95]}"(acc[NV > 1 ? 1 : 0]),
+			       "+{v[0:15]}"(V0), "+{v[16:31]}"(V1), "+{s[84:99]}"(P0), "+{s[20:35]}"(P1)
+			     : : PBC_DMA_CLOBBERS);
+	} else {
+		asm volatile(PBC_DMA_ASM_TEXT
+			     : "+{v[32:63]}"(acc[0]), "+{v[64:95]}"(acc[NV > 1 ? 1 : 0]),
+			       "+{v[96:111]}"(acc8),
+			       "+{v[0:15]}"(V0), "+{v[16:31]}"(V1), "+{s[84:99]}"(P0), "+{s[20:35]}"(P1)
+			     : : PBC_DMA_CLOBBERS);
+	}
+	if (P1[11] != 0 && (tid & 63) == 0)
+		*fl.y_nonfinite = 1;
+	// ---- partial results: part[(split*Kp + k) * ncol + c] ------------------------
+	const int lane2 = (int) __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+	const int64_t c0 = wv * CBW;
+	double *__restrict__ dst = part + ((int64_t) split * Kp + k0 + lane2) * ncol + c0;
+#pragma unroll
+	for (int ii = 0; ii < (NV > 2 ? 2 : NV); ii++)
+#pragma unroll
+		for (int jj = 0; jj < 16; jj++)
+			if (ii * 16 + jj < CBW && c0 + ii * 16 + jj < ncol) dst[ii * 16 + jj] = acc[ii][jj];
+	if constexpr (NV > 2) {
+#pragma unroll
+		for (int jj = 0; jj < 8; jj++)
+			if (32 + jj < CBW && c0 + 32 + jj < ncol) dst[32 + jj] = acc8[jj];
 	}
 }
 
@@ -553,16 +779,38 @@ __global__ void pbc_reduce_kernel(const double *__restrict__ part, int nsplit, i
 // launch
 // ---------------------------------------------------------------------------
 // Row splits: enough workgroups to fill the chip, every split non-empty.
-static int pick_nsplit(const svt_dev_pbc *P, int K, int64_t *pps_out)
+static bool pbc_dma_ok(const svt_dev_pbc *P, int tr_y)
+{
+	return !tr_y && P->WPB == 16 && P->logR == 7 && P->nrow >= 256 &&
+	       g_pbc_debug != 9;                    // 9: force the register-staged kernel (tuning)
+}
+
+static int pick_nsplit(const svt_dev_pbc *P, int K, bool dma, int64_t *pps_out)
 {
 	const int64_t kt = ((int64_t) K + 63) / 64;
-	int64_t s = (512 + P->nblocks * kt - 1) / (P->nblocks * kt);   // aim for >= 512 workgroups
-	s = (s + 7) / 8 * 8;                                           // whole XCD rounds
-	if (g_pbc_nsplit > 0) s = g_pbc_nsplit;                        // tuning override
+	const int64_t units = P->nblocks * kt;
+	int64_t s;
+	if (dma && P->npanels >= 8 * 16) {
+		// One workgroup per CU (LDS, VGPRs), 32 CUs per XCD, the column blocks of a
+		// (split, dense tile) pair share an XCD: take the number of splits per XCD
+		// that leaves the last round of each XCD fullest.
+		int64_t best = 1;
+		double best_eff = 0.0;
+		for (int64_t sx = 1; sx <= 16 && P->npanels / (8 * sx) >= 16; sx++) {
+			const int64_t u = units * sx, rounds = (u + 31) / 32;
+			const double eff = (double) u / (double) (rounds * 32);
+			if (eff > best_eff + 1e-9) { best_eff = eff; best = sx; }
+		}
+		s = 8 * best;
+	} else {
+		s = (512 + units - 1) / units;          // aim for >= 512 workgroups
+		s = (s + 7) / 8 * 8;                    // whole XCD rounds
+	}
+	if (g_pbc_nsplit > 0) s = g_pbc_nsplit;        // tuning override
 	if (s > P->npanels) s = P->npanels;
 	if (s < 1) s = 1;
 	const int64_t pps = (P->npanels + s - 1) / s;
-	s = (P->npanels + pps - 1) / pps;                              // drop empty splits
+	s = (P->npanels + pps - 1) / pps;              // drop empty splits
 	if (pps_out) *pps_out = pps;
 	return (int) s;
 }
@@ -570,9 +818,13 @@ static int pick_nsplit(const svt_dev_pbc *P, int K, int64_t *pps_out)
 extern "C" size_t svt_dev_crossprod_pbc_ws_bytes(const svt_dev_pbc *P, int K)
 {
 	const int64_t Kp = ((int64_t) K + 63) / 64 * 64;
-	const int ns = pick_nsplit(P, K, NULL);
-	// [flags 256 B][partials][general-path workspace]
-	return 256 + (size_t) ns * Kp * (P->ncol > 0 ? P->ncol : 1) * 8 +
+	int ns = pick_nsplit(P, K, false, NULL);
+	if (pbc_dma_ok(P, 0)) {
+		const int nd = pick_nsplit(P, K, true, NULL);
+		if (nd > ns) ns = nd;
+	}
+	// [flags][partials][general-path workspace]
+	return PBC_FLAG_BYTES + (size_t) ns * Kp * (P->ncol > 0 ? P->ncol : 1) * 8 +
 	       crossprod_ws_bytes(P->nrow, P->ncol, K);
 }
 
@@ -585,16 +837,35 @@ static void launch_main(const svt_dev_pbc *P, const double *Y, int64_t ldY, int 
 	const size_t lds = (size_t) 64 * (R + 1) * 8;
 	dim3 grid((unsigned) nsplit, (unsigned) (Kp / 64), (unsigned) P->nblocks);
 	void (*kern)(const uint4 *, const int64_t *, int64_t, const double *,
-		     int64_t, int64_t, int, int64_t, int64_t, double *, int64_t, PbcFlags);
+		     int64_t, int64_t, int, int64_t, int64_t, double *, int64_t, PbcFlags, int);
 	if (tr_y)
-		kern = g_pbc_debug == 2 ? crossprod_pbc_kernel<NV, WPB, LOGR, true, 2> :
-					  crossprod_pbc_kernel<NV, WPB, LOGR, true, 0>;
+		kern = crossprod_pbc_kernel<NV, WPB, LOGR, true, 0>;
 	else
 		kern = g_pbc_debug == 2 ? crossprod_pbc_kernel<NV, WPB, LOGR, false, 2> :
+		       g_pbc_debug == 3 ? crossprod_pbc_kernel<NV, WPB, LOGR, false, 3> :
 					  crossprod_pbc_kernel<NV, WPB, LOGR, false, 0>;
 	(void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
 	hipLaunchKernelGGL(kern, grid, dim3(WPB * 64), lds, s, P->rec, P->tile_ptr, P->npanels,
-			   Y, ldY, P->nrow, K, P->ncol, pps, part, Kp, fl);
+			   Y, ldY, P->nrow, K, P->ncol, pps, part, Kp, fl, P->CBW);
+}
+
+template <int NV>
+static void launch_dma(const svt_dev_pbc *P, const double *Y, int64_t ldY, int K, int nsplit,
+		       int64_t pps, double *part, int64_t Kp, PbcFlags fl, hipStream_t s)
+{
+	const size_t lds = (size_t) 2 * PBC_DMA_BUF;
+	const int kt = (int) (Kp / 64);
+	// L2 touches of the record stream: ~1.5 tiles' worth of 128-byte lines
+	const double tile_bytes = P->ngroups * P->npanels > 0 ?
+		(double) P->nrec * 16.0 / (double) (P->ngroups * P->npanels) : 0.0;
+	int rt_lines = (int) (tile_bytes * 1.5 / 128.0) + 2;
+	if (rt_lines > 32) rt_lines = 32;
+	auto kern = (g_pbc_debug == 3 && NV <= 2) ? crossprod_pbc_dma_kernel<(NV <= 2 ? NV : 2), true>
+						  : crossprod_pbc_dma_kernel<NV, false>;
+	(void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+	hipLaunchKernelGGL(kern, dim3((unsigned) ((int64_t) nsplit * kt * P->nblocks)), dim3(1024), lds, s,
+			   P->rec, P->tile_ptr, P->npanels, Y, ldY, P->nrow, K, P->ncol, P->CBW, nsplit,
+			   (int) P->nblocks, pps, part, Kp, fl, rt_lines);
 }
 
 int launch_crossprod_general_if(const CrossprodArgs &a, const int *flag, hipStream_t s);
@@ -614,14 +885,23 @@ extern "C" int svt_dev_crossprod_pbc_phase(const svt_dev_pbc *P, const svt_dev_c
 		return svt_set_error("svt_dev_crossprod_pbc: workspace too small");
 	const int64_t Kp = ((int64_t) K + 63) / 64 * 64;
 	int64_t pps = 1;
-	const int nsplit = pick_nsplit(P, K, &pps);
+	const bool dma = pbc_dma_ok(P, tr_y);
+	const int nsplit = pick_nsplit(P, K, dma, &pps);
 	PbcFlags fl;
 	fl.y_nonfinite = (int *) ws;
-	double *part = (double *) ((char *) ws + 256);
+	double *part = (double *) ((char *) ws + PBC_FLAG_BYTES);
 	void *gen_ws = (char *) part + (size_t) nsplit * Kp * P->ncol * 8;
 	if (phase == 1) {
 		HIP_TRY(hipMemsetAsync(ws, 0, 256, s));
-		const int key = (P->CBW / 16) * 10000 + P->WPB * 100 + P->logR;
+		const int nv = (P->CBW + 15) / 16;
+		if (dma && P->CBW <= 40) {
+			if (nv == 1) launch_dma<1>(P, Y, ldY, K, nsplit, pps, part, Kp, fl, s);
+			else if (nv == 2) launch_dma<2>(P, Y, ldY, K, nsplit, pps, part, Kp, fl, s);
+			else launch_dma<3>(P, Y, ldY, K, nsplit, pps, part, Kp, fl, s);
+			HIP_TRY(hipGetLastError());
+			return 0;
+		}
+		const int key = nv * 10000 + P->WPB * 100 + P->logR;
 #define PBC_CASE(NV, WPB, LOGR) \
 		case (NV) * 10000 + (WPB) * 100 + (LOGR): \
 			launch_main<NV, WPB, LOGR>(P, Y, ldY, tr_y, K, nsplit, pps, part, Kp, fl, s); break;
@@ -631,8 +911,10 @@ extern "C" int svt_dev_crossprod_pbc_phase(const svt_dev_pbc *P, const svt_dev_c
 		PBC_CASE(2, 8, 7) PBC_CASE(3, 8, 7) PBC_CASE(4, 8, 7)
 		PBC_CASE(2, 8, 6) PBC_CASE(4, 4, 5)
 		default:
-			return svt_set_error("svt_dev_crossprod_pbc: unsupported (CBW=%d, WPB=%d, logR=%d)",
-					     P->CBW, P->WPB, P->logR);
+			// no panel kernel for this layout / orientation (e.g. row-major Y with
+			// 40 columns per wavefront): raise the flag that sends the whole
+			// product through the general kernels in phase 2
+			HIP_TRY(hipMemsetAsync(ws, 1, 4, s));
 		}
 #undef PBC_CASE
 		HIP_TRY(hipGetLastError());

@@ -16,8 +16,10 @@ def _dev(cp, ri, v, nrow):
     return DeviceCSC.from_host(nrow, cp, ri, v)
 
 
-@pytest.mark.parametrize("cfg", [(32, 16, 7), (16, 16, 7), (48, 8, 7), (64, 8, 7), (32, 8, 6), (64, 4, 5), (32, 16, 8)])
-@pytest.mark.parametrize("shape", [(5000, 300, 70), (70000, 1100, 128), (300, 17, 5)])
+@pytest.mark.parametrize("cfg", [(32, 16, 7), (16, 16, 7), (40, 16, 7), (24, 16, 7), (5, 16, 7), (48, 8, 7),
+                                 (64, 8, 7), (32, 8, 6), (64, 4, 5), (32, 16, 8), (20, 16, 8)])
+@pytest.mark.parametrize("shape", [(5000, 300, 70), (70000, 1100, 128), (300, 17, 5), (4096, 700, 64),
+                                   (1281, 90, 3), (1282, 90, 130)])
 def test_pbc_crossprod_matches_oracle(hip, oracle, cfg, shape):
     from sparsearray_amd.device import PbcPlan
     nrow, ncol, K = shape
@@ -63,6 +65,61 @@ def test_pbc_special_values_take_general_path(hip, oracle):
         torch.cuda.synchronize()
         assert_equal(out.cpu().numpy().T, want, tol=1e-9, atol=1e-11, strict_na=True,
                      what=f"poison={poison}")
+
+
+@pytest.mark.parametrize("cbw", [32, 40])
+def test_pbc_dma_path_prescan_sees_every_dense_entry(hip, oracle, cbw):
+    """The LDS-DMA kernel never sees Y in registers: its finiteness prescan reads
+    each workgroup's share of the landed panels back from LDS.  One poisoned
+    entry anywhere (first/last row, last partial panel, tail of K, every column
+    block's share) must switch the whole product to the general semantics."""
+    from sparsearray_amd.device import PbcPlan
+    nrow, ncol, K = 20000 + 77, 2100, 70
+    cp, ri, v = random_csc(nrow, ncol, 0.005, seed=31)
+    x = SVT_SparseArray.from_csc((nrow, ncol), "double", cp, ri, v)
+    A = _dev(cp, ri, v, nrow)
+    plan = PbcPlan(A, K, cbw, 16, 7)
+    rng = np.random.default_rng(32)
+    y0 = rng.uniform(-1, 1, (nrow, K))
+    spots = [(0, 0), (nrow - 1, K - 1), (nrow - 1, 0), (0, K - 1), (127, 63), (128, 64), (nrow - 70, 5),
+             (12345, 69)] + [(int(r), int(k)) for r, k in zip(rng.integers(0, nrow, 6), rng.integers(0, K, 6))]
+    out = torch.zeros((K, ncol), dtype=torch.float64, device="cuda")
+    for r, k in spots:
+        y = y0.copy()
+        y[r, k] = np.inf if (r + k) % 2 else np.nan
+        want = oracle.crossprod(x, y)
+        Yd = torch.as_tensor(np.ascontiguousarray(y.T), device="cuda")
+        plan.run(Yd, nrow, out)
+        torch.cuda.synchronize()
+        assert_equal(out.cpu().numpy().T, want, tol=1e-9, atol=1e-11, strict_na=True, what=f"poison at {(r, k)}")
+    want = oracle.crossprod(x, y0)
+    Yd = torch.as_tensor(np.ascontiguousarray(y0.T), device="cuda")
+    plan.run(Yd, nrow, out)
+    torch.cuda.synchronize()
+    assert_equal(out.cpu().numpy().T, want, tol=1e-9, atol=1e-11, what="clean")
+
+
+def test_pbc_dma_path_ragged_columns(hip, oracle):
+    """Empty columns, one very long column, empty row ranges (empty tiles)."""
+    from sparsearray_amd.device import PbcPlan
+    nrow, ncol, K = 40000, 530, 128
+    rng = np.random.default_rng(33)
+    dense = np.zeros((nrow, ncol))
+    dense[:, 7] = rng.uniform(-1, 1, nrow)                       # full column
+    for c in range(0, ncol, 3):
+        rows = rng.integers(20000, 26000, 40)                    # a band: most tiles empty
+        dense[rows, c] = rng.uniform(-1, 1, 40)
+    dense[nrow - 1, ncol - 1] = 2.5
+    x = SVT_SparseArray.from_dense(dense)
+    cp, ri, v = x.to_csc()
+    y = rng.uniform(-1, 1, (nrow, K))
+    want = oracle.crossprod(x, y)
+    A = _dev(cp, ri, v, nrow)
+    Yd = torch.as_tensor(np.ascontiguousarray(y.T), device="cuda")
+    out = torch.zeros((K, ncol), dtype=torch.float64, device="cuda")
+    PbcPlan(A, K, 40, 16, 7).run(Yd, nrow, out)
+    torch.cuda.synchronize()
+    assert_equal(out.cpu().numpy().T, want, tol=1e-9, atol=1e-11, what="ragged")
 
 
 def test_device_stats(hip, oracle):

@@ -20,6 +20,7 @@ p.add_argument("--density", type=float, default=0.01)
 p.add_argument("--K", type=int, default=128)
 p.add_argument("--cfgs", default="32,16,8")
 p.add_argument("--ablate", action="store_true")
+p.add_argument("--prof", action="store_true", help="per-section cycle counts of workgroup 0")
 p.add_argument("--reps", type=int, default=5)
 p.add_argument("--nsplits", default="0")
 a = p.parse_args()
@@ -58,6 +59,17 @@ for cfg in a.cfgs.split(";"):
             lib.svt_dev_pbc_set_debug(mode)
             ms = timed(lambda: plan.run(Y, a.nrow, out), a.reps)
             row.append(f"[nsplit {ns}] {name} {ms:.3f} ms ({A.nnz / ms / 1e6:.1f} GNZ/s)")
+        if a.prof:
+            import ctypes
+            lib.svt_dev_pbc_set_debug(3)
+            ms = timed(lambda: plan.run(Y, a.nrow, out), 2)
+            buf = (ctypes.c_ulonglong * 128)()
+            lib.svt_dev_pbc_read_prof.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+            assert lib.svt_dev_pbc_read_prof(plan.ws.data_ptr(), buf) == 0
+            row.append(f"\n  prof build {ms:.3f} ms; per wavefront cycles "
+                       "[fetch|records, records|dma-wait, barrier1|barrier, commit|issue, barrier2|prescan, panels] (register-staged|DMA kernel):")
+            for w in range(wpb):
+                row.append("\n    w%02d " % w + " ".join("%9d" % buf[w * 8 + i] for i in range(6)))
         lib.svt_dev_pbc_set_debug(0)
     lib.svt_dev_pbc_set_debug(100)
     print("  ".join(row), flush=True)
