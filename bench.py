@@ -39,7 +39,7 @@ def parse():
     p.add_argument("--K", type=int, default=128)
     p.add_argument("--path", choices=["pbc", "v1"], default="pbc",
                    help="pbc: panel-blocked LDS kernel (default); v1: gather kernel")
-    p.add_argument("--cbw", type=int, default=32)
+    p.add_argument("--cbw", type=int, default=40)
     p.add_argument("--wpb", type=int, default=16)
     p.add_argument("--logr", type=int, default=7)
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -126,7 +126,7 @@ def main():
         plan = PbcPlan(A, K, a.cbw, a.wpb, a.logr)
         torch.cuda.synchronize()
         layout_ms = (time.perf_counter() - t_l) * 1e3
-        kernel_name = "crossprod_pbc_kernel"
+        kernel_name = "crossprod_pbc_dma_kernel"
 
         def step(ev=None):
             if ev is not None:

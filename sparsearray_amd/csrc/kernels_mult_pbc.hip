@@ -577,11 +577,16 @@ crossprod_pbc_kernel(const uint4 *__restrict__ rec,
 //     and no ds_write pass.  LDS image: [dense column][128 rows + 1 pad], i.e.
 //     odd columns start 8 mod 16 bytes (tools/micro/stage_bench.hip checks that
 //     the DMA accepts that) so the lane = dense-column reads stay conflict-free.
-//   * L2 touches (one dword per 128-byte line) of this wavefront's records two
-//     panels ahead and of this workgroup's share of the Y panel three panels
-//     ahead, issued AFTER the DMA pieces so that the in-order vmcnt wait for the
-//     pieces does not wait for them: each touch gets two panel periods to land
-//     and the DMA / scalar loads that follow hit L2.
+//   * an L2 touch (one dword per 128-byte line) of this wavefront's records two
+//     panels ahead, issued AFTER the DMA pieces so that the in-order vmcnt wait
+//     for the pieces does not wait for it: without it every scalar load of the
+//     record stream pays an HBM miss (7.6 ms instead of 5.2 at BASELINE config 2).
+//   * the scalar loads of the record stream are prefetched into the scalar cache
+//     in batches (6 lines once per 6 phases): one L2 round trip per trip instead
+//     of one per phase (5.26 -> 4.39 ms).
+//   * the DMA pieces of the next panel are issued from inside the record loop,
+//     staggered by wavefront, instead of all 64 at the barrier: the texture
+//     addresser takes ~20 cycles per piece and a burst blocks the issuing waves.
 //   * the whole panel loop is one asm statement (pbc_dma_asm.inc, generated by
 //     tools/gen_pbc_asm.py): the scalar-load pipeline of the record stream runs
 //     on across panel boundaries (only the LDS reads restart), loads use
@@ -628,7 +633,6 @@ crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restric
 	const int k0 = kh * 64;
 	const int64_t wv = (int64_t) b * 16 + w;
 	const int64_t *__restrict__ tb = tile_ptr + (wv * npanels + pa);
-	const int64_t lastfull = nrow / 128 - 1;    // >= 1 (nrow >= 256)
 	const bool partial = (nrow & 127) != 0;
 
 	// NV == 3 keeps 40 columns (16 + 16 + 8): all 128 VGPRs are spoken for
@@ -663,11 +667,13 @@ crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restric
 			const uint64_t src = (uint64_t) (uintptr_t) (Y + (int64_t) kk * ldY + (pa + 1) * 128);
 			P1[2 * q] = (uint32_t) src; P1[2 * q + 1] = (uint32_t) (src >> 32);
 		}
+		P1[8] = (uint32_t) (w & 3);                     // stagger of the DMA issue, in phases
+		P1[9] = (1u << rt_lines) - 1u;                  // lanes of the record touch (rt_lines <= 31)
+		P1[10] = 0xFFFFFFFFu;                           // "pieces of the first panel are issued"
+		const int64_t lastfull = nrow / 128 - 1;        // >= 1 (nrow >= 256)
 		const int64_t ty = pa + PBC_DMA_YAHEAD < lastfull ? pa + PBC_DMA_YAHEAD : lastfull;
 		const uint64_t ytb = (uint64_t) (uintptr_t) (Y + (int64_t) k0 * ldY + ty * 128);
-		P1[8] = (uint32_t) ytb; P1[9] = (uint32_t) (ytb >> 32);
-		P1[10] = lastfull > PBC_DMA_YAHEAD ? (uint32_t) (lastfull - PBC_DMA_YAHEAD) : 0u;
-		P1[11] = 0; P1[12] = 0; P1[13] = 0; P1[14] = 0; P1[15] = 0;
+		P1[11] = 0; P1[12] = (uint32_t) ytb; P1[13] = (uint32_t) (ytb >> 32); P1[14] = 0; P1[15] = 0;
 	}
 	// ---- per-lane constants (VGPR vector pinned to v[0:15]) -----------------------
 	u32x16 V0 = 0, V1 = 0;
@@ -676,16 +682,20 @@ crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restric
 		V0[0] = (uint32_t) lane * PBC_DMA_ROW;
 		V0[1] = (uint32_t) lane * 16u;
 		V0[2] = lane < rt_lines ? (uint32_t) lane * 128u : 0u;
-		// dense touch: lanes 32.. take this wavefront's lines of the block's share
+		// dense touch: the first lanes take this wavefront's lines of the block's share
+		// (512 lines of 128 bytes per panel, split over the column blocks)
 		const int lines_blk = (512 + nblocks - 1) / nblocks;
-		const int nl = (lines_blk + 15) / 16;           // <= 32
+		const int nl = (lines_blk + 15) / 16;           // 1 .. 32 lanes
 		uint32_t yto = 0;
-		if (lane >= 32 && lane - 32 < nl && (uint64_t) ldY * 8 * 64 < 0xFFFFFFFFull) {
-			int ln = (b * lines_blk + w * nl + (lane - 32)) % 512;
+		if ((uint64_t) ldY * 8 * 64 < 0xFFFFFFFFull) {
+			const int ln = (b * lines_blk + w * nl + (lane < nl ? lane : 0)) % 512;
 			int kr = ln >> 3;
 			if (k0 + kr > K - 1) kr = K - 1 - k0;
 			yto = (uint32_t) ((int64_t) kr * ldY * 8 + (ln & 7) * 128);
 		}
+		const int64_t lastfull = nrow / 128 - 1;
+		V0[15] = lane == 0 ? (nl >= 32 ? 0xFFFFFFFFu : (1u << nl) - 1u)
+				   : (lastfull > PBC_DMA_YAHEAD ? (uint32_t) (lastfull - PBC_DMA_YAHEAD) : 0u);
 		V0[3] = yto;
 		const int chunk = (8192 + nblocks - 1) / nblocks;
 		const int nit = (chunk + 1023) / 1024;
@@ -718,12 +728,12 @@ crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restric
 			     : "+{v[32:63]}"(acc[0]), "+{v[64:95]}"(acc[NV > 1 ? 1 : 0]),
 			       "+{v[0:15]}"(V0), "+{v[16:31]}"(V1), "+{s[84:99]}"(P0), "+{s[20:35]}"(P1),
 			       "+{v[96:111]}"(PV)
-			     : : PBC_DMA_CLOBBERS, "v112", "v113");
+			     : : PBC_DMA_CLOBBERS, "v112", "v113", "s100", "s101");
 		if (blockIdx.x == 0 && (tid & 63) == 0) {
 			unsigned long long *o = (unsigned long long *) (fl.y_nonfinite + 64) + w * 8;
 			// [rec, dma wait, barrier, issue, prescan, panels]
-			for (int i = 0; i < 5; i++) o[i] = PV[i];
-			o[5] = (unsigned long long) (pb - pa);
+			// [tail wait, dma wait, barrier, issue, prescan, dispatch, stub, phases]
+			for (int i = 0; i < 8; i++) o[i] = PV[i];
 		}
 	} else if constexpr (NV == 1) {
 		asm volatile(PBC_DMA_ASM_TEXT
@@ -859,7 +869,7 @@ static void launch_dma(const svt_dev_pbc *P, const double *Y, int64_t ldY, int K
 	const double tile_bytes = P->ngroups * P->npanels > 0 ?
 		(double) P->nrec * 16.0 / (double) (P->ngroups * P->npanels) : 0.0;
 	int rt_lines = (int) (tile_bytes * 1.5 / 128.0) + 2;
-	if (rt_lines > 32) rt_lines = 32;
+	if (rt_lines > 31) rt_lines = 31;
 	auto kern = (g_pbc_debug == 3 && NV <= 2) ? crossprod_pbc_dma_kernel<(NV <= 2 ? NV : 2), true>
 						  : crossprod_pbc_dma_kernel<NV, false>;
 	(void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);

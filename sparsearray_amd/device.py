@@ -135,7 +135,7 @@ class PbcPlan:
     """Fast path of crossprod(A, Y) for f64: panel-blocked copy of A (built
     once, here) + workspace for K dense columns."""
 
-    def __init__(self, A: DeviceCSC, K: int, CBW: int = 32, WPB: int = 16, logR: int = 7):
+    def __init__(self, A: DeviceCSC, K: int, CBW: int = 40, WPB: int = 16, logR: int = 7):
         assert A.Rtype == REALSXP
         self.A, self.K = A, int(K)
         self._p = _lib().svt_dev_pbc_build(A.handle, CBW, WPB, logR)

@@ -69,7 +69,7 @@ for cfg in a.cfgs.split(";"):
             row.append(f"\n  prof build {ms:.3f} ms; per wavefront cycles "
                        "[fetch|records, records|dma-wait, barrier1|barrier, commit|issue, barrier2|prescan, panels] (register-staged|DMA kernel):")
             for w in range(wpb):
-                row.append("\n    w%02d " % w + " ".join("%9d" % buf[w * 8 + i] for i in range(6)))
+                row.append("\n    w%02d " % w + " ".join("%9d" % buf[w * 8 + i] for i in range(8)))
         lib.svt_dev_pbc_set_debug(0)
     lib.svt_dev_pbc_set_debug(100)
     print("  ".join(row), flush=True)
