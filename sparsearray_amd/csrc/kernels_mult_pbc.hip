@@ -53,6 +53,8 @@ typedef double d8 __attribute__((ext_vector_type(8)));
 struct svt_dev_pbc {
 	int64_t nrow, ncol, nnz, nrec;
 	int CBW, WPB, logR;
+	int fmt;               // record format: 0 = 16-byte records, batches of 4 (register-staged
+	                       // kernel); 1 = 12-byte records, batches of 8 (LDS-DMA kernel)
 	int64_t ngroups, nblocks, npanels;
 	uint4 *rec;            // [nrec] 16-byte records
 	int64_t *tile_ptr;     // [ngroups*npanels + 1]
@@ -60,6 +62,9 @@ struct svt_dev_pbc {
 };
 
 #define PCH 256            // panels per build chunk
+static int g_pbc_debug = 0;
+static int g_pbc_nsplit = 0;
+static int g_pbc_stagger = 2;
 
 // ---------------------------------------------------------------------------
 // layout build
@@ -82,13 +87,25 @@ __device__ inline int64_t lower_bound_row(const int32_t *__restrict__ row, int64
 // One wavefront per (group of CBW columns, chunk of PCH panels).  MODE 0: count
 // the records of each tile (rounded up to PBC_BATCH).  MODE 1: write records to
 // their final position and zero-fill the padding.
-template <int MODE>
+//
+// FMT 1 (see tools/gen_pbc_asm.py): batches of 8 records, 96 bytes = 8 x u32 meta
+// (8*row << 16 | last-batch-of-tile flag << 15 | 2*column) then 8 x f64 value; every
+// tile has at least one batch (an all-zero one if it holds no nonzero).
+__device__ inline void pbc1_store(uint4 *rec, int64_t ridx, uint32_t meta, double x)
+{
+	char *base = (char *) rec + (ridx >> 3) * 96;
+	((uint32_t *) base)[ridx & 7] = meta;
+	((double *) (base + 32))[ridx & 7] = x;
+}
+
+template <int MODE, int FMT>
 __global__ void __launch_bounds__(64)
 pbc_pass_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__ row_idx,
 		const double *__restrict__ val, int64_t ncol, int CBW, int logR,
 		int64_t npanels, int64_t *__restrict__ counts_or_ptr,
 		uint4 *__restrict__ rec, int *__restrict__ col_has_na)
 {
+	constexpr int BATCH = FMT == 1 ? 8 : PBC_BATCH;
 	__shared__ int64_t fill[PCH];
 	const int lane = threadIdx.x;
 	const int64_t wv = blockIdx.x;
@@ -123,12 +140,17 @@ pbc_pass_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__
 			__syncthreads();
 			if (MODE == 1 && active) {
 				const double x = val[k];
-				uint4 t;
-				t.x = (uint32_t) (r - (int32_t) ((p + p0) << logR)) * 8u;
-				t.y = (uint32_t) (c - c0) * 2u;
-				t.z = (uint32_t) __double2loint(x);
-				t.w = (uint32_t) __double2hiint(x);
-				rec[pos] = t;
+				const uint32_t ro = (uint32_t) (r - (int32_t) ((p + p0) << logR)) * 8u;
+				if (FMT == 1) {
+					pbc1_store(rec, pos, (ro << 16) | (uint32_t) (c - c0) * 2u, x);
+				} else {
+					uint4 t;
+					t.x = ro;
+					t.y = (uint32_t) (c - c0) * 2u;
+					t.z = (uint32_t) __double2loint(x);
+					t.w = (uint32_t) __double2hiint(x);
+					rec[pos] = t;
+				}
 				if (svt_is_na(x)) saw_na = 1;
 			}
 			if (is_last) fill[p] += rank + 1;
@@ -140,11 +162,18 @@ pbc_pass_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__
 	for (int i = lane; i < PCH; i += 64) {
 		if (p0 + i >= npanels) continue;
 		if (MODE == 0) {
-			counts_or_ptr[TILE_OF(p0 + i)] = (fill[i] + PBC_BATCH - 1) / PBC_BATCH * PBC_BATCH;
+			int64_t n = (fill[i] + BATCH - 1) / BATCH * BATCH;
+			if (FMT == 1 && n == 0) n = BATCH;          // no tile without a batch
+			counts_or_ptr[TILE_OF(p0 + i)] = n;
 		} else {
 			// fill[i] = one past the last real record; pad up to the next tile
 			const int64_t stop = counts_or_ptr[TILE_OF(p0 + i) + 1];
-			for (int64_t q = fill[i]; q < stop; q++) rec[q] = make_uint4(0, 0, 0, 0);
+			for (int64_t q = fill[i]; q < stop; q++) {
+				if (FMT == 1) pbc1_store(rec, q, 0u, 0.0);
+				else rec[q] = make_uint4(0, 0, 0, 0);
+			}
+			if (FMT == 1)                               // flag the tile's last batch
+				atomicOr((unsigned int *) ((char *) rec + ((stop - 8) >> 3) * 96), 0x8000u);
 		}
 	}
 #undef TILE_OF
@@ -173,6 +202,8 @@ extern "C" svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB
 	svt_dev_pbc *h = (svt_dev_pbc *) calloc(1, sizeof(*h));
 	h->nrow = A->nrow; h->ncol = A->ncol; h->nnz = A->nnz;
 	h->CBW = CBW; h->WPB = WPB; h->logR = logR;
+	// the LDS-DMA kernel wants 16 wavefronts, 128-row panels, <= 40 columns each
+	h->fmt = (WPB == 16 && logR == 7 && CBW <= 40 && A->nrow >= 256 && g_pbc_debug != 9) ? 1 : 0;
 	const int64_t CB = (int64_t) CBW * WPB;
 	h->nblocks = (A->ncol + CB - 1) / CB;
 	h->ngroups = h->nblocks * WPB;                // one group per wavefront
@@ -187,9 +218,14 @@ extern "C" svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB
 		     hipMemset(h->col_has_na, 0, (size_t) (A->ncol > 0 ? A->ncol : 1) * 4) == hipSuccess;
 	if (ok && A->ncol > 0 && A->nnz > 0) {
 		dim3 grid((unsigned) h->ngroups, (unsigned) ((h->npanels + PCH - 1) / PCH));
-		hipLaunchKernelGGL(pbc_pass_kernel<0>, grid, dim3(64), 0, 0, A->col_ptr, A->row_idx,
-				   (const double *) A->val, A->ncol, CBW, logR, h->npanels,
-				   h->tile_ptr, (uint4 *) NULL, h->col_has_na);
+		if (h->fmt == 1)
+			hipLaunchKernelGGL((pbc_pass_kernel<0, 1>), grid, dim3(64), 0, 0, A->col_ptr, A->row_idx,
+					   (const double *) A->val, A->ncol, CBW, logR, h->npanels,
+					   h->tile_ptr, (uint4 *) NULL, h->col_has_na);
+		else
+			hipLaunchKernelGGL((pbc_pass_kernel<0, 0>), grid, dim3(64), 0, 0, A->col_ptr, A->row_idx,
+					   (const double *) A->val, A->ncol, CBW, logR, h->npanels,
+					   h->tile_ptr, (uint4 *) NULL, h->col_has_na);
 		// exclusive scan in place over ntiles+1 entries (last entry = total)
 		ok = hipcub::DeviceScan::ExclusiveSum(NULL, tmp_bytes, h->tile_ptr, h->tile_ptr,
 						      (int) (ntiles + 1)) == hipSuccess &&
@@ -204,19 +240,25 @@ extern "C" svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB
 			for (int i = 0; i < PBC_TP_PAD; i++) pad[i] = nrec;
 			ok = hipMemcpy(h->tile_ptr + ntiles + 1, pad, sizeof(pad), hipMemcpyHostToDevice) == hipSuccess;
 		}
+		const size_t rbytes = h->fmt == 1 ? 12 : 16;
 		if (ok && (nrec + PBC_SLACK) * 16 >= ((int64_t) 1 << 32)) {
 			svt_set_error("svt_dev_pbc_build: operand too large for 32-bit record offsets");
 			if (tmp) (void) hipFree(tmp);
 			svt_dev_pbc_release(h);
 			return NULL;
 		}
-		if (ok) ok = hipMalloc((void **) &h->rec, (size_t) (nrec + PBC_SLACK) * 16) == hipSuccess &&
+		if (ok) ok = hipMalloc((void **) &h->rec, (size_t) nrec * rbytes + PBC_SLACK * 16) == hipSuccess &&
 			     // the look-ahead stages of the kernels read up to 3 batches past the end
-			     hipMemset(h->rec + nrec, 0, (size_t) PBC_SLACK * 16) == hipSuccess;
+			     hipMemset((char *) h->rec + (size_t) nrec * rbytes, 0, (size_t) PBC_SLACK * 16) == hipSuccess;
 		if (ok) {
-			hipLaunchKernelGGL(pbc_pass_kernel<1>, grid, dim3(64), 0, 0, A->col_ptr,
-					   A->row_idx, (const double *) A->val, A->ncol, CBW, logR,
-					   h->npanels, h->tile_ptr, h->rec, h->col_has_na);
+			if (h->fmt == 1)
+				hipLaunchKernelGGL((pbc_pass_kernel<1, 1>), grid, dim3(64), 0, 0, A->col_ptr,
+						   A->row_idx, (const double *) A->val, A->ncol, CBW, logR,
+						   h->npanels, h->tile_ptr, h->rec, h->col_has_na);
+			else
+				hipLaunchKernelGGL((pbc_pass_kernel<1, 0>), grid, dim3(64), 0, 0, A->col_ptr,
+						   A->row_idx, (const double *) A->val, A->ncol, CBW, logR,
+						   h->npanels, h->tile_ptr, h->rec, h->col_has_na);
 			ok = hipDeviceSynchronize() == hipSuccess;
 		}
 	}
@@ -232,11 +274,10 @@ extern "C" svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB
 // ---------------------------------------------------------------------------
 // main kernel
 // ---------------------------------------------------------------------------
-static int g_pbc_debug = 0;
-static int g_pbc_nsplit = 0;
 extern "C" void svt_dev_pbc_set_debug(int mode)
 {
-	if (mode >= 100) g_pbc_nsplit = mode - 100;   // 100 + n: force n row splits (tuning)
+	if (mode >= 200) g_pbc_stagger = mode - 200;  // 200 + m: DMA issue stagger mode (tuning)
+	else if (mode >= 100) g_pbc_nsplit = mode - 100;   // 100 + n: force n row splits (tuning)
 	else g_pbc_debug = mode;
 }
 
@@ -602,8 +643,9 @@ crossprod_pbc_kernel(const uint4 *__restrict__ rec,
 // ---------------------------------------------------------------------------
 #include "pbc_dma_asm.inc"
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define PBC_DMA_YAHEAD 3
-#define PBC_DMA_CLOBBERS "memory", "scc", "vcc", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83"
+#define PBC_DMA_CLOBBERS "memory", "scc", "vcc", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99"
 
 template <int NV, bool PROF>
 __global__ void __launch_bounds__(1024)
@@ -611,7 +653,7 @@ crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restric
 			 int64_t npanels, const double *__restrict__ Y, int64_t ldY, int64_t nrow,
 			 int K, int64_t ncol, int CBW, int nsplit, int nblocks,
 			 int64_t panels_per_split, double *__restrict__ part, int64_t Kp,
-			 PbcFlags fl, int rt_lines)
+			 PbcFlags fl, int rt_lines, int rt_ahead, int stag_mode)
 {
 	extern __shared__ double ylds[];            // 2 buffers x [64][129]
 	const int tid = threadIdx.x;
@@ -633,76 +675,58 @@ crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restric
 	const int k0 = kh * 64;
 	const int64_t wv = (int64_t) b * 16 + w;
 	const int64_t *__restrict__ tb = tile_ptr + (wv * npanels + pa);
-	const bool partial = (nrow & 127) != 0;
 
-	// NV == 3 keeps 40 columns (16 + 16 + 8): all 128 VGPRs are spoken for
-	// otherwise and the compiler needs a few for itself
+	// NV == 3 keeps 40 columns (16 + 16 + 8)
 	d16 acc[NV > 2 ? 2 : NV];
 	d8 acc8 = 0.0;
 #pragma unroll
 	for (int i = 0; i < (NV > 2 ? 2 : NV); i++) acc[i] = 0.0;
+	const bool partial = (nrow & 127) != 0;
 
-	// ---- wave-uniform state (SGPR vectors pinned to s[84:99], s[20:35]) ----------
-	u32x16 P0, P1;
+	// ---- wave-uniform state (SGPR vectors pinned to s[8:11], s[12:27]) ------------
+	u32x4 PA;
+	u32x16 PB;
 	{
-		const uint64_t recp = (uint64_t) (uintptr_t) rec, tpp = (uint64_t) (uintptr_t) (tb + 3);
-		P0[0] = (uint32_t) recp; P0[1] = (uint32_t) (recp >> 32);
-		P0[2] = (uint32_t) tpp; P0[3] = (uint32_t) (tpp >> 32);
-		P0[4] = (uint32_t) tb[0] * 16u;                 // stream cursor (bytes)
-		P0[5] = (uint32_t) pa; P0[6] = (uint32_t) pb;
-		P0[7] = 0;
-		P0[8] = (uint32_t) tb[0]; P0[9] = (uint32_t) tb[1]; P0[10] = (uint32_t) tb[2];
-		P0[11] = PBC_DMA_BUF;                           // toggles to 0 for the first panel
-		P0[12] = (uint32_t) (w * 4 * PBC_DMA_ROW + PBC_DMA_BUF);
-		// finiteness prescan: this block's share of the 8192 doubles of a panel
-		const int chunk = (8192 + nblocks - 1) / nblocks;
-		const int nit = (chunk + 1023) / 1024;
-		P0[13] = (uint32_t) nit;
-		P0[14] = partial ? (uint32_t) (npanels - 1) : 0xFFFFFFFFu;
-		P0[15] = partial ? (uint32_t) ((128 - (nrow & 127)) * 8) : 0u;
+		const uint64_t recp = (uint64_t) (uintptr_t) rec;
+		PA[0] = (uint32_t) recp; PA[1] = (uint32_t) (recp >> 32);
+		PA[2] = (uint32_t) tb[0] * 12u;                 // stream cursor (bytes)
+		PA[3] = (uint32_t) pa;
+		PB[0] = (uint32_t) pb;
+		PB[1] = PBC_DMA_BUF;                            // toggles to 0 for the first panel
+		PB[2] = (uint32_t) (w * 4 * PBC_DMA_ROW + PBC_DMA_BUF);
+		PB[3] = 0;
+		// stagger of the DMA issue, in phases
+		PB[4] = stag_mode == 0 ? 0u : stag_mode == 1 ? (uint32_t) (w & 1) :
+			stag_mode == 2 ? (uint32_t) (w & 3) : (uint32_t) ((w >> 2) & 1);
+		PB[5] = 0xFFFFFFFFu;                            // "pieces of the first panel are issued"
+		PB[6] = 0;
+		PB[7] = (1u << rt_lines) - 1u;                  // lanes of the record touch (rt_lines <= 31)
 #pragma unroll
 		for (int q = 0; q < 4; q++) {
 			int kk = k0 + w * 4 + q;
 			if (kk > K - 1) kk = K - 1;                 // tail of K: a valid column, never stored
 			const uint64_t src = (uint64_t) (uintptr_t) (Y + (int64_t) kk * ldY + (pa + 1) * 128);
-			P1[2 * q] = (uint32_t) src; P1[2 * q + 1] = (uint32_t) (src >> 32);
+			PB[8 + 2 * q] = (uint32_t) src; PB[9 + 2 * q] = (uint32_t) (src >> 32);
 		}
-		P1[8] = (uint32_t) (w & 3);                     // stagger of the DMA issue, in phases
-		P1[9] = (1u << rt_lines) - 1u;                  // lanes of the record touch (rt_lines <= 31)
-		P1[10] = 0xFFFFFFFFu;                           // "pieces of the first panel are issued"
-		const int64_t lastfull = nrow / 128 - 1;        // >= 1 (nrow >= 256)
-		const int64_t ty = pa + PBC_DMA_YAHEAD < lastfull ? pa + PBC_DMA_YAHEAD : lastfull;
-		const uint64_t ytb = (uint64_t) (uintptr_t) (Y + (int64_t) k0 * ldY + ty * 128);
-		P1[11] = 0; P1[12] = (uint32_t) ytb; P1[13] = (uint32_t) (ytb >> 32); P1[14] = 0; P1[15] = 0;
 	}
 	// ---- per-lane constants (VGPR vector pinned to v[0:15]) -----------------------
 	u32x16 V0 = 0, V1 = 0;
+	u32x4 V2 = 0;
 	{
 		const int lane = tid & 63;
 		V0[0] = (uint32_t) lane * PBC_DMA_ROW;
 		V0[1] = (uint32_t) lane * 16u;
-		V0[2] = lane < rt_lines ? (uint32_t) lane * 128u : 0u;
-		// dense touch: the first lanes take this wavefront's lines of the block's share
-		// (512 lines of 128 bytes per panel, split over the column blocks)
-		const int lines_blk = (512 + nblocks - 1) / nblocks;
-		const int nl = (lines_blk + 15) / 16;           // 1 .. 32 lanes
-		uint32_t yto = 0;
-		if ((uint64_t) ldY * 8 * 64 < 0xFFFFFFFFull) {
-			const int ln = (b * lines_blk + w * nl + (lane < nl ? lane : 0)) % 512;
-			int kr = ln >> 3;
-			if (k0 + kr > K - 1) kr = K - 1 - k0;
-			yto = (uint32_t) ((int64_t) kr * ldY * 8 + (ln & 7) * 128);
-		}
-		const int64_t lastfull = nrow / 128 - 1;
-		V0[15] = lane == 0 ? (nl >= 32 ? 0xFFFFFFFFu : (1u << nl) - 1u)
-				   : (lastfull > PBC_DMA_YAHEAD ? (uint32_t) (lastfull - PBC_DMA_YAHEAD) : 0u);
-		V0[3] = yto;
+		V0[2] = (lane < rt_lines ? (uint32_t) lane * 128u : 0u) + (uint32_t) rt_ahead;
+		// finiteness prescan: this block's share of the 8192 doubles of a panel
 		const int chunk = (8192 + nblocks - 1) / nblocks;
 		const int nit = (chunk + 1023) / 1024;
 		int e0 = b * chunk;
 		if (e0 > 8192 - nit * 1024) e0 = 8192 - nit * 1024;
 		const int e = e0 + tid;
-		V0[4] = (uint32_t) ((e >> 7) * PBC_DMA_ROW + (e & 127) * 8);
+		V0[3] = (uint32_t) ((e >> 7) * PBC_DMA_ROW + (e & 127) * 8);
+		V0[7] = lane == 0 ? (uint32_t) nit :
+			lane == 1 ? (partial ? (uint32_t) (npanels - 1) : 0xFFFFFFFFu) :
+				    (partial ? (uint32_t) ((128 - (nrow & 127)) * 8) : 0u);
 	}
 	// ---- first panel: straight into buffer 0 ---------------------------------------
 	{
@@ -721,38 +745,35 @@ crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restric
 		}
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	}
+#define PBC_DMA_STATE "+{v[0:15]}"(V0), "+{v[16:31]}"(V1), "+{v[32:35]}"(V2), "+{s[8:11]}"(PA), "+{s[12:27]}"(PB)
 	if constexpr (PROF) {
-		// tuning build (NV <= 2): cycles per section in v[96:100], see gen_pbc_asm.py
+		// tuning build (NV <= 2): cycles per section in v[116:123], see gen_pbc_asm.py
 		u32x16 PV = 0;
 		asm volatile(PBC_DMA_ASM_TEXT_PROF
-			     : "+{v[32:63]}"(acc[0]), "+{v[64:95]}"(acc[NV > 1 ? 1 : 0]),
-			       "+{v[0:15]}"(V0), "+{v[16:31]}"(V1), "+{s[84:99]}"(P0), "+{s[20:35]}"(P1),
-			       "+{v[96:111]}"(PV)
-			     : : PBC_DMA_CLOBBERS, "v112", "v113", "s100", "s101");
+			     : "+{v[36:67]}"(acc[0]), "+{v[68:99]}"(acc[NV > 1 ? 1 : 0]), PBC_DMA_STATE,
+			       "+{v[112:127]}"(PV)
+			     : : PBC_DMA_CLOBBERS, "s100", "s101");
 		if (blockIdx.x == 0 && (tid & 63) == 0) {
 			unsigned long long *o = (unsigned long long *) (fl.y_nonfinite + 64) + w * 8;
-			// [rec, dma wait, barrier, issue, prescan, panels]
-			// [tail wait, dma wait, barrier, issue, prescan, dispatch, stub, phases]
-			for (int i = 0; i < 8; i++) o[i] = PV[i];
+			// [-, dma wait, barrier, issue, prescan, dispatch, stub, phases]
+			for (int i = 0; i < 8; i++) o[i] = PV[4 + i];
 		}
 	} else if constexpr (NV == 1) {
 		asm volatile(PBC_DMA_ASM_TEXT
-			     : "+{v[32:63]}"(acc[0]), "+{v[0:15]}"(V0), "+{v[16:31]}"(V1),
-			       "+{s[84:99]}"(P0), "+{s[20:35]}"(P1)
+			     : "+{v[36:67]}"(acc[0]), PBC_DMA_STATE
 			     : : PBC_DMA_CLOBBERS);
 	} else if constexpr (NV == 2) {
 		asm volatile(PBC_DMA_ASM_TEXT
-			     : "+{v[32:63]}"(acc[0]), "+{v[64:95]}"(acc[NV > 1 ? 1 : 0]),
-			       "+{v[0:15]}"(V0), "+{v[16:31]}"(V1), "+{s[84:99]}"(P0), "+{s[20:35]}"(P1)
+			     : "+{v[36:67]}"(acc[0]), "+{v[68:99]}"(acc[NV > 1 ? 1 : 0]), PBC_DMA_STATE
 			     : : PBC_DMA_CLOBBERS);
 	} else {
 		asm volatile(PBC_DMA_ASM_TEXT
-			     : "+{v[32:63]}"(acc[0]), "+{v[64:95]}"(acc[NV > 1 ? 1 : 0]),
-			       "+{v[96:111]}"(acc8),
-			       "+{v[0:15]}"(V0), "+{v[16:31]}"(V1), "+{s[84:99]}"(P0), "+{s[20:35]}"(P1)
+			     : "+{v[36:67]}"(acc[0]), "+{v[68:99]}"(acc[NV > 1 ? 1 : 0]),
+			       "+{v[100:115]}"(acc8), PBC_DMA_STATE
 			     : : PBC_DMA_CLOBBERS);
 	}
-	if (P1[11] != 0 && (tid & 63) == 0)
+#undef PBC_DMA_STATE
+	if (PB[6] != 0 && (tid & 63) == 0)
 		*fl.y_nonfinite = 1;
 	// ---- partial results: part[(split*Kp + k) * ncol + c] ------------------------
 	const int lane2 = (int) __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -791,8 +812,7 @@ __global__ void pbc_reduce_kernel(const double *__restrict__ part, int nsplit, i
 // Row splits: enough workgroups to fill the chip, every split non-empty.
 static bool pbc_dma_ok(const svt_dev_pbc *P, int tr_y)
 {
-	return !tr_y && P->WPB == 16 && P->logR == 7 && P->nrow >= 256 &&
-	       g_pbc_debug != 9;                    // 9: force the register-staged kernel (tuning)
+	return !tr_y && P->fmt == 1;                // the layout was built for it
 }
 
 static int pick_nsplit(const svt_dev_pbc *P, int K, bool dma, int64_t *pps_out)
@@ -867,15 +887,20 @@ static void launch_dma(const svt_dev_pbc *P, const double *Y, int64_t ldY, int K
 	const int kt = (int) (Kp / 64);
 	// L2 touches of the record stream: ~1.5 tiles' worth of 128-byte lines
 	const double tile_bytes = P->ngroups * P->npanels > 0 ?
-		(double) P->nrec * 16.0 / (double) (P->ngroups * P->npanels) : 0.0;
+		(double) P->nrec * 12.0 / (double) (P->ngroups * P->npanels) : 0.0;
 	int rt_lines = (int) (tile_bytes * 1.5 / 128.0) + 2;
 	if (rt_lines > 31) rt_lines = 31;
+	// the touch starts ~2 tiles past the scalar-load cursor (the PBC_SLACK records
+	// past the end of the stream absorb it at the end: 320 * 16 = 5120 bytes)
+	int rt_ahead = ((int) (2.0 * tile_bytes) + 127) / 128 * 128;
+	if (rt_ahead + rt_lines * 128 > 4608) rt_ahead = 4608 - rt_lines * 128;
+	if (rt_ahead < 0) rt_ahead = 0;
 	auto kern = (g_pbc_debug == 3 && NV <= 2) ? crossprod_pbc_dma_kernel<(NV <= 2 ? NV : 2), true>
 						  : crossprod_pbc_dma_kernel<NV, false>;
 	(void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
 	hipLaunchKernelGGL(kern, dim3((unsigned) ((int64_t) nsplit * kt * P->nblocks)), dim3(1024), lds, s,
 			   P->rec, P->tile_ptr, P->npanels, Y, ldY, P->nrow, K, P->ncol, P->CBW, nsplit,
-			   (int) P->nblocks, pps, part, Kp, fl, rt_lines);
+			   (int) P->nblocks, pps, part, Kp, fl, rt_lines, rt_ahead, g_pbc_stagger);
 }
 
 int launch_crossprod_general_if(const CrossprodArgs &a, const int *flag, hipStream_t s);
@@ -904,14 +929,15 @@ extern "C" int svt_dev_crossprod_pbc_phase(const svt_dev_pbc *P, const svt_dev_c
 	if (phase == 1) {
 		HIP_TRY(hipMemsetAsync(ws, 0, 256, s));
 		const int nv = (P->CBW + 15) / 16;
-		if (dma && P->CBW <= 40) {
+		if (dma) {
 			if (nv == 1) launch_dma<1>(P, Y, ldY, K, nsplit, pps, part, Kp, fl, s);
 			else if (nv == 2) launch_dma<2>(P, Y, ldY, K, nsplit, pps, part, Kp, fl, s);
 			else launch_dma<3>(P, Y, ldY, K, nsplit, pps, part, Kp, fl, s);
 			HIP_TRY(hipGetLastError());
 			return 0;
 		}
-		const int key = nv * 10000 + P->WPB * 100 + P->logR;
+		// format-1 layouts have no register-staged kernel (row-major Y): general path
+		const int key = P->fmt == 1 ? -1 : nv * 10000 + P->WPB * 100 + P->logR;
 #define PBC_CASE(NV, WPB, LOGR) \
 		case (NV) * 10000 + (WPB) * 100 + (LOGR): \
 			launch_main<NV, WPB, LOGR>(P, Y, ldY, tr_y, K, nsplit, pps, part, Kp, fl, s); break;

@@ -23,6 +23,7 @@ p.add_argument("--ablate", action="store_true")
 p.add_argument("--prof", action="store_true", help="per-section cycle counts of workgroup 0")
 p.add_argument("--reps", type=int, default=5)
 p.add_argument("--nsplits", default="0")
+p.add_argument("--staggers", default="2")
 a = p.parse_args()
 
 dev = torch.device("cuda", 0)
@@ -49,8 +50,9 @@ for cfg in a.cfgs.split(";"):
     plan = PbcPlan(A, a.K, cbw, wpb, logr)
     torch.cuda.synchronize(); build = (time.perf_counter() - t0) * 1e3
     row = [f"cfg cbw={cbw} wpb={wpb} logR={logr}: build {build:.1f} ms"]
-    for ns in (int(x) for x in a.nsplits.split(",")):
+    for ns, stg in ((int(x), int(y)) for x in a.nsplits.split(",") for y in a.staggers.split(",")):
         lib.svt_dev_pbc_set_debug(100 + ns)
+        lib.svt_dev_pbc_set_debug(200 + stg)
         del plan
         plan = PbcPlan(A, a.K, cbw, wpb, logr)      # workspace depends on the split count
         for mode, name in ((0, "full"), (2, "no-compute")):
@@ -58,7 +60,7 @@ for cfg in a.cfgs.split(";"):
                 continue
             lib.svt_dev_pbc_set_debug(mode)
             ms = timed(lambda: plan.run(Y, a.nrow, out), a.reps)
-            row.append(f"[nsplit {ns}] {name} {ms:.3f} ms ({A.nnz / ms / 1e6:.1f} GNZ/s)")
+            row.append(f"[nsplit {ns} stagger {stg}] {name} {ms:.3f} ms ({A.nnz / ms / 1e6:.1f} GNZ/s)")
         if a.prof:
             import ctypes
             lib.svt_dev_pbc_set_debug(3)
