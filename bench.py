@@ -238,6 +238,18 @@ def main():
         ):
             ms = timed(fn)
             ex[name] = {"ms": ms, "GNZ/s": nnz / ms / 1e6, "GB/s": nbytes / ms / 1e6}
+        # config 2b: A %*% Y2 (Y2 = ncol x K) = crossprod(t(A), Y2), t(A) and its layout built on device
+        torch.cuda.synchronize(); t_t = time.perf_counter()
+        T = A.t()
+        torch.cuda.synchronize(); tr_ms = (time.perf_counter() - t_t) * 1e3
+        plan_t = PbcPlan(T, K, a.cbw, a.wpb, a.logr)
+        Y2 = synth.random_dense(ncol, K, seed=202, device=dev)
+        out2 = torch.empty((K, nrow), dtype=torch.float64, device=dev)
+        ms = timed(lambda: plan_t.run(Y2, ncol, out2))
+        ex["matmul_A_Y(2b)"] = {"ms": ms, "GNZ/s": nnz / ms / 1e6,
+                                "GB/s": (nnz * 12 + ncol * K * 8 + nrow * K * 8) / ms / 1e6,
+                                "transpose_ms_once": tr_ms}
+        del plan_t, T, out2
         res["extras"] = ex
     if world == 1 and not a.no_cpu_baseline:
         ns = max(1, min(ncol, int(1e8 / max(nnz / ncol, 1))))   # <= 1e8 nz x K: 10-30 core-seconds

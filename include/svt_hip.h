@@ -268,6 +268,16 @@ int svt_dev_rowsums(const svt_dev_csc *A, int na_rm, int64_t inner,
 int svt_dev_rowsum(const svt_dev_csc *A, const int *group, int ngroup,
 		   int na_rm, double *out, void *stream);
 
+/* t(A) for a 2-d operand, CSC -> CSC (device counterpart of transpose_2D_SVT,
+   src/SparseArray_aperm.c:148-423; every `%*%` / tcrossprod starts with it,
+   R/SparseMatrix-mult.R:165-206).  The caller provides the output arrays
+   (out_col_ptr int64[nrow+1], out_row_idx int32[nnz], out_val like A's) and
+   svt_dev_transpose_ws_bytes() bytes of workspace; entries of every output leaf
+   come out in ascending offset order. */
+size_t svt_dev_transpose_ws_bytes(int64_t nrow, int64_t nnz);
+int svt_dev_transpose(const svt_dev_csc *A, int64_t *out_col_ptr, int32_t *out_row_idx,
+		      void *out_val, void *ws, size_t ws_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -806,6 +806,16 @@ __global__ void pbc_reduce_kernel(const double *__restrict__ part, int nsplit, i
 	out[c * sc + (int64_t) k * sk] = s;
 }
 
+// Single row split: the product kernel wrote `out` itself; only the leaves
+// holding an R NA remain to be patched.
+__global__ void pbc_nafix_kernel(const int *__restrict__ col_has_na, int K, int64_t ncol,
+				 double *__restrict__ out, int64_t sc, int64_t sk)
+{
+	const int64_t c = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= ncol || !col_has_na[c]) return;
+	for (int k = 0; k < K; k++) out[c * sc + (int64_t) k * sk] = svt_na_real();
+}
+
 // ---------------------------------------------------------------------------
 // launch
 // ---------------------------------------------------------------------------
@@ -820,7 +830,9 @@ static int pick_nsplit(const svt_dev_pbc *P, int K, bool dma, int64_t *pps_out)
 	const int64_t kt = ((int64_t) K + 63) / 64;
 	const int64_t units = P->nblocks * kt;
 	int64_t s;
-	if (dma && P->npanels >= 8 * 16) {
+	if (units >= 512) {
+		s = 1;                                  // enough column blocks: no row split, no partials
+	} else if (dma && P->npanels >= 8 * 16) {
 		// One workgroup per CU (LDS, VGPRs), 32 CUs per XCD, the column blocks of a
 		// (split, dense tile) pair share an XCD: take the number of splits per XCD
 		// that leaves the last round of each XCD fullest.
@@ -836,7 +848,7 @@ static int pick_nsplit(const svt_dev_pbc *P, int K, bool dma, int64_t *pps_out)
 		s = (512 + units - 1) / units;          // aim for >= 512 workgroups
 		s = (s + 7) / 8 * 8;                    // whole XCD rounds
 	}
-	if (g_pbc_nsplit > 0) s = g_pbc_nsplit;        // tuning override
+	if (g_pbc_nsplit > 0 && units < 512) s = g_pbc_nsplit;   // tuning override
 	if (s > P->npanels) s = P->npanels;
 	if (s < 1) s = 1;
 	const int64_t pps = (P->npanels + s - 1) / s;
@@ -926,6 +938,10 @@ extern "C" int svt_dev_crossprod_pbc_phase(const svt_dev_pbc *P, const svt_dev_c
 	fl.y_nonfinite = (int *) ws;
 	double *part = (double *) ((char *) ws + PBC_FLAG_BYTES);
 	void *gen_ws = (char *) part + (size_t) nsplit * Kp * P->ncol * 8;
+	// one split, whole 64-wide dense tiles, result laid out like the partials:
+	// the product kernel writes `out` directly
+	const bool direct = nsplit == 1 && Kp == K && out_stride_c == 1 && out_stride_k == P->ncol;
+	if (direct) part = out;
 	if (phase == 1) {
 		HIP_TRY(hipMemsetAsync(ws, 0, 256, s));
 		const int nv = (P->CBW + 15) / 16;
@@ -956,9 +972,14 @@ extern "C" int svt_dev_crossprod_pbc_phase(const svt_dev_pbc *P, const svt_dev_c
 		HIP_TRY(hipGetLastError());
 		return 0;
 	}
-	dim3 rgrid((unsigned) ((P->ncol + 255) / 256), (unsigned) K);
-	hipLaunchKernelGGL(pbc_reduce_kernel, rgrid, dim3(256), 0, s, part, nsplit, Kp, K, P->ncol,
-			   P->col_has_na, out, out_stride_c, out_stride_k);
+	if (direct) {
+		hipLaunchKernelGGL(pbc_nafix_kernel, dim3((unsigned) ((P->ncol + 255) / 256)), dim3(256), 0, s,
+				   P->col_has_na, K, P->ncol, out, out_stride_c, out_stride_k);
+	} else {
+		dim3 rgrid((unsigned) ((P->ncol + 255) / 256), (unsigned) K);
+		hipLaunchKernelGGL(pbc_reduce_kernel, rgrid, dim3(256), 0, s, part, nsplit, Kp, K, P->ncol,
+				   P->col_has_na, out, out_stride_c, out_stride_k);
+	}
 	HIP_TRY(hipGetLastError());
 	// General (slow-path) semantics if the dense operand is not finite.
 	CrossprodArgs a;

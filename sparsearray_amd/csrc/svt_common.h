@@ -151,6 +151,11 @@ int launch_rowstats(const RowStatsArgs &a, int64_t nnz, hipStream_t s);      // 
 size_t rowstats_panel_ws_bytes(int64_t nrow, int64_t ncol);
 int launch_rowstats_panel(const RowStatsArgs &a, void *ws, hipStream_t s);      // LDS row panels
 
+size_t transpose_ws_bytes(int64_t nrow, int64_t nnz);
+int launch_transpose(const int64_t *col_ptr, const int32_t *row_idx, const void *val, int Rtype,
+		     int64_t nrow, int64_t ncol, int64_t nnz, int64_t *out_ptr, int32_t *out_idx,
+		     void *out_val, void *ws, hipStream_t s);
+
 struct GroupSumArgs {
 	const int64_t *col_ptr64;   // one of the two col_ptr flavours is set
 	const int32_t *col_ptr32;

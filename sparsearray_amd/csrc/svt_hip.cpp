@@ -345,6 +345,20 @@ extern "C" int svt_dev_rowsums(const svt_dev_csc *A, int na_rm, int64_t inner,
 	return launch_rowstats_panel(a, ws, (hipStream_t) stream);
 }
 
+extern "C" size_t svt_dev_transpose_ws_bytes(int64_t nrow, int64_t nnz)
+{
+	return transpose_ws_bytes(nrow, nnz);
+}
+
+extern "C" int svt_dev_transpose(const svt_dev_csc *A, int64_t *out_col_ptr, int32_t *out_row_idx,
+				 void *out_val, void *ws, size_t ws_bytes, void *stream)
+{
+	if (ws_bytes < transpose_ws_bytes(A->nrow, A->nnz))
+		return svt_set_error("svt_dev_transpose: workspace too small");
+	return launch_transpose(A->col_ptr, A->row_idx, A->val, A->Rtype, A->nrow, A->ncol, A->nnz,
+				out_col_ptr, out_row_idx, out_val, ws, (hipStream_t) stream);
+}
+
 extern "C" int svt_dev_rowsum(const svt_dev_csc *A, const int *group, int ngroup,
 			      int na_rm, double *out, void *stream)
 {

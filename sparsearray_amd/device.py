@@ -56,6 +56,9 @@ def _lib():
         lib.svt_dev_rowsums.argtypes = [c_void_p, c_int, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]
         lib.svt_dev_rowsum.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]
         lib.svt_colStats_out_Rtype.argtypes = [c_int, c_int]
+        lib.svt_dev_transpose_ws_bytes.restype = c_size_t
+        lib.svt_dev_transpose_ws_bytes.argtypes = [c_int64, c_int64]
+        lib.svt_dev_transpose.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
         _protos_done = True
     return lib
 
@@ -96,6 +99,17 @@ class DeviceCSC:
     @property
     def handle(self):
         return c_void_p(self._h)
+
+    def t(self) -> "DeviceCSC":
+        """t(x) on the device (2-d operands)."""
+        dev = self.val.device
+        cp = torch.empty(self.nrow + 1, dtype=torch.int64, device=dev)
+        ri = torch.empty(self.nnz, dtype=torch.int32, device=dev)
+        vv = torch.empty(self.nnz, dtype=self.val.dtype, device=dev)
+        ws = torch.empty(_lib().svt_dev_transpose_ws_bytes(self.nrow, self.nnz), dtype=torch.uint8, device=dev)
+        _check(_lib().svt_dev_transpose(self.handle, cp.data_ptr(), ri.data_ptr(), vv.data_ptr(),
+                                        ws.data_ptr(), ws.numel(), _stream()))
+        return DeviceCSC(self.ncol, cp, ri, vv, logical=self.Rtype == LGLSXP)
 
     def __del__(self):
         try:

@@ -122,6 +122,44 @@ def test_pbc_dma_path_ragged_columns(hip, oracle):
     assert_equal(out.cpu().numpy().T, want, tol=1e-9, atol=1e-11, what="ragged")
 
 
+@pytest.mark.parametrize("shape", [(3000, 700, 0.01), (257, 5, 0.3), (40, 20000, 0.002), (1, 9, 1.0)])
+@pytest.mark.parametrize("dtype", ["double", "integer"])
+def test_device_transpose(hip, shape, dtype):
+    """t(A) on the device == t() of the host mirror (leaf entries in ascending order)."""
+    nrow, ncol, dens = shape
+    cp, ri, v = random_csc(nrow, ncol, dens, seed=41)
+    if dtype == "integer":
+        v = np.round(v * 100).astype(np.int32)
+    x = SVT_SparseArray.from_csc((nrow, ncol), dtype, cp, ri, v)
+    tcp, tri, tv = x.t().to_csc()
+    A = _dev(cp, ri, v, nrow)
+    T = A.t()
+    torch.cuda.synchronize()
+    assert (T.nrow, T.ncol, T.nnz) == (ncol, nrow, len(v))
+    assert np.array_equal(T.col_ptr.cpu().numpy(), tcp)
+    assert np.array_equal(T.row_idx.cpu().numpy(), tri)
+    assert np.array_equal(T.val.cpu().numpy(), tv)
+
+
+def test_device_matmul_through_transpose(hip, oracle):
+    """x %*% y = crossprod(t(x), y) (R/SparseMatrix-mult.R:195-215) with everything on the
+    device: transpose, panel-blocked layout of t(x), product; many column blocks, one row split."""
+    from sparsearray_amd.device import PbcPlan
+    nrow, ncol, K = 60000, 900, 64
+    cp, ri, v = random_csc(nrow, ncol, 0.01, seed=42)
+    v = v.copy()
+    v[7] = NA_real
+    x = SVT_SparseArray.from_csc((nrow, ncol), "double", cp, ri, v)
+    y = np.random.default_rng(43).uniform(-1, 1, (ncol, K))
+    want = oracle.matmul(x, y)                                          # nrow x K
+    T = _dev(cp, ri, v, nrow).t()                                       # ncol x nrow
+    Yd = torch.as_tensor(np.ascontiguousarray(y.T), device="cuda")      # (K, ncol)
+    out = torch.zeros((K, nrow), dtype=torch.float64, device="cuda")
+    PbcPlan(T, K).run(Yd, ncol, out)
+    torch.cuda.synchronize()
+    assert_equal(out.cpu().numpy().T, want, tol=1e-9, atol=1e-11, strict_na=True, what="matmul")
+
+
 def test_device_stats(hip, oracle):
     from sparsearray_amd.device import colstats, rowsum, rowsums
     nrow, ncol = 30000, 64

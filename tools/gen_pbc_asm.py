@@ -159,21 +159,12 @@ def gen(prof):
     e("16:")
     e("s_mov_b32 s17, s16")                        # arm the staggered issue of the next panel
     e("s_add_u32 s11, s11, 1")
-    # finite check of this workgroup's share of the panel (m0 = iterations left)
+    # finite check of this workgroup's share of the panel: the first read rides on
+    # the resume stub's LDS wait, the rest (few column blocks only) loop at 12
     e("v_readlane_b32 vcc_lo, v7, 0")
     e("v_add_u32 v6, s13, v3")
     e("s_mov_b32 m0, vcc_lo")
-    e("12:")
-    e("ds_read_b64 v[8:9], v6")
-    e(f"v_add_u32 v6, {CHK}, v6")
-    e("s_waitcnt lgkmcnt(0)")
-    e("v_cmp_class_f64 vcc, v[8:9], v10")
-    e("s_or_b32 s18, s18, vcc_lo")
-    e("s_or_b32 s18, s18, vcc_hi")
-    e("s_sub_u32 m0, m0, 1")
-    e("s_cmp_lg_u32 m0, 0")
-    e("s_cbranch_scc1 12b")
-    stamp(4)                                       # finiteness prescan
+    stamp(4)                                       # boundary bookkeeping
     e("s_cmp_lt_u32 s15, 1")
     e("s_cbranch_scc1 40f")
     e("s_cmp_eq_u32 s15, 1")
@@ -185,15 +176,29 @@ def gen(prof):
         stamp(5)                                   # dispatch
         addr8(X1[i])
         read8()
-        e("s_waitcnt lgkmcnt(0)")
-        stamp(6)                                   # resume stub
-        e(f"s_branch {20 + (i + 1) % 3}f")
+        e("s_branch 12f")
+    e("12:")
+    e("ds_read_b64 v[8:9], v6")
+    e(f"v_add_u32 v6, {CHK}, v6")
+    e("s_waitcnt lgkmcnt(0)")
+    e("v_cmp_class_f64 vcc, v[8:9], v10")
+    e("s_or_b32 s18, s18, vcc_lo")
+    e("s_or_b32 s18, s18, vcc_hi")
+    e("s_sub_u32 m0, m0, 1")
+    e("s_cmp_lg_u32 m0, 0")
+    e("s_cbranch_scc1 12b")
+    stamp(6)                                       # resume stub + finiteness prescan
+    e("s_cmp_lt_u32 s15, 1")
+    e("s_cbranch_scc1 21f")
+    e("s_cmp_eq_u32 s15, 1")
+    e("s_cbranch_scc1 22f")
+    e("s_branch 20f")
     # ---------------------------------------------------------------- the 3 phases
     for i in range(3):
         e(f"{20 + i}:")
         if "noload" not in EXP:
             load(X2[i], BATCH * i)
-        if i == 0 and "nokpf" not in EXP:
+        if i == 0 and "kpf" in EXP and "nokpf" not in EXP:   # no gain with 8-record phases: off
             # Scalar-cache prefetch, batched: the lines of the NEXT trip miss together
             # under this phase's wait; the record loads of the next trip then hit the
             # scalar cache instead of paying an L2 round trip in every phase.
