@@ -111,7 +111,12 @@ template <> struct ValTraits<int> {
 	static __device__ inline double as_double(int v) { return (double) v; }
 };
 
-template <typename T, int NT>
+// CAP > 0: the first pass keeps the
+// column in registers (CAP values per thread, all loads in flight at once) and
+// the centred second pass runs from there instead of re-reading it -- the
+// two-pass arithmetic of the reference (src/SparseArray_summarization.c:70-109)
+// with one trip to memory.  Columns longer than NT*CAP take the re-read path.
+template <typename T, int NT, int CAP>
 __global__ void __launch_bounds__(256)
 colstats_kernel(StatsArgs a)
 {
@@ -142,17 +147,16 @@ colstats_kernel(StatsArgs a)
 	double mm = is_min ? INFINITY : -INFINITY;
 
 	// ---- pass 1: flags, NA count, sum / product / extremum -------------
-	for (int64_t k = beg + tid; k < end; k += NT) {
-		const T v = val[k];
+	auto step1 = [&](const T v) {
 		if (VT::is_missing(v)) {
 			nacnt++;
 			flags |= VT::is_na(v) ? F_NA : F_NAN;
 			if (narm)
-				continue;
+				return;
 			// fall through: NaN/NA take part in the IEEE reduction
 			// (ints: the value is never used once F_NA is set)
 			if (!is_dbl)
-				continue;
+				return;
 		} else {
 			if (v != (T) 0) flags |= F_TRUE; else flags |= F_ZERO;
 			flags |= F_HAVE;
@@ -161,6 +165,21 @@ colstats_kernel(StatsArgs a)
 		if (oc == SVT_OP_PROD) acc *= d;
 		else if (is_minmax) { if (d == d) mm = is_min ? (d < mm ? d : mm) : (d > mm ? d : mm); }
 		else acc += d;
+	};
+	T cache[CAP > 0 ? CAP : 1];
+	const bool cached = CAP > 0 && nz <= (int64_t) NT * CAP;   // uniform per column
+	if (cached) {
+#pragma unroll
+		for (int i = 0; i < CAP; i++) {
+			const int64_t k = beg + tid + (int64_t) i * NT;
+			cache[i] = k < end ? val[k] : (T) 0;
+		}
+#pragma unroll
+		for (int i = 0; i < CAP; i++)
+			if (beg + tid + (int64_t) i * NT < end) step1(cache[i]);
+	} else {
+		for (int64_t k = beg + tid; k < end; k += NT)
+			step1(val[k]);
 	}
 	flags = red_or<NT>(flags, my_sm);
 	nacnt = red_sum_ll<NT>(nacnt, my_sm);
@@ -223,12 +242,19 @@ colstats_kernel(StatsArgs a)
 		if (c != c)
 			c = brk_na ? NAr : acc / n_eff;
 		double acc2 = 0.0;
-		for (int64_t k = beg + tid; k < end; k += NT) {
-			const T v = val[k];
+		auto step2 = [&](const T v) {
 			if (VT::is_missing(v) && (narm || !is_dbl))
-				continue;
+				return;
 			const double d = VT::as_double(v) - c;
 			acc2 += d * d;
+		};
+		if (cached) {
+#pragma unroll
+			for (int i = 0; i < CAP; i++)
+				if (beg + tid + (int64_t) i * NT < end) step2(cache[i]);
+		} else {
+			for (int64_t k = beg + tid; k < end; k += NT)
+				step2(val[k]);
 		}
 		acc2 = red_sum<NT>(acc2, my_sm);
 		if (brk_na) { rd = NAr; break; }
@@ -261,12 +287,22 @@ int launch_colstats(const StatsArgs &a, int64_t nnz, hipStream_t s)
 	const bool is_dbl = a.Rtype == SVT_REALSXP;
 	if (avg >= 1024) {
 		dim3 grid((unsigned) a.nseg), block(256);
-		if (is_dbl) hipLaunchKernelGGL((colstats_kernel<double, 256>), grid, block, 0, s, a);
-		else hipLaunchKernelGGL((colstats_kernel<int, 256>), grid, block, 0, s, a);
+		if (avg <= 256 * 40) {               // (also faster for one-pass ops: all loads in flight)
+			if (is_dbl) hipLaunchKernelGGL((colstats_kernel<double, 256, 48>), grid, block, 0, s, a);
+			else hipLaunchKernelGGL((colstats_kernel<int, 256, 48>), grid, block, 0, s, a);
+		} else {
+			if (is_dbl) hipLaunchKernelGGL((colstats_kernel<double, 256, 0>), grid, block, 0, s, a);
+			else hipLaunchKernelGGL((colstats_kernel<int, 256, 0>), grid, block, 0, s, a);
+		}
 	} else {
 		dim3 grid((unsigned) ((a.nseg + 3) / 4)), block(256);
-		if (is_dbl) hipLaunchKernelGGL((colstats_kernel<double, 64>), grid, block, 0, s, a);
-		else hipLaunchKernelGGL((colstats_kernel<int, 64>), grid, block, 0, s, a);
+		if (avg >= 16) {
+			if (is_dbl) hipLaunchKernelGGL((colstats_kernel<double, 64, 16>), grid, block, 0, s, a);
+			else hipLaunchKernelGGL((colstats_kernel<int, 64, 16>), grid, block, 0, s, a);
+		} else {
+			if (is_dbl) hipLaunchKernelGGL((colstats_kernel<double, 64, 0>), grid, block, 0, s, a);
+			else hipLaunchKernelGGL((colstats_kernel<int, 64, 0>), grid, block, 0, s, a);
+		}
 	}
 	HIP_TRY(hipGetLastError());
 	return 0;
