@@ -146,7 +146,8 @@ def gen(prof):
     e("17:")
     e("s_waitcnt vmcnt(1)")                        # own pieces of this panel (the younger touch may fly)
     stamp(1)                                       # own DMA pieces
-    e("s_barrier")                                 # everybody's pieces; everybody done with the previous panel
+    if "nobarrier" not in EXP:
+        e("s_barrier")                             # everybody's pieces; everybody done with the previous panel
     stamp(2)                                       # barrier
     e(f"s_xor_b32 s13, s13, {BUF}")
     e("v_add_u32 v4, s13, v0")

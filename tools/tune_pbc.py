@@ -24,6 +24,7 @@ p.add_argument("--prof", action="store_true", help="per-section cycle counts of 
 p.add_argument("--reps", type=int, default=5)
 p.add_argument("--nsplits", default="0")
 p.add_argument("--staggers", default="2")
+p.add_argument("--ldy0", action="store_true", help="timing experiment: all dense columns alias column 0 (8 MB, cache resident)")
 a = p.parse_args()
 
 dev = torch.device("cuda", 0)
@@ -59,7 +60,7 @@ for cfg in a.cfgs.split(";"):
             if mode and not a.ablate:
                 continue
             lib.svt_dev_pbc_set_debug(mode)
-            ms = timed(lambda: plan.run(Y, a.nrow, out), a.reps)
+            ms = timed(lambda: plan.run(Y, 0 if a.ldy0 else a.nrow, out), a.reps)
             row.append(f"[nsplit {ns} stagger {stg}] {name} {ms:.3f} ms ({A.nnz / ms / 1e6:.1f} GNZ/s)")
         if a.prof:
             import ctypes
