@@ -698,7 +698,7 @@ crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restric
 		// stagger of the DMA issue, in phases
 		PB[4] = stag_mode == 0 ? 0u : stag_mode == 1 ? (uint32_t) (w & 1) :
 			stag_mode == 2 ? (uint32_t) (w & 3) : (uint32_t) ((w >> 2) & 1);
-		PB[5] = 0xFFFFFFFFu;                            // "pieces of the first panel are issued"
+		PB[5] = PBC_DMA_S17_INIT;                       // "pieces of the first panel are issued"
 		PB[6] = 0;
 		PB[7] = (1u << rt_lines) - 1u;                  // lanes of the record touch (rt_lines <= 31)
 #pragma unroll

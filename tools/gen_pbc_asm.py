@@ -58,6 +58,13 @@ YV = 20               # v[20:21] .. v[34:35]
 ACC = 36
 
 EXP = os.environ.get("PBC_EXP", "")      # timing experiments only (results are wrong)
+# DMA issue: "stagger" = all 4 pieces of a wavefront at once, after s16 (= w & 3) phases;
+# "pieces" = every wavefront issues NPP pieces at the end of each of its first 4/NPP phases.
+# Measured at config 2a (tools/debug/exp_issue.sh): stagger 2.14 ms, pieces/2 2.50 ms,
+# pieces/1 2.85 ms -- a lone DMA piece between record phases stalls its wavefront for
+# ~260 cycles, four back to back for ~130 each.
+ISSUE_MODE = os.environ.get("PBC_ISSUE", "stagger")
+NPP = int(os.environ.get("PBC_NPP", "1"))
 PROF = False
 out = []
 
@@ -139,7 +146,10 @@ def gen(prof):
     e("s_cmp_ge_u32 s11, s12")
     e("s_cbranch_scc1 90f")
     # pieces of this panel not issued yet (tile shorter than the stagger)? do it now
-    e("s_cmp_lt_i32 s17, 0")
+    if ISSUE_MODE == "pieces":
+        e("s_cmp_ge_u32 s17, 4")
+    else:
+        e("s_cmp_lt_i32 s17, 0")
     e("s_cbranch_scc1 17f")
     e("s_mov_b32 vcc_hi, 3")
     e("s_branch 60f")
@@ -158,7 +168,10 @@ def gen(prof):
     e("s_nop 3")                                   # (VALU-written SGPR read by a VALU)
     e("v_add_u32 v4, vcc_lo, v4")                  # to end at the last row; rows sit further in
     e("16:")
-    e("s_mov_b32 s17, s16")                        # arm the staggered issue of the next panel
+    if ISSUE_MODE == "pieces":
+        e("s_mov_b32 s17, 0")                      # pieces of the next panel issued so far
+    else:
+        e("s_mov_b32 s17, s16")                    # arm the staggered issue of the next panel
     e("s_add_u32 s11, s11, 1")
     # finite check of this workgroup's share of the panel: the first read rides on
     # the resume stub's LDS wait, the rest (few column blocks only) loop at 12
@@ -212,7 +225,10 @@ def gen(prof):
             e(f"s_add_u32 s10, s10, {TRIP}")
         e(f"s_bitcmp1_b32 s{BLK[X0[i]]}, 15")      # last batch of the tile?
         e(f"s_cbranch_scc1 {30 + i}f")
-        e("s_sub_u32 s17, s17, 1")                 # stagger expired: issue the next panel's pieces
+        if ISSUE_MODE == "pieces":
+            e("s_cmp_lt_u32 s17, 4")               # pieces of the next panel left to issue
+        else:
+            e("s_sub_u32 s17, s17, 1")             # stagger expired: issue the next panel's pieces
         e(f"s_cbranch_scc1 {70 + i}f")
     e("s_branch 20b")
     for i in range(3):
@@ -225,33 +241,95 @@ def gen(prof):
         e("s_branch 60f")
     # ---- issue the DMA pieces of panel s11 (the one after the current) + the
     # ---- record touch; returns to phase vcc_hi+1 (0..2) or to the boundary (3)
-    e("60:")
-    stamp(7)
-    e("s_mov_b32 s17, -1")
-    e("s_cmp_ge_u32 s11, s12")
-    e("s_cbranch_scc1 61f")
-    e("v_readlane_b32 vcc_lo, v7, 1")
-    e("s_cmp_lg_u32 s11, vcc_lo")
-    e("s_cbranch_scc1 15f")
-    e("v_readlane_b32 vcc_lo, v7, 2")
-    for q in range(4):                             # partial last panel: its window ends at the
-        e(f"s_sub_u32 s{20 + 2 * q}, s{20 + 2 * q}, vcc_lo")   # last row (rows nrow-128 .. nrow-1)
-        e(f"s_subb_u32 s{21 + 2 * q}, s{21 + 2 * q}, 0")
-    e("15:")
-    e("s_sub_u32 m0, s14, s13")                    # first piece, other buffer
-    for q in range(4):
-        if q:
-            e(f"s_add_u32 m0, m0, {ROW}")
+    if ISSUE_MODE == "pieces":
+        e("60:")
+        stamp(7)
+        e("s_cmp_lt_u32 s11, s12")
+        e("s_cbranch_scc1 63f")
+        e("s_mov_b32 s17, 4")                      # no next panel
+        e("s_branch 61f")
+        e("63:")
+        e("s_cmp_lg_u32 s17, 0")                   # first piece: a partial last panel's window
+        e("s_cbranch_scc1 64f")                    # ends at the last row (rows nrow-128 .. nrow-1)
+        e("v_readlane_b32 vcc_lo, v7, 1")
+        e("s_cmp_lg_u32 s11, vcc_lo")
+        e("s_cbranch_scc1 64f")
+        e("v_readlane_b32 vcc_lo, v7, 2")
+        for q in range(4):
+            e(f"s_sub_u32 s{20 + 2 * q}, s{20 + 2 * q}, vcc_lo")
+            e(f"s_subb_u32 s{21 + 2 * q}, s{21 + 2 * q}, 0")
+        e("64:")
+        e(f"s_mul_i32 vcc_lo, s17, {ROW}")
+        e("s_sub_u32 m0, s14, s13")                # piece s17, other buffer
+        e("s_add_u32 m0, m0, vcc_lo")
+        e("s_cmp_lt_u32 s17, 2")
+        e("s_cbranch_scc1 66f")
+        e("s_cmp_eq_u32 s17, 2")
+        e("s_cbranch_scc1 67f")
+        e("global_load_lds_dwordx4 v1, s[26:27]")
+        e("s_branch 65f")
+        e("67:")
         e("s_nop 0")
-        e(f"global_load_lds_dwordx4 v1, s[{20 + 2 * q}:{21 + 2 * q}]")
-    for q in range(4):
-        e(f"s_add_u32 s{20 + 2 * q}, s{20 + 2 * q}, 1024")
-        e(f"s_addc_u32 s{21 + 2 * q}, s{21 + 2 * q}, 0")
-    e("v_add_u32 v6, s10, v2")                     # records ~2 panels ahead towards L2
-    e("s_mov_b32 exec_lo, s19")
-    e("s_mov_b32 exec_hi, 0")
-    e("global_load_dword v5, v6, s[8:9]")
-    e("s_mov_b64 exec, -1")
+        e("global_load_lds_dwordx4 v1, s[24:25]")
+        e("s_branch 65f")
+        e("66:")
+        e("s_cmp_eq_u32 s17, 0")
+        e("s_cbranch_scc1 68f")
+        e("global_load_lds_dwordx4 v1, s[22:23]")
+        e("s_branch 65f")
+        e("68:")
+        e("s_nop 0")
+        e("global_load_lds_dwordx4 v1, s[20:21]")
+        e("65:")
+        e("s_add_u32 s17, s17, 1")
+        if NPP == 2:
+            e("s_bitcmp1_b32 s17, 0")              # pieces go out in pairs
+            e("s_cbranch_scc1 64b")
+        elif NPP == 4:
+            e("s_cmp_lt_u32 s17, 4")
+            e("s_cbranch_scc1 64b")
+        e("s_cmp_lt_u32 s17, 4")
+        e("s_cbranch_scc0 69f")
+        e("s_cmp_eq_u32 vcc_hi, 3")                # called from the boundary: all that is left
+        e("s_cbranch_scc1 64b")
+        e("s_branch 61f")
+        e("69:")                                   # 4th piece out: advance the bases, touch
+        for q in range(4):
+            e(f"s_add_u32 s{20 + 2 * q}, s{20 + 2 * q}, 1024")
+            e(f"s_addc_u32 s{21 + 2 * q}, s{21 + 2 * q}, 0")
+        e("v_add_u32 v6, s10, v2")                 # records ~2 panels ahead towards L2
+        e("s_mov_b32 exec_lo, s19")
+        e("s_mov_b32 exec_hi, 0")
+        e("global_load_dword v5, v6, s[8:9]")
+        e("s_mov_b64 exec, -1")
+    else:
+        e("60:")
+        stamp(7)
+        e("s_mov_b32 s17, -1")
+        e("s_cmp_ge_u32 s11, s12")
+        e("s_cbranch_scc1 61f")
+        e("v_readlane_b32 vcc_lo, v7, 1")
+        e("s_cmp_lg_u32 s11, vcc_lo")
+        e("s_cbranch_scc1 15f")
+        e("v_readlane_b32 vcc_lo, v7, 2")
+        for q in range(4):                             # partial last panel: its window ends at the
+            e(f"s_sub_u32 s{20 + 2 * q}, s{20 + 2 * q}, vcc_lo")   # last row (rows nrow-128 .. nrow-1)
+            e(f"s_subb_u32 s{21 + 2 * q}, s{21 + 2 * q}, 0")
+        e("15:")
+        e("s_sub_u32 m0, s14, s13")                    # first piece, other buffer
+        for q in range(4):
+            if q:
+                e(f"s_add_u32 m0, m0, {ROW}")
+            e("s_nop 0")
+            e(f"global_load_lds_dwordx4 v1, s[{20 + 2 * q}:{21 + 2 * q}]")
+        for q in range(4):
+            e(f"s_add_u32 s{20 + 2 * q}, s{20 + 2 * q}, 1024")
+            e(f"s_addc_u32 s{21 + 2 * q}, s{21 + 2 * q}, 0")
+        e("v_add_u32 v6, s10, v2")                     # records ~2 panels ahead towards L2
+        e("s_mov_b32 exec_lo, s19")
+        e("s_mov_b32 exec_hi, 0")
+        e("global_load_dword v5, v6, s[8:9]")
+        e("s_mov_b64 exec, -1")
     e("61:")
     stamp(3)                                       # DMA + touch issue
     e("s_cmp_lt_u32 vcc_hi, 1")
@@ -271,6 +349,7 @@ dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
 with open(dst, "w") as f:
     f.write("// Generated by tools/gen_pbc_asm.py -- do not edit; see that file for the register map.\n")
     f.write(f"#define PBC_DMA_ROW {ROW}\n#define PBC_DMA_BUF {BUF}\n#define PBC_DMA_BATCH_BYTES {BATCH}\n")
+    f.write("#define PBC_DMA_S17_INIT %s\n" % ("4u" if ISSUE_MODE == "pieces" else "0xFFFFFFFFu"))
     for name, prof in (("PBC_DMA_ASM_TEXT", False), ("PBC_DMA_ASM_TEXT_PROF", True)):
         lines = gen(prof)
         f.write(f"#define {name} \\\n")
