@@ -944,6 +944,12 @@ extern "C" int svt_dev_crossprod_pbc_phase(const svt_dev_pbc *P, const svt_dev_c
 	if (direct) part = out;
 	if (phase == 1) {
 		HIP_TRY(hipMemsetAsync(ws, 0, 256, s));
+		if (P->rec == NULL) {
+			// no nonzero at all (no record stream was built): the general kernels
+			// produce the zeros -- or the NaNs, if Y is not finite
+			HIP_TRY(hipMemsetAsync(ws, 1, 4, s));
+			return 0;
+		}
 		const int nv = (P->CBW + 15) / 16;
 		if (dma) {
 			if (nv == 1) launch_dma<1>(P, Y, ldY, K, nsplit, pps, part, Kp, fl, s);

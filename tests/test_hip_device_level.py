@@ -99,6 +99,39 @@ def test_pbc_dma_path_prescan_sees_every_dense_entry(hip, oracle, cbw):
     assert_equal(out.cpu().numpy().T, want, tol=1e-9, atol=1e-11, what="clean")
 
 
+@pytest.mark.parametrize("case", ["dense", "one_column", "wide_K", "min_rows", "below_min_rows", "empty",
+                                  "one_nonzero", "tall_thin"])
+def test_pbc_odd_shapes(hip, oracle, case):
+    """Shapes at the edges of the panel kernels' preconditions."""
+    from sparsearray_amd.device import PbcPlan
+    nrow, ncol, K, dens = {"dense": (700, 90, 64, 0.5), "one_column": (5000, 1, 64, 0.3),
+                           "wide_K": (3000, 200, 200, 0.02), "min_rows": (256, 50, 10, 0.1),
+                           "below_min_rows": (255, 50, 10, 0.1), "empty": (1000, 70, 8, 0.0),
+                           "one_nonzero": (1000, 70, 8, 0.0), "tall_thin": (200000, 3, 5, 0.001)}[case]
+    cp, ri, v = random_csc(nrow, ncol, dens, seed=51)
+    if case == "one_nonzero":
+        cp = np.zeros(ncol + 1, dtype=np.int64); cp[41:] = 1
+        ri = np.array([999], dtype=np.int32); v = np.array([-2.5])
+    x = SVT_SparseArray.from_csc((nrow, ncol), "double", cp, ri, v)
+    # the device layout has leaves only: an all-empty operand is a tree of NULL
+    # leaves, not the `SVT == NULL` object the reference short-circuits on
+    # (src/SparseMatrix_mult.c:389-390); that flag is host-level business
+    x.svt_is_null = False
+    rng = np.random.default_rng(52)
+    A = _dev(cp, ri, v, nrow)
+    plan = PbcPlan(A, K)
+    for poison in (False, True):
+        y = rng.uniform(-1, 1, (nrow, K))
+        if poison:
+            y[nrow // 2, K - 1] = np.nan
+        want = oracle.crossprod(x, y)
+        Yd = torch.as_tensor(np.ascontiguousarray(y.T), device="cuda")
+        out = torch.full((K, ncol), 7.0, dtype=torch.float64, device="cuda")
+        plan.run(Yd, nrow, out)
+        torch.cuda.synchronize()
+        assert_equal(out.cpu().numpy().T, want, tol=1e-9, atol=1e-11, what=f"{case} poison={poison}")
+
+
 def test_pbc_dma_path_ragged_columns(hip, oracle):
     """Empty columns, one very long column, empty row ranges (empty tiles)."""
     from sparsearray_amd.device import PbcPlan
