@@ -268,6 +268,16 @@ int svt_dev_rowsums(const svt_dev_csc *A, int na_rm, int64_t inner,
 int svt_dev_rowsum(const svt_dev_csc *A, const int *group, int ngroup,
 		   int na_rm, double *out, void *stream);
 
+/* Thread control (C_get_num_procs / C_get_max_threads / C_set_max_threads,
+   src/thread_control.c:47-66; R/thread-control.R sets the team size around every
+   .Call and restores it).  The device kernels have no thread team to size: the
+   library reports the host's processor count, remembers the value it is given
+   and returns the previous one, so SparseArray.Call() keeps working unchanged.
+   No HIP call is made. */
+int svt_get_num_procs(void);
+int svt_get_max_threads(void);
+int svt_set_max_threads(int nthread);
+
 /* t(A) for a 2-d operand, CSC -> CSC (device counterpart of transpose_2D_SVT,
    src/SparseArray_aperm.c:148-423; every `%*%` / tcrossprod starts with it,
    R/SparseMatrix-mult.R:165-206).  The caller provides the output arrays

@@ -75,6 +75,19 @@ class CAbiDispatcher:
             raise SparseArrayError(f"unknown entry point {name}")
         return getattr(self, name)(*args)
 
+    # thread control (src/thread_control.c:47-66) -------------------------------
+    def C_get_num_procs(self):
+        return int(self._fn("get_num_procs")())
+
+    def C_get_max_threads(self):
+        return int(self._fn("get_max_threads")())
+
+    def C_set_max_threads(self, nthread: int):
+        """Returns the previous value (the reference returns it too, R/thread-control.R:60-66)."""
+        f = self._fn("set_max_threads")
+        f.argtypes = [ctypes.c_int]
+        return int(f(int(nthread)))
+
     # crossprod ---------------------------------------------------------------
     def C_crossprod2_SVT_mat(self, x: SVT_SparseArray, y: np.ndarray, tr_y: bool):
         y = _F(y)

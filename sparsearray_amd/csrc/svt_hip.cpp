@@ -7,6 +7,7 @@
 // launch the kernels and copy the result back.  No arithmetic of the hot path
 // happens on the host.
 #include "svt_common.h"
+#include <unistd.h>
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -49,6 +50,24 @@ extern "C" int svt_init(int device)
 				     "carries gfx950 (MI355X) code only", device, g_arch);
 	g_device = device;
 	return 0;
+}
+
+// ---- thread control (src/thread_control.c:47-66) ---------------------------------
+static int g_max_threads = 0;
+extern "C" int svt_get_num_procs(void)
+{
+	const long n = sysconf(_SC_NPROCESSORS_ONLN);
+	return n > 0 ? (int) n : 0;
+}
+extern "C" int svt_get_max_threads(void)
+{
+	return g_max_threads > 0 ? g_max_threads : svt_get_num_procs();
+}
+extern "C" int svt_set_max_threads(int nthread)
+{
+	const int prev = svt_get_max_threads();
+	if (nthread > 0) g_max_threads = nthread;
+	return prev;
 }
 
 static int ensure_init()

@@ -26,6 +26,19 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, sym), f"libsvt_hip.so does not export {sym}"
 
 
+def test_thread_control_entry_points_need_no_gpu():
+    """C_get_num_procs / C_get_max_threads / C_set_max_threads (src/thread_control.c:47-66):
+    set returns the previous value, get returns what was set."""
+    from sparsearray_amd._hip import load_library
+    lib = load_library()
+    assert lib.svt_get_num_procs() >= 1
+    first = lib.svt_get_max_threads()
+    assert first >= 1
+    assert lib.svt_set_max_threads(3) == first
+    assert lib.svt_get_max_threads() == 3
+    assert lib.svt_set_max_threads(first) == 3
+
+
 def test_product_fails_loudly_without_gpu():
     """On a box without an MI355X the product path must raise, not fall back."""
     import torch
