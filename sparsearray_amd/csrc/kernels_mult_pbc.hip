@@ -644,6 +644,7 @@ crossprod_pbc_kernel(const uint4 *__restrict__ rec,
 #include "pbc_dma_asm.inc"
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 #define PBC_DMA_YAHEAD 3
 #define PBC_DMA_CLOBBERS "memory", "scc", "vcc", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99"
 
@@ -698,7 +699,7 @@ crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restric
 		// stagger of the DMA issue, in phases
 		PB[4] = stag_mode == 0 ? 0u : stag_mode == 1 ? (uint32_t) (w & 1) :
 			stag_mode == 2 ? (uint32_t) (w & 3) : (uint32_t) ((w >> 2) & 1);
-		PB[5] = PBC_DMA_S17_INIT;                       // "pieces of the first panel are issued"
+		PB[5] = 0xFFFFFFFFu;                       // "pieces of the first panel are issued"
 		PB[6] = 0;
 		PB[7] = (1u << rt_lines) - 1u;                  // lanes of the record touch (rt_lines <= 31)
 #pragma unroll
@@ -745,12 +746,23 @@ crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restric
 		}
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	}
+#if PBC_DMA_YSETS == 2
+	u32x8 V3 = 0;
+#define PBC_DMA_STATE "+{v[0:15]}"(V0), "+{v[16:31]}"(V1), "+{v[32:39]}"(V3), "+{v[40:43]}"(V2), "+{s[8:11]}"(PA), "+{s[12:27]}"(PB)
+#define PBC_ACC0 "+{v[44:75]}"
+#define PBC_ACC1 "+{v[76:107]}"
+#define PBC_ACC2 "+{v[108:123]}"
+#else
 #define PBC_DMA_STATE "+{v[0:15]}"(V0), "+{v[16:31]}"(V1), "+{v[32:35]}"(V2), "+{s[8:11]}"(PA), "+{s[12:27]}"(PB)
+#define PBC_ACC0 "+{v[36:67]}"
+#define PBC_ACC1 "+{v[68:99]}"
+#define PBC_ACC2 "+{v[100:115]}"
+#endif
 	if constexpr (PROF) {
 		// tuning build (NV <= 2): cycles per section in v[116:123], see gen_pbc_asm.py
 		u32x16 PV = 0;
 		asm volatile(PBC_DMA_ASM_TEXT_PROF
-			     : "+{v[36:67]}"(acc[0]), "+{v[68:99]}"(acc[NV > 1 ? 1 : 0]), PBC_DMA_STATE,
+			     : PBC_ACC0(acc[0]), PBC_ACC1(acc[NV > 1 ? 1 : 0]), PBC_DMA_STATE,
 			       "+{v[112:127]}"(PV)
 			     : : PBC_DMA_CLOBBERS, "s100", "s101");
 		if (blockIdx.x == 0 && (tid & 63) == 0) {
@@ -760,18 +772,21 @@ crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restric
 		}
 	} else if constexpr (NV == 1) {
 		asm volatile(PBC_DMA_ASM_TEXT
-			     : "+{v[36:67]}"(acc[0]), PBC_DMA_STATE
+			     : PBC_ACC0(acc[0]), PBC_DMA_STATE
 			     : : PBC_DMA_CLOBBERS);
 	} else if constexpr (NV == 2) {
 		asm volatile(PBC_DMA_ASM_TEXT
-			     : "+{v[36:67]}"(acc[0]), "+{v[68:99]}"(acc[NV > 1 ? 1 : 0]), PBC_DMA_STATE
+			     : PBC_ACC0(acc[0]), PBC_ACC1(acc[NV > 1 ? 1 : 0]), PBC_DMA_STATE
 			     : : PBC_DMA_CLOBBERS);
 	} else {
 		asm volatile(PBC_DMA_ASM_TEXT
-			     : "+{v[36:67]}"(acc[0]), "+{v[68:99]}"(acc[NV > 1 ? 1 : 0]),
-			       "+{v[100:115]}"(acc8), PBC_DMA_STATE
+			     : PBC_ACC0(acc[0]), PBC_ACC1(acc[NV > 1 ? 1 : 0]),
+			       PBC_ACC2(acc8), PBC_DMA_STATE
 			     : : PBC_DMA_CLOBBERS);
 	}
+#undef PBC_ACC0
+#undef PBC_ACC1
+#undef PBC_ACC2
 #undef PBC_DMA_STATE
 	if (PB[6] != 0 && (tid & 63) == 0)
 		*fl.y_nonfinite = 1;

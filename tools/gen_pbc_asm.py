@@ -3,8 +3,9 @@
 crossprod_pbc_dma_kernel (kernels_mult_pbc.hip) as one inline-asm string.
 
 Why generated: the loop is a 3-stage software pipeline over three rotating SGPR
-blocks (3 phases), with a resume stub per phase for panel boundaries and an
-out-of-line DMA issue routine; the variants differ only in register numbers.
+blocks and YSETS sets of y registers (3 * YSETS phases), with a resume stub per
+phase for panel boundaries and an out-of-line DMA issue routine; the variants
+differ only in register numbers.
 
 Record stream ("format 1", built by pbc_pass_kernel<.., 1>): batches of 8 records,
 96 bytes each = 8 x u32 meta followed by 8 x f64 value.
@@ -16,14 +17,22 @@ one batch, so the loop needs no tile table.
 
 Pipeline, per phase (one batch of 8 records each):
     L(k+2)  s_load_dwordx8 + s_load_dwordx16        -> block X2
-    A(k+1)  8 LDS addresses from block X1
-    F(k) / D(k+1) interleaved in VGPR-index mode: acc[c_j] += a_j * y_j, then the
-            LDS read of record j of the NEXT batch lands in the same y_j
+    D(k+1)  8 LDS addresses from block X1 (computed in the low half of the
+            destination register pair), 8 ds_read_b64 -> y set SD
+    F(k)    acc[c_j] += a_j * y_j in VGPR-index mode, y set SF
     one s_waitcnt lgkmcnt(0), flag test, DMA-stagger countdown
-Measured (tools/debug/exp_pbc.sh): what a phase costs is the scalar-load round trip
-behind its single wait, not its instructions -- twice the work per phase ran
-1.5 % slower -- hence 8 records per phase (the SGPR file allows no more: 3 x 24)
-and a batched scalar-cache prefetch (6 lines once per trip).
+YSETS = 2: D runs ahead of F into the other y set, so the LDS latency hides under
+the 16 instructions of F.  YSETS = 1: the read that refills y_j is issued right
+behind the FMA that consumed it (16 VGPRs fewer, LDS latency of the last read
+exposed at the wait).
+Measured (tools/debug/exp_pbc.sh): what a phase costs is the round trips behind its
+single wait, not its instructions -- twice the work per phase ran 1.5 % slower --
+hence 8 records per phase (the SGPR file allows no more: 3 x 24).
+
+DMA issue: all 4 pieces of a wavefront at once, after s16 (= w & 3) phases.
+Alternatives measured at config 2a: every piece on its own between phases 2.85 ms,
+in pairs 2.50 ms, staggered batches of four 2.14 ms (a lone piece stalls its
+wavefront ~260 cycles, four back to back ~130 each); all 64 at the barrier 2.32 ms.
 
 Register map (fixed physical registers; the kernel pins C++ vectors to them):
   SGPR  s[28:51] s[52:75] s[76:99]   record blocks A, B, C (+0..7 meta, +8..23 values)
@@ -41,8 +50,10 @@ Register map (fixed physical registers; the kernel pins C++ vectors to them):
         v5 touch destination (never read)   v6 scratch address
         v7 constants by lane: [0] finite-check iterations, [1] index of the partial
            last panel (or ~0), [2] byte shift of that panel's window
-        v[8:9] check value  v10 class mask  v[12:19] LDS addresses
-        v[20:35] y values   v[36:...] partial sums (register-indexed: v[36 + 2*column])
+        v[8:9] check value  v10 class mask  v11 spare
+        v[12:27] y set a, v[28:43] y set b (YSETS = 2)  /  v[12:19] addresses,
+        v[20:35] y (YSETS = 1)
+        v[ACC:...] partial sums (register-indexed: v[ACC + 2*column]), ACC = 44 / 36
 """
 import os
 
@@ -50,21 +61,19 @@ ROW = 1032            # bytes per dense column in an LDS buffer: (128 + 1) * 8
 BUF = 64 * ROW        # bytes per buffer
 CHK = 8 * ROW         # 1024 threads = 8 dense columns per finite-check step
 BATCH = 96            # bytes per batch of 8 records
-TRIP = 3 * BATCH
-
-BLK = {"A": 28, "B": 52, "C": 76}
-ADDR = 12             # v12..v19
-YV = 20               # v[20:21] .. v[34:35]
-ACC = 36
 
 EXP = os.environ.get("PBC_EXP", "")      # timing experiments only (results are wrong)
-# DMA issue: "stagger" = all 4 pieces of a wavefront at once, after s16 (= w & 3) phases;
-# "pieces" = every wavefront issues NPP pieces at the end of each of its first 4/NPP phases.
-# Measured at config 2a (tools/debug/exp_issue.sh): stagger 2.14 ms, pieces/2 2.50 ms,
-# pieces/1 2.85 ms -- a lone DMA piece between record phases stalls its wavefront for
-# ~260 cycles, four back to back for ~130 each.
-ISSUE_MODE = os.environ.get("PBC_ISSUE", "stagger")
-NPP = int(os.environ.get("PBC_NPP", "1"))
+YSETS = int(os.environ.get("PBC_YSETS", "1"))   # 2 measured equal (2.118 vs 2.105 ms): not the LDS latency
+NPH = 3 * YSETS
+TRIP = NPH * BATCH
+BLK = {"A": 28, "B": 52, "C": 76}
+if YSETS == 2:
+    YSET = [12, 28]
+    ACC = 44
+else:
+    ADDR = 12
+    YSET = [20]
+    ACC = 36
 PROF = False
 out = []
 
@@ -85,6 +94,15 @@ def stamp(bucket):
     e("v_mov_b32 v126, s100")
 
 
+def dispatch(reg, labels, direction):
+    """Branch to labels[reg] (compare chain; the last label is the fall-through)."""
+    n = len(labels)
+    for i, lab in enumerate(labels[:-1]):
+        e(f"s_cmp_eq_u32 {reg}, {i}")
+        e(f"s_cbranch_scc1 {lab}{direction}")
+    e(f"s_branch {labels[n - 1]}{direction}")
+
+
 def load(blk, off):
     r = BLK[blk]
     o = f" offset:{off}" if off else ""
@@ -92,21 +110,43 @@ def load(blk, off):
     e(f"s_load_dwordx16 s[{r + 8}:{r + 23}], s[8:9], s10 offset:{off + 32}")
 
 
-def addr8(blk):
-    r = BLK[blk]
-    for j in range(8):
-        e(f"v_add_u32_sdwa v{ADDR + j}, s{r + j}, v4 dst_sel:DWORD dst_unused:UNUSED_PAD "
-          f"src0_sel:WORD_1 src1_sel:DWORD")
+X0 = ["A", "B", "C"]      # block whose FMAs run in phase i (i % 3)
+X1 = ["B", "C", "A"]      # block whose LDS reads are issued
+X2 = ["C", "A", "B"]      # block being loaded
 
 
-def read8():
-    for j in range(8):
-        e(f"ds_read_b64 v[{YV + 2 * j}:{YV + 2 * j + 1}], v{ADDR + j}")
+def sd(i):                # y set written by the LDS reads of phase i
+    return YSET[(i + 1) % YSETS]
 
 
-def fd8(blk):
-    """FMAs of block blk, each followed by the LDS read that refills its y."""
-    r = BLK[blk]
+def sf(i):                # y set consumed by the FMAs of phase i
+    return YSET[i % YSETS]
+
+
+def sdwa_add(dst, src_s):
+    e(f"v_add_u32_sdwa v{dst}, s{src_s}, v4 dst_sel:DWORD dst_unused:UNUSED_PAD "
+      f"src0_sel:WORD_1 src1_sel:DWORD")
+
+
+def d8(i):
+    """LDS reads of block X1(i) into y set sd(i) (two-set form and resume stubs)."""
+    r = BLK[X1[i % 3]]
+    y = sd(i)
+    if YSETS == 2:
+        for j in range(8):
+            sdwa_add(y + 2 * j, r + j)
+        for j in range(8):
+            e(f"ds_read_b64 v[{y + 2 * j}:{y + 2 * j + 1}], v{y + 2 * j}")
+    else:
+        for j in range(8):
+            sdwa_add(ADDR + j, r + j)
+        for j in range(8):
+            e(f"ds_read_b64 v[{y + 2 * j}:{y + 2 * j + 1}], v{ADDR + j}")
+
+
+def f8(i, interleave):
+    r = BLK[X0[i % 3]]
+    y = sf(i)
     for j in range(8):
         if "nofma" not in EXP:
             if j == 0:
@@ -114,15 +154,11 @@ def fd8(blk):
             else:
                 e(f"s_set_gpr_idx_idx s{r + j}")
             e(f"v_fma_f64 v[{ACC}:{ACC + 1}], s[{r + 8 + 2 * j}:{r + 9 + 2 * j}], "
-              f"v[{YV + 2 * j}:{YV + 2 * j + 1}], v[{ACC}:{ACC + 1}]")
-        e(f"ds_read_b64 v[{YV + 2 * j}:{YV + 2 * j + 1}], v{ADDR + j}")
+              f"v[{y + 2 * j}:{y + 2 * j + 1}], v[{ACC}:{ACC + 1}]")
+        if interleave:   # single y set: refill y_j for the next batch right away
+            e(f"ds_read_b64 v[{y + 2 * j}:{y + 2 * j + 1}], v{ADDR + j}")
     if "nofma" not in EXP:
         e("s_set_gpr_idx_off")
-
-
-X0 = ["A", "B", "C"]      # block whose FMAs run in phase i
-X1 = ["B", "C", "A"]      # block whose LDS reads are issued
-X2 = ["C", "A", "B"]      # block being loaded
 
 
 def gen(prof):
@@ -133,12 +169,13 @@ def gen(prof):
         e("s_memtime s[100:101]")
         e("s_waitcnt lgkmcnt(0)")
         e("v_mov_b32 v126, s100")
+    ph = [f"{20 + i}" for i in range(NPH)]          # phase labels
     # ---------------------------------------------------------------- setup
     e("v_mov_b32 v10, 0x207")                      # class mask: sNaN | qNaN | -Inf | +Inf
     load("A", 0)
     load("B", BATCH)
     e(f"s_add_u32 s10, s10, {2 * BATCH}")
-    e("s_mov_b32 s15, 2")
+    e(f"s_mov_b32 s15, {NPH - 1}")
     # ---------------------------------------------------------------- panel boundary
     e("10:")
     stamp(7)                                       # phases
@@ -146,12 +183,9 @@ def gen(prof):
     e("s_cmp_ge_u32 s11, s12")
     e("s_cbranch_scc1 90f")
     # pieces of this panel not issued yet (tile shorter than the stagger)? do it now
-    if ISSUE_MODE == "pieces":
-        e("s_cmp_ge_u32 s17, 4")
-    else:
-        e("s_cmp_lt_i32 s17, 0")
+    e("s_cmp_lt_i32 s17, 0")
     e("s_cbranch_scc1 17f")
-    e("s_mov_b32 vcc_hi, 3")
+    e(f"s_mov_b32 vcc_hi, {NPH}")
     e("s_branch 60f")
     e("17:")
     e("s_waitcnt vmcnt(1)")                        # own pieces of this panel (the younger touch may fly)
@@ -168,10 +202,7 @@ def gen(prof):
     e("s_nop 3")                                   # (VALU-written SGPR read by a VALU)
     e("v_add_u32 v4, vcc_lo, v4")                  # to end at the last row; rows sit further in
     e("16:")
-    if ISSUE_MODE == "pieces":
-        e("s_mov_b32 s17, 0")                      # pieces of the next panel issued so far
-    else:
-        e("s_mov_b32 s17, s16")                    # arm the staggered issue of the next panel
+    e("s_mov_b32 s17, s16")                        # arm the staggered issue of the next panel
     e("s_add_u32 s11, s11, 1")
     # finite check of this workgroup's share of the panel: the first read rides on
     # the resume stub's LDS wait, the rest (few column blocks only) loop at 12
@@ -179,17 +210,12 @@ def gen(prof):
     e("v_add_u32 v6, s13, v3")
     e("s_mov_b32 m0, vcc_lo")
     stamp(4)                                       # boundary bookkeeping
-    e("s_cmp_lt_u32 s15, 1")
-    e("s_cbranch_scc1 40f")
-    e("s_cmp_eq_u32 s15, 1")
-    e("s_cbranch_scc1 41f")
-    e("s_branch 42f")
+    dispatch("s15", [f"{40 + i}" for i in range(NPH)], "f")
     # ---------------------------------------------------------------- resume stubs
-    for i in range(3):
+    for i in range(NPH):
         e(f"{40 + i}:")
         stamp(5)                                   # dispatch
-        addr8(X1[i])
-        read8()
+        d8(i)
         e("s_branch 12f")
     e("12:")
     e("ds_read_b64 v[8:9], v6")
@@ -202,143 +228,66 @@ def gen(prof):
     e("s_cmp_lg_u32 m0, 0")
     e("s_cbranch_scc1 12b")
     stamp(6)                                       # resume stub + finiteness prescan
-    e("s_cmp_lt_u32 s15, 1")
-    e("s_cbranch_scc1 21f")
-    e("s_cmp_eq_u32 s15, 1")
-    e("s_cbranch_scc1 22f")
-    e("s_branch 20f")
-    # ---------------------------------------------------------------- the 3 phases
-    for i in range(3):
-        e(f"{20 + i}:")
-        if "noload" not in EXP:
-            load(X2[i], BATCH * i)
-        if i == 0 and "kpf" in EXP and "nokpf" not in EXP:   # no gain with 8-record phases: off
-            # Scalar-cache prefetch, batched: the lines of the NEXT trip miss together
-            # under this phase's wait; the record loads of the next trip then hit the
-            # scalar cache instead of paying an L2 round trip in every phase.
-            for j in range(6):
-                e(f"s_load_dword vcc_lo, s[8:9], s10 offset:{TRIP + 64 * j}")
-        addr8(X1[i])
-        fd8(X0[i])
-        e("s_waitcnt lgkmcnt(0)")
-        if i == 2:
-            e(f"s_add_u32 s10, s10, {TRIP}")
-        e(f"s_bitcmp1_b32 s{BLK[X0[i]]}, 15")      # last batch of the tile?
-        e(f"s_cbranch_scc1 {30 + i}f")
-        if ISSUE_MODE == "pieces":
-            e("s_cmp_lt_u32 s17, 4")               # pieces of the next panel left to issue
+    dispatch("s15", [ph[(i + 1) % NPH] for i in range(NPH)], "f")
+    # ---------------------------------------------------------------- the phases
+    for i in range(NPH):
+        e(f"{ph[i]}:")
+        load(X2[i % 3], BATCH * i)
+        if YSETS == 2:
+            d8(i)
+            f8(i, False)
         else:
-            e("s_sub_u32 s17, s17, 1")             # stagger expired: issue the next panel's pieces
+            for j in range(8):
+                sdwa_add(ADDR + j, BLK[X1[i % 3]] + j)
+            f8(i, True)
+        e("s_waitcnt lgkmcnt(0)")
+        if i == NPH - 1:
+            e(f"s_add_u32 s10, s10, {TRIP}")
+        e(f"s_bitcmp1_b32 s{BLK[X0[i % 3]]}, 15")  # last batch of the tile?
+        e(f"s_cbranch_scc1 {30 + i}f")
+        e("s_sub_u32 s17, s17, 1")                 # stagger expired: issue the next panel's pieces
         e(f"s_cbranch_scc1 {70 + i}f")
-    e("s_branch 20b")
-    for i in range(3):
+    e(f"s_branch {ph[0]}b")
+    for i in range(NPH):
         e(f"{30 + i}:")
         e(f"s_mov_b32 s15, {i}")
         e("s_branch 10b")
-    for i in range(3):
+    for i in range(NPH):
         e(f"{70 + i}:")
         e(f"s_mov_b32 vcc_hi, {i}")
         e("s_branch 60f")
     # ---- issue the DMA pieces of panel s11 (the one after the current) + the
-    # ---- record touch; returns to phase vcc_hi+1 (0..2) or to the boundary (3)
-    if ISSUE_MODE == "pieces":
-        e("60:")
-        stamp(7)
-        e("s_cmp_lt_u32 s11, s12")
-        e("s_cbranch_scc1 63f")
-        e("s_mov_b32 s17, 4")                      # no next panel
-        e("s_branch 61f")
-        e("63:")
-        e("s_cmp_lg_u32 s17, 0")                   # first piece: a partial last panel's window
-        e("s_cbranch_scc1 64f")                    # ends at the last row (rows nrow-128 .. nrow-1)
-        e("v_readlane_b32 vcc_lo, v7, 1")
-        e("s_cmp_lg_u32 s11, vcc_lo")
-        e("s_cbranch_scc1 64f")
-        e("v_readlane_b32 vcc_lo, v7, 2")
-        for q in range(4):
-            e(f"s_sub_u32 s{20 + 2 * q}, s{20 + 2 * q}, vcc_lo")
-            e(f"s_subb_u32 s{21 + 2 * q}, s{21 + 2 * q}, 0")
-        e("64:")
-        e(f"s_mul_i32 vcc_lo, s17, {ROW}")
-        e("s_sub_u32 m0, s14, s13")                # piece s17, other buffer
-        e("s_add_u32 m0, m0, vcc_lo")
-        e("s_cmp_lt_u32 s17, 2")
-        e("s_cbranch_scc1 66f")
-        e("s_cmp_eq_u32 s17, 2")
-        e("s_cbranch_scc1 67f")
-        e("global_load_lds_dwordx4 v1, s[26:27]")
-        e("s_branch 65f")
-        e("67:")
+    # ---- record touch; returns to phase vcc_hi+1 or (vcc_hi = NPH) to the boundary
+    e("60:")
+    stamp(7)
+    e("s_mov_b32 s17, -1")
+    e("s_cmp_ge_u32 s11, s12")
+    e("s_cbranch_scc1 61f")
+    e("v_readlane_b32 vcc_lo, v7, 1")
+    e("s_cmp_lg_u32 s11, vcc_lo")
+    e("s_cbranch_scc1 15f")
+    e("v_readlane_b32 vcc_lo, v7, 2")
+    for q in range(4):                             # partial last panel: its window ends at the
+        e(f"s_sub_u32 s{20 + 2 * q}, s{20 + 2 * q}, vcc_lo")   # last row (rows nrow-128 .. nrow-1)
+        e(f"s_subb_u32 s{21 + 2 * q}, s{21 + 2 * q}, 0")
+    e("15:")
+    e("s_sub_u32 m0, s14, s13")                    # first piece, other buffer
+    for q in range(4):
+        if q:
+            e(f"s_add_u32 m0, m0, {ROW}")
         e("s_nop 0")
-        e("global_load_lds_dwordx4 v1, s[24:25]")
-        e("s_branch 65f")
-        e("66:")
-        e("s_cmp_eq_u32 s17, 0")
-        e("s_cbranch_scc1 68f")
-        e("global_load_lds_dwordx4 v1, s[22:23]")
-        e("s_branch 65f")
-        e("68:")
-        e("s_nop 0")
-        e("global_load_lds_dwordx4 v1, s[20:21]")
-        e("65:")
-        e("s_add_u32 s17, s17, 1")
-        if NPP == 2:
-            e("s_bitcmp1_b32 s17, 0")              # pieces go out in pairs
-            e("s_cbranch_scc1 64b")
-        elif NPP == 4:
-            e("s_cmp_lt_u32 s17, 4")
-            e("s_cbranch_scc1 64b")
-        e("s_cmp_lt_u32 s17, 4")
-        e("s_cbranch_scc0 69f")
-        e("s_cmp_eq_u32 vcc_hi, 3")                # called from the boundary: all that is left
-        e("s_cbranch_scc1 64b")
-        e("s_branch 61f")
-        e("69:")                                   # 4th piece out: advance the bases, touch
-        for q in range(4):
-            e(f"s_add_u32 s{20 + 2 * q}, s{20 + 2 * q}, 1024")
-            e(f"s_addc_u32 s{21 + 2 * q}, s{21 + 2 * q}, 0")
-        e("v_add_u32 v6, s10, v2")                 # records ~2 panels ahead towards L2
-        e("s_mov_b32 exec_lo, s19")
-        e("s_mov_b32 exec_hi, 0")
-        e("global_load_dword v5, v6, s[8:9]")
-        e("s_mov_b64 exec, -1")
-    else:
-        e("60:")
-        stamp(7)
-        e("s_mov_b32 s17, -1")
-        e("s_cmp_ge_u32 s11, s12")
-        e("s_cbranch_scc1 61f")
-        e("v_readlane_b32 vcc_lo, v7, 1")
-        e("s_cmp_lg_u32 s11, vcc_lo")
-        e("s_cbranch_scc1 15f")
-        e("v_readlane_b32 vcc_lo, v7, 2")
-        for q in range(4):                             # partial last panel: its window ends at the
-            e(f"s_sub_u32 s{20 + 2 * q}, s{20 + 2 * q}, vcc_lo")   # last row (rows nrow-128 .. nrow-1)
-            e(f"s_subb_u32 s{21 + 2 * q}, s{21 + 2 * q}, 0")
-        e("15:")
-        e("s_sub_u32 m0, s14, s13")                    # first piece, other buffer
-        for q in range(4):
-            if q:
-                e(f"s_add_u32 m0, m0, {ROW}")
-            e("s_nop 0")
-            e(f"global_load_lds_dwordx4 v1, s[{20 + 2 * q}:{21 + 2 * q}]")
-        for q in range(4):
-            e(f"s_add_u32 s{20 + 2 * q}, s{20 + 2 * q}, 1024")
-            e(f"s_addc_u32 s{21 + 2 * q}, s{21 + 2 * q}, 0")
-        e("v_add_u32 v6, s10, v2")                     # records ~2 panels ahead towards L2
-        e("s_mov_b32 exec_lo, s19")
-        e("s_mov_b32 exec_hi, 0")
-        e("global_load_dword v5, v6, s[8:9]")
-        e("s_mov_b64 exec, -1")
+        e(f"global_load_lds_dwordx4 v1, s[{20 + 2 * q}:{21 + 2 * q}]")
+    for q in range(4):
+        e(f"s_add_u32 s{20 + 2 * q}, s{20 + 2 * q}, 1024")
+        e(f"s_addc_u32 s{21 + 2 * q}, s{21 + 2 * q}, 0")
+    e("v_add_u32 v6, s10, v2")                     # records ~2 panels ahead towards L2
+    e("s_mov_b32 exec_lo, s19")
+    e("s_mov_b32 exec_hi, 0")
+    e("global_load_dword v5, v6, s[8:9]")
+    e("s_mov_b64 exec, -1")
     e("61:")
     stamp(3)                                       # DMA + touch issue
-    e("s_cmp_lt_u32 vcc_hi, 1")
-    e("s_cbranch_scc1 21b")
-    e("s_cmp_eq_u32 vcc_hi, 1")
-    e("s_cbranch_scc1 22b")
-    e("s_cmp_eq_u32 vcc_hi, 2")
-    e("s_cbranch_scc1 20b")
-    e("s_branch 17b")
+    dispatch("vcc_hi", [ph[(i + 1) % NPH] for i in range(NPH)] + ["17"], "b")
     e("90:")
     e("s_waitcnt vmcnt(0) lgkmcnt(0)")
     return out
@@ -349,7 +298,7 @@ dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
 with open(dst, "w") as f:
     f.write("// Generated by tools/gen_pbc_asm.py -- do not edit; see that file for the register map.\n")
     f.write(f"#define PBC_DMA_ROW {ROW}\n#define PBC_DMA_BUF {BUF}\n#define PBC_DMA_BATCH_BYTES {BATCH}\n")
-    f.write("#define PBC_DMA_S17_INIT %s\n" % ("4u" if ISSUE_MODE == "pieces" else "0xFFFFFFFFu"))
+    f.write(f"#define PBC_DMA_YSETS {YSETS}\n")
     for name, prof in (("PBC_DMA_ASM_TEXT", False), ("PBC_DMA_ASM_TEXT_PROF", True)):
         lines = gen(prof)
         f.write(f"#define {name} \\\n")
