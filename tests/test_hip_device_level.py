@@ -99,14 +99,16 @@ def test_pbc_dma_path_prescan_sees_every_dense_entry(hip, oracle, cbw):
     assert_equal(out.cpu().numpy().T, want, tol=1e-9, atol=1e-11, what="clean")
 
 
-@pytest.mark.parametrize("case", ["dense", "one_column", "wide_K", "min_rows", "below_min_rows", "empty",
-                                  "one_nonzero", "tall_thin"])
+@pytest.mark.parametrize("case", ["dense", "one_column", "wide_K", "min_rows", "below_min_rows", "two_panels",
+                                  "two_panels_ragged", "three_panels", "empty", "one_nonzero", "tall_thin"])
 def test_pbc_odd_shapes(hip, oracle, case):
     """Shapes at the edges of the panel kernels' preconditions."""
     from sparsearray_amd.device import PbcPlan
     nrow, ncol, K, dens = {"dense": (700, 90, 64, 0.5), "one_column": (5000, 1, 64, 0.3),
-                           "wide_K": (3000, 200, 200, 0.02), "min_rows": (256, 50, 10, 0.1),
-                           "below_min_rows": (255, 50, 10, 0.1), "empty": (1000, 70, 8, 0.0),
+                           "wide_K": (3000, 200, 200, 0.02), "min_rows": (192, 50, 10, 0.1),
+                           "below_min_rows": (191, 50, 10, 0.1), "two_panels": (193, 50, 10, 0.1),
+                           "two_panels_ragged": (255, 50, 70, 0.1), "three_panels": (288, 50, 64, 0.1),
+                           "empty": (1000, 70, 8, 0.0),
                            "one_nonzero": (1000, 70, 8, 0.0), "tall_thin": (200000, 3, 5, 0.001)}[case]
     cp, ri, v = random_csc(nrow, ncol, dens, seed=51)
     if case == "one_nonzero":
