@@ -791,18 +791,37 @@ crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restric
 	if (PB[6] != 0 && (tid & 63) == 0)
 		*fl.y_nonfinite = 1;
 	// ---- partial results: part[(split*Kp + k) * ncol + c] ------------------------
+	// A lane holds one dense column k of its wavefront's CBW sparse columns: stored
+	// straight from registers that is 64 eight-byte writes ncol*8 bytes apart per
+	// instruction.  The Y buffers are free now: 16 dense columns at a time go through
+	// LDS as [k][16*CBW (+1)] and leave as whole rows of the workgroup's 16*CBW
+	// columns (matters when the result is large: x %*% y writes nrow x K).
 	const int lane2 = (int) __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-	const int64_t c0 = wv * CBW;
-	double *__restrict__ dst = part + ((int64_t) split * Kp + k0 + lane2) * ncol + c0;
+	const int CWG = 16 * CBW, LS = CWG + 1;
+	const int64_t cwg0 = (int64_t) b * CWG;
+	__syncthreads();
+#pragma unroll 1
+	for (int q = 0; q < 4; q++) {
+		if ((lane2 >> 4) == q) {
+			double *row = ylds + (lane2 & 15) * LS + w * CBW;
 #pragma unroll
-	for (int ii = 0; ii < (NV > 2 ? 2 : NV); ii++)
+			for (int ii = 0; ii < (NV > 2 ? 2 : NV); ii++)
 #pragma unroll
-		for (int jj = 0; jj < 16; jj++)
-			if (ii * 16 + jj < CBW && c0 + ii * 16 + jj < ncol) dst[ii * 16 + jj] = acc[ii][jj];
-	if constexpr (NV > 2) {
+				for (int jj = 0; jj < 16; jj++)
+					if (ii * 16 + jj < CBW) row[ii * 16 + jj] = acc[ii][jj];
+			if constexpr (NV > 2) {
 #pragma unroll
-		for (int jj = 0; jj < 8; jj++)
-			if (32 + jj < CBW && c0 + 32 + jj < ncol) dst[32 + jj] = acc8[jj];
+				for (int jj = 0; jj < 8; jj++)
+					if (32 + jj < CBW) row[32 + jj] = acc8[jj];
+			}
+		}
+		__syncthreads();
+		for (int idx = tid; idx < 16 * CWG; idx += 1024) {
+			const int kk = idx / CWG, cc = idx - kk * CWG;
+			if (cwg0 + cc < ncol)
+				part[((int64_t) split * Kp + k0 + q * 16 + kk) * ncol + cwg0 + cc] = ylds[kk * LS + cc];
+		}
+		__syncthreads();
 	}
 }
 
