@@ -77,6 +77,105 @@ static int ensure_init()
 	return svt_init(0);
 }
 
+// ---- host -> device staging ----------------------------------------------------------
+// .Call hands over pageable host memory.  hipMemcpy() from pageable memory runs at a
+// few GB/s; instead the bytes go through two pinned buffers: a small thread team
+// gathers the next chunk (for an SVT: the leaves' nzoffs / nzvals, scattered over
+// the R heap) into one buffer while the previous one is in flight on a copy stream
+// (the reference's counterpart is the leaf walk of
+// src/SVT_SparseArray_class.c:598-633, which never leaves the host).
+#include <functional>
+#include <thread>
+
+struct Stager {
+	static const size_t CHUNK = (size_t) 48 << 20;      // bytes per pinned buffer
+	char *buf[2] = {NULL, NULL};
+	hipEvent_t done[2];
+	hipStream_t stream = NULL;
+	bool ok = false;
+	int next = 0;
+	bool busy[2] = {false, false};
+
+	int init()
+	{
+		if (ok) return 0;
+		for (int i = 0; i < 2; i++) {
+			HIP_TRY(hipHostMalloc((void **) &buf[i], CHUNK, hipHostMallocDefault));
+			HIP_TRY(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+		}
+		HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+		ok = true;
+		return 0;
+	}
+	// a free pinned buffer (waits for the copy that last used it)
+	int acquire(char **p, int *slot)
+	{
+		if (init()) return -1;
+		const int i = next;
+		next ^= 1;
+		if (busy[i]) { HIP_TRY(hipEventSynchronize(done[i])); busy[i] = false; }
+		*p = buf[i]; *slot = i;
+		return 0;
+	}
+	int send(int slot, void *dst, size_t off_in_buf, size_t n)
+	{
+		if (n) HIP_TRY(hipMemcpyAsync(dst, buf[slot] + off_in_buf, n, hipMemcpyHostToDevice, stream));
+		return 0;
+	}
+	int commit(int slot)
+	{
+		HIP_TRY(hipEventRecord(done[slot], stream));
+		busy[slot] = true;
+		return 0;
+	}
+	int drain()
+	{
+		if (!ok) return 0;
+		HIP_TRY(hipStreamSynchronize(stream));
+		busy[0] = busy[1] = false;
+		return 0;
+	}
+};
+static Stager g_stager;
+
+// run fn(t, nt) on a small team (the calling thread is one of them)
+static void team_run(int nt, const std::function<void(int, int)> &fn)
+{
+	std::vector<std::thread> th;
+	for (int t = 1; t < nt; t++) th.emplace_back(fn, t, nt);
+	fn(0, nt);
+	for (auto &x : th) x.join();
+}
+
+static int team_size(size_t bytes)
+{
+	int nt = svt_get_max_threads();
+	if (nt > 8) nt = 8;
+	if (bytes < ((size_t) 4 << 20) || nt < 1) nt = 1;
+	return nt;
+}
+
+// contiguous host array -> device, through the pinned buffers
+static int staged_copy(void *dst, const void *src, size_t n)
+{
+	if (n < ((size_t) 1 << 20)) {
+		if (n) HIP_TRY(hipMemcpy(dst, src, n, hipMemcpyHostToDevice));
+		return 0;
+	}
+	for (size_t off = 0; off < n; off += Stager::CHUNK) {
+		const size_t len = n - off < Stager::CHUNK ? n - off : Stager::CHUNK;
+		char *b; int slot;
+		if (g_stager.acquire(&b, &slot)) return -1;
+		const char *s0 = (const char *) src + off;
+		team_run(team_size(len), [&](int t, int nt) {
+			const size_t a = len * t / nt, e = len * (t + 1) / nt;
+			memcpy(b + a, s0 + a, e - a);
+		});
+		if (g_stager.send(slot, (char *) dst + off, 0, len) || g_stager.commit(slot)) return -1;
+	}
+	return g_stager.drain();
+}
+
 // ---- small RAII device buffer --------------------------------------------------
 struct DevBuf {
 	void *p = nullptr;
@@ -94,8 +193,7 @@ struct DevBuf {
 	int upload(const void *src, size_t n)
 	{
 		if (alloc(n)) return -1;
-		if (n) HIP_TRY(hipMemcpy(p, src, n, hipMemcpyHostToDevice));
-		return 0;
+		return staged_copy(p, src, n);
 	}
 	int zero()
 	{
@@ -123,62 +221,32 @@ static int check_view(const svt_view *x)
 	return 0;
 }
 
-struct HostCSC {
-	std::vector<int64_t> col_ptr;
-	std::vector<int32_t> row_idx;
-	std::vector<char> val;
-};
-
-static int marshal(const svt_view *x, HostCSC &h)
-{
-	const int64_t n = x->nleaves;
-	const size_t esz = elt_size(x->Rtype);
-	const int dim0 = x->dim[0];
-	h.col_ptr.assign((size_t) n + 1, 0);
-	for (int64_t j = 0; j < n; j++) {
-		int c = x->svt_is_null ? 0 : x->nzcount[j];
-		if (c < 0 || c > dim0)
-			return svt_set_error("invalid SVT leaf (nzcount %d, dim %d)", c, dim0);
-		h.col_ptr[j + 1] = h.col_ptr[j] + c;
-	}
-	const int64_t nnz = h.col_ptr[n];
-	h.row_idx.resize((size_t) nnz);
-	h.val.resize((size_t) nnz * esz);
-	for (int64_t j = 0; j < n; j++) {
-		const int64_t s = h.col_ptr[j], c = h.col_ptr[j + 1] - s;
-		if (c == 0) continue;
-		const int32_t *offs = x->nzoffs[j];
-		if (offs == NULL)
-			return svt_set_error("invalid SVT leaf (NULL nzoffs)");
-		memcpy(&h.row_idx[(size_t) s], offs, (size_t) c * 4);
-		const void *v = x->nzvals[j];
-		if (v != NULL) {
-			memcpy(&h.val[(size_t) s * esz], v, (size_t) c * esz);
-		} else if (esz == 8) {     // lacunar leaf: all ones
-			double *d = (double *) &h.val[(size_t) s * esz];
-			for (int64_t k = 0; k < c; k++) d[k] = 1.0;
-		} else {
-			int *d = (int *) &h.val[(size_t) s * esz];
-			for (int64_t k = 0; k < c; k++) d[k] = 1;
-		}
-	}
-	return 0;
-}
-
 extern "C" svt_dev_csc *svt_upload(const svt_view *x)
 {
 	if (ensure_init() || check_view(x))
 		return NULL;
-	HostCSC h;
-	if (marshal(x, h))
-		return NULL;
+	const int64_t n = x->nleaves;
+	const size_t esz = elt_size(x->Rtype);
+	const int dim0 = x->dim[0];
+	std::vector<int64_t> col_ptr((size_t) n + 1, 0);
+	for (int64_t j = 0; j < n; j++) {
+		const int c = x->svt_is_null ? 0 : x->nzcount[j];
+		if (c < 0 || c > dim0) {
+			svt_set_error("invalid SVT leaf (nzcount %d, dim %d)", c, dim0);
+			return NULL;
+		}
+		if (c > 0 && x->nzoffs[j] == NULL) {
+			svt_set_error("invalid SVT leaf (NULL nzoffs)");
+			return NULL;
+		}
+		col_ptr[j + 1] = col_ptr[j] + c;
+	}
 	svt_dev_csc *d = (svt_dev_csc *) calloc(1, sizeof(*d));
 	d->Rtype = x->Rtype;
 	d->owned = 1;
-	d->nrow = x->dim[0];
-	d->ncol = x->nleaves;
-	d->nnz = h.col_ptr[(size_t) x->nleaves];
-	const size_t esz = elt_size(x->Rtype);
+	d->nrow = dim0;
+	d->ncol = n;
+	d->nnz = col_ptr[(size_t) n];
 	const size_t nn = (size_t) (d->nnz > 0 ? d->nnz : 1);
 	if (hipMalloc((void **) &d->col_ptr, (size_t) (d->ncol + 1) * 8) != hipSuccess ||
 	    hipMalloc((void **) &d->row_idx, nn * 4) != hipSuccess ||
@@ -188,16 +256,50 @@ extern "C" svt_dev_csc *svt_upload(const svt_view *x)
 		svt_release(d);
 		return NULL;
 	}
-	hipError_t e = hipMemcpy(d->col_ptr, h.col_ptr.data(), (size_t) (d->ncol + 1) * 8,
-				 hipMemcpyHostToDevice);
-	if (e == hipSuccess && d->nnz)
-		e = hipMemcpy(d->row_idx, h.row_idx.data(), (size_t) d->nnz * 4,
-			      hipMemcpyHostToDevice);
-	if (e == hipSuccess && d->nnz)
-		e = hipMemcpy(d->val, h.val.data(), (size_t) d->nnz * esz,
-			      hipMemcpyHostToDevice);
-	if (e != hipSuccess) {
-		svt_set_error("H2D copy failed: %s", hipGetErrorString(e));
+	bool ok = hipMemcpy(d->col_ptr, col_ptr.data(), (size_t) (d->ncol + 1) * 8,
+			    hipMemcpyHostToDevice) == hipSuccess;
+	// leaves j0 .. j1-1 per trip: as many as fit one pinned buffer
+	// ([offsets of the chunk][values of the chunk], 4 + esz bytes per nonzero)
+	const int64_t cap = (int64_t) (Stager::CHUNK / (4 + esz));
+	int64_t j0 = 0;
+	while (ok && j0 < n) {
+		int64_t j1 = j0;
+		while (j1 < n && col_ptr[j1 + 1] - col_ptr[j0] <= cap) j1++;
+		if (j1 == j0) j1 = j0 + 1;                  // (a leaf never exceeds cap: dim0 < 2^31)
+		const int64_t k0 = col_ptr[j0], cnt = col_ptr[j1] - k0;
+		if (cnt > 0) {
+			char *b; int slot;
+			if (g_stager.acquire(&b, &slot)) { ok = false; break; }
+			int32_t *so = (int32_t *) b;
+			char *sv = b + (size_t) cnt * 4;
+			team_run(team_size((size_t) cnt * (4 + esz)), [&](int t, int nt) {
+				const int64_t ja = j0 + (j1 - j0) * t / nt, jb = j0 + (j1 - j0) * (t + 1) / nt;
+				for (int64_t j = ja; j < jb; j++) {
+					const int64_t s = col_ptr[j] - k0, c = col_ptr[j + 1] - col_ptr[j];
+					if (c == 0) continue;
+					memcpy(so + s, x->nzoffs[j], (size_t) c * 4);
+					const void *v = x->nzvals[j];
+					if (v != NULL) {
+						memcpy(sv + (size_t) s * esz, v, (size_t) c * esz);
+					} else if (esz == 8) {      // lacunar leaf: all ones
+						double *o = (double *) sv + s;
+						for (int64_t k = 0; k < c; k++) o[k] = 1.0;
+					} else {
+						int *o = (int *) sv + s;
+						for (int64_t k = 0; k < c; k++) o[k] = 1;
+					}
+				}
+			});
+			ok = g_stager.send(slot, d->row_idx + k0, 0, (size_t) cnt * 4) == 0 &&
+			     g_stager.send(slot, (char *) d->val + (size_t) k0 * esz, (size_t) cnt * 4,
+					   (size_t) cnt * esz) == 0 &&
+			     g_stager.commit(slot) == 0;
+		}
+		j0 = j1;
+	}
+	if (ok) ok = g_stager.drain() == 0;
+	if (!ok) {
+		if (svt_last_error()[0] == '\0') svt_set_error("H2D copy failed");
 		svt_release(d);
 		return NULL;
 	}
@@ -427,6 +529,29 @@ static int dev_crossprod_chunked(const svt_dev_csc *A, const void *Y_dev, int64_
 {
 	if (K <= 0 || A->ncol <= 0)
 		return 0;
+	// Large double products with a column-major dense operand take the panel-blocked
+	// kernels: the one-off layout build (a few ms at 1e8 nonzeros)
+	// pays for itself within the call.  Below the threshold the general kernels run,
+	// whose sums are bit-identical to the reference's sequential ones; above it the
+	// row-split partial sums differ from those in the last bits (parity bar: 1e-6).
+	if (A->Rtype == SVT_REALSXP && !tr_y && A->nrow >= 256 &&
+	    (double) A->nnz * (double) K >= 268435456.0) {
+		svt_dev_pbc *P = svt_dev_pbc_build(A, 40, 16, 7);
+		if (P == NULL)
+			return -1;
+		const int kc = K < 512 ? (int) K : 512;
+		DevBuf ws;
+		int rc = ws.alloc(svt_dev_crossprod_pbc_ws_bytes(P, kc));
+		for (int64_t k0 = 0; rc == 0 && k0 < K; k0 += kc) {
+			const int kn = (int) (K - k0 < kc ? K - k0 : kc);
+			rc = svt_dev_crossprod_pbc(P, A, (const double *) Y_dev + k0 * ldY, ldY, kn, 0,
+						   out_dev + k0 * sk, sc, sk, ws.p, ws.bytes, 0);
+		}
+		if (rc == 0 && hipDeviceSynchronize() != hipSuccess)
+			rc = svt_set_error("device error in the panel-blocked crossprod");
+		svt_dev_pbc_release(P);
+		return rc;
+	}
 	const int kc = chunk_K(A->nrow, K);
 	DevBuf ws;
 	if (ws.alloc(crossprod_ws_bytes(A->nrow, A->ncol, kc)))

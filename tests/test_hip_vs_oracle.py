@@ -33,6 +33,21 @@ def _sprinkle(x, seed, what):
 SPECIAL_D = [NA_real, np.nan, np.inf, -np.inf]
 
 
+def test_crossprod_large_takes_panel_kernels(hip, oracle):
+    """nnz * K >= 2^28: the host-level entry points build the panel-blocked layout
+    and run the LDS-DMA kernel (svt_hip.cpp, dev_crossprod_chunked); row-split
+    partial sums, so the bar is the tolerance, not bit identity.  A NaN in the
+    dense operand sends the same call through the general kernels on the device."""
+    x = _svt(300_000, 2000, 0.01, 5)                    # 6e6 nonzeros
+    x = _sprinkle(x, 6, [NA_real])                      # some leaves hold an R NA
+    rng = np.random.default_rng(7)
+    y = rng.uniform(-1, 1, (300_000, 70))               # K = 70: a partial dense tile too
+    assert_equal(hip.crossprod(x, y), oracle.crossprod(x, y), tol=1e-9, atol=1e-11, strict_na=True)
+    assert_equal(hip.crossprod(y, x), oracle.crossprod(y, x), tol=1e-9, atol=1e-11, strict_na=True)
+    y[123_456, 3] = np.nan
+    assert_equal(hip.crossprod(x, y), oracle.crossprod(x, y), tol=1e-9, atol=1e-11, strict_na=True)
+
+
 @pytest.mark.parametrize("seed", [1, 2])
 @pytest.mark.parametrize("K", [1, 7, 64, 130])
 def test_crossprod_svt_dense(hip, oracle, seed, K):

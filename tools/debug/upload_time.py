@@ -1,0 +1,34 @@
+"""Host-level cost at BASELINE config 2: svt_upload() (marshal + H2D) and the whole
+C_crossprod2_SVT_mat call (run on the GPU box)."""
+import ctypes, os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from sparsearray_amd import synth, _hip
+from sparsearray_amd.svt import make_view_from_csc
+lib = _hip.init()
+nrow, ncol, K = 1_000_000, 10_000, 128
+dev = torch.device("cuda", 0)
+cp, ri, v = synth.random_device_csc(nrow, ncol, 0.01, seed=1, device=dev)
+cp, ri, v = cp.cpu().numpy(), ri.cpu().numpy(), v.cpu().numpy()
+view = make_view_from_csc((nrow, ncol), "double", cp, ri, v)
+lib.svt_upload.restype = ctypes.c_void_p
+lib.svt_upload.argtypes = [ctypes.c_void_p]
+lib.svt_release.argtypes = [ctypes.c_void_p]
+for rep in range(3):
+    t0 = time.perf_counter()
+    h = lib.svt_upload(ctypes.addressof(view))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"svt_upload: {dt*1e3:.1f} ms  ({(len(ri)*12)/dt/1e9:.1f} GB/s)")
+    lib.svt_release(h)
+y = np.asfortranarray(np.random.default_rng(2).uniform(-1, 1, (nrow, K)))
+out = np.zeros((ncol, K), order="F")
+fn = lib.svt_crossprod2_SVT_mat
+fn.restype = ctypes.c_int
+fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+for rep in range(2):
+    t0 = time.perf_counter()
+    rc = fn(ctypes.addressof(view), y.ctypes.data, nrow, K, 14, 0, out.ctypes.data)
+    dt = time.perf_counter() - t0
+    print(f"C_crossprod2_SVT_mat host level: rc={rc} {dt*1e3:.1f} ms  ({len(ri)/dt/1e9:.2f} GNZ/s)")
