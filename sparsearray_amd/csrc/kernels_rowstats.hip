@@ -203,20 +203,26 @@ __global__ void __launch_bounds__(256)
 rowpanel_table_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__ row_idx,
 		      int64_t ncol, int64_t npan, int32_t *__restrict__ pt)
 {
-	const int64_t j = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
-	const int lane = threadIdx.x & 63;
+	// long leaves: the whole workgroup on one leaf; short ones: a wavefront each
+	const bool wide = gridDim.x == (unsigned) ncol;
+	const int64_t j = wide ? (int64_t) blockIdx.x : (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
+	const int tid = wide ? threadIdx.x : (threadIdx.x & 63);
+	const int nt = wide ? 256 : SVT_WAVE;
 	if (j >= ncol)
 		return;
 	const int64_t beg = col_ptr[j], end = col_ptr[j + 1];
-	for (int64_t k = beg + lane; k < end; k += SVT_WAVE) {
+	for (int64_t k = beg + tid; k < end; k += nt) {
 		const int64_t p = row_idx[k] / ROWPANEL;
-		const int64_t pp = k == beg ? -1 : row_idx[k - 1] / ROWPANEL;
-		for (int64_t q = pp + 1; q <= p; q++)
+		// previous offset: the lane below holds it, except at the start of a wavefront
+		int prev = __shfl_up((int) p, 1, 64);
+		if ((threadIdx.x & 63) == 0 || k == beg)
+			prev = k == beg ? -1 : row_idx[k - 1] / ROWPANEL;
+		for (int64_t q = (int64_t) prev + 1; q <= p; q++)
 			pt[q * ncol + j] = (int32_t) (k - beg);
 	}
 	// boundaries past the last offset (all of them for an empty leaf)
 	const int64_t pl = end > beg ? row_idx[end - 1] / ROWPANEL : -1;
-	for (int64_t q = pl + 1 + lane; q <= npan; q += SVT_WAVE)
+	for (int64_t q = pl + 1 + tid; q <= npan; q += nt)
 		pt[q * ncol + j] = (int32_t) (end - beg);
 }
 
@@ -365,9 +371,12 @@ int launch_rowstats_panel(const RowStatsArgs &a, void *ws, hipStream_t s)
 	int32_t *pt = (int32_t *) ws;
 	if (a.inner > 65535)
 		return svt_set_error("row stats: more than 65535 output columns per panel row");
-	if (a.ncol > 0)
-		hipLaunchKernelGGL(rowpanel_table_kernel, dim3((unsigned) ((a.ncol + 3) / 4)), dim3(256),
-				   0, s, a.col_ptr, a.row_idx, a.ncol, npan, pt);
+	if (a.ncol > 0) {
+		// (grid == ncol selects the workgroup-per-leaf form; never equal to (ncol+3)/4 for ncol > 1)
+		const bool wide = a.nnz_hint / a.ncol >= 1024 && a.ncol > 1;
+		hipLaunchKernelGGL(rowpanel_table_kernel, dim3((unsigned) (wide ? a.ncol : (a.ncol + 3) / 4)),
+				   dim3(256), 0, s, a.col_ptr, a.row_idx, a.ncol, npan, pt);
+	}
 	// lanes per leaf segment ~ mean segment length (nnz unknown here: the
 	// caller passes it in a.nnz_hint, 0 = assume long segments)
 	int G = 64;
