@@ -82,6 +82,7 @@ typedef struct svt_view {
 	const int32_t *nzcount;
 	const int32_t *const *nzoffs;
 	const void *const *nzvals;
+	int32_t na_background;        /* NaArray: the implicit value is NA, not zero (R/NaArray-class.R) */
 } svt_view;
 
 /* ---------------------------------------------------------------------- */
@@ -166,6 +167,8 @@ typedef struct svt_dev_csc {
 	int64_t *col_ptr;
 	int32_t *row_idx;
 	void *val;
+	int32_t na_background; /* NaArray operand: implicit entries are NA (col stats / summarization
+	                          only; set by svt_upload(), 0 for wrapped buffers) */
 } svt_dev_csc;
 
 /* Marshal + H2D.  Returns NULL on error. */

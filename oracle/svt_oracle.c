@@ -719,6 +719,7 @@ enum { ST_NOT_SET = 1, ST_SET = 2, ST_BREAK = 3 };   /* .h:50-52 */
 typedef struct {
 	int opcode, in_Rtype, na_rm;
 	double center;
+	int na_bg;        /* NaArray: the implicit value is NA (Rvector_summarization.c:1078-1106) */
 } sum_op;
 
 typedef struct {
@@ -1004,19 +1005,38 @@ static void feed_leaf(const leaf_t *lf, const sum_op *op, sum_res *r)
 	}
 }
 
-/* Rvector_summarization.c:1078-1177, zero background only */
+/* Rvector_summarization.c:1078-1177 (zero background and, for NaArray objects,
+   NA background: the implicit values count as NAs, :1086-1106) */
 static int finish_res(sum_res *r, const sum_op *op)
 {
 	if (r->status == ST_BREAK)
 		return 0;
 	int oc = op->opcode;
 	int64_t zerocount = r->in_length - r->in_nzcount;
-	if (oc == ORC_OP_COUNTNAS)
+	if (oc == ORC_OP_COUNTNAS) {
+		if (op->na_bg)
+			r->buf.d[0] += (double) zerocount;
 		return 0;
+	}
 	int64_t n_eff = r->in_length;
-	if (op->na_rm)
+	if (op->na_rm) {
+		if (op->na_bg)
+			n_eff = r->in_nzcount;
 		n_eff -= r->in_nacount;
-	if (zerocount != 0 && r->one_zero) {
+	}
+	if (zerocount != 0 && op->na_bg) {
+		/* summarize_one_NA(), :1033-1076: nothing to do under na.rm */
+		if (!op->na_rm) {
+			static const int iNA = NA_INT;
+			const double dNA = NA_REAL;
+			sum_op op0 = *op;
+			op0.na_rm = 0;
+			r->status = op->in_Rtype == ORC_DBL ?
+				feed_doubles(&dNA, 1, &op0, r) : feed_ints(&iNA, 1, &op0, r);
+			if (r->status == ST_BREAK)
+				return 0;
+		}
+	} else if (zerocount != 0 && r->one_zero) {
 		static const int i0 = 0;
 		static const double d0 = 0.0;
 		int64_t keep = r->in_nacount;
@@ -1036,7 +1056,8 @@ static int finish_res(sum_res *r, const sum_op *op)
 		r->buf.d[0] /= (double) n_eff;
 		break;
 	    case ORC_OP_CENTERED_X2_SUM: case ORC_OP_VAR1: case ORC_OP_SD1:
-		r->buf.d[0] += op->center * op->center * zerocount;
+		if (!op->na_bg)
+			r->buf.d[0] += op->center * op->center * zerocount;
 		if (oc == ORC_OP_CENTERED_X2_SUM)
 			break;
 		if (n_eff <= 1) {
@@ -1121,7 +1142,7 @@ int orc_summarize_SVT(const orc_svt *x, int opcode, int na_rm, double center,
 {
 	if (check_op_type(opcode, x->Rtype))
 		return -1;
-	sum_op op = { opcode, x->Rtype, na_rm, center };
+	sum_op op = { opcode, x->Rtype, na_rm, center, x->na_background };
 	sum_res r;
 	if (summarize_leaf_range(x, 0, x->nleaves, &op, &r))
 		return -1;
@@ -1138,7 +1159,7 @@ int orc_summarize_SVT(const orc_svt *x, int opcode, int na_rm, double center,
  */
 int orc_colStats_out_Rtype(int opcode, int in_Rtype)
 {
-	sum_op op = { opcode, in_Rtype, 0, 0.0 };
+	sum_op op = { opcode, in_Rtype, 0, 0.0, 0 };
 	sum_res r;
 	if (init_res(&op, &r))
 		return -1;
@@ -1152,7 +1173,7 @@ int orc_colStats_SVT(const orc_svt *x, int opcode, int na_rm, double center,
 		return -1;
 	if (dims < 1 || dims > x->ndim)
 		return fail("'dims' must be >= 1 and <= %d", x->ndim);
-	sum_op op = { opcode, x->Rtype, na_rm, center };
+	sum_op op = { opcode, x->Rtype, na_rm, center, x->na_background };
 	int out_Rtype = orc_colStats_out_Rtype(opcode, x->Rtype);
 	/* one result per generalized column = 'inner' consecutive leaves */
 	int64_t inner = 1, nout = 1;
@@ -1323,6 +1344,9 @@ static void scatter_leaf(const leaf_t *lf, int Rtype, int opcode, int narm,
 int orc_rowStats_SVT(const orc_svt *x, int opcode, int na_rm,
 		     const double *center, int dims, void *out, int *warn)
 {
+	if (x->na_background)
+		return fail("row statistics of NaArray objects are not implemented on the "
+			    "device yet (src/SparseArray_matrixStats.c:756-1019)");
 	*warn = 0;
 	if (check_op_type(opcode, x->Rtype))
 		return -1;

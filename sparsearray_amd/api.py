@@ -138,7 +138,17 @@ class Session:
         _check_crossprod_input_type(x.type)
         return self.SparseArray_Call("C_crossprod1_SVT", x)
 
+    @staticmethod
+    def _no_NaArray(what, *objs):
+        """crossprod()/%*%/rowsum() have methods for SVT_SparseMatrix only
+        (R/SparseMatrix-mult.R, R/rowsum-methods.R): an NaArray operand is an error."""
+        for o in objs:
+            if isinstance(o, SVT_SparseArray) and o.na_background:
+                raise SparseArrayError(f"unable to find an inherited method for function "
+                                       f"'{what}' for signature 'x = \"NaMatrix\"'")
+
     def crossprod(self, x, y=None):
+        self._no_NaArray("crossprod", x, y)
         xs, ys = isinstance(x, SVT_SparseArray), isinstance(y, SVT_SparseArray)
         if xs and y is None:
             return self._crossprod1_SparseMatrix(x)
@@ -151,6 +161,7 @@ class Session:
         raise TypeError("crossprod() needs at least one SVT_SparseArray")
 
     def tcrossprod(self, x, y=None):
+        self._no_NaArray("tcrossprod", x, y)
         xs, ys = isinstance(x, SVT_SparseArray), isinstance(y, SVT_SparseArray)
         if xs and y is None:
             return self._crossprod1_SparseMatrix(x.t())
@@ -164,6 +175,7 @@ class Session:
 
     def matmul(self, x, y):
         """``x %*% y`` (R/SparseMatrix-mult.R:195-215)."""
+        self._no_NaArray("%*%", x, y)
         xs, ys = isinstance(x, SVT_SparseArray), isinstance(y, SVT_SparseArray)
         if xs and ys:
             return self._crossprod2_SparseMatrix_SparseMatrix(x.t(), y)
@@ -349,6 +361,7 @@ class Session:
 
     def rowsum(self, x, group, reorder=True, na_rm=False):
         """Returns (matrix ngroup x ncol, ugroup)."""
+        self._no_NaArray("rowsum", x)
         if isinstance(x, SVT_SparseArray):
             nrow = x.dim[0]
         else:
@@ -367,6 +380,7 @@ class Session:
 
     def colsum(self, x, group, reorder=True, na_rm=False):
         """Returns (matrix nrow x ngroup, ugroup)."""
+        self._no_NaArray("colsum", x)
         if isinstance(x, SVT_SparseArray):
             ncol = x.dim[1]
         else:

@@ -187,8 +187,15 @@ colstats_kernel(StatsArgs a)
 	else if (is_minmax) mm = red_min<NT>(mm, my_sm, is_min);
 	else acc = red_sum<NT>(acc, my_sm);
 
+	// NaArray (a.na_bg): the zerocount implicit values are NAs -- they count as
+	// NAs, one NA is fed to the op unless na.rm, and no implicit zero takes part
+	// (Rvector_summarization.c:1086-1106)
+	const bool nabg = a.na_bg != 0;
+	const int64_t implicit_na = nabg ? zerocount : 0;
+	const int64_t zeros = nabg ? 0 : zerocount;            // implicit zeros
+	if (implicit_na > 0 && !narm) flags |= F_NA;
 	const bool brk_na = (flags & F_NA) && !narm;   // "breaking value" NA
-	const double n_eff = (double) (a.seg_len - (narm ? nacnt : 0));
+	const double n_eff = narm ? (double) ((nabg ? nz : a.seg_len) - nacnt) : (double) a.seg_len;
 	const double NAr = svt_na_real();
 	double rd = 0.0;
 	int ri = 0;
@@ -196,16 +203,16 @@ colstats_kernel(StatsArgs a)
 
 	switch (oc) {
 	case SVT_OP_ANYNA:
-		ri = (flags & (F_NA | F_NAN)) ? 1 : 0;
+		ri = ((flags & (F_NA | F_NAN)) || implicit_na > 0) ? 1 : 0;
 		break;
 	case SVT_OP_COUNTNAS:
-		rd = (double) nacnt;
+		rd = (double) (nacnt + implicit_na);
 		break;
 	case SVT_OP_ANY:      // src/Rvector_summarization.c:260-284
 		ri = (flags & F_TRUE) ? 1 : (brk_na ? NA_INT : 0);
 		break;
 	case SVT_OP_ALL:      // :289-313 plus the implicit zero of :1100-1106
-		ri = ((flags & F_ZERO) || zerocount > 0) ? 0 : (brk_na ? NA_INT : 1);
+		ri = ((flags & F_ZERO) || zeros > 0) ? 0 : (brk_na ? NA_INT : 1);
 		break;
 	case SVT_OP_SUM:
 		rd = brk_na ? NAr : acc;
@@ -215,19 +222,19 @@ colstats_kernel(StatsArgs a)
 		break;
 	case SVT_OP_PROD:
 		if (brk_na) rd = NAr;
-		else rd = zerocount > 0 ? acc * 0.0 : acc;
+		else rd = zeros > 0 ? acc * 0.0 : acc;
 		break;
 	case SVT_OP_MIN: case SVT_OP_MAX:
 		if (is_dbl) {
 			if (brk_na) { rd = NAr; break; }
 			if ((flags & F_NAN) && !narm) { rd = NAN; break; }
-			if (zerocount > 0)
+			if (zeros > 0)
 				mm = is_min ? (0.0 < mm ? 0.0 : mm) : (0.0 > mm ? 0.0 : mm);
 			rd = mm;
 		} else {
 			if (brk_na) { ri = NA_INT; break; }
 			bool have = (flags & F_HAVE) != 0;
-			if (zerocount > 0) {
+			if (zeros > 0) {
 				mm = have ? (is_min ? (0.0 < mm ? 0.0 : mm) : (0.0 > mm ? 0.0 : mm)) : 0.0;
 				have = true;
 			}
@@ -258,7 +265,7 @@ colstats_kernel(StatsArgs a)
 		}
 		acc2 = red_sum<NT>(acc2, my_sm);
 		if (brk_na) { rd = NAr; break; }
-		rd = acc2 + c * c * (double) zerocount;
+		rd = acc2 + c * c * (double) zeros;
 		if (oc == SVT_OP_CENTERED_X2_SUM) break;
 		if (n_eff <= 1.0) { rd = NAr; break; }
 		rd /= (n_eff - 1.0);

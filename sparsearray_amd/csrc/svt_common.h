@@ -125,6 +125,7 @@ struct StatsArgs {
 	double center;
 	void *out;
 	int *warn_flag;
+	int na_bg;          // NaArray: implicit values are NAs (Rvector_summarization.c:1078-1106)
 };
 int launch_colstats(const StatsArgs &a, int64_t nnz, hipStream_t s);
 

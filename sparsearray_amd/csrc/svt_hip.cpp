@@ -244,6 +244,7 @@ extern "C" svt_dev_csc *svt_upload(const svt_view *x)
 	svt_dev_csc *d = (svt_dev_csc *) calloc(1, sizeof(*d));
 	d->Rtype = x->Rtype;
 	d->owned = 1;
+	d->na_background = x->na_background != 0;
 	d->nrow = dim0;
 	d->ncol = n;
 	d->nnz = col_ptr[(size_t) n];
@@ -440,7 +441,7 @@ extern "C" int svt_dev_colstats(const svt_dev_csc *A, int opcode, int na_rm,
 	a.col_ptr = A->col_ptr; a.val = A->val; a.Rtype = A->Rtype;
 	a.nseg = A->ncol / inner; a.inner = inner; a.seg_len = inner * A->nrow;
 	a.opcode = opcode; a.na_rm = na_rm; a.center = center;
-	a.out = out; a.warn_flag = warn_flag;
+	a.out = out; a.warn_flag = warn_flag; a.na_bg = A->na_background;
 	return launch_colstats(a, A->nnz, (hipStream_t) stream);
 }
 
@@ -507,6 +508,8 @@ static int check_mult_view(const svt_view *x, const char *what)
 	// get_and_check_input_Rtype(), src/SparseMatrix_mult.c:915-928
 	if (x->Rtype != SVT_REALSXP && x->Rtype != SVT_INTSXP)
 		return svt_set_error("input type is not supported yet");
+	if (x->na_background)      // crossprod()/%*% have no NaArray methods (R/SparseMatrix-mult.R)
+		return svt_set_error("NaArray objects are not supported by this operation");
 	return 0;
 }
 
@@ -828,6 +831,9 @@ extern "C" int svt_rowStats_SVT(const svt_view *x, int opcode, int na_rm,
 		return -1;
 	if (dims < 1 || dims > x->ndim - 1)
 		return svt_set_error("'dims' must be >= 1 and <= %d", x->ndim - 1);
+	if (x->na_background)
+		return svt_set_error("row statistics of NaArray objects are not implemented on the "
+				     "device yet (src/SparseArray_matrixStats.c:756-1019)");
 	if (opcode != SVT_OP_COUNTNAS && opcode != SVT_OP_ANYNA &&
 	    opcode != SVT_OP_MIN && opcode != SVT_OP_MAX &&
 	    opcode != SVT_OP_SUM && opcode != SVT_OP_CENTERED_X2_SUM)
@@ -952,6 +958,8 @@ static int xsum_SVT(const svt_view *x, const int *group, int ngroup, int na_rm,
 		return -1;
 	if (x->ndim != 2)
 		return svt_set_error("input object must have 2 dimensions");
+	if (x->na_background)      // rowsum()/colsum() have no NaArray methods (R/rowsum-methods.R)
+		return svt_set_error("NaArray objects are not supported by this operation");
 	if (x->Rtype != SVT_REALSXP && x->Rtype != SVT_INTSXP)
 		return svt_set_error("rowsum() and colsum() do not support "
 				     "SVT_SparseMatrix objects of this type at the moment");

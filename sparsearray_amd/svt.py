@@ -63,11 +63,15 @@ class SVT_SparseArray:
     (column-major over dims 2..N): ``None`` for an empty leaf, else
     ``(nzoffs int32 ascending, nzvals)`` with ``nzvals is None`` for a lacunar
     leaf (all ones, src/leaf_utils.h:28-34).  ``svt_is_null`` mirrors
-    ``x@SVT == NULL`` (all-zero array).
+    ``x@SVT == NULL`` (all-zero array).  ``na_background=True`` makes the
+    object an NaArray (R/NaArray-class.R): the implicit value is NA instead of
+    zero and the leaves hold the non-NA entries (``R_IsNA`` for doubles: a NaN
+    is stored, src/Rvector_utils.c:586-596); no lacunar leaves then.
     """
 
     def __init__(self, dim: Sequence[int], type: str, leaves: List[Leaf],
-                 dimnames=None, svt_is_null: Optional[bool] = None):
+                 dimnames=None, svt_is_null: Optional[bool] = None,
+                 na_background: bool = False):
         self.dim = tuple(int(d) for d in dim)
         if type not in _RTYPE_OF:
             raise ValueError(f"unsupported type {type!r}")
@@ -80,6 +84,7 @@ class SVT_SparseArray:
         if svt_is_null is None:
             svt_is_null = all(lf is None for lf in leaves)
         self.svt_is_null = bool(svt_is_null)
+        self.na_background = bool(na_background)
         self._keepalive = None
 
     # -- basic accessors -----------------------------------------------------
@@ -101,7 +106,7 @@ class SVT_SparseArray:
     # -- coercion from / to dense -------------------------------------------
     @classmethod
     def from_dense(cls, a, type: Optional[str] = None, dimnames=None,
-                   lacunar: bool = True) -> "SVT_SparseArray":
+                   lacunar: bool = True, na_background: bool = False) -> "SVT_SparseArray":
         a = np.asarray(a)
         if type is None:
             type = r_type_of(a)
@@ -116,20 +121,26 @@ class SVT_SparseArray:
         leaves: List[Leaf] = []
         for j in range(flat.shape[1]):
             col = flat[:, j]
-            nz = np.flatnonzero(col != 0).astype(np.int32)
+            if na_background:
+                keep = ~is_NA_real(col) if type == "double" else col != NA_integer
+            else:
+                keep = col != 0
+            nz = np.flatnonzero(keep).astype(np.int32)
             if nz.size == 0:
                 leaves.append(None)
                 continue
             vals = np.ascontiguousarray(col[nz])
-            if lacunar and np.all(vals == 1):
+            if lacunar and not na_background and np.all(vals == 1):
                 leaves.append((nz, None))
             else:
                 leaves.append((nz, vals))
-        return cls(dim, type, leaves, dimnames=dimnames)
+        return cls(dim, type, leaves, dimnames=dimnames, na_background=na_background)
 
     def to_dense(self) -> np.ndarray:
         n0 = self.dim[0]
         flat = np.zeros((n0, len(self.leaves)), dtype=self.np_dtype, order="F")
+        if self.na_background:
+            flat[...] = NA_real if self.type == "double" else NA_integer
         for j, lf in enumerate(self.leaves):
             if lf is None:
                 continue
@@ -153,7 +164,7 @@ class SVT_SparseArray:
             v[lf[1] == NA_integer] = NA_real
             leaves.append((lf[0], v))
         return SVT_SparseArray(self.dim, "double", leaves, self.dimnames,
-                               self.svt_is_null)
+                               self.svt_is_null, self.na_background)
 
     def t(self) -> "SVT_SparseArray":
         """2-D transposition (reference: C_transpose_2D_SVT,
@@ -181,14 +192,14 @@ class SVT_SparseArray:
         for i in range(nrow):
             if offs_out[i] is None:
                 leaves.append(None)
-            elif np.all(vals_out[i] == 1):
+            elif not self.na_background and np.all(vals_out[i] == 1):
                 leaves.append((offs_out[i], None))
             else:
                 leaves.append((offs_out[i], vals_out[i]))
         dn = None
         if self.dimnames is not None:
             dn = [self.dimnames[1], self.dimnames[0]]
-        return SVT_SparseArray((ncol, nrow), self.type, leaves, dn)
+        return SVT_SparseArray((ncol, nrow), self.type, leaves, dn, na_background=self.na_background)
 
     # -- CSC marshalling (model: dump_SVT_to_CsparseMatrix_slots,
     #    src/SVT_SparseArray_class.c:598-633) ---------------------------------
@@ -237,6 +248,7 @@ class svt_view(ctypes.Structure):
         ("nzcount", ctypes.POINTER(ctypes.c_int32)),
         ("nzoffs", ctypes.POINTER(ctypes.c_void_p)),
         ("nzvals", ctypes.POINTER(ctypes.c_void_p)),
+        ("na_background", ctypes.c_int32),
     ]
 
 
@@ -268,6 +280,7 @@ def make_view(x: SVT_SparseArray) -> svt_view:
     v.ndim = x.ndim
     v.dim = dim.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
     v.svt_is_null = int(x.svt_is_null)
+    v.na_background = int(x.na_background)
     v.nleaves = n
     v.nzcount = nzcount.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
     v.nzoffs = offs_p.ctypes.data_as(ctypes.POINTER(ctypes.c_void_p))
@@ -296,6 +309,7 @@ def make_view_from_csc(dim, type, col_ptr, row_idx, val) -> svt_view:
     v.ndim = len(dim)
     v.dim = dim.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
     v.svt_is_null = int(col_ptr[-1] == 0)
+    v.na_background = 0
     v.nleaves = n
     v.nzcount = nzcount.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
     v.nzoffs = offs_p.ctypes.data_as(ctypes.POINTER(ctypes.c_void_p))

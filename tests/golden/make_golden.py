@@ -53,8 +53,12 @@ def enc(a):
             "hex": np.asfortranarray(a).tobytes(order="F").hex()}
 
 
-def svt(dense, type_):
-    return {"__svt__": True, "type": type_, "dense": enc(dense)}
+def svt(dense, type_, na_bg=False):
+    """na_bg: an NaArray (as(dense, "NaArray")): same dense object, NA background."""
+    o = {"__svt__": True, "type": type_, "dense": enc(dense)}
+    if na_bg:
+        o["na_background"] = True
+    return o
 
 
 CASES = []
@@ -459,8 +463,13 @@ ms1 = np.array([[0, 0, NA, 0, NA],
 ms2 = (ms1 == NA_INT).astype(np.int32)   # is.na(m1), logical
 
 
-def matrixstats_2d(m, t, src, with_anyall_pinned):
-    S = svt(m, t)
+def matrixstats_2d(m, t, src, with_anyall_pinned, na_bg=False):
+    """na_bg: the same cases on as(m, "NaArray") (tests/testthat/test-NaArray-matrixStats.R:
+    expected = the same base-R results on the same dense matrix); col* only, the
+    row* statistics of NaArray objects are not implemented yet."""
+    if na_bg:
+        emitted = len(CASES)
+    S = svt(m, t, na_bg)
     tm = np.asfortranarray(m.T)
     for narm in (False, True):
         kw = {"na_rm": narm}
@@ -486,17 +495,24 @@ def matrixstats_2d(m, t, src, with_anyall_pinned):
             case(src, pre + "Sds", [S], stat_col(mm, lambda v: r_sd(v, narm)), "equal", kwargs=kw)
     # zero-row object: NA + warning for the col ops (:173-192)
     z = m[0:0, :]
-    Z = svt(z, t)
+    Z = svt(z, t, na_bg)
     na5 = np.full(5, NA_INT, dtype=np.int32)
     case(src, "colMins", [Z], na5, warn="NAs introduced")
     case(src, "colMaxs", [Z], na5, warn="NAs introduced")
     case(src, "colRanges", [Z], np.stack([na5, na5], axis=-1), warn="NAs introduced")
     case(src, "rowMins", [Z], np.zeros(0, np.int32))
     case(src, "rowMaxs", [Z], np.zeros(0, np.int32))
+    if na_bg:
+        CASES[emitted:] = [c for c in CASES[emitted:] if not c["fn"].startswith("row")]
+        for i, c in enumerate(CASES):
+            c["id"] = i
 
 
 matrixstats_2d(ms1, "integer", SRC_MS + ":141-192", with_anyall_pinned=False)
 matrixstats_2d(ms2, "logical", SRC_MS + ":194-242", with_anyall_pinned=True)
+SRC_NM = "tests/testthat/test-NaArray-matrixStats.R"
+matrixstats_2d(ms1, "integer", SRC_NM + ":130-178", with_anyall_pinned=False, na_bg=True)
+matrixstats_2d(ms2, "logical", SRC_NM + ":180-228", with_anyall_pinned=True, na_bg=True)
 
 # E. col/rowAnyNAs (:69-106)
 an1 = np.array([[0, 0, 155], [0, 8, -1]], dtype=np.int32, order="F")
@@ -512,6 +528,9 @@ for m, t in ((an1, "integer"), (an1n, "integer"), (an2, "logical"), (an2n, "logi
     case(SRC_MS + ":69-106", "rowAnyNAs", [svt(m, t)],
          stat_col(np.asfortranarray(m.T), r_anyNA, dtype=np.int32))
     case("tests/testthat/test-SparseArray-summarization.R:2-31", "anyNA", [svt(m, t)],
+         np.int32(r_anyNA(m.reshape(-1))))
+    case(SRC_NM + ":56-100", "colAnyNAs", [svt(m, t, True)], stat_col(m, r_anyNA, dtype=np.int32))
+    case("tests/testthat/test-NaArray-summarization.R:1-31", "anyNA", [svt(m, t, True)],
          np.int32(r_anyNA(m.reshape(-1))))
 
 # ---------------------------------------------------------------------------
@@ -603,8 +622,8 @@ def int_or_double(v):
     return np.float64(v)
 
 
-def summarize_cases(a, t, src):
-    S = svt(a, t)
+def summarize_cases(a, t, src, na_bg=False):
+    S = svt(a, t, na_bg)
     v = a.reshape(-1, order="F")
     isint = t != "double"
     for narm in (False, True):
@@ -631,7 +650,7 @@ def summarize_cases(a, t, src):
         case(src, "var", [S], np.float64(r_var(v, narm)), "equal", kwargs=kw)
         case(src, "sd", [S], np.float64(r_sd(v, narm)), "equal", kwargs=kw)
     if isint:
-        Z = svt(a[0:0, :], t)
+        Z = svt(a[0:0, :], t, na_bg)
         case(src, "min", [Z], np.int32(NA_INT), warn="NAs introduced")
         case(src, "max", [Z], np.int32(NA_INT), warn="NAs introduced")
         case(src, "range", [Z], np.array([NA_INT, NA_INT], np.int32), warn="NAs introduced")
@@ -644,6 +663,35 @@ case(SRC_SU + ":113-115", "anyNA", [S3d], np.int32(1))
 case(SRC_SU + ":116-117", "any", [S3d], None, error="does not support")
 case(SRC_SU + ":116-117", "all", [S3d], None, error="does not support")
 summarize_cases(a3, "double", SRC_SU + ":118-125")
+SRC_NS = "tests/testthat/test-NaArray-summarization.R"
+summarize_cases(ms1, "integer", SRC_NS + ":56-77", na_bg=True)
+summarize_cases(ms2, "logical", SRC_NS + ":79-100", na_bg=True)
+case(SRC_NS + ":104-110", "anyNA", [svt(a3_clean, "double", True)], np.int32(0))
+case(SRC_NS + ":111-114", "anyNA", [svt(a3, "double", True)], np.int32(1))
+case(SRC_NS + ":115-116", "any", [svt(a3, "double", True)], None, error="does not support")
+summarize_cases(a3, "double", SRC_NS + ":117-124", na_bg=True)
+# 3-D NaArray with an NA background proper (test-NaArray-matrixStats.R:232-252): col* part
+na3 = np.full((6, 5, 4), NA_REAL, dtype=np.float64, order="F")
+na3[0, :, 1] = [1e12, -1234.55, -2.1, -1, -0.55]
+na3[2, :, 1] = [-0.55, 0, 1e-10, 0.88, 1]
+na3[4, :, 1] = [math.pi, 10.33, 3.4567895e8, 300, 2009.01]
+na3[5, 2:4, 1] = [0, NAN]
+for dims in (1, 2):
+    for narm in (False, True):
+        kw = {"na_rm": narm, "dims": dims}
+        N3 = svt(na3, "double", True)
+        case(SRC_NM + ":232-252", "colSums", [N3], stat_col(na3, lambda v: r_sum(v, narm), dims), "equal", kwargs=kw)
+        case(SRC_NM + ":232-252", "colMeans", [N3], stat_col(na3, lambda v: r_mean(v, narm), dims), "equal", kwargs=kw)
+        case(SRC_NM + ":232-252", "colMins", [N3], stat_col(na3, lambda v: r_minmax_d(v, narm, True), dims), kwargs=kw)
+        case(SRC_NM + ":232-252", "colMaxs", [N3], stat_col(na3, lambda v: r_minmax_d(v, narm, False), dims), kwargs=kw)
+# min/max torture, 2-D ints (test-NaArray-matrixStats.R:256-270): col* part
+for m in (np.array([[0, -8, NA_INT], [NA_INT, NA_INT, 1]], dtype=np.int32, order="F"),
+          np.array([[NA_INT, 0, NA_INT, NA_INT], [8, 9, 1, 1], [-8, -9, -10, -11]], dtype=np.int32, order="F")):
+    for narm in (False, True):
+        for nm, is_min in (("colMins", True), ("colMaxs", False)):
+            case(SRC_NM + ":256-270", nm, [svt(m, "integer", True)],
+                 stat_col(m, lambda v: r_minmax_i(v, narm, is_min), dtype=np.int32), kwargs={"na_rm": narm},
+                 warn=None)
 
 # ---------------------------------------------------------------------------
 # I. rowsum / colsum   tests/testthat/test-rowsum-methods.R:61-89

@@ -29,7 +29,8 @@ def dec(o, lacunar=True):
         return a.reshape(o["shape"], order="F").copy(order="F")
     if isinstance(o, dict) and o.get("__svt__"):
         return SVT_SparseArray.from_dense(dec(o["dense"]), type=o["type"],
-                                          lacunar=lacunar)
+                                          lacunar=lacunar,
+                                          na_background=bool(o.get("na_background", False)))
     if isinstance(o, dict) and o.get("__dgc__"):
         return (tuple(o["dim"]), dec(o["p"]), dec(o["i"]), dec(o["x"]))
     return o

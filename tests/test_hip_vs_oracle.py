@@ -126,6 +126,54 @@ def test_matrixstats_double(hip, oracle, shape, density, na_rm):
 
 
 @pytest.mark.parametrize("na_rm", [False, True])
+@pytest.mark.parametrize("shape,fill,type_", [((3000, 200), 0.9, "double"), ((500, 40, 6), 0.3, "double"),
+                                              ((4000, 64), 0.6, "integer")])
+def test_matrixstats_NaArray_col_ops(hip, oracle, shape, fill, type_, na_rm):
+    """NaArray operands (NA background, R/NaArray-matrixStats.R): column statistics and
+    whole-array summaries; some columns have no NA at all, some nothing but NAs."""
+    rng = np.random.default_rng(17)
+    if type_ == "double":
+        a = np.round(rng.normal(size=shape), 2)
+        a[rng.random(shape) < 0.02] = np.nan                # stored NaNs next to the NA background
+        a[rng.random(shape) > fill] = NA_real
+        a[:, 0] = np.round(rng.normal(size=a[:, 0].shape), 2)    # complete
+        a[:, 1] = NA_real                                         # empty
+    else:
+        a = rng.integers(-20, 20, shape).astype(np.int32)
+        a[rng.random(shape) > fill] = NA_integer
+        a[:, 0] = 3
+        a[:, 1] = NA_integer
+    x = SVT_SparseArray.from_dense(np.asfortranarray(a), type_, na_background=True)
+    ops = ["colSums", "colMeans", "colVars", "colSds", "colMins", "colMaxs", "colProds",
+           "colAnyNAs", "colCountNAs"] + (["colAnys", "colAlls"] if type_ == "integer" else [])
+    import warnings
+    for dims in range(1, len(shape)):
+        for op in ops:
+            kw = {} if "AnyNAs" in op or "CountNAs" in op else {"na_rm": na_rm}
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                got = getattr(hip, op)(x, dims=dims, **kw)
+                want = getattr(oracle, op)(x, dims=dims, **kw)
+            if got.dtype == np.int32:
+                assert_identical(got, want, op)
+            else:
+                assert_equal(got, want, tol=1e-6, what=f"{op} dims={dims}", atol=1e-9,
+                             strict_na=op[3:] in ("Mins", "Maxs", "Sums"))
+    for op in ["sum", "mean", "min", "max", "var", "anyNA"]:
+        kw = {} if op == "anyNA" else {"na_rm": na_rm}
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            got, want = getattr(hip, op)(x, **kw), getattr(oracle, op)(x, **kw)
+        assert_equal(np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64), tol=1e-6, atol=1e-9, what=op)
+    for sess in (hip, oracle):
+        with pytest.raises(Exception, match="NaArray"):
+            sess.rowSums(x)
+        if len(shape) == 2:
+            with pytest.raises(Exception, match="NaMatrix"):
+                sess.crossprod(x, np.ones((shape[0], 2)))
+
+
+@pytest.mark.parametrize("na_rm", [False, True])
 def test_matrixstats_int_exact(hip, oracle, na_rm):
     x = _sprinkle(_svt(5000, 64, 0.05, 12, "int"), 12, [NA_integer, -7])
     for op in ["colSums", "colMeans", "colMins", "colMaxs", "colAnys", "colAlls",
