@@ -1344,12 +1344,26 @@ static void scatter_leaf(const leaf_t *lf, int Rtype, int opcode, int narm,
 int orc_rowStats_SVT(const orc_svt *x, int opcode, int na_rm,
 		     const double *center, int dims, void *out, int *warn)
 {
-	if (x->na_background)
-		return fail("row statistics of NaArray objects are not implemented on the "
-			    "device yet (src/SparseArray_matrixStats.c:756-1019)");
 	*warn = 0;
 	if (check_op_type(opcode, x->Rtype))
 		return -1;
+	const int na_bg = x->na_background != 0;
+	if (na_bg && opcode == ORC_OP_CENTERED_X2_SUM)   /* :639-642 */
+		return fail("operation not yet supported on NaArray objects");
+	if (na_bg && opcode == ORC_OP_ANYNA) {
+		/* SVT_rowAnyNAs(), :880-910: count the NAs, then compare with 0 */
+		int64_t inner_ = 1;
+		for (int a = 1; a < dims && a < x->ndim; a++)
+			inner_ *= x->dim[a];
+		int64_t n_ = inner_ * x->dim[0];
+		double *cnt = (double *) malloc(sizeof(double) * (n_ > 0 ? n_ : 1));
+		int rc = orc_rowStats_SVT(x, ORC_OP_COUNTNAS, na_rm, center, dims, cnt, warn);
+		if (rc == 0)
+			for (int64_t i = 0; i < n_; i++)
+				((int *) out)[i] = cnt[i] != 0.0;
+		free(cnt);
+		return rc;
+	}
 	if (dims < 1 || dims > x->ndim - 1)
 		return fail("'dims' must be >= 1 and <= %d", x->ndim - 1);
 	if (opcode != ORC_OP_COUNTNAS && opcode != ORC_OP_ANYNA &&
@@ -1370,7 +1384,11 @@ int orc_rowStats_SVT(const orc_svt *x, int opcode, int na_rm,
 
 	/* initialisation: :840-1060 */
 	switch (opcode) {
-	    case ORC_OP_COUNTNAS: case ORC_OP_SUM:
+	    case ORC_OP_COUNTNAS:   /* :856-878: an NaArray starts from nstrata */
+		for (int64_t i = 0; i < out_len; i++)
+			((double *) out)[i] = na_bg ? (double) nstrata : 0.0;
+		break;
+	    case ORC_OP_SUM:
 		memset(out, 0, sizeof(double) * out_len);
 		break;
 	    case ORC_OP_ANYNA:
@@ -1405,14 +1423,54 @@ int orc_rowStats_SVT(const orc_svt *x, int opcode, int na_rm,
 		}
 		nzcvg = (int64_t *) calloc(out_len, sizeof(int64_t));
 	}
-	if (nstrata != 0 && !x->svt_is_null) {
+	/* NA background, na.rm=FALSE, anything but countNAs: a NULL leaf / subtree turns
+	   its whole slice of 'out' into NAs (update_out_for_rowStats_NULL, :756-768) */
+	const int null_gives_na = na_bg && !na_rm && opcode != ORC_OP_COUNTNAS;
+	if (nstrata != 0 && (!x->svt_is_null || null_gives_na)) {
 		/* the DFS of :774-829 visits leaves in flat order */
 		for (int64_t j = 0; j < x->nleaves; j++) {
 			leaf_t lf = get_leaf(x, j);
-			if (lf.n == 0)
-				continue;
 			int64_t base = (j % inner) * dim0;
 			size_t esz = out_Rtype == ORC_DBL ? 8 : 4;
+			if (lf.n == 0) {
+				if (null_gives_na)
+					for (int i = 0; i < dim0; i++) {
+						if (out_Rtype == ORC_DBL)
+							((double *) out)[base + i] = NA_REAL;
+						else
+							((int *) out)[base + i] = NA_INT;
+					}
+				continue;
+			}
+			if (na_bg && opcode == ORC_OP_COUNTNAS) {
+				/* :516-535: every stored non-NA value takes one off */
+				for (int k = 0; k < lf.n; k++)
+					if (lf.val == NULL || !leaf_val_is_na(&lf, x->Rtype, k))
+						((double *) out)[base + lf.off[k]]--;
+				continue;
+			}
+			if (na_bg && opcode == ORC_OP_SUM && !na_rm) {
+				/* rowSums(<NaArray>, na.rm=FALSE), :612-634: walk all the
+				   positions, the implicit ones are NAs */
+				double *o = (double *) out + base;
+				int k = 0;
+				for (int i = 0; i < dim0; i++) {
+					if (k < lf.n && lf.off[k] == i) {
+						double v;
+						if (x->Rtype == ORC_DBL) {
+							v = ((const double *) lf.val)[k];
+						} else {
+							int iv = ((const int *) lf.val)[k];
+							v = iv == NA_INT ? NA_REAL : (double) iv;
+						}
+						o[i] += v;
+						k++;
+					} else {
+						o[i] = NA_REAL;
+					}
+				}
+				continue;
+			}
 			scatter_leaf(&lf, x->Rtype, opcode, na_rm,
 				     center ? center + base : NULL,
 				     (char *) out + base * esz,
@@ -1427,14 +1485,14 @@ int orc_rowStats_SVT(const orc_svt *x, int opcode, int na_rm,
 			if (out_Rtype == ORC_DBL) {
 				double *o = (double *) out + i;
 				if (cv < nstrata)
-					upd_double_minmax(0.0, na_rm, o,
+					upd_double_minmax(na_bg ? NA_REAL : 0.0, na_rm, o,
 							  cv == 0, is_min);
 				if (na_rm && is_R_NA(*o))
 					*o = is_min ? INFINITY : -INFINITY;
 			} else {
 				int *o = (int *) out + i;
 				if (cv < nstrata)
-					upd_int_minmax(0, na_rm, o,
+					upd_int_minmax(na_bg ? NA_INT : 0, na_rm, o,
 						       cv == 0, is_min);
 				if (na_rm && *o == NA_INT)
 					*warn = 1;

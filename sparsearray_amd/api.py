@@ -216,6 +216,11 @@ class Session:
                 "length(dim(x)) for the row*() functions")
         if dims == 0:
             return self._colStats(op, x, na_rm, center, x.ndim)
+        if x.na_background and op not in ("countNAs", "anyNA", "min", "max", "sum"):
+            # rowAnys/Alls/Prods/Means/Vars/Sds: no NaArray methods (commented out in
+            # R/NaArray-matrixStats.R:187-330)
+            raise SparseArrayError(f"unable to find an inherited method for the row {op} "
+                                   f"statistic for signature 'x = \"NaArray\"'")
         if op not in ("countNAs", "anyNA", "min", "max", "sum",
                       "centered_X2_sum"):
             return self._OLD_rowStats(op, x, na_rm, center, dims)
@@ -290,6 +295,8 @@ class Session:
 
     def rowMeans(self, x, na_rm=False, dims=1):
         # :511-516
+        if x.na_background:
+            return self._rowStats("mean", x, na_rm, dims=dims)     # raises: no NaArray method
         sums = self.rowSums(x, na_rm, dims)
         nvals = self._rowCountVals(x, na_rm, dims)
         with np.errstate(all="ignore"):
@@ -305,6 +312,8 @@ class Session:
 
     def rowVars(self, x, na_rm=False, center=None, dims=1):
         # :645-660
+        if x.na_background:
+            return self._rowStats("var1", x, na_rm, dims=dims)     # raises: no NaArray method
         nvals = self._rowCountVals(x, na_rm, dims)
         with np.errstate(all="ignore"):
             if center is None:

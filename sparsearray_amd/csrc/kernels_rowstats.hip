@@ -249,6 +249,11 @@ rowstats_panel_kernel(RowStatsArgs a, const int32_t *__restrict__ pt, int64_t np
 	const T *__restrict__ val = (const T *) a.val;
 	const int32_t *__restrict__ row = a.row_idx;
 	const double NAr = svt_na_real();
+	// NaArray (a.na_bg): cells covered fewer than nstrata times hold implicit NAs:
+	//   countNAs / anyNA: count the stored non-NA values, result nstrata - count (!= 0)
+	//   sum, na.rm=FALSE: NA_real_ wherever the coverage is short (:612-634)
+	//   min / max: the NA background joins instead of the implicit zero (:914-961)
+	const bool nabg = a.na_bg != 0;
 
 	for (int r = tid; r < np; r += ROWPANEL_NT) {
 		if (is_minmax) {
@@ -259,10 +264,11 @@ rowstats_panel_kernel(RowStatsArgs a, const int32_t *__restrict__ pt, int64_t np
 			const double c = a.center ? a.center[cell0 + r] : 0.0;
 			cen[r] = c;
 			accd[r] = a.center ? c * c * (double) a.nstrata : 0.0;
-		} else if (oc == SVT_OP_ANYNA) {
+		} else if (oc == SVT_OP_ANYNA && !nabg) {
 			((int *) lds64)[r] = 0;
 		} else {
 			accd[r] = 0.0;
+			if (nabg) cov[r] = 0;
 		}
 	}
 	__syncthreads();
@@ -287,12 +293,14 @@ rowstats_panel_kernel(RowStatsArgs a, const int32_t *__restrict__ pt, int64_t np
 			const bool miss = is_dbl ? (v != v) : ((int) v == NA_INT);
 			switch (oc) {
 			case SVT_OP_ANYNA:
-				if (miss) ((int *) lds64)[r] = 1;
+				if (nabg) { if (!miss) atomicAdd(accd + r, 1.0); }
+				else if (miss) ((int *) lds64)[r] = 1;
 				break;
 			case SVT_OP_COUNTNAS:
-				if (miss) atomicAdd(accd + r, 1.0);
+				if (nabg ? !miss : miss) atomicAdd(accd + r, 1.0);
 				break;
 			case SVT_OP_SUM:
+				if (nabg && !narm) atomicAdd(cov + r, 1u);
 				if (miss && narm) break;
 				atomicAdd(accd + r, (!is_dbl && miss) ? NAr : (double) v);
 				break;
@@ -324,8 +332,17 @@ rowstats_panel_kernel(RowStatsArgs a, const int32_t *__restrict__ pt, int64_t np
 	for (int r = tid; r < np; r += ROWPANEL_NT) {
 		const int64_t cell = cell0 + r;
 		if (!is_minmax) {
-			if (oc == SVT_OP_ANYNA) ((int *) a.out)[cell] = ((int *) lds64)[r];
-			else ((double *) a.out)[cell] = accd[r];
+			if (nabg && (oc == SVT_OP_ANYNA || oc == SVT_OP_COUNTNAS)) {
+				const double nas = (double) a.nstrata - accd[r];
+				if (oc == SVT_OP_ANYNA) ((int *) a.out)[cell] = nas != 0.0;
+				else ((double *) a.out)[cell] = nas;
+			} else if (oc == SVT_OP_ANYNA) {
+				((int *) a.out)[cell] = ((int *) lds64)[r];
+			} else if (nabg && oc == SVT_OP_SUM && !narm && (int64_t) cov[r] < a.nstrata) {
+				((double *) a.out)[cell] = NAr;
+			} else {
+				((double *) a.out)[cell] = accd[r];
+			}
 			continue;
 		}
 		// NA > NaN > extremum; the implicit zero joins when the cell was
@@ -336,10 +353,10 @@ rowstats_panel_kernel(RowStatsArgs a, const int32_t *__restrict__ pt, int64_t np
 		bool have = (fl & RF_HAVE) != 0;
 		if (is_dbl) {
 			double m = have ? ordered_to_f64(lds64[r]) : 0.0, res;
-			if (!narm && (fl & RF_NA)) res = NAr;
+			if (!narm && ((fl & RF_NA) || (nabg && partial))) res = NAr;
 			else if (!narm && (fl & RF_NAN)) res = NAN;
 			else {
-				if (partial) {
+				if (partial && !nabg) {
 					m = have ? (is_min ? (0.0 < m ? 0.0 : m) : (0.0 > m ? 0.0 : m)) : 0.0;
 					have = true;
 				}
@@ -348,9 +365,9 @@ rowstats_panel_kernel(RowStatsArgs a, const int32_t *__restrict__ pt, int64_t np
 			((double *) a.out)[cell] = res;
 		} else {
 			int m = have ? (int) ((long long) lds64[r] - 0x80000000LL) : 0, res;
-			if (!narm && (fl & RF_NA)) res = NA_INT;
+			if (!narm && ((fl & RF_NA) || (nabg && partial))) res = NA_INT;
 			else {
-				if (partial) {
+				if (partial && !nabg) {
 					m = have ? (is_min ? (0 < m ? 0 : m) : (0 > m ? 0 : m)) : 0;
 					have = true;
 				}

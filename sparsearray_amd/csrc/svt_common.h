@@ -146,6 +146,7 @@ struct RowStatsArgs {
 	void *scratch;          // device scratch (see rowstats_scratch_bytes)
 	int *warn_flag;
 	int64_t nnz_hint;       // nonzeros of the operand (launch tuning only), 0 = unknown
+	int na_bg;              // NaArray: implicit entries are NAs (SparseArray_matrixStats.c:756-1019)
 };
 size_t rowstats_scratch_bytes(int opcode, int out_Rtype, int64_t out_len);
 int launch_rowstats(const RowStatsArgs &a, int64_t nnz, hipStream_t s);      // memory atomics

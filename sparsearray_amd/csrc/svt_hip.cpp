@@ -464,6 +464,7 @@ extern "C" int svt_dev_rowsums(const svt_dev_csc *A, int na_rm, int64_t inner,
 	a.inner = inner; a.nstrata = A->ncol / inner;
 	a.out_len = inner * A->nrow;
 	a.opcode = SVT_OP_SUM; a.na_rm = na_rm; a.out = out; a.nnz_hint = A->nnz;
+	a.na_bg = A->na_background;
 	return launch_rowstats_panel(a, ws, (hipStream_t) stream);
 }
 
@@ -831,9 +832,8 @@ extern "C" int svt_rowStats_SVT(const svt_view *x, int opcode, int na_rm,
 		return -1;
 	if (dims < 1 || dims > x->ndim - 1)
 		return svt_set_error("'dims' must be >= 1 and <= %d", x->ndim - 1);
-	if (x->na_background)
-		return svt_set_error("row statistics of NaArray objects are not implemented on the "
-				     "device yet (src/SparseArray_matrixStats.c:756-1019)");
+	if (x->na_background && opcode == SVT_OP_CENTERED_X2_SUM)   // :639-642
+		return svt_set_error("operation not yet supported on NaArray objects");
 	if (opcode != SVT_OP_COUNTNAS && opcode != SVT_OP_ANYNA &&
 	    opcode != SVT_OP_MIN && opcode != SVT_OP_MAX &&
 	    opcode != SVT_OP_SUM && opcode != SVT_OP_CENTERED_X2_SUM)
@@ -876,6 +876,9 @@ extern "C" int svt_rowStats_SVT(const svt_view *x, int opcode, int na_rm,
 	a.opcode = opcode; a.na_rm = na_rm;
 	a.center = center ? C.as<double>() : NULL;
 	a.out = O.p; a.scratch = S.p; a.warn_flag = W.as<int>(); a.nnz_hint = A.h->nnz;
+	a.na_bg = x->na_background != 0;
+	if (a.na_bg && inner > 65535)
+		return svt_set_error("row statistics of NaArray objects: more than 65535 output columns");
 	if (inner <= 65535) {
 		DevBuf T;
 		if (T.alloc(rowstats_panel_ws_bytes(a.nrow, a.ncol)) || launch_rowstats_panel(a, T.p, 0))

@@ -503,7 +503,10 @@ def matrixstats_2d(m, t, src, with_anyall_pinned, na_bg=False):
     case(src, "rowMins", [Z], np.zeros(0, np.int32))
     case(src, "rowMaxs", [Z], np.zeros(0, np.int32))
     if na_bg:
-        CASES[emitted:] = [c for c in CASES[emitted:] if not c["fn"].startswith("row")]
+        # row* methods the reference defines for NaArray objects (R/NaArray-matrixStats.R;
+        # rowAnys/Alls/Prods/Means/Vars/Sds are commented out there)
+        ok_row = {"rowMins", "rowMaxs", "rowRanges", "rowSums", "rowSums2", "rowAnyNAs"}
+        CASES[emitted:] = [c for c in CASES[emitted:] if not c["fn"].startswith("row") or c["fn"] in ok_row]
         for i, c in enumerate(CASES):
             c["id"] = i
 
@@ -530,6 +533,8 @@ for m, t in ((an1, "integer"), (an1n, "integer"), (an2, "logical"), (an2n, "logi
     case("tests/testthat/test-SparseArray-summarization.R:2-31", "anyNA", [svt(m, t)],
          np.int32(r_anyNA(m.reshape(-1))))
     case(SRC_NM + ":56-100", "colAnyNAs", [svt(m, t, True)], stat_col(m, r_anyNA, dtype=np.int32))
+    case(SRC_NM + ":56-100", "rowAnyNAs", [svt(m, t, True)],
+         stat_col(np.asfortranarray(m.T), r_anyNA, dtype=np.int32))
     case("tests/testthat/test-NaArray-summarization.R:1-31", "anyNA", [svt(m, t, True)],
          np.int32(r_anyNA(m.reshape(-1))))
 
@@ -684,6 +689,9 @@ for dims in (1, 2):
         case(SRC_NM + ":232-252", "colMeans", [N3], stat_col(na3, lambda v: r_mean(v, narm), dims), "equal", kwargs=kw)
         case(SRC_NM + ":232-252", "colMins", [N3], stat_col(na3, lambda v: r_minmax_d(v, narm, True), dims), kwargs=kw)
         case(SRC_NM + ":232-252", "colMaxs", [N3], stat_col(na3, lambda v: r_minmax_d(v, narm, False), dims), kwargs=kw)
+        case(SRC_NM + ":232-252", "rowSums", [N3], stat_row(na3, lambda v: r_sum(v, narm), dims), "equal", kwargs=kw)
+        case(SRC_NM + ":232-252", "rowMins", [N3], stat_row(na3, lambda v: r_minmax_d(v, narm, True), dims), kwargs=kw)
+        case(SRC_NM + ":232-252", "rowMaxs", [N3], stat_row(na3, lambda v: r_minmax_d(v, narm, False), dims), kwargs=kw)
 # min/max torture, 2-D ints (test-NaArray-matrixStats.R:256-270): col* part
 for m in (np.array([[0, -8, NA_INT], [NA_INT, NA_INT, 1]], dtype=np.int32, order="F"),
           np.array([[NA_INT, 0, NA_INT, NA_INT], [8, 9, 1, 1], [-8, -9, -10, -11]], dtype=np.int32, order="F")):
@@ -692,6 +700,9 @@ for m in (np.array([[0, -8, NA_INT], [NA_INT, NA_INT, 1]], dtype=np.int32, order
             case(SRC_NM + ":256-270", nm, [svt(m, "integer", True)],
                  stat_col(m, lambda v: r_minmax_i(v, narm, is_min), dtype=np.int32), kwargs={"na_rm": narm},
                  warn=None)
+            case(SRC_NM + ":256-270", "row" + nm[3:], [svt(m, "integer", True)],
+                 stat_col(np.asfortranarray(m.T), lambda v: r_minmax_i(v, narm, is_min), dtype=np.int32),
+                 kwargs={"na_rm": narm}, warn=None)
 
 # ---------------------------------------------------------------------------
 # I. rowsum / colsum   tests/testthat/test-rowsum-methods.R:61-89

@@ -158,16 +158,33 @@ def test_matrixstats_NaArray_col_ops(hip, oracle, shape, fill, type_, na_rm):
                 assert_identical(got, want, op)
             else:
                 assert_equal(got, want, tol=1e-6, what=f"{op} dims={dims}", atol=1e-9,
-                             strict_na=op[3:] in ("Mins", "Maxs", "Sums"))
+                             strict_na=op[3:] in ("Mins", "Maxs"))
     for op in ["sum", "mean", "min", "max", "var", "anyNA"]:
         kw = {} if op == "anyNA" else {"na_rm": na_rm}
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             got, want = getattr(hip, op)(x, **kw), getattr(oracle, op)(x, **kw)
         assert_equal(np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64), tol=1e-6, atol=1e-9, what=op)
+    # row statistics the reference defines for NaArray objects
+    for dims in range(1, len(shape)):
+        for op in ["rowSums", "rowMins", "rowMaxs", "rowAnyNAs", "rowCountNAs"]:
+            kw = {} if "AnyNAs" in op or "CountNAs" in op else {"na_rm": na_rm}
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                got = getattr(hip, op)(x, dims=dims, **kw)
+                want = getattr(oracle, op)(x, dims=dims, **kw)
+            if got.dtype == np.int32:
+                assert_identical(got, want, op)
+            else:
+                # NA + NaN in one cell: which payload an IEEE sum keeps is not pinned
+                # (SURVEY.md section 8a notes); min/max return NA_real_ explicitly
+                assert_equal(got, want, tol=1e-6, what=f"{op} dims={dims}", atol=1e-9,
+                             strict_na=op[3:] in ("Mins", "Maxs"))
     for sess in (hip, oracle):
         with pytest.raises(Exception, match="NaArray"):
-            sess.rowSums(x)
+            sess.rowMeans(x)
+        with pytest.raises(Exception, match="NaArray"):
+            sess.rowVars(x)
         if len(shape) == 2:
             with pytest.raises(Exception, match="NaMatrix"):
                 sess.crossprod(x, np.ones((shape[0], 2)))
