@@ -541,8 +541,8 @@ static int dev_crossprod_chunked(const svt_dev_csc *A, const void *Y_dev, int64_
 	if (A->Rtype == SVT_REALSXP && !tr_y && A->nrow >= 256 &&
 	    (double) A->nnz * (double) K >= 268435456.0) {
 		svt_dev_pbc *P = svt_dev_pbc_build(A, 40, 16, 7);
-		if (P == NULL)
-			return -1;
+		if (P == NULL)                 // e.g. more records than 32-bit stream offsets reach:
+			goto general;          // the general kernels take any size
 		const int kc = K < 512 ? (int) K : 512;
 		DevBuf ws;
 		int rc = ws.alloc(svt_dev_crossprod_pbc_ws_bytes(P, kc));
@@ -556,6 +556,7 @@ static int dev_crossprod_chunked(const svt_dev_csc *A, const void *Y_dev, int64_
 		svt_dev_pbc_release(P);
 		return rc;
 	}
+general:
 	const int kc = chunk_K(A->nrow, K);
 	DevBuf ws;
 	if (ws.alloc(crossprod_ws_bytes(A->nrow, A->ncol, kc)))
