@@ -648,24 +648,39 @@ static int dev_crossprod_pp(const svt_dev_csc *other, const svt_dev_csc *pp,
 	const int64_t K = pp->ncol, nrow = pp->nrow;
 	if (K <= 0 || other->ncol <= 0)
 		return 0;
-	const int kc = chunk_K(nrow, K);
+	int kc = chunk_K(nrow, K);
 	const size_t esz = elt_size(pp->Rtype);
+	// large double products: panel-blocked layout of `other`, built once, against
+	// every densified chunk (same threshold and caveat as dev_crossprod_chunked)
+	svt_dev_pbc *P = NULL;
+	if (other->Rtype == SVT_REALSXP && nrow >= 256 &&
+	    (double) other->nnz * (double) K >= 268435456.0) {
+		P = svt_dev_pbc_build(other, 40, 16, 7);
+		if (P != NULL && kc > 512) kc = 512;
+	}
 	DevBuf dense, ws;
+	int rc = 0;
 	if (dense.alloc((size_t) (nrow > 0 ? nrow : 1) * kc * esz) ||
-	    ws.alloc(crossprod_ws_bytes(nrow, other->ncol, kc)))
-		return -1;
-	for (int64_t k0 = 0; k0 < K; k0 += kc) {
+	    ws.alloc(P ? svt_dev_crossprod_pbc_ws_bytes(P, kc)
+		       : crossprod_ws_bytes(nrow, other->ncol, kc)))
+		rc = -1;
+	for (int64_t k0 = 0; rc == 0 && k0 < K; k0 += kc) {
 		const int kn = (int) (K - k0 < kc ? K - k0 : kc);
 		if (launch_densify(pp->col_ptr, pp->row_idx, pp->val, pp->Rtype, nrow,
 				   k0, kn, dense.p, 0))
-			return -1;
-		if (svt_dev_crossprod_csc_dense(other, dense.p, nrow, kn, 0,
-						out_dev + k0 * sk, sc, sk,
-						ws.p, ws.bytes, 0))
-			return -1;
+			rc = -1;
+		else if (P)
+			rc = svt_dev_crossprod_pbc(P, other, (const double *) dense.p, nrow, kn, 0,
+						   out_dev + k0 * sk, sc, sk, ws.p, ws.bytes, 0);
+		else
+			rc = svt_dev_crossprod_csc_dense(other, dense.p, nrow, kn, 0,
+							 out_dev + k0 * sk, sc, sk,
+							 ws.p, ws.bytes, 0);
 	}
-	HIP_TRY(hipDeviceSynchronize());
-	return 0;
+	if (rc == 0 && hipDeviceSynchronize() != hipSuccess)
+		rc = svt_set_error("device error in the sparse x sparse crossprod");
+	if (P) svt_dev_pbc_release(P);
+	return rc;
 }
 
 static int64_t view_nzcount(const svt_view *x)   // _REC_nzcount_SVT, SVT_SparseArray_class.c:200-218

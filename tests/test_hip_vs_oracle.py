@@ -46,6 +46,9 @@ def test_crossprod_large_takes_panel_kernels(hip, oracle):
     assert_equal(hip.crossprod(y, x), oracle.crossprod(y, x), tol=1e-9, atol=1e-11, strict_na=True)
     y[123_456, 3] = np.nan
     assert_equal(hip.crossprod(x, y), oracle.crossprod(x, y), tol=1e-9, atol=1e-11, strict_na=True)
+    # sparse x sparse through the same kernels (the other operand densified in chunks)
+    z = _svt(300_000, 60, 0.02, 8)      # (clean: a dirty leaf costs the oracle a full-length walk per dot)
+    assert_equal(hip.crossprod(x, z), oracle.crossprod(x, z), tol=1e-9, atol=1e-11, strict_na=True)
 
 
 @pytest.mark.parametrize("seed", [1, 2])
