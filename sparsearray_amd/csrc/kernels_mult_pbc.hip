@@ -65,6 +65,7 @@ struct svt_dev_pbc {
 static int g_pbc_debug = 0;
 static int g_pbc_nsplit = 0;
 static int g_pbc_stagger = 2;
+static int g_pbc_ahead10 = 20;     // record touch: look-ahead in tenths of a tile
 
 // ---------------------------------------------------------------------------
 // layout build
@@ -276,7 +277,8 @@ extern "C" svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB
 // ---------------------------------------------------------------------------
 extern "C" void svt_dev_pbc_set_debug(int mode)
 {
-	if (mode >= 200) g_pbc_stagger = mode - 200;  // 200 + m: DMA issue stagger mode (tuning)
+	if (mode >= 300) g_pbc_ahead10 = mode - 300;  // 300 + t: record-touch look-ahead, tenths of a tile (tuning)
+	else if (mode >= 200) g_pbc_stagger = mode - 200;  // 200 + m: DMA issue stagger mode (tuning)
 	else if (mode >= 100) g_pbc_nsplit = mode - 100;   // 100 + n: force n row splits (tuning)
 	else g_pbc_debug = mode;
 }
@@ -938,7 +940,7 @@ static void launch_dma(const svt_dev_pbc *P, const double *Y, int64_t ldY, int K
 	if (rt_lines > 31) rt_lines = 31;
 	// the touch starts ~2 tiles past the scalar-load cursor (the PBC_SLACK records
 	// past the end of the stream absorb it at the end: 320 * 16 = 5120 bytes)
-	int rt_ahead = ((int) (2.0 * tile_bytes) + 127) / 128 * 128;
+	int rt_ahead = ((int) (g_pbc_ahead10 * 0.1 * tile_bytes) + 127) / 128 * 128;
 	if (rt_ahead + rt_lines * 128 > 4608) rt_ahead = 4608 - rt_lines * 128;
 	if (rt_ahead < 0) rt_ahead = 0;
 	auto kern = (g_pbc_debug == 3 && NV <= 2) ? crossprod_pbc_dma_kernel<(NV <= 2 ? NV : 2), true>

@@ -231,6 +231,8 @@ def gen(prof):
     dispatch("s15", [ph[(i + 1) % NPH] for i in range(NPH)], "f")
     # ---------------------------------------------------------------- the phases
     for i in range(NPH):
+        if i == 0 and "align" in EXP:
+            e(".p2align 6")                        # (experiment: loop head on a 64-byte boundary)
         e(f"{ph[i]}:")
         load(X2[i % 3], BATCH * i)
         if YSETS == 2:

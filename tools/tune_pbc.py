@@ -24,6 +24,7 @@ p.add_argument("--prof", action="store_true", help="per-section cycle counts of 
 p.add_argument("--reps", type=int, default=5)
 p.add_argument("--nsplits", default="0")
 p.add_argument("--staggers", default="2")
+p.add_argument("--aheads", default="20", help="record-touch look-ahead, tenths of a tile")
 p.add_argument("--ldy0", action="store_true", help="timing experiment: all dense columns alias column 0 (8 MB, cache resident)")
 a = p.parse_args()
 
@@ -51,8 +52,10 @@ for cfg in a.cfgs.split(";"):
     plan = PbcPlan(A, a.K, cbw, wpb, logr)
     torch.cuda.synchronize(); build = (time.perf_counter() - t0) * 1e3
     row = [f"cfg cbw={cbw} wpb={wpb} logR={logr}: build {build:.1f} ms"]
-    for ns, stg in ((int(x), int(y)) for x in a.nsplits.split(",") for y in a.staggers.split(",")):
+    for ns, stg, ah in ((int(x), int(y), int(z)) for x in a.nsplits.split(",") for y in a.staggers.split(",")
+                        for z in a.aheads.split(",")):
         lib.svt_dev_pbc_set_debug(100 + ns)
+        lib.svt_dev_pbc_set_debug(300 + ah)
         lib.svt_dev_pbc_set_debug(200 + stg)
         del plan
         plan = PbcPlan(A, a.K, cbw, wpb, logr)      # workspace depends on the split count
@@ -61,7 +64,7 @@ for cfg in a.cfgs.split(";"):
                 continue
             lib.svt_dev_pbc_set_debug(mode)
             ms = timed(lambda: plan.run(Y, 0 if a.ldy0 else a.nrow, out), a.reps)
-            row.append(f"[nsplit {ns} stagger {stg}] {name} {ms:.3f} ms ({A.nnz / ms / 1e6:.1f} GNZ/s)")
+            row.append(f"[nsplit {ns} stagger {stg} ahead {ah}] {name} {ms:.3f} ms ({A.nnz / ms / 1e6:.1f} GNZ/s)")
         if a.prof:
             import ctypes
             lib.svt_dev_pbc_set_debug(3)
