@@ -291,6 +291,20 @@ size_t svt_dev_transpose_ws_bytes(int64_t nrow, int64_t nnz);
 int svt_dev_transpose(const svt_dev_csc *A, int64_t *out_col_ptr, int32_t *out_row_idx,
 		      void *out_val, void *ws, size_t ws_bytes, void *stream);
 
+/* aperm(x, perm) for an N-d operand (C_aperm_SVT, src/SparseArray_aperm.c:935-970;
+   R/SparseArray-aperm.R).  `dim` are the array's ndim extents (dim[0] = A->nrow,
+   prod(dim[1..]) = A->ncol), `perm` is 1-based as in R.  Output: the CSC layout of
+   the permuted array, prod(dim[perm[1..]]) + 1 column pointers and A->nnz entries
+   (caller-allocated); 1 <= ndim <= 8. */
+size_t svt_dev_aperm_ws_bytes(int64_t nnz, int ndim, const int64_t *dim);
+int svt_dev_aperm(const svt_dev_csc *A, int ndim, const int64_t *dim, const int *perm,
+		  int64_t *out_col_ptr, int32_t *out_row_idx, void *out_val,
+		  void *ws, size_t ws_bytes, void *stream);
+/* Host level: same, on host buffers (x->nleaves leaves in, out_* as above with
+   nnz = sum of x->nzcount). */
+int svt_aperm_SVT(const svt_view *x, const int *perm, int64_t *out_col_ptr,
+		  int32_t *out_row_idx, void *out_val);
+
 #ifdef __cplusplus
 }
 #endif

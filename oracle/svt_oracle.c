@@ -1713,3 +1713,77 @@ int orc_colsum_dgCMatrix(int nrow, int ncol, const double *xx, const int *xi,
 	}
 	return 0;
 }
+
+/* ========================================================================
+ * aperm -- SparseArray_aperm.c.  The reference has a leaf-preserving fast
+ * path (perm[1] == 1, :949-957) and a counting-sort path that shatters the
+ * leaves (:892-929); both produce the unique SVT of base::aperm(dense): here
+ * the nonzeros are keyed by their linear index in the permuted array and
+ * sorted.
+ */
+typedef struct { unsigned long long key; int64_t leaf; int k; } aperm_ent;
+
+static int aperm_cmp(const void *a, const void *b)
+{
+	unsigned long long x = ((const aperm_ent *) a)->key, y = ((const aperm_ent *) b)->key;
+	return x < y ? -1 : x > y;
+}
+
+int orc_aperm_SVT(const orc_svt *x, const int *perm, int64_t *out_col_ptr,
+		  int32_t *out_row_idx, void *out_val)
+{
+	int nd = x->ndim;
+	if (nd < 1 || nd > 8)
+		return fail("aperm: between 1 and 8 dimensions are supported");
+	int seen[8] = {0};
+	int64_t mul[8], m = 1, new_nl = 1;
+	for (int a = 0; a < nd; a++) {
+		if (perm[a] < 1 || perm[a] > nd || seen[perm[a] - 1])
+			return fail("'perm' must be a permutation of 1:%d", nd);
+		seen[perm[a] - 1] = 1;
+		mul[perm[a] - 1] = m;
+		m *= x->dim[perm[a] - 1];
+		if (a >= 1)
+			new_nl *= x->dim[perm[a] - 1];
+	}
+	int64_t new_dim0 = x->dim[perm[0] - 1];
+	int64_t nnz = 0;
+	if (!x->svt_is_null)
+		for (int64_t j = 0; j < x->nleaves; j++)
+			nnz += x->nzcount[j];
+	aperm_ent *e = (aperm_ent *) malloc(sizeof(aperm_ent) * (nnz > 0 ? nnz : 1));
+	int64_t n = 0;
+	for (int64_t j = 0; j < x->nleaves && nnz > 0; j++) {
+		leaf_t lf = get_leaf(x, j);
+		unsigned long long base = 0;
+		int64_t rest = j;
+		for (int a = 1; a < nd; a++) {
+			base += (unsigned long long) (rest % x->dim[a]) * (unsigned long long) mul[a];
+			rest /= x->dim[a];
+		}
+		for (int k = 0; k < lf.n; k++) {
+			e[n].key = base + (unsigned long long) lf.off[k] * (unsigned long long) mul[0];
+			e[n].leaf = j;
+			e[n].k = k;
+			n++;
+		}
+	}
+	qsort(e, (size_t) n, sizeof(aperm_ent), aperm_cmp);
+	int64_t pos = 0;
+	for (int64_t L = 0; L <= new_nl; L++) {
+		unsigned long long lim = (unsigned long long) L * (unsigned long long) new_dim0;
+		while (pos < n && e[pos].key < lim)
+			pos++;
+		out_col_ptr[L] = pos;
+	}
+	for (int64_t i = 0; i < n; i++) {
+		leaf_t lf = get_leaf(x, e[i].leaf);
+		out_row_idx[i] = (int32_t) (e[i].key % (unsigned long long) (new_dim0 > 0 ? new_dim0 : 1));
+		if (x->Rtype == ORC_DBL)
+			((double *) out_val)[i] = lf.val ? ((const double *) lf.val)[e[i].k] : 1.0;
+		else
+			((int *) out_val)[i] = lf.val ? ((const int *) lf.val)[e[i].k] : 1;
+	}
+	free(e);
+	return 0;
+}

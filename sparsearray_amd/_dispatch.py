@@ -214,6 +214,33 @@ class CAbiDispatcher:
                                     int(na_rm), _ptr(out)))
         return out
 
+    # aperm (src/SparseArray_aperm.c:935-970) ------------------------------------
+    def C_aperm_SVT(self, x: SVT_SparseArray, perm):
+        """Returns the permuted array as an SVT_SparseArray."""
+        perm = np.asarray(perm, dtype=np.int32)
+        if perm.size != x.ndim:
+            raise SparseArrayError("'perm' must have one element per dimension")
+        if sorted(perm.tolist()) != list(range(1, x.ndim + 1)):
+            raise SparseArrayError(f"'perm' must be a permutation of 1:{x.ndim}")
+        new_dim = tuple(x.dim[p - 1] for p in perm)
+        nnz = x.nzcount()
+        new_nl = int(np.prod(new_dim[1:], dtype=np.int64)) if x.ndim > 1 else 1
+        cp = np.zeros(new_nl + 1, dtype=np.int64)
+        ri = np.zeros(max(nnz, 1), dtype=np.int32)
+        vv = np.zeros(max(nnz, 1), dtype=x.np_dtype)
+        view = make_view(x)
+        f = self._fn("aperm_SVT")
+        f.restype = ctypes.c_int
+        f.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        self._check(f(ctypes.addressof(view), perm.ctypes.data, cp.ctypes.data, ri.ctypes.data,
+                      vv.ctypes.data))
+        dn = None
+        if x.dimnames is not None:
+            dn = [x.dimnames[p - 1] for p in perm]
+        ans = SVT_SparseArray.from_csc(new_dim, x.type, cp, ri[:nnz], vv[:nnz], dimnames=dn)
+        ans.na_background = x.na_background
+        return ans
+
     def C_rowsum_dgCMatrix(self, x, group, ngroup, na_rm):
         """``x`` = ((nrow, ncol), p, i, x) -- the dgCMatrix slots."""
         return self._dgc("rowsum_dgCMatrix", x, group, ngroup, na_rm,

@@ -243,14 +243,27 @@ class Session:
                           "infinite values to integers")
         return ans
 
+    def aperm(self, x, perm=None):
+        """aperm(x, perm) (R/SparseArray-aperm.R:24-60); perm is 1-based, default: reversal."""
+        if perm is None:
+            perm = list(range(x.ndim, 0, -1))
+        perm = [int(p) for p in perm]
+        if len(perm) != x.ndim or sorted(perm) != list(range(1, x.ndim + 1)):
+            raise SparseArrayError(f"'perm' must be a permutation of 1:{x.ndim}")
+        if perm == list(range(1, x.ndim + 1)):
+            return x
+        return self.SparseArray_Call("C_aperm_SVT", x, perm)
+
     def _OLD_rowStats(self, op, x, na_rm, center, dims):
-        # .OLD_rowStats_SparseArray (:122-190): transpose then col stats.
-        if x.ndim > 2:
-            raise SparseArrayError(
-                f"row {op}() on >2-D objects goes through aperm() in the "
-                "reference; not on the device path")
-        tx = x.t()
-        return self._colStats(op, tx, na_rm, center, x.ndim - dims)
+        # .OLD_rowStats_SparseArray (:122-190): "aperm(colStats(aperm(x), dims=ndim-dims))",
+        # the semantically plain form of :115-118 (the slice-wise tricks of :150-189
+        # only avoid the reference's expensive multidimensional transposition)
+        tx = x.t() if x.ndim == 2 else self.aperm(x)
+        ans = self._colStats(op, tx, na_rm, center, x.ndim - dims)
+        if isinstance(ans, np.ndarray) and ans.ndim > 1:
+            ans = np.ascontiguousarray(np.transpose(ans))
+            ans = np.asfortranarray(ans)
+        return ans
 
     def _colCountVals(self, x, na_rm=False, dims=1):
         ans = float(np.prod(x.dim[:dims], dtype=np.float64))

@@ -102,3 +102,154 @@ int launch_transpose(const int64_t *col_ptr, const int32_t *row_idx, const void 
 	HIP_TRY(hipGetLastError());
 	return 0;
 }
+
+// ---------------------------------------------------------------------------
+// N-d aperm (C_aperm_SVT, src/SparseArray_aperm.c:148-930).  The device layout
+// knows leaves only, so the caller passes the array's dims.  Every nonzero gets
+// the 64-bit key  new_leaf * new_dim0 + new_row  (its linear index in the
+// permuted array), one radix sort over ceil(log2(prod(dim))) bits orders them
+// the way the permuted SVT stores them, one pass gathers.  The reference
+// distinguishes leaf-preserving permutations (perm[1] == 1: pointer shuffle,
+// :949-957) from those that shatter leaves (counting sort, :892-929); the key
+// sort covers both.
+// ---------------------------------------------------------------------------
+struct ApermDims {
+	int ndim;
+	int64_t dim[8];      // old dims
+	int perm[8];         // 0-based: new axis a takes old axis perm[a]
+	int64_t mul[8];      // multiplier of old axis a in the new linear index
+};
+
+__global__ void aperm_key_kernel(const int64_t *__restrict__ col_ptr,
+				 const int32_t *__restrict__ row_idx, int64_t ncol, int64_t nnz,
+				 ApermDims d, unsigned long long *__restrict__ keys,
+				 uint32_t *__restrict__ pos)
+{
+	const int64_t k = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= nnz) return;
+	int64_t lo = 0, hi = ncol;                  // leaf of position k
+	while (lo < hi) {
+		const int64_t mid = (lo + hi + 1) >> 1;
+		if (col_ptr[mid] <= k) lo = mid; else hi = mid - 1;
+	}
+	unsigned long long key = (unsigned long long) row_idx[k] * (unsigned long long) d.mul[0];
+	int64_t rest = lo;
+	for (int a = 1; a < d.ndim; a++) {
+		const int64_t ia = rest % d.dim[a];
+		rest /= d.dim[a];
+		key += (unsigned long long) ia * (unsigned long long) d.mul[a];
+	}
+	keys[k] = key;
+	pos[k] = (uint32_t) k;
+}
+
+__global__ void aperm_bounds_kernel(const unsigned long long *__restrict__ skeys, int64_t nnz,
+				    int64_t nleaves, int64_t dim0, int64_t *__restrict__ out_ptr)
+{
+	const int64_t j = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if (j > nleaves) return;
+	const unsigned long long key = (unsigned long long) j * (unsigned long long) dim0;
+	int64_t lo = 0, hi = nnz;
+	while (lo < hi) {
+		const int64_t mid = (lo + hi) >> 1;
+		if (skeys[mid] < key) lo = mid + 1; else hi = mid;
+	}
+	out_ptr[j] = lo;
+}
+
+template <typename T>
+__global__ void aperm_gather_kernel(const unsigned long long *__restrict__ skeys,
+				    const uint32_t *__restrict__ perm, const T *__restrict__ val,
+				    int64_t nnz, int64_t dim0, int32_t *__restrict__ out_idx,
+				    T *__restrict__ out_val)
+{
+	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nnz) return;
+	out_idx[i] = (int32_t) (skeys[i] % (unsigned long long) dim0);
+	out_val[i] = val[perm[i]];
+}
+
+static int aperm_bits(const int64_t *dim, int ndim)
+{
+	double tot = 1.0;
+	for (int a = 0; a < ndim; a++) tot *= (double) (dim[a] > 0 ? dim[a] : 1);
+	int b = 1;
+	while (b < 64 && ldexp(1.0, b) < tot) b++;
+	return b;
+}
+
+static size_t aperm_sort_tmp(int64_t nnz, int bits)
+{
+	size_t b = 0;
+	(void) hipcub::DeviceRadixSort::SortPairs(NULL, b, (const unsigned long long *) NULL,
+						  (unsigned long long *) NULL, (const uint32_t *) NULL,
+						  (uint32_t *) NULL, (int) nnz, 0, bits);
+	return b;
+}
+
+// [keys nnz*8][sorted keys nnz*8][pos nnz*4][sorted pos nnz*4][sort temp]
+size_t aperm_ws_bytes(int64_t nnz, const int64_t *dim, int ndim)
+{
+	const size_t n = (size_t) (nnz > 0 ? nnz : 1);
+	const size_t a8 = (n * 8 + 255) / 256 * 256, a4 = (n * 4 + 255) / 256 * 256;
+	return 2 * a8 + 2 * a4 + aperm_sort_tmp(nnz, aperm_bits(dim, ndim)) + 256;
+}
+
+int launch_aperm(const int64_t *col_ptr, const int32_t *row_idx, const void *val, int Rtype,
+		 int64_t ncol, int64_t nnz, const int64_t *dim, int ndim, const int *perm,
+		 int64_t *out_ptr, int32_t *out_idx, void *out_val, void *ws, hipStream_t s)
+{
+	if (ndim < 1 || ndim > 8)
+		return svt_set_error("aperm: between 1 and 8 dimensions are supported");
+	if (nnz >= ((int64_t) 1 << 31))
+		return svt_set_error("aperm: more than 2^31-1 nonzeros");
+	ApermDims d;
+	d.ndim = ndim;
+	bool seen[8] = {false, false, false, false, false, false, false, false};
+	double total = 1.0;
+	for (int a = 0; a < ndim; a++) {
+		if (perm[a] < 0 || perm[a] >= ndim || seen[perm[a]])
+			return svt_set_error("'perm' must be a permutation of 1:%d", ndim);
+		seen[perm[a]] = true;
+		d.dim[a] = dim[a];
+		d.perm[a] = perm[a];
+		total *= (double) (dim[a] > 0 ? dim[a] : 1);
+	}
+	if (total >= 9.2e18)
+		return svt_set_error("aperm: array too large for 64-bit linear indices");
+	// multiplier of old axis perm[a] = product of the new dims below new axis a
+	int64_t m = 1;
+	for (int a = 0; a < ndim; a++) {
+		d.mul[perm[a]] = m;
+		m *= dim[perm[a]];
+	}
+	const int64_t new_dim0 = dim[perm[0]];
+	int64_t new_nleaves = 1;
+	for (int a = 1; a < ndim; a++) new_nleaves *= dim[perm[a]];
+	const unsigned nbl = (unsigned) ((new_nleaves + 1 + 255) / 256);
+	if (nnz == 0) {
+		HIP_TRY(hipMemsetAsync(out_ptr, 0, (size_t) (new_nleaves + 1) * 8, s));
+		return 0;
+	}
+	const size_t n = (size_t) nnz;
+	const size_t a8 = (n * 8 + 255) / 256 * 256, a4 = (n * 4 + 255) / 256 * 256;
+	unsigned long long *keys = (unsigned long long *) ws;
+	unsigned long long *skeys = (unsigned long long *) ((char *) ws + a8);
+	uint32_t *pos = (uint32_t *) ((char *) ws + 2 * a8);
+	uint32_t *spos = (uint32_t *) ((char *) ws + 2 * a8 + a4);
+	void *tmp = (char *) ws + 2 * a8 + 2 * a4;
+	const int bits = aperm_bits(dim, ndim);
+	size_t tb = aperm_sort_tmp(nnz, bits);
+	const unsigned nb = (unsigned) ((nnz + 255) / 256);
+	hipLaunchKernelGGL(aperm_key_kernel, dim3(nb), dim3(256), 0, s, col_ptr, row_idx, ncol, nnz, d, keys, pos);
+	HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tb, keys, skeys, pos, spos, (int) nnz, 0, bits, s));
+	hipLaunchKernelGGL(aperm_bounds_kernel, dim3(nbl), dim3(256), 0, s, skeys, nnz, new_nleaves, new_dim0, out_ptr);
+	if (Rtype == SVT_REALSXP)
+		hipLaunchKernelGGL(aperm_gather_kernel<double>, dim3(nb), dim3(256), 0, s, skeys, spos,
+				   (const double *) val, nnz, new_dim0, out_idx, (double *) out_val);
+	else
+		hipLaunchKernelGGL(aperm_gather_kernel<int32_t>, dim3(nb), dim3(256), 0, s, skeys, spos,
+				   (const int32_t *) val, nnz, new_dim0, out_idx, (int32_t *) out_val);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}

@@ -158,6 +158,11 @@ int launch_transpose(const int64_t *col_ptr, const int32_t *row_idx, const void 
 		     int64_t nrow, int64_t ncol, int64_t nnz, int64_t *out_ptr, int32_t *out_idx,
 		     void *out_val, void *ws, hipStream_t s);
 
+size_t aperm_ws_bytes(int64_t nnz, const int64_t *dim, int ndim);
+int launch_aperm(const int64_t *col_ptr, const int32_t *row_idx, const void *val, int Rtype,
+		 int64_t ncol, int64_t nnz, const int64_t *dim, int ndim, const int *perm,
+		 int64_t *out_ptr, int32_t *out_idx, void *out_val, void *ws, hipStream_t s);
+
 struct GroupSumArgs {
 	const int64_t *col_ptr64;   // one of the two col_ptr flavours is set
 	const int32_t *col_ptr32;

@@ -482,6 +482,71 @@ extern "C" int svt_dev_transpose(const svt_dev_csc *A, int64_t *out_col_ptr, int
 				out_col_ptr, out_row_idx, out_val, ws, (hipStream_t) stream);
 }
 
+static int aperm_args(int ndim, const int *perm, int *perm0)
+{
+	if (ndim < 1 || ndim > 8)
+		return svt_set_error("aperm: between 1 and 8 dimensions are supported");
+	for (int a = 0; a < ndim; a++) {
+		if (perm[a] < 1 || perm[a] > ndim)
+			return svt_set_error("'perm' must be a permutation of 1:%d", ndim);
+		perm0[a] = perm[a] - 1;
+	}
+	return 0;
+}
+
+extern "C" size_t svt_dev_aperm_ws_bytes(int64_t nnz, int ndim, const int64_t *dim)
+{
+	return aperm_ws_bytes(nnz, dim, ndim);
+}
+
+extern "C" int svt_dev_aperm(const svt_dev_csc *A, int ndim, const int64_t *dim, const int *perm,
+			     int64_t *out_col_ptr, int32_t *out_row_idx, void *out_val,
+			     void *ws, size_t ws_bytes, void *stream)
+{
+	int perm0[8];
+	if (aperm_args(ndim, perm, perm0))
+		return -1;
+	int64_t nl = 1;
+	for (int a = 1; a < ndim; a++) nl *= dim[a];
+	if (dim[0] != A->nrow || nl != A->ncol)
+		return svt_set_error("aperm: 'dim' does not match the operand");
+	if (ws_bytes < aperm_ws_bytes(A->nnz, dim, ndim))
+		return svt_set_error("svt_dev_aperm: workspace too small");
+	return launch_aperm(A->col_ptr, A->row_idx, A->val, A->Rtype, A->ncol, A->nnz, dim, ndim,
+			    perm0, out_col_ptr, out_row_idx, out_val, ws, (hipStream_t) stream);
+}
+
+// C_aperm_SVT, src/SparseArray_aperm.c:935-970
+extern "C" int svt_aperm_SVT(const svt_view *x, const int *perm, int64_t *out_col_ptr,
+			     int32_t *out_row_idx, void *out_val)
+{
+	if (ensure_init() || check_view(x))
+		return -1;
+	int perm0[8];
+	if (aperm_args(x->ndim, perm, perm0))
+		return -1;
+	int64_t dim[8], new_nl = 1;
+	for (int a = 0; a < x->ndim; a++) dim[a] = x->dim[a];
+	for (int a = 1; a < x->ndim; a++) new_nl *= dim[perm0[a]];
+	CscGuard A(svt_upload(x));
+	if (A.h == NULL) return -1;
+	const size_t esz = elt_size(x->Rtype);
+	const size_t nn = (size_t) (A.h->nnz > 0 ? A.h->nnz : 1);
+	DevBuf P, I, V, W;
+	if (P.alloc((size_t) (new_nl + 1) * 8) || I.alloc(nn * 4) || V.alloc(nn * esz) ||
+	    W.alloc(aperm_ws_bytes(A.h->nnz, dim, x->ndim)))
+		return -1;
+	if (launch_aperm(A.h->col_ptr, A.h->row_idx, A.h->val, A.h->Rtype, A.h->ncol, A.h->nnz, dim,
+			 x->ndim, perm0, P.as<int64_t>(), I.as<int32_t>(), V.p, W.p, 0))
+		return -1;
+	HIP_TRY(hipMemcpy(out_col_ptr, P.p, (size_t) (new_nl + 1) * 8, hipMemcpyDeviceToHost));
+	if (A.h->nnz) {
+		HIP_TRY(hipMemcpy(out_row_idx, I.p, (size_t) A.h->nnz * 4, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(out_val, V.p, (size_t) A.h->nnz * esz, hipMemcpyDeviceToHost));
+	}
+	return 0;
+}
+
 extern "C" int svt_dev_rowsum(const svt_dev_csc *A, const int *group, int ngroup,
 			      int na_rm, double *out, void *stream)
 {

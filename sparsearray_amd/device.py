@@ -59,6 +59,10 @@ def _lib():
         lib.svt_dev_transpose_ws_bytes.restype = c_size_t
         lib.svt_dev_transpose_ws_bytes.argtypes = [c_int64, c_int64]
         lib.svt_dev_transpose.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+        lib.svt_dev_aperm_ws_bytes.restype = c_size_t
+        lib.svt_dev_aperm_ws_bytes.argtypes = [c_int64, c_int, c_void_p]
+        lib.svt_dev_aperm.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_size_t, c_void_p]
         _protos_done = True
     return lib
 
@@ -110,6 +114,25 @@ class DeviceCSC:
         _check(_lib().svt_dev_transpose(self.handle, cp.data_ptr(), ri.data_ptr(), vv.data_ptr(),
                                         ws.data_ptr(), ws.numel(), _stream()))
         return DeviceCSC(self.ncol, cp, ri, vv, logical=self.Rtype == LGLSXP)
+
+    def aperm(self, dim, perm):
+        """aperm(x, perm) on the device for the N-d array of extents ``dim`` stored in
+        this layout (dim[0] == nrow, prod(dim[1:]) == ncol); ``perm`` is 1-based.
+        Returns (DeviceCSC of the permuted array, its dim)."""
+        dim = np.asarray(dim, dtype=np.int64)
+        perm = np.asarray(perm, dtype=np.int32)
+        new_dim = tuple(int(dim[p - 1]) for p in perm)
+        new_nl = int(np.prod(new_dim[1:], dtype=np.int64)) if len(new_dim) > 1 else 1
+        dev = self.val.device
+        cp = torch.empty(new_nl + 1, dtype=torch.int64, device=dev)
+        ri = torch.empty(self.nnz, dtype=torch.int32, device=dev)
+        vv = torch.empty(self.nnz, dtype=self.val.dtype, device=dev)
+        nb = _lib().svt_dev_aperm_ws_bytes(self.nnz, len(dim), dim.ctypes.data)
+        ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        _check(_lib().svt_dev_aperm(self.handle, len(dim), dim.ctypes.data, perm.ctypes.data,
+                                    cp.data_ptr(), ri.data_ptr(), vv.data_ptr(), ws.data_ptr(),
+                                    ws.numel(), _stream()))
+        return DeviceCSC(new_dim[0], cp, ri, vv, logical=self.Rtype == LGLSXP), new_dim
 
     def __del__(self):
         try:

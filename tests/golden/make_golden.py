@@ -705,6 +705,39 @@ for m in (np.array([[0, -8, NA_INT], [NA_INT, NA_INT, 1]], dtype=np.int32, order
                  kwargs={"na_rm": narm}, warn=None)
 
 # ---------------------------------------------------------------------------
+# H2. aperm   tests/testthat/test-SparseArray-aperm.R:42-140 (expected: base::aperm)
+# ---------------------------------------------------------------------------
+SRC_AP = "tests/testthat/test-SparseArray-aperm.R"
+ap2 = np.arange(1, 121, dtype=np.int32).reshape((8, 15), order="F").copy(order="F")
+case(SRC_AP + ":44-52", "aperm", [svt(ap2, "integer")], np.asfortranarray(ap2.T))
+case(SRC_AP + ":44-52", "aperm", [svt(ap2, "integer")], ap2, kwargs={"perm": [1, 2]})
+ap3 = np.arange(1, 361, dtype=np.int32).reshape((8, 3, 15), order="F").copy(order="F")
+ap3[:, :, [10, 14]] = 0
+ap3[:, 0:2, 13] = 0
+ap3[[0, 1, 2, 3, 5], 2, 12] = 0
+for perm in ([1, 2, 3], [3, 2, 1], [1, 3, 2], [2, 1, 3], [2, 3, 1], [3, 1, 2]):
+    want = np.asfortranarray(np.transpose(ap3, [p - 1 for p in perm]))
+    case(SRC_AP + ":54-93", "aperm", [svt(ap3, "integer")], want, kwargs={"perm": perm})
+    case(SRC_AP + ":54-93", "aperm", [svt(ap3.astype(np.float64) * 0.5, "double")],
+         np.asfortranarray(np.transpose(ap3.astype(np.float64) * 0.5, [p - 1 for p in perm])),
+         kwargs={"perm": perm})
+ap4 = np.zeros((5, 4, 3, 6), dtype=np.float64, order="F")
+ap4 = set_lin(ap4, [1, 17, 18, 60, 61, 119, 200, 201, 202, 300, 359, 360],
+              [1.5, -2, NA_REAL, 4, NAN, 6, 7.25, 8, -9, 1e10, 11, 12])
+for perm in ([4, 3, 2, 1], [1, 3, 2, 4], [2, 4, 1, 3], [3, 1, 4, 2], [1, 2, 4, 3], [4, 1, 2, 3]):
+    case(SRC_AP + ":95-140", "aperm", [svt(ap4, "double")],
+         np.asfortranarray(np.transpose(ap4, [p - 1 for p in perm])), kwargs={"perm": perm})
+case(SRC_AP + ":95-140", "aperm", [svt(ap4[:, :, 0:0, :], "double")],
+     np.asfortranarray(np.transpose(ap4[:, :, 0:0, :], [3, 2, 1, 0])))
+# row statistics of >2-D arrays that have no native kernel go through aperm
+# (R/SparseArray-matrixStats.R:115-118)
+for dims in (1, 2):
+    case(SRC_MS + ":244-270", "rowProds", [svt(a3_clean, "double")],
+         stat_row(a3_clean, lambda v: r_prod(v, False), dims), "equal", kwargs={"dims": dims})
+    case(SRC_MS + ":244-270", "rowMeans", [svt(a3, "double")],
+         stat_row(a3, lambda v: r_mean(v, True), dims), "equal", kwargs={"dims": dims, "na_rm": True})
+
+# ---------------------------------------------------------------------------
 # I. rowsum / colsum   tests/testthat/test-rowsum-methods.R:61-89
 # ---------------------------------------------------------------------------
 SRC_RS = "tests/testthat/test-rowsum-methods.R"

@@ -176,6 +176,28 @@ def test_device_transpose(hip, shape, dtype):
     assert np.array_equal(T.val.cpu().numpy(), tv)
 
 
+@pytest.mark.parametrize("perm", [(3, 2, 1), (1, 3, 2), (2, 3, 1), (3, 1, 2), (2, 1, 3)])
+def test_device_aperm(hip, perm):
+    """aperm() of a 3-d array held in the device layout == numpy's transpose of the dense array."""
+    dim = (700, 40, 23)
+    rng = np.random.default_rng(44)
+    a = np.zeros(dim, order="F")
+    idx = rng.choice(a.size, size=20000, replace=False)
+    a.reshape(-1, order="F")[idx] = rng.normal(size=idx.size)
+    x = SVT_SparseArray.from_dense(a, "double", lacunar=False)
+    cp, ri, v = x.to_csc()
+    A = _dev(cp, ri, v, dim[0])
+    T, new_dim = A.aperm(dim, perm)
+    torch.cuda.synchronize()
+    want = SVT_SparseArray.from_dense(np.asfortranarray(np.transpose(a, [p - 1 for p in perm])), "double",
+                                      lacunar=False)
+    wcp, wri, wv = want.to_csc()
+    assert new_dim == want.dim
+    assert np.array_equal(T.col_ptr.cpu().numpy(), wcp)
+    assert np.array_equal(T.row_idx.cpu().numpy(), wri)
+    assert np.array_equal(T.val.cpu().numpy(), wv)
+
+
 def test_device_matmul_through_transpose(hip, oracle):
     """x %*% y = crossprod(t(x), y) (R/SparseMatrix-mult.R:195-215) with everything on the
     device: transpose, panel-blocked layout of t(x), product; many column blocks, one row split."""
