@@ -284,6 +284,226 @@ colstats_kernel(StatsArgs a)
 	}
 }
 
+// --------------------------------------------------------------------------
+// Few, very long segments (whole-array sum(), colSums(dims = ndim - 1) of a 3-d
+// array, ...): one workgroup per segment would leave the chip idle, so every
+// segment is cut into NCHUNK element ranges, one workgroup each, whose partial
+// states are combined in chunk order by a small second kernel.  var1 / sd1 /
+// centered sums keep the reference's two passes (mean first,
+// src/SparseArray_summarization.c:70-109): state + mean, then the centred
+// squares, 4 launches.  colstats_final() is the same post-processing as in
+// colstats_kernel (Rvector_summarization.c:1078-1177).
+// --------------------------------------------------------------------------
+struct ColState {
+	int flags;
+	int pad;
+	long long nacnt;
+	double acc;       // sum or product
+	double mm;        // extremum
+};
+
+__device__ inline double colstats_neff(const StatsArgs &a, const ColState &st, int64_t nz)
+{
+	const bool narm = a.na_rm != 0, nabg = a.na_bg != 0;
+	return narm ? (double) ((nabg ? nz : a.seg_len) - st.nacnt) : (double) a.seg_len;
+}
+
+__device__ inline bool colstats_brk(const StatsArgs &a, const ColState &st, int64_t nz)
+{
+	int flags = st.flags;
+	if (a.na_bg && a.seg_len - nz > 0 && !a.na_rm) flags |= F_NA;
+	return (flags & F_NA) && !a.na_rm;
+}
+
+// centre used by the two-pass ops
+__device__ inline double colstats_center(const StatsArgs &a, const ColState &st, int64_t nz)
+{
+	double c = a.center;
+	if (c != c)
+		c = colstats_brk(a, st, nz) ? svt_na_real() : st.acc / colstats_neff(a, st, nz);
+	return c;
+}
+
+__device__ inline void colstats_final(const StatsArgs &a, int64_t g, const ColState &st, int64_t nz,
+				      double c, double acc2, bool is_dbl)
+{
+	const int oc = a.opcode;
+	const bool narm = a.na_rm != 0, nabg = a.na_bg != 0;
+	const int64_t zerocount = a.seg_len - nz;
+	const int64_t implicit_na = nabg ? zerocount : 0;
+	const int64_t zeros = nabg ? 0 : zerocount;
+	int flags = st.flags;
+	if (implicit_na > 0 && !narm) flags |= F_NA;
+	const bool brk_na = (flags & F_NA) && !narm;
+	const double n_eff = colstats_neff(a, st, nz);
+	const double NAr = svt_na_real();
+	const bool is_minmax = oc == SVT_OP_MIN || oc == SVT_OP_MAX, is_min = oc == SVT_OP_MIN;
+	double rd = 0.0, mm = st.mm;
+	int ri = 0, warn = 0;
+	switch (oc) {
+	case SVT_OP_ANYNA: ri = ((flags & (F_NA | F_NAN)) || implicit_na > 0) ? 1 : 0; break;
+	case SVT_OP_COUNTNAS: rd = (double) (st.nacnt + implicit_na); break;
+	case SVT_OP_ANY: ri = (flags & F_TRUE) ? 1 : (brk_na ? NA_INT : 0); break;
+	case SVT_OP_ALL: ri = ((flags & F_ZERO) || zeros > 0) ? 0 : (brk_na ? NA_INT : 1); break;
+	case SVT_OP_SUM: rd = brk_na ? NAr : st.acc; break;
+	case SVT_OP_MEAN: rd = brk_na ? NAr : st.acc / n_eff; break;
+	case SVT_OP_PROD: rd = brk_na ? NAr : (zeros > 0 ? st.acc * 0.0 : st.acc); break;
+	case SVT_OP_MIN: case SVT_OP_MAX:
+		if (is_dbl) {
+			if (brk_na) { rd = NAr; break; }
+			if ((flags & F_NAN) && !narm) { rd = NAN; break; }
+			if (zeros > 0) mm = is_min ? (0.0 < mm ? 0.0 : mm) : (0.0 > mm ? 0.0 : mm);
+			rd = mm;
+		} else {
+			if (brk_na) { ri = NA_INT; break; }
+			bool have = (flags & F_HAVE) != 0;
+			if (zeros > 0) {
+				mm = have ? (is_min ? (0.0 < mm ? 0.0 : mm) : (0.0 > mm ? 0.0 : mm)) : 0.0;
+				have = true;
+			}
+			if (!have) { ri = NA_INT; warn = 1; }
+			else ri = (int) mm;
+		}
+		break;
+	case SVT_OP_CENTERED_X2_SUM: case SVT_OP_VAR1: case SVT_OP_SD1:
+		if (brk_na) { rd = NAr; break; }
+		rd = acc2 + c * c * (double) zeros;
+		if (oc == SVT_OP_CENTERED_X2_SUM) break;
+		if (n_eff <= 1.0) { rd = NAr; break; }
+		rd /= (n_eff - 1.0);
+		if (oc == SVT_OP_SD1) rd = sqrt(rd);
+		break;
+	default: break;
+	}
+	const bool out_is_int = oc == SVT_OP_ANYNA || oc == SVT_OP_ANY || oc == SVT_OP_ALL ||
+		(is_minmax && !is_dbl);
+	if (out_is_int) ((int *) a.out)[g] = ri;
+	else ((double *) a.out)[g] = rd;
+	if (warn && a.warn_flag) *a.warn_flag = 1;
+}
+
+// PASS 1: state of one chunk;  PASS 2: centred squares of one chunk
+template <typename T, int PASS>
+__global__ void __launch_bounds__(256)
+colstats_chunk_kernel(StatsArgs a, int nchunk, ColState *__restrict__ st, const double *__restrict__ centers,
+		      double *__restrict__ acc2_out)
+{
+	__shared__ double sm[4 * (256 / SVT_WAVE)];
+	typedef ValTraits<T> VT;
+	const bool is_dbl = sizeof(T) == 8;
+	const int64_t g = blockIdx.y;
+	const int ch = blockIdx.x, tid = threadIdx.x;
+	const T *__restrict__ val = (const T *) a.val;
+	const int64_t sbeg = a.col_ptr[g * a.inner], send = a.col_ptr[(g + 1) * a.inner];
+	const int64_t nz = send - sbeg;
+	const int64_t beg = sbeg + nz * ch / nchunk, end = sbeg + nz * (ch + 1) / nchunk;
+	const int oc = a.opcode;
+	const bool narm = a.na_rm != 0;
+	if (PASS == 1) {
+		const bool is_minmax = oc == SVT_OP_MIN || oc == SVT_OP_MAX, is_min = oc == SVT_OP_MIN;
+		int flags = 0;
+		long long nacnt = 0;
+		double acc = (oc == SVT_OP_PROD) ? 1.0 : 0.0, mm = is_min ? INFINITY : -INFINITY;
+		for (int64_t k = beg + tid; k < end; k += 256) {
+			const T v = val[k];
+			if (VT::is_missing(v)) {
+				nacnt++;
+				flags |= VT::is_na(v) ? F_NA : F_NAN;
+				if (narm || !is_dbl) continue;
+			} else {
+				flags |= (v != (T) 0) ? F_TRUE : F_ZERO;
+				flags |= F_HAVE;
+			}
+			const double d = VT::as_double(v);
+			if (oc == SVT_OP_PROD) acc *= d;
+			else if (is_minmax) { if (d == d) mm = is_min ? (d < mm ? d : mm) : (d > mm ? d : mm); }
+			else acc += d;
+		}
+		flags = red_or<256>(flags, sm);
+		nacnt = red_sum_ll<256>(nacnt, sm);
+		if (oc == SVT_OP_PROD) acc = red_prod<256>(acc, sm);
+		else if (is_minmax) mm = red_min<256>(mm, sm, is_min);
+		else acc = red_sum<256>(acc, sm);
+		if (tid == 0) {
+			ColState o;
+			o.flags = flags; o.pad = 0; o.nacnt = nacnt; o.acc = acc; o.mm = mm;
+			st[g * nchunk + ch] = o;
+		}
+	} else {
+		const double c = centers[g];
+		double acc2 = 0.0;
+		for (int64_t k = beg + tid; k < end; k += 256) {
+			const T v = val[k];
+			if (VT::is_missing(v) && (narm || !is_dbl)) continue;
+			const double d = VT::as_double(v) - c;
+			acc2 += d * d;
+		}
+		acc2 = red_sum<256>(acc2, sm);
+		if (tid == 0) acc2_out[g * nchunk + ch] = acc2;
+	}
+}
+
+// STAGE 1: combine the chunk states (chunk order); final result, or the centre for
+// pass 2.  STAGE 2: combine the centred squares, final result.
+template <int STAGE>
+__global__ void colstats_combine_kernel(StatsArgs a, int nchunk, ColState *__restrict__ st,
+					double *__restrict__ centers, const double *__restrict__ acc2_in,
+					int two_pass, int is_dbl)
+{
+	const int64_t g = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= a.nseg) return;
+	const int64_t nz = a.col_ptr[(g + 1) * a.inner] - a.col_ptr[g * a.inner];
+	if (STAGE == 1) {
+		const int oc = a.opcode;
+		const bool is_min = oc == SVT_OP_MIN;
+		ColState t = st[g * nchunk];
+		for (int c = 1; c < nchunk; c++) {
+			const ColState u = st[g * nchunk + c];
+			t.flags |= u.flags;
+			t.nacnt += u.nacnt;
+			if (oc == SVT_OP_PROD) t.acc *= u.acc; else t.acc += u.acc;
+			t.mm = is_min ? (u.mm < t.mm ? u.mm : t.mm) : (u.mm > t.mm ? u.mm : t.mm);
+		}
+		if (two_pass) {
+			st[g * nchunk] = t;
+			centers[g] = colstats_center(a, t, nz);
+		} else {
+			colstats_final(a, g, t, nz, 0.0, 0.0, is_dbl != 0);
+		}
+	} else {
+		double acc2 = 0.0;
+		for (int c = 0; c < nchunk; c++) acc2 += acc2_in[g * nchunk + c];
+		colstats_final(a, g, st[g * nchunk], nz, centers[g], acc2, is_dbl != 0);
+	}
+}
+
+static int launch_colstats_split(const StatsArgs &a, int nchunk, hipStream_t s)
+{
+	const bool is_dbl = a.Rtype == SVT_REALSXP;
+	const bool two_pass = a.opcode == SVT_OP_CENTERED_X2_SUM || a.opcode == SVT_OP_VAR1 ||
+			      a.opcode == SVT_OP_SD1;
+	const size_t n = (size_t) a.nseg * nchunk;
+	const size_t b_st = (n * sizeof(ColState) + 255) / 256 * 256, b_c = ((size_t) a.nseg * 8 + 255) / 256 * 256;
+	char *scr = NULL;
+	HIP_TRY(hipMallocAsync((void **) &scr, b_st + b_c + n * 8 + 256, s));   // stream-ordered scratch
+	ColState *st = (ColState *) scr;
+	double *centers = (double *) (scr + b_st), *acc2 = (double *) (scr + b_st + b_c);
+	dim3 grid((unsigned) nchunk, (unsigned) a.nseg), cgrid((unsigned) ((a.nseg + 255) / 256));
+	if (is_dbl) hipLaunchKernelGGL((colstats_chunk_kernel<double, 1>), grid, dim3(256), 0, s, a, nchunk, st, centers, acc2);
+	else hipLaunchKernelGGL((colstats_chunk_kernel<int, 1>), grid, dim3(256), 0, s, a, nchunk, st, centers, acc2);
+	hipLaunchKernelGGL(colstats_combine_kernel<1>, cgrid, dim3(256), 0, s, a, nchunk, st, centers, acc2,
+			   (int) two_pass, (int) is_dbl);
+	if (two_pass) {
+		if (is_dbl) hipLaunchKernelGGL((colstats_chunk_kernel<double, 2>), grid, dim3(256), 0, s, a, nchunk, st, centers, acc2);
+		else hipLaunchKernelGGL((colstats_chunk_kernel<int, 2>), grid, dim3(256), 0, s, a, nchunk, st, centers, acc2);
+		hipLaunchKernelGGL(colstats_combine_kernel<2>, cgrid, dim3(256), 0, s, a, nchunk, st, centers, acc2,
+				   (int) two_pass, (int) is_dbl);
+	}
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipFreeAsync(scr, s));
+	return 0;
+}
+
 int launch_colstats(const StatsArgs &a, int64_t nnz, hipStream_t s)
 {
 	if (a.nseg <= 0)
@@ -292,6 +512,13 @@ int launch_colstats(const StatsArgs &a, int64_t nnz, hipStream_t s)
 		return svt_set_error("too many generalized columns");
 	const int64_t avg = nnz / a.nseg;
 	const bool is_dbl = a.Rtype == SVT_REALSXP;
+	if (a.nseg < 512 && avg >= 65536 && a.nseg <= 65535) {
+		// few long segments: ~1024 workgroups in all, >= 16K elements each
+		int64_t nchunk = (1024 + a.nseg - 1) / a.nseg;
+		if (nchunk > avg / 16384) nchunk = avg / 16384;
+		if (nchunk >= 2)
+			return launch_colstats_split(a, (int) nchunk, s);
+	}
 	if (avg >= 1024) {
 		dim3 grid((unsigned) a.nseg), block(256);
 		if (avg <= 256 * 40) {               // (also faster for one-pass ops: all loads in flight)

@@ -86,3 +86,66 @@ def test_full_size_poisoned_dense_entry_switches_semantics(operands):
     assert not torch.isfinite(got[5]).any()
     keep = [k for k in range(K) if k != 5]
     assert float((got[keep] - clean[keep]).abs().max()) <= 1e-9 * float(clean.abs().max())
+
+
+# ---------------------------------------------------------------------------
+# BASELINE.json config 5: 2e4 x 2e4 x 64 @ 0.5 % (1.28e8 nonzeros, 1.28e6 leaves)
+# ---------------------------------------------------------------------------
+D5 = (20_000, 20_000, 64)
+
+
+@pytest.fixture(scope="module")
+def array5(hip):
+    from sparsearray_amd import synth
+    from sparsearray_amd.device import DeviceCSC
+    dev = torch.device("cuda", 0)
+    cp, ri, v = synth.random_device_csc(D5[0], D5[1] * D5[2], 0.005, seed=5, device=dev)
+    return DeviceCSC(D5[0], cp, ri, v)
+
+
+def test_config5_col_stats_match_segment_sums(array5):
+    """colSums(dims=1) (one result per leaf) and colSums(dims=2) (one per 2e4 leaves)
+    against prefix sums of the value array (torch)."""
+    from sparsearray_amd.device import colstats
+    A = array5
+    csum = torch.cumsum(A.val, 0)
+    csum = torch.cat([torch.zeros(1, dtype=csum.dtype, device=csum.device), csum])
+    want1 = csum[A.col_ptr[1:]] - csum[A.col_ptr[:-1]]
+    got1, _ = colstats(A, "sum")
+    torch.cuda.synchronize()
+    scale = torch.cumsum(A.val.abs(), 0)[-1] / A.ncol * 50 + 1.0
+    assert float((got1 - want1).abs().max()) <= 1e-9 * float(scale)
+    got2, _ = colstats(A, "sum", inner=D5[1])
+    torch.cuda.synchronize()
+    want2 = want1.view(D5[2], D5[1]).sum(dim=1)
+    assert got2.numel() == D5[2]
+    assert float(((got2 - want2).abs() / want2.abs().clamp_min(1.0)).max()) <= 1e-9
+    # colMeans / colVars agree with each other through the textbook identity
+    # on a sample of leaves
+    mean, _ = colstats(A, "mean")
+    var, _ = colstats(A, "var1")
+    torch.cuda.synchronize()
+    for j in (0, 12345, A.ncol - 1):
+        lo, hi = int(A.col_ptr[j]), int(A.col_ptr[j + 1])
+        x = torch.zeros(D5[0], dtype=torch.float64, device=A.val.device)
+        x[A.row_idx[lo:hi].long()] = A.val[lo:hi]
+        assert abs(float(mean[j]) - float(x.mean())) <= 1e-12
+        assert abs(float(var[j]) - float(x.var(unbiased=True))) <= 1e-12 * max(1.0, float(x.var()))
+
+
+def test_config5_rowsums_dims2_match_scatter_add(array5):
+    """rowSums(dims=2): out[r, j2] = sum over the 64 slices -- 2e4 x 2e4 doubles (3.2 GB) --
+    against torch.index_add_ on the flattened output."""
+    from sparsearray_amd.device import rowsums
+    A = array5
+    inner = D5[1]
+    got = rowsums(A, inner=inner)
+    torch.cuda.synchronize()
+    leaf = torch.repeat_interleave(torch.arange(A.ncol, device=A.val.device), A.col_ptr[1:] - A.col_ptr[:-1])
+    cell = (leaf % inner) * D5[0] + A.row_idx.long()
+    del leaf
+    want = torch.zeros(inner * D5[0], dtype=torch.float64, device=A.val.device)
+    want.index_add_(0, cell, A.val)
+    torch.cuda.synchronize()
+    assert float((got - want).abs().max()) <= 1e-11
+    assert float(got.abs().sum()) > 0
