@@ -113,6 +113,14 @@ int svt_crossprod2_mat_SVT(const void *x, int x_nrow, int x_ncol, int x_Rtype,
 int svt_crossprod2_SVT_SVT(const svt_view *x, const svt_view *y, double *out);
 /* C_crossprod1_SVT, src/SparseMatrix_mult.c:1104-1140. */
 int svt_crossprod1_SVT(const svt_view *x, double *out);
+/* x %*% y in one call (R/SparseMatrix-mult.R:195-215: the R methods transpose x on the host
+   with C_transpose_2D_SVT, src/SparseArray_aperm.c:348-423, then call C_crossprod2_SVT_mat /
+   C_crossprod2_SVT_SVT).  Here x is uploaded once and transposed on the device.
+   out: nrow(x) x ncol(y) doubles, column-major.  Same checks and messages as the
+   crossprod2 entry points. */
+int svt_matmul_SVT_mat(const svt_view *x, const void *y, int y_nrow, int y_ncol,
+		       int y_Rtype, double *out);
+int svt_matmul_SVT_SVT(const svt_view *x, const svt_view *y, double *out);
 
 /* C_summarize_SVT, src/SparseArray_summarization.c:112-142.  The result is
    left in out_d[0..1] or out_i[0..1] according to *out_Rtype. */

@@ -59,6 +59,11 @@ class CAbiDispatcher:
             "rowsum_dgCMatrix": (I, [I, I, P, P, P, P, I, I, P]),
             "colsum_dgCMatrix": (I, [I, I, P, P, P, P, I, I, P]),
         }
+        # x %*% y in one call (device-side transposition): HIP library only
+        for name, sig in (("matmul_SVT_mat", (I, [V, P, I, I, I, P])),
+                          ("matmul_SVT_SVT", (I, [V, V, P]))):
+            if hasattr(self.lib, self.prefix + name):
+                protos[name] = sig
         for name, (res, args) in protos.items():
             f = self._fn(name)
             f.restype = res
@@ -113,6 +118,23 @@ class CAbiDispatcher:
         out = np.zeros((x.dim[1], y.dim[1]), dtype=np.float64, order="F")
         xv, yv = make_view(x), make_view(y)
         self._check(self._fn("crossprod2_SVT_SVT")(byref(xv), byref(yv), _ptr(out)))
+        return out
+
+    def has_entry(self, name: str) -> bool:
+        return hasattr(self.lib, self.prefix + name[2:])
+
+    def C_matmul_SVT_mat(self, x: SVT_SparseArray, y: np.ndarray):
+        y = _F(y)
+        out = np.zeros((x.dim[0], y.shape[1]), dtype=np.float64, order="F")
+        xv = make_view(x)
+        self._check(self._fn("matmul_SVT_mat")(
+            byref(xv), _ptr(y), y.shape[0], y.shape[1], _RT[r_type_of(y)], _ptr(out)))
+        return out
+
+    def C_matmul_SVT_SVT(self, x: SVT_SparseArray, y: SVT_SparseArray):
+        out = np.zeros((x.dim[0], y.dim[1]), dtype=np.float64, order="F")
+        xv, yv = make_view(x), make_view(y)
+        self._check(self._fn("matmul_SVT_SVT")(byref(xv), byref(yv), _ptr(out)))
         return out
 
     def C_crossprod1_SVT(self, x: SVT_SparseArray):

@@ -132,6 +132,32 @@ class Session:
             x, y = x.with_type(xy), y.with_type(xy)
         return self.SparseArray_Call("C_crossprod2_SVT_SVT", x, y)
 
+    def _matmul_fused(self, x, y):
+        # argument checks of .crossprod2_SparseMatrix_{matrix,SparseMatrix} on (t(x), y)
+        if x.ndim != 2:
+            raise SparseArrayError("input objects must have 2 dimensions")
+        if isinstance(y, SVT_SparseArray):
+            if y.ndim != 2:
+                raise SparseArrayError("input objects must have 2 dimensions")
+            if x.dim[1] != y.dim[0]:
+                raise SparseArrayError("non-conformable arguments")
+            ytype = y.type
+        else:
+            y = _as_R_matrix(y)
+            if x.dim[1] != y.shape[0]:
+                raise SparseArrayError("non-conformable arguments")
+            ytype = r_type_of(y)
+        if x.type == ytype:
+            _check_crossprod_input_type(x.type)
+        else:
+            xy = _common_type(x.type, ytype)
+            _check_crossprod_input_type(xy)
+            x = x.with_type(xy)
+            y = y.with_type(xy) if isinstance(y, SVT_SparseArray) else _dense_to_double(y)
+        if isinstance(y, SVT_SparseArray):
+            return self.SparseArray_Call("C_matmul_SVT_SVT", x, y)
+        return self.SparseArray_Call("C_matmul_SVT_mat", x, y)
+
     def _crossprod1_SparseMatrix(self, x):
         if x.ndim != 2:
             raise SparseArrayError("'x' must have 2 dimensions")
@@ -177,9 +203,17 @@ class Session:
         """``x %*% y`` (R/SparseMatrix-mult.R:195-215)."""
         self._no_NaArray("%*%", x, y)
         xs, ys = isinstance(x, SVT_SparseArray), isinstance(y, SVT_SparseArray)
+        # The R methods transpose x first (t() = C_transpose_2D_SVT on the host).  The
+        # HIP library offers the product in one call, with the transposition on the
+        # device (svt_matmul_SVT_*, include/svt_hip.h); same checks, same coercions.
+        has = getattr(self._call, "has_entry", lambda name: False)
         if xs and ys:
+            if has("C_matmul_SVT_SVT"):
+                return self._matmul_fused(x, y)
             return self._crossprod2_SparseMatrix_SparseMatrix(x.t(), y)
         if xs:
+            if has("C_matmul_SVT_mat"):
+                return self._matmul_fused(x, y)
             return self._crossprod2_SparseMatrix_matrix(x.t(), y)
         if ys:
             return self._crossprod2_matrix_SparseMatrix(x, y, True)

@@ -7,8 +7,9 @@
 // streaming segmented reduction over that slice (row_idx is never read).
 //
 // Two launch shapes share one body:
-//   NT = 64  : one wavefront per segment, 4 segments per 256-thread workgroup
+//   NT = 16  : 16 lanes per segment, 16 segments per 256-thread workgroup
 //              (short leaves: config 1 / config 5, ~100 nz per leaf)
+//   NT = 64  : one wavefront per segment, 4 segments per workgroup
 //   NT = 256 : one workgroup per segment (long leaves: config 2, ~1e4 nz)
 //
 // Sequential NA/NaN rules of src/Rvector_summarization.c:177-734 restated as
@@ -25,9 +26,20 @@
 #define F_ZERO  8   // a stored value == 0 (not expected in a valid SVT)
 #define F_HAVE 16   // at least one non-NA value went into min/max
 
+// 16-lane groups (NT = 16): xor butterflies stay inside an aligned group and leave
+// the result in every lane of it
+template <typename V, typename F>
+__device__ inline V grp16(V v, F f)
+{
+#pragma unroll
+	for (int m = 8; m >= 1; m >>= 1) v = f(v, __shfl_xor(v, m, SVT_WAVE));
+	return v;
+}
+
 template <int NT>
 __device__ inline double red_sum(double v, double *sm)
 {
+	if (NT == 16) return grp16(v, [](double a, double b) { return a + b; });
 	v = wave_sum(v);
 	if (NT == SVT_WAVE)
 		return __shfl(v, 0, SVT_WAVE);
@@ -42,6 +54,7 @@ __device__ inline double red_sum(double v, double *sm)
 template <int NT>
 __device__ inline double red_prod(double v, double *sm)
 {
+	if (NT == 16) return grp16(v, [](double a, double b) { return a * b; });
 	v = wave_prod(v);
 	if (NT == SVT_WAVE)
 		return __shfl(v, 0, SVT_WAVE);
@@ -56,6 +69,9 @@ __device__ inline double red_prod(double v, double *sm)
 template <int NT>
 __device__ inline double red_min(double v, double *sm, bool is_min)
 {
+	if (NT == 16)
+		return is_min ? grp16(v, [](double a, double b) { return b < a ? b : a; })
+			      : grp16(v, [](double a, double b) { return b > a ? b : a; });
 	v = is_min ? wave_min(v) : wave_max(v);
 	if (NT == SVT_WAVE)
 		return __shfl(v, 0, SVT_WAVE);
@@ -71,6 +87,7 @@ __device__ inline double red_min(double v, double *sm, bool is_min)
 template <int NT>
 __device__ inline long long red_sum_ll(long long v, double *sm)
 {
+	if (NT == 16) return grp16(v, [](long long a, long long b) { return a + b; });
 	v = wave_sum_ll(v);
 	if (NT == SVT_WAVE)
 		return __shfl(v, 0, SVT_WAVE);
@@ -86,6 +103,7 @@ __device__ inline long long red_sum_ll(long long v, double *sm)
 template <int NT>
 __device__ inline int red_or(int v, double *sm)
 {
+	if (NT == 16) return grp16(v, [](int a, int b) { return a | b; });
 	v = wave_or(v);
 	if (NT == SVT_WAVE)
 		return __shfl(v, 0, SVT_WAVE);
@@ -122,12 +140,12 @@ colstats_kernel(StatsArgs a)
 {
 	__shared__ double sm[4 * (256 / SVT_WAVE)];
 	const int per_block = 256 / NT;
-	const int sub = NT == 256 ? 0 : (threadIdx.x >> 6);
-	const int tid = NT == 256 ? threadIdx.x : (threadIdx.x & 63);
+	const int sub = NT == 256 ? 0 : (NT == 16 ? (threadIdx.x >> 4) : (threadIdx.x >> 6));
+	const int tid = NT == 256 ? threadIdx.x : (threadIdx.x & (NT - 1));
 	const int64_t g = (int64_t) blockIdx.x * per_block + sub;
-	if (NT == SVT_WAVE && g >= a.nseg)
-		return;   // whole wave exits together; no barriers on this path
-	double *my_sm = sm + sub * 4;
+	if (NT <= SVT_WAVE && g >= a.nseg)
+		return;   // whole wave / 16-lane group exits together; no barriers on this path
+	double *my_sm = sm + (NT == 16 ? 0 : sub * 4);
 	(void) my_sm;
 	const T *__restrict__ val = (const T *) a.val;
 	const int64_t beg = a.col_ptr[g * a.inner];
@@ -404,12 +422,11 @@ colstats_chunk_kernel(StatsArgs a, int nchunk, ColState *__restrict__ st, const 
 		int flags = 0;
 		long long nacnt = 0;
 		double acc = (oc == SVT_OP_PROD) ? 1.0 : 0.0, mm = is_min ? INFINITY : -INFINITY;
-		for (int64_t k = beg + tid; k < end; k += 256) {
-			const T v = val[k];
+		auto step1 = [&](const T v) {
 			if (VT::is_missing(v)) {
 				nacnt++;
 				flags |= VT::is_na(v) ? F_NA : F_NAN;
-				if (narm || !is_dbl) continue;
+				if (narm || !is_dbl) return;
 			} else {
 				flags |= (v != (T) 0) ? F_TRUE : F_ZERO;
 				flags |= F_HAVE;
@@ -418,7 +435,16 @@ colstats_chunk_kernel(StatsArgs a, int nchunk, ColState *__restrict__ st, const 
 			if (oc == SVT_OP_PROD) acc *= d;
 			else if (is_minmax) { if (d == d) mm = is_min ? (d < mm ? d : mm) : (d > mm ? d : mm); }
 			else acc += d;
+		};
+		int64_t k = beg + tid;
+		for (; k + 7 * 256 < end; k += 8 * 256) {      // 8 loads in flight per thread
+			T v[8];
+#pragma unroll
+			for (int u = 0; u < 8; u++) v[u] = val[k + u * 256];
+#pragma unroll
+			for (int u = 0; u < 8; u++) step1(v[u]);
 		}
+		for (; k < end; k += 256) step1(val[k]);
 		flags = red_or<256>(flags, sm);
 		nacnt = red_sum_ll<256>(nacnt, sm);
 		if (oc == SVT_OP_PROD) acc = red_prod<256>(acc, sm);
@@ -432,12 +458,20 @@ colstats_chunk_kernel(StatsArgs a, int nchunk, ColState *__restrict__ st, const 
 	} else {
 		const double c = centers[g];
 		double acc2 = 0.0;
-		for (int64_t k = beg + tid; k < end; k += 256) {
-			const T v = val[k];
-			if (VT::is_missing(v) && (narm || !is_dbl)) continue;
+		auto step2 = [&](const T v) {
+			if (VT::is_missing(v) && (narm || !is_dbl)) return;
 			const double d = VT::as_double(v) - c;
 			acc2 += d * d;
+		};
+		int64_t k = beg + tid;
+		for (; k + 7 * 256 < end; k += 8 * 256) {
+			T v[8];
+#pragma unroll
+			for (int u = 0; u < 8; u++) v[u] = val[k + u * 256];
+#pragma unroll
+			for (int u = 0; u < 8; u++) step2(v[u]);
 		}
+		for (; k < end; k += 256) step2(val[k]);
 		acc2 = red_sum<256>(acc2, sm);
 		if (tid == 0) acc2_out[g * nchunk + ch] = acc2;
 	}
@@ -530,7 +564,12 @@ int launch_colstats(const StatsArgs &a, int64_t nnz, hipStream_t s)
 		}
 	} else {
 		dim3 grid((unsigned) ((a.nseg + 3) / 4)), block(256);
-		if (avg >= 16) {
+		if (avg < 160) {
+			// short leaves (config 1 / config 5, ~100 nonzeros): 16 lanes per segment
+			dim3 grid16((unsigned) ((a.nseg + 15) / 16));
+			if (is_dbl) hipLaunchKernelGGL((colstats_kernel<double, 16, 16>), grid16, block, 0, s, a);
+			else hipLaunchKernelGGL((colstats_kernel<int, 16, 16>), grid16, block, 0, s, a);
+		} else if (avg >= 16) {
 			if (is_dbl) hipLaunchKernelGGL((colstats_kernel<double, 64, 16>), grid, block, 0, s, a);
 			else hipLaunchKernelGGL((colstats_kernel<int, 64, 16>), grid, block, 0, s, a);
 		} else {

@@ -790,6 +790,113 @@ extern "C" int svt_crossprod2_SVT_SVT(const svt_view *x, const svt_view *y, doub
 	return 0;
 }
 
+// t(A) on the device, as a handle that owns its buffers (A may be released afterwards).
+static svt_dev_csc *dev_transposed(const svt_dev_csc *A)
+{
+	svt_dev_csc *T = (svt_dev_csc *) calloc(1, sizeof(*T));
+	if (T == NULL) { svt_set_error("out of memory"); return NULL; }
+	T->Rtype = A->Rtype; T->owned = 1;
+	T->nrow = A->ncol; T->ncol = A->nrow; T->nnz = A->nnz;
+	const size_t n = A->nnz > 0 ? (size_t) A->nnz : 1;
+	DevBuf ws;
+	if (hipMalloc((void **) &T->col_ptr, ((size_t) T->ncol + 1) * 8) != hipSuccess ||
+	    hipMalloc((void **) &T->row_idx, n * 4) != hipSuccess ||
+	    hipMalloc(&T->val, n * elt_size(A->Rtype)) != hipSuccess ||
+	    ws.alloc(transpose_ws_bytes(A->nrow, A->nnz))) {
+		svt_set_error("device allocation failed (transposed operand)");
+		svt_release(T);
+		return NULL;
+	}
+	if (launch_transpose(A->col_ptr, A->row_idx, A->val, A->Rtype, A->nrow, A->ncol, A->nnz,
+			     T->col_ptr, T->row_idx, T->val, ws.p, 0) ||
+	    hipDeviceSynchronize() != hipSuccess) {
+		if (svt_last_error()[0] == '\0') svt_set_error("device transposition failed");
+		svt_release(T);
+		return NULL;
+	}
+	return T;
+}
+
+// x %*% y, y an ordinary matrix: the R method (R/SparseMatrix-mult.R:195-215) is
+// .crossprod2_SparseMatrix_matrix(t(x), y), i.e. C_transpose_2D_SVT on the host
+// followed by C_crossprod2_SVT_mat.  Here the transposition happens on the device,
+// between the upload and the product (no second marshalling of a 1e8-nonzero tree).
+extern "C" int svt_matmul_SVT_mat(const svt_view *x, const void *y, int y_nrow,
+				  int y_ncol, int y_Rtype, double *out)
+{
+	if (ensure_init() || check_mult_view(x, "input objects"))
+		return -1;
+	const int out_nrow = x->dim[0], in_nrow = x->dim[1];
+	if (in_nrow != y_nrow)
+		return svt_set_error("input objects are non-conformable");
+	if (y_Rtype == SVT_LGLSXP) y_Rtype = SVT_INTSXP;
+	if (x->Rtype != y_Rtype)
+		return svt_set_error("SparseArray internal error in "
+				     "C_crossprod2_SVT_mat():\n"
+				     "    'x_Rtype != TYPEOF(y)' not supported yet");
+	const size_t out_n = (size_t) out_nrow * y_ncol;
+	memset(out, 0, out_n * sizeof(double));
+	if (x->svt_is_null || out_n == 0)
+		return 0;
+	svt_dev_csc *T;
+	{
+		CscGuard A(svt_upload(x));
+		if (A.h == NULL) return -1;
+		T = dev_transposed(A.h);
+	}                                   // x's own device copy is released here
+	CscGuard TA(T);
+	if (T == NULL) return -1;
+	DevBuf Y, O;
+	if (Y.upload(y, (size_t) y_nrow * y_ncol * elt_size(y_Rtype)) ||
+	    O.alloc(out_n * 8) || O.zero())
+		return -1;
+	if (dev_crossprod_chunked(T, Y.p, y_nrow, y_ncol, 0, O.as<double>(), 1, out_nrow))
+		return -1;
+	HIP_TRY(hipMemcpy(out, O.p, out_n * 8, hipMemcpyDeviceToHost));
+	return 0;
+}
+
+// x %*% y, both SVT_SparseMatrix: .crossprod2_SparseMatrix_SparseMatrix(t(x), y) with
+// the transposition on the device; operand to expand chosen as C_crossprod2_SVT_SVT
+// does (src/SparseMatrix_mult.c:1075-1097; nzcount(t(x)) == nzcount(x)).
+extern "C" int svt_matmul_SVT_SVT(const svt_view *x, const svt_view *y, double *out)
+{
+	if (ensure_init() || check_mult_view(x, "input objects") ||
+	    check_mult_view(y, "input objects"))
+		return -1;
+	if (x->dim[1] != y->dim[0])
+		return svt_set_error("input SVT_SparseMatrix objects are non-conformable");
+	if (x->Rtype != y->Rtype)
+		return svt_set_error("input SVT_SparseMatrix objects must have the "
+				     "same type() for now");
+	const int out_nrow = x->dim[0], out_ncol = y->dim[1];
+	const size_t out_n = (size_t) out_nrow * out_ncol;
+	memset(out, 0, out_n * sizeof(double));
+	if (out_n == 0)
+		return 0;
+	const int64_t Lpp_nops = view_nzcount(y) * out_nrow;
+	const int64_t Rpp_nops = view_nzcount(x) * out_ncol;
+	svt_dev_csc *T;
+	{
+		CscGuard X(svt_upload(x));
+		if (X.h == NULL) return -1;
+		T = dev_transposed(X.h);
+	}
+	CscGuard TX(T), Y(svt_upload(y));
+	if (T == NULL || Y.h == NULL) return -1;
+	DevBuf O;
+	if (O.alloc(out_n * 8) || O.zero())
+		return -1;
+	int rc;
+	if (Lpp_nops < Rpp_nops)
+		rc = dev_crossprod_pp(Y.h, T, O.as<double>(), out_nrow, 1);
+	else
+		rc = dev_crossprod_pp(T, Y.h, O.as<double>(), 1, out_nrow);
+	if (rc) return -1;
+	HIP_TRY(hipMemcpy(out, O.p, out_n * 8, hipMemcpyDeviceToHost));
+	return 0;
+}
+
 // C_crossprod1_SVT, src/SparseMatrix_mult.c:1104-1140
 extern "C" int svt_crossprod1_SVT(const svt_view *x, double *out)
 {

@@ -103,6 +103,64 @@ def test_sparse_sparse_and_matmul(hip, oracle, seed):
     assert_identical(hip.matmul(a, c), oracle.matmul(a, c))
 
 
+def _transposed(x):
+    """t(x) of a 2-d SVT through scipy (the host mirror's own t() walks element by element)."""
+    import scipy.sparse as sp
+    cp = np.zeros(x.dim[1] + 1, dtype=np.int64)
+    ri, vv = [], []
+    for j, lf in enumerate(x.leaves):
+        n = 0 if lf is None else len(lf[0])
+        cp[j + 1] = cp[j] + n
+        if n:
+            ri.append(lf[0]); vv.append(lf[1])
+    m = sp.csc_matrix((np.concatenate(vv), np.concatenate(ri), cp), shape=x.dim)
+    t = m.T.tocsc()
+    t.sort_indices()
+    return SVT_SparseArray.from_csc((x.dim[1], x.dim[0]), x.type, t.indptr.astype(np.int64),
+                                    t.indices.astype(np.int32), t.data)
+
+
+@pytest.mark.parametrize("seed", [8, 9])
+def test_matmul_one_call(hip, oracle, seed):
+    """x %*% y through svt_matmul_SVT_{mat,SVT}: x is transposed on the device inside the
+    call; the reference does t(x) on the host, then the crossprod2 entry points."""
+    x = _sprinkle(_svt(700, 300, 0.03, seed), seed, SPECIAL_D)       # 700 x 300
+    rng = np.random.default_rng(seed)
+    y = rng.uniform(-1, 1, (300, 11))
+    assert_equal(hip.matmul(x, y), oracle.matmul(x, y), tol=1e-12, strict_na=True)
+    y[rng.integers(0, 300, 3), rng.integers(0, 11, 3)] = [np.inf, np.nan, NA_real]
+    assert_equal(hip.matmul(x, y), oracle.matmul(x, y), tol=1e-12, strict_na=True)
+    b = _svt(300, 40, 0.1, seed + 1)
+    # (a row of x holding both an NA and a NaN: which payload the sum keeps depends on the
+    # operand order of each addition, which neither R nor IEEE 754 pins -- NaN-ness must agree)
+    assert_equal(hip.matmul(x, b), oracle.matmul(x, b), tol=1e-12)
+    xi = _svt(700, 300, 0.03, seed + 2, "int")
+    bi = _sprinkle(_svt(300, 9, 0.2, seed + 3, "int"), seed, [NA_integer])
+    assert_identical(hip.matmul(xi, bi), oracle.matmul(xi, bi))
+    yi = rng.integers(-5, 6, (300, 4)).astype(np.int32)
+    assert_identical(hip.matmul(xi, yi), oracle.matmul(xi, yi))
+    assert_equal(hip.matmul(xi, y), oracle.matmul(xi, y), tol=1e-12, strict_na=True)   # int x double
+    from sparsearray_amd import SparseArrayError
+    with pytest.raises(SparseArrayError, match="non-conformable"):
+        hip.matmul(x, np.zeros((299, 2)))
+    with pytest.raises(SparseArrayError, match="non-conformable"):
+        hip.matmul(x, _svt(299, 4, 0.1, 1))
+    e = SVT_SparseArray((700, 300), "double", [None] * 300)
+    assert not hip.matmul(e, y).any()
+
+
+def test_matmul_one_call_large(hip, oracle):
+    """nnz * K >= 2^28: transposition + panel-blocked layout + LDS-DMA kernel in one call."""
+    xt = _svt(2000, 300_000, 0.01, 21)          # t(x): what crossprod() would be given
+    x = _transposed(xt)                          # 300000 x 2000, 6e6 nonzeros
+    rng = np.random.default_rng(22)
+    y = rng.uniform(-1, 1, (2000, 70))
+    want = oracle.crossprod(xt, y)               # = x %*% y
+    assert_equal(hip.matmul(x, y), want, tol=1e-9, atol=1e-11)
+    b = _svt(2000, 50, 0.05, 23)
+    assert_equal(hip.matmul(x, b), oracle.crossprod(xt, b), tol=1e-9, atol=1e-11)
+
+
 OPS_COL = ["colSums", "colMeans", "colVars", "colSds", "colMins", "colMaxs",
            "colProds", "colAnyNAs", "colCountNAs"]
 OPS_ROW = ["rowSums", "rowMeans", "rowVars", "rowSds", "rowMins", "rowMaxs",
@@ -191,6 +249,56 @@ def test_matrixstats_NaArray_col_ops(hip, oracle, shape, fill, type_, na_rm):
         if len(shape) == 2:
             with pytest.raises(Exception, match="NaMatrix"):
                 sess.crossprod(x, np.ones((shape[0], 2)))
+
+
+@pytest.mark.parametrize("na_rm", [False, True])
+@pytest.mark.parametrize("type_", ["double", "integer", "NaArray"])
+def test_colstats_few_long_segments(hip, oracle, type_, na_rm):
+    """A handful of very long generalized columns and whole-array summaries: the
+    device cuts each segment into chunks (kernels_colstats.hip, launch_colstats_split)
+    and combines the partial states; same answers as one pass per segment."""
+    import warnings
+    rng = np.random.default_rng(23)
+    shape = (180_000, 3, 2)
+    if type_ == "integer":
+        a = rng.integers(-9, 10, shape).astype(np.int32)
+        a[rng.random(shape) < 0.4] = 0
+        a[77, 1, 0] = NA_integer
+        a[:, 2, 1] = np.abs(a[:, 2, 1]) + 1        # a column without zeros (colAlls)
+        x = SVT_SparseArray.from_dense(np.asfortranarray(a), "integer")
+    else:
+        a = np.round(rng.normal(size=shape), 3)
+        if type_ == "NaArray":
+            a[rng.random(shape) < 0.3] = NA_real
+            a[:, 0, 1] = np.round(rng.normal(size=shape[0]), 3)      # complete column
+        else:
+            a[rng.random(shape) < 0.4] = 0.0
+            a[170_000, 1, 0] = NA_real
+        a[5, 2, 0] = np.nan
+        a[9, 0, 0] = np.inf
+        x = SVT_SparseArray.from_dense(np.asfortranarray(a), "double", na_background=type_ == "NaArray")
+    ops = OPS_COL + (["colAnys", "colAlls"] if type_ == "integer" else [])
+    for dims in (1, 2):
+        for op in ops:
+            kw = {} if "AnyNAs" in op or "CountNAs" in op else {"na_rm": na_rm}
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                got = getattr(hip, op)(x, dims=dims, **kw)
+                want = getattr(oracle, op)(x, dims=dims, **kw)
+            if got.dtype == np.int32:
+                assert_identical(got, want, op)
+            else:
+                assert_equal(got, want, tol=1e-9, what=f"{op} dims={dims}", atol=1e-9,
+                             strict_na=op[3:] in ("Mins", "Maxs"))
+    sops = ["sum", "mean", "min", "max", "range", "anyNA"] + \
+        (["any", "all"] if type_ == "integer" else ["var", "sd", "prod"])
+    for op in sops:
+        kw = {} if op == "anyNA" else {"na_rm": na_rm}
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            got, want = getattr(hip, op)(x, **kw), getattr(oracle, op)(x, **kw)
+        assert_equal(np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64),
+                     tol=1e-9, atol=1e-9, what=op)
 
 
 @pytest.mark.parametrize("na_rm", [False, True])
