@@ -106,6 +106,8 @@ def dispatch(reg, labels, direction):
 def load(blk, off):
     r = BLK[blk]
     o = f" offset:{off}" if off else ""
+    if "nosmem" in EXP:                            # (experiment: fixed 7 batches per tile, no record loads)
+        return
     e(f"s_load_dwordx8 s[{r}:{r + 7}], s[8:9], s10{o}")
     e(f"s_load_dwordx16 s[{r + 8}:{r + 23}], s[8:9], s10 offset:{off + 32}")
 
@@ -138,6 +140,8 @@ def d8(i):
         for j in range(8):
             e(f"ds_read_b64 v[{y + 2 * j}:{y + 2 * j + 1}], v{y + 2 * j}")
     else:
+        if "nolds" in EXP:
+            return
         for j in range(8):
             sdwa_add(ADDR + j, r + j)
         for j in range(8):
@@ -155,7 +159,7 @@ def f8(i, interleave):
                 e(f"s_set_gpr_idx_idx s{r + j}")
             e(f"v_fma_f64 v[{ACC}:{ACC + 1}], s[{r + 8 + 2 * j}:{r + 9 + 2 * j}], "
               f"v[{y + 2 * j}:{y + 2 * j + 1}], v[{ACC}:{ACC + 1}]")
-        if interleave:   # single y set: refill y_j for the next batch right away
+        if interleave and "nolds" not in EXP:   # single y set: refill y_j for the next batch right away
             e(f"ds_read_b64 v[{y + 2 * j}:{y + 2 * j + 1}], v{ADDR + j}")
     if "nofma" not in EXP:
         e("s_set_gpr_idx_off")
@@ -172,12 +176,20 @@ def gen(prof):
     ph = [f"{20 + i}" for i in range(NPH)]          # phase labels
     # ---------------------------------------------------------------- setup
     e("v_mov_b32 v10, 0x207")                      # class mask: sNaN | qNaN | -Inf | +Inf
+    if "nosmem" in EXP:                            # constant, valid records (row j, column 5j, value 1.0)
+        for r in BLK.values():
+            for j in range(8):
+                e(f"s_mov_b32 s{r + j}, {((8 * j) << 16) | (2 * 5 * j)}")
+                e(f"s_mov_b32 s{r + 8 + 2 * j}, 0")
+                e(f"s_mov_b32 s{r + 9 + 2 * j}, 0x3ff00000")
     load("A", 0)
     load("B", BATCH)
     e(f"s_add_u32 s10, s10, {2 * BATCH}")
     e(f"s_mov_b32 s15, {NPH - 1}")
     # ---------------------------------------------------------------- panel boundary
     e("10:")
+    if "nosmem" in EXP:
+        e("s_mov_b32 s99, 7")
     stamp(7)                                       # phases
     e("s_waitcnt lgkmcnt(0)")
     e("s_cmp_ge_u32 s11, s12")
@@ -222,8 +234,9 @@ def gen(prof):
     e(f"v_add_u32 v6, {CHK}, v6")
     e("s_waitcnt lgkmcnt(0)")
     e("v_cmp_class_f64 vcc, v[8:9], v10")
-    e("s_or_b32 s18, s18, vcc_lo")
-    e("s_or_b32 s18, s18, vcc_hi")
+    if "nocheck" not in EXP:
+        e("s_or_b32 s18, s18, vcc_lo")
+        e("s_or_b32 s18, s18, vcc_hi")
     e("s_sub_u32 m0, m0, 1")
     e("s_cmp_lg_u32 m0, 0")
     e("s_cbranch_scc1 12b")
@@ -239,13 +252,18 @@ def gen(prof):
             d8(i)
             f8(i, False)
         else:
-            for j in range(8):
-                sdwa_add(ADDR + j, BLK[X1[i % 3]] + j)
+            if "nolds" not in EXP:
+                for j in range(8):
+                    sdwa_add(ADDR + j, BLK[X1[i % 3]] + j)
             f8(i, True)
         e("s_waitcnt lgkmcnt(0)")
         if i == NPH - 1:
             e(f"s_add_u32 s10, s10, {TRIP}")
-        e(f"s_bitcmp1_b32 s{BLK[X0[i % 3]]}, 15")  # last batch of the tile?
+        if "nosmem" in EXP:
+            e("s_sub_u32 s99, s99, 1")
+            e("s_cmp_eq_u32 s99, 0")
+        else:
+            e(f"s_bitcmp1_b32 s{BLK[X0[i % 3]]}, 15")  # last batch of the tile?
         e(f"s_cbranch_scc1 {30 + i}f")
         e("s_sub_u32 s17, s17, 1")                 # stagger expired: issue the next panel's pieces
         e(f"s_cbranch_scc1 {70 + i}f")
@@ -278,7 +296,8 @@ def gen(prof):
         if q:
             e(f"s_add_u32 m0, m0, {ROW}")
         e("s_nop 0")
-        e(f"global_load_lds_dwordx4 v1, s[{20 + 2 * q}:{21 + 2 * q}]")
+        if "nodma" not in EXP:
+            e(f"global_load_lds_dwordx4 v1, s[{20 + 2 * q}:{21 + 2 * q}]")
     for q in range(4):
         e(f"s_add_u32 s{20 + 2 * q}, s{20 + 2 * q}, 1024")
         e(f"s_addc_u32 s{21 + 2 * q}, s{21 + 2 * q}, 0")
