@@ -46,6 +46,7 @@
 #include "svt_common.h"
 
 #include <hipcub/hipcub.hpp>
+#include <vector>
 
 typedef double d16 __attribute__((ext_vector_type(16)));
 typedef double d8 __attribute__((ext_vector_type(8)));
@@ -242,8 +243,18 @@ extern "C" svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB
 			ok = hipMemcpy(h->tile_ptr + ntiles + 1, pad, sizeof(pad), hipMemcpyHostToDevice) == hipSuccess;
 		}
 		const size_t rbytes = h->fmt == 1 ? 12 : 16;
-		if (ok && (nrec + PBC_SLACK) * 16 >= ((int64_t) 1 << 32)) {
-			svt_set_error("svt_dev_pbc_build: operand too large for 32-bit record offsets");
+		// the kernels walk one group's stream with a 32-bit byte cursor
+		bool too_big = false;
+		const int64_t ngroups = h->ngroups;
+		if (ok) {
+			std::vector<int64_t> gp((size_t) ngroups + 1);
+			ok = hipMemcpy2D(gp.data(), 8, h->tile_ptr, (size_t) h->npanels * 8, 8,
+					 (size_t) ngroups + 1, hipMemcpyDeviceToHost) == hipSuccess;
+			for (int64_t g = 0; ok && g < ngroups; g++)
+				if ((gp[g + 1] - gp[g] + PBC_SLACK) * 16 >= ((int64_t) 1 << 32)) too_big = true;
+		}
+		if (ok && too_big) {
+			svt_set_error("svt_dev_pbc_build: a column group too large for 32-bit record offsets");
 			if (tmp) (void) hipFree(tmp);
 			svt_dev_pbc_release(h);
 			return NULL;
@@ -512,9 +523,10 @@ crossprod_pbc_kernel(const uint4 *__restrict__ rec,
 	}
 	__syncthreads();
 	const int64_t *__restrict__ tb = tile_ptr + (wv * npanels + pa);
-	// byte offset of the wavefront's current batch (32-bit: svt_dev_pbc_build
-	// refuses layouts of 4 GiB or more)
-	uint32_t off = (uint32_t) tb[0] * 16u;
+	// byte offset of the wavefront's current batch, relative to its own first record
+	// (32-bit: svt_dev_pbc_build refuses layouts in which one group's stream reaches 4 GiB)
+	const uint4 *__restrict__ rec_w = rec + tb[0];
+	uint32_t off = 0;
 
 	unsigned long long pr[6] = {0, 0, 0, 0, 0, 0}, tq = 0;
 #define PBC_PROF(i) if (DBG == 3) { const unsigned long long t_ = __builtin_readcyclecounter(); pr[i] += t_ - tq; tq = t_; }
@@ -549,26 +561,26 @@ crossprod_pbc_kernel(const uint4 *__restrict__ rec,
 			if constexpr (NV == 1) {
 				asm volatile(PBC_PANEL_TXT
 					     : "+{v[64:95]}"(acc[0]), PBC_PANEL_OPS
-					     : [base] "s"(rec), [lb] "v"(lane_base)
+					     : [base] "s"(rec_w), [lb] "v"(lane_base)
 					     : PBC_PANEL_CLOBBERS);
 			} else if constexpr (NV == 2) {
 				asm volatile(PBC_PANEL_TXT
 					     : "+{v[64:95]}"(acc[0]), "+{v[96:127]}"(acc[NV > 1 ? 1 : 0]),
 					       PBC_PANEL_OPS
-					     : [base] "s"(rec), [lb] "v"(lane_base)
+					     : [base] "s"(rec_w), [lb] "v"(lane_base)
 					     : PBC_PANEL_CLOBBERS);
 			} else if constexpr (NV == 3) {
 				asm volatile(PBC_PANEL_TXT
 					     : "+{v[64:95]}"(acc[0]), "+{v[96:127]}"(acc[NV > 1 ? 1 : 0]),
 					       "+{v[128:159]}"(acc[NV > 2 ? 2 : 0]), PBC_PANEL_OPS
-					     : [base] "s"(rec), [lb] "v"(lane_base)
+					     : [base] "s"(rec_w), [lb] "v"(lane_base)
 					     : PBC_PANEL_CLOBBERS);
 			} else {
 				asm volatile(PBC_PANEL_TXT
 					     : "+{v[64:95]}"(acc[0]), "+{v[96:127]}"(acc[NV > 1 ? 1 : 0]),
 					       "+{v[128:159]}"(acc[NV > 2 ? 2 : 0]),
 					       "+{v[160:191]}"(acc[NV > 3 ? 3 : 0]), PBC_PANEL_OPS
-					     : [base] "s"(rec), [lb] "v"(lane_base)
+					     : [base] "s"(rec_w), [lb] "v"(lane_base)
 					     : PBC_PANEL_CLOBBERS);
 			}
 		}
@@ -624,9 +636,6 @@ crossprod_pbc_kernel(const uint4 *__restrict__ rec,
 //     panels ahead, issued AFTER the DMA pieces so that the in-order vmcnt wait
 //     for the pieces does not wait for it: without it every scalar load of the
 //     record stream pays an HBM miss (7.6 ms instead of 5.2 at BASELINE config 2).
-//   * the scalar loads of the record stream are prefetched into the scalar cache
-//     in batches (6 lines once per 6 phases): one L2 round trip per trip instead
-//     of one per phase (5.26 -> 4.39 ms).
 //   * the DMA pieces of the next panel are issued from inside the record loop,
 //     staggered by wavefront, instead of all 64 at the barrier: the texture
 //     addresser takes ~20 cycles per piece and a burst blocks the issuing waves.
@@ -690,9 +699,10 @@ crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restric
 	u32x4 PA;
 	u32x16 PB;
 	{
-		const uint64_t recp = (uint64_t) (uintptr_t) rec;
+		// record base = this wavefront's first record; the 32-bit stream cursor is relative to it
+		const uint64_t recp = (uint64_t) (uintptr_t) rec + (uint64_t) tb[0] * 12u;
 		PA[0] = (uint32_t) recp; PA[1] = (uint32_t) (recp >> 32);
-		PA[2] = (uint32_t) tb[0] * 12u;                 // stream cursor (bytes)
+		PA[2] = 0;                                      // stream cursor (bytes)
 		PA[3] = (uint32_t) pa;
 		PB[0] = (uint32_t) pb;
 		PB[1] = PBC_DMA_BUF;                            // toggles to 0 for the first panel

@@ -149,3 +149,43 @@ def test_config5_rowsums_dims2_match_scatter_add(array5):
     torch.cuda.synchronize()
     assert float((got - want).abs().max()) <= 1e-11
     assert float(got.abs().sum()) > 0
+
+
+# ---------------------------------------------------------------------------
+# BASELINE config 4 at full size on ONE GPU (1e7 x 5e4 @ 0.1 %, 5e8 nonzeros, 6 GB of CSC):
+# the record stream is > 4 GiB, the kernels' 32-bit cursors are per column group.
+# ---------------------------------------------------------------------------
+def test_config4_full_size_crossprod_and_colsums(hip):
+    from sparsearray_amd import synth
+    from sparsearray_amd.device import DeviceCSC, PbcPlan, colstats
+    dev = torch.device("cuda", 0)
+    nrow, ncol, Kc = 10_000_000, 50_000, 64
+    cp, ri, v = synth.random_device_csc(nrow, ncol, 0.001, seed=4, device=dev)
+    A = DeviceCSC(nrow, cp, ri, v)
+    assert A.nnz > 4.9e8
+    plan = PbcPlan(A, Kc)
+    Y = synth.random_dense(nrow, Kc, seed=104, device=dev)
+    out = torch.zeros((Kc, ncol), dtype=torch.float64, device=dev)
+    plan.run(Y, nrow, out)
+    torch.cuda.synchronize()
+    g = torch.Generator().manual_seed(2)
+    cols = torch.randint(0, ncol, (48,), generator=g).tolist() + [0, ncol - 1, ncol // 2]
+    worst = 0.0
+    for c in cols:
+        lo, hi = int(A.col_ptr[c]), int(A.col_ptr[c + 1])
+        rows = A.row_idx[lo:hi].long()
+        prod = Y[:, rows] * A.val[lo:hi]
+        worst = max(worst, float(((out[:, c] - prod.sum(dim=1)).abs() /
+                                  prod.abs().sum(dim=1).clamp_min(1e-300)).max()))
+    assert worst <= 1e-12, worst
+    # dense operand of ones: every dense column of the product is colSums(A)
+    cs, _ = colstats(A, "sum")
+    Y.fill_(1.0)
+    plan.run(Y, nrow, out)
+    torch.cuda.synchronize()
+    assert float((out - cs[None, :]).abs().max() / cs.abs().max()) <= 1e-12
+    # colSums against a segmented torch reduction
+    want = torch.zeros(ncol, dtype=torch.float64, device=dev)
+    seg = torch.repeat_interleave(torch.arange(ncol, device=dev), A.col_ptr[1:] - A.col_ptr[:-1])
+    want.index_add_(0, seg, A.val)
+    assert float((cs - want).abs().max() / want.abs().max()) <= 1e-12
