@@ -97,6 +97,22 @@ const char *svt_last_error(void);
 /* "gfx950" etc. of the selected device, or "" before svt_init(). */
 const char *svt_device_arch(void);
 
+/*
+ * Resident operands (off by default).  R code calls the entry points below over and over
+ * on the same object, and each call marshals and uploads the whole tree again.  With a
+ * byte limit > 0 the host-level entry points keep the device copy of every SVT operand
+ * (plus what they derive from it: the panel-blocked layout, t(x)) up to that many bytes,
+ * least recently used first out, and recognise the operand of a later call by a
+ * fingerprint of its view: dims, type, and per leaf the host pointers, the count and
+ * three sampled (offset, value) pairs.  R vectors are not modified once shared; callers
+ * that overwrite leaves in place must call svt_resident_clear().  This is the device-side
+ * counterpart of the reference operating in place on host memory
+ * (src/SVT_SparseArray_class.c:598-633 walks the leaves on every call, at no cost).
+ */
+int svt_resident_set_limit(size_t bytes);          /* 0 = off, frees everything */
+void svt_resident_clear(void);
+void svt_resident_stats(size_t *bytes, int64_t *entries, int64_t *hits, int64_t *misses);
+
 /* ---------------------------------------------------------------------- */
 /* 1. Host level: the .Call entry points                                   */
 /* ---------------------------------------------------------------------- */
@@ -234,6 +250,8 @@ int svt_dev_crossprod_csc_dense(const svt_dev_csc *A, const void *Y,
 typedef struct svt_dev_pbc svt_dev_pbc;
 svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB, int logR);
 void svt_dev_pbc_release(svt_dev_pbc *P);
+/* Device bytes held by a layout (records + tile table + flags). */
+size_t svt_dev_pbc_bytes(const svt_dev_pbc *P);
 size_t svt_dev_crossprod_pbc_ws_bytes(const svt_dev_pbc *P, int K);
 int svt_dev_crossprod_pbc(const svt_dev_pbc *P, const svt_dev_csc *A,
 			  const double *Y, int64_t ldY, int K, int tr_y,

@@ -120,6 +120,25 @@ class CAbiDispatcher:
         self._check(self._fn("crossprod2_SVT_SVT")(byref(xv), byref(yv), _ptr(out)))
         return out
 
+    # resident operands (include/svt_hip.h; HIP library only) --------------------
+    def resident_set_limit(self, nbytes: int):
+        f = self._fn("resident_set_limit")
+        f.argtypes = [ctypes.c_size_t]
+        f.restype = c_int
+        self._check(f(int(nbytes)))
+
+    def resident_clear(self):
+        f = self._fn("resident_clear")
+        f.restype = None
+        f()
+
+    def resident_stats(self) -> dict:
+        f = self._fn("resident_stats")
+        f.restype = None
+        b, e, h, m = ctypes.c_size_t(0), ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+        f(byref(b), byref(e), byref(h), byref(m))
+        return {"bytes": b.value, "entries": e.value, "hits": h.value, "misses": m.value}
+
     def has_entry(self, name: str) -> bool:
         return hasattr(self.lib, self.prefix + name[2:])
 

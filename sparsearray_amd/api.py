@@ -72,6 +72,17 @@ class Session:
     def __init__(self, call: Callable):
         self._call = call
 
+    # Resident operands: keep device copies of SVT operands across calls (opt-in; see
+    # include/svt_hip.h).  In the R package this would be an option() read by the glue.
+    def resident_set_limit(self, nbytes: int):
+        self._call.resident_set_limit(nbytes)
+
+    def resident_clear(self):
+        self._call.resident_clear()
+
+    def resident_stats(self) -> dict:
+        return self._call.resident_stats()
+
     # SparseArray.Call(), R/thread-control.R:87-92
     def SparseArray_Call(self, name: str, *args):
         return self._call(name, *args)

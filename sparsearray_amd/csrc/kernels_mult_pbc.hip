@@ -190,6 +190,13 @@ extern "C" void svt_dev_pbc_release(svt_dev_pbc *h)
 	free(h);
 }
 
+extern "C" size_t svt_dev_pbc_bytes(const svt_dev_pbc *h)
+{
+	if (h == NULL) return 0;
+	return (size_t) h->nrec * (h->fmt == 1 ? 12 : 16) + PBC_SLACK * 16 +
+	       (size_t) (h->ngroups * h->npanels + 1 + PBC_TP_PAD) * 8 + (size_t) h->ncol * 4;
+}
+
 // Not on the launch path: allocates, synchronises.
 extern "C" svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB, int logR)
 {

@@ -85,6 +85,8 @@ static int ensure_init()
 // (the reference's counterpart is the leaf walk of
 // src/SVT_SparseArray_class.c:598-633, which never leaves the host).
 #include <functional>
+#include <mutex>
+#include <vector>
 #include <thread>
 
 struct Stager {
@@ -335,11 +337,200 @@ extern "C" void svt_release(svt_dev_csc *h)
 	free(h);
 }
 
+// ---- resident operands (opt-in) -------------------------------------------------------
+// R code keeps calling the entry points on the same object (colSums(x); colVars(x);
+// crossprod(x, y1); crossprod(x, y2) ...), and every call marshals and uploads the whole
+// tree again (26 ms of a 54 ms crossprod at BASELINE config 2).  With a byte limit set
+// (svt_resident_set_limit), the host-level entry points keep the device copy of an
+// operand -- and the layouts derived from it: panel-blocked records, t(x) -- and find it
+// again through a fingerprint of the view: dims, type, and per leaf the two host
+// pointers, the count and the first / middle / last (offset, value).  R vectors are
+// immutable once shared, so equal pointers + counts + samples mean equal contents for
+// well-behaved callers; code that overwrites leaves in place must call
+// svt_resident_clear().  Off by default.  
+struct Resident {
+	uint64_t key;
+	svt_dev_csc *csc;
+	svt_dev_pbc *pbc;        // panel-blocked layout of csc, built on first use
+	svt_dev_csc *tr;         // t(csc), built on first use
+	svt_dev_pbc *tr_pbc;     // layout of t(csc)
+	size_t bytes;
+	uint64_t stamp;
+	int pins;
+};
+static std::vector<Resident> g_res;
+static std::mutex g_res_mu;
+static size_t g_res_limit = 0, g_res_bytes = 0;
+static uint64_t g_res_clock = 0, g_res_hits = 0, g_res_misses = 0;
+
+static size_t csc_bytes(const svt_dev_csc *c)
+{
+	return (size_t) (c->ncol + 1) * 8 + (size_t) c->nnz * (4 + elt_size(c->Rtype));
+}
+
+static size_t pbc_bytes(const svt_dev_pbc *P) { return svt_dev_pbc_bytes(P); }
+
+static void resident_free(Resident &r)
+{
+	if (r.pbc) svt_dev_pbc_release(r.pbc);
+	if (r.tr_pbc) svt_dev_pbc_release(r.tr_pbc);
+	svt_release(r.tr);
+	svt_release(r.csc);
+}
+
+// drop least-recently-used unpinned entries until `need` more bytes fit
+static void resident_make_room(size_t need)
+{
+	while (g_res_bytes + need > g_res_limit) {
+		int victim = -1;
+		for (size_t i = 0; i < g_res.size(); i++)
+			if (g_res[i].pins == 0 && (victim < 0 || g_res[i].stamp < g_res[victim].stamp))
+				victim = (int) i;
+		if (victim < 0) return;
+		g_res_bytes -= g_res[victim].bytes;
+		resident_free(g_res[victim]);
+		g_res.erase(g_res.begin() + victim);
+	}
+}
+
+extern "C" int svt_resident_set_limit(size_t bytes)
+{
+	std::lock_guard<std::mutex> lk(g_res_mu);
+	g_res_limit = bytes;
+	resident_make_room(0);
+	return 0;
+}
+
+extern "C" void svt_resident_clear(void)
+{
+	std::lock_guard<std::mutex> lk(g_res_mu);
+	const size_t keep = g_res_limit;
+	g_res_limit = 0;
+	resident_make_room(0);
+	g_res_limit = keep;
+}
+
+extern "C" void svt_resident_stats(size_t *bytes, int64_t *entries, int64_t *hits, int64_t *misses)
+{
+	std::lock_guard<std::mutex> lk(g_res_mu);
+	if (bytes) *bytes = g_res_bytes;
+	if (entries) *entries = (int64_t) g_res.size();
+	if (hits) *hits = (int64_t) g_res_hits;
+	if (misses) *misses = (int64_t) g_res_misses;
+}
+
+static inline uint64_t fp_mix(uint64_t h, uint64_t v)
+{
+	h ^= v + 0x9E3779B97F4A7C15ULL + (h << 6) + (h >> 2);
+	h *= 0xFF51AFD7ED558CCDULL;
+	return h ^ (h >> 33);
+}
+
+static uint64_t view_fingerprint(const svt_view *x)
+{
+	uint64_t h = fp_mix(0x5356545F48495031ULL, (uint64_t) x->Rtype);
+	h = fp_mix(h, (uint64_t) x->ndim);
+	for (int a = 0; a < x->ndim; a++) h = fp_mix(h, (uint64_t) x->dim[a]);
+	h = fp_mix(h, (uint64_t) x->svt_is_null * 2 + (uint64_t) (x->na_background != 0));
+	h = fp_mix(h, (uint64_t) x->nleaves);
+	if (x->svt_is_null) return h;
+	const size_t esz = elt_size(x->Rtype);
+	for (int64_t j = 0; j < x->nleaves; j++) {
+		const int n = x->nzcount[j];
+		h = fp_mix(h, (uint64_t) n);
+		if (n <= 0) continue;
+		h = fp_mix(h, (uint64_t) (uintptr_t) x->nzoffs[j]);
+		h = fp_mix(h, (uint64_t) (uintptr_t) x->nzvals[j]);
+		const int at[3] = { 0, n / 2, n - 1 };
+		for (int t = 0; t < 3; t++) {
+			uint64_t v = (uint64_t) (uint32_t) x->nzoffs[j][at[t]];
+			if (x->nzvals[j] != NULL) {               // (NULL: lacunar leaf, all ones)
+				uint64_t bits = 0;
+				memcpy(&bits, (const char *) x->nzvals[j] + (size_t) at[t] * esz, esz);
+				v ^= bits * 0x9E3779B97F4A7C15ULL;
+			}
+			h = fp_mix(h, v);
+		}
+	}
+	return h;
+}
+
+// An operand of a host-level call: resident if the cache is on (found or inserted, pinned
+// for the lifetime of the guard), else uploaded for this call and released with the guard.
 struct CscGuard {
 	svt_dev_csc *h;
-	explicit CscGuard(svt_dev_csc *p) : h(p) {}
-	~CscGuard() { svt_release(h); }
+	uint64_t key;            // != 0: h belongs to the resident set
+	explicit CscGuard(svt_dev_csc *p) : h(p), key(0) {}
+	explicit CscGuard(const svt_view *x) : h(NULL), key(0)
+	{
+		if (g_res_limit == 0) { h = svt_upload(x); return; }
+		const uint64_t k = view_fingerprint(x) | 1;
+		{
+			std::lock_guard<std::mutex> lk(g_res_mu);
+			for (Resident &r : g_res)
+				if (r.key == k) {
+					r.pins++; r.stamp = ++g_res_clock; g_res_hits++;
+					h = r.csc; key = k;
+					return;
+				}
+			g_res_misses++;
+		}
+		h = svt_upload(x);
+		if (h == NULL) return;
+		std::lock_guard<std::mutex> lk(g_res_mu);
+		const size_t nb = csc_bytes(h);
+		resident_make_room(nb);
+		if (g_res_bytes + nb > g_res_limit) return;        // does not fit: one-call operand
+		Resident r = { k, h, NULL, NULL, NULL, nb, ++g_res_clock, 1 };
+		g_res.push_back(r);
+		g_res_bytes += nb;
+		key = k;
+	}
+	~CscGuard()
+	{
+		if (key == 0) { svt_release(h); return; }
+		std::lock_guard<std::mutex> lk(g_res_mu);
+		for (Resident &r : g_res)
+			if (r.key == key) { r.pins--; return; }
+	}
+	void drop()              // a one-call operand that is no longer needed
+	{
+		if (key == 0) { svt_release(h); h = NULL; }
+	}
+	CscGuard(const CscGuard &) = delete;
+	CscGuard &operator=(const CscGuard &) = delete;
 };
+
+// The panel-blocked layout of a resident operand lives with it; for a one-call operand it
+// is built and released by the caller.  *owned tells which.
+static svt_dev_pbc *pbc_for(const svt_dev_csc *A, int *owned)
+{
+	*owned = 1;
+	{
+		std::lock_guard<std::mutex> lk(g_res_mu);
+		for (Resident &r : g_res)
+			if (r.csc == A || r.tr == A) {
+				svt_dev_pbc *&slot = r.csc == A ? r.pbc : r.tr_pbc;
+				if (slot != NULL) { *owned = 0; return slot; }
+				break;
+			}
+	}
+	svt_dev_pbc *P = svt_dev_pbc_build(A, 40, 16, 7);
+	if (P == NULL) return NULL;
+	std::lock_guard<std::mutex> lk(g_res_mu);
+	for (Resident &r : g_res)
+		if (r.csc == A || r.tr == A) {
+			const size_t nb = pbc_bytes(P);
+			resident_make_room(nb);                   // (the entry itself is pinned by its guard)
+			if (g_res_bytes + nb <= g_res_limit) {
+				(r.csc == A ? r.pbc : r.tr_pbc) = P;
+				r.bytes += nb; g_res_bytes += nb;
+				*owned = 0;
+			}
+			break;
+		}
+	return P;
+}
 
 // ==================================================================================
 // Device level
@@ -528,7 +719,7 @@ extern "C" int svt_aperm_SVT(const svt_view *x, const int *perm, int64_t *out_co
 	int64_t dim[8], new_nl = 1;
 	for (int a = 0; a < x->ndim; a++) dim[a] = x->dim[a];
 	for (int a = 1; a < x->ndim; a++) new_nl *= dim[perm0[a]];
-	CscGuard A(svt_upload(x));
+	CscGuard A(x);
 	if (A.h == NULL) return -1;
 	const size_t esz = elt_size(x->Rtype);
 	const size_t nn = (size_t) (A.h->nnz > 0 ? A.h->nnz : 1);
@@ -605,7 +796,8 @@ static int dev_crossprod_chunked(const svt_dev_csc *A, const void *Y_dev, int64_
 	// row-split partial sums differ from those in the last bits (parity bar: 1e-6).
 	if (A->Rtype == SVT_REALSXP && !tr_y && A->nrow >= 256 &&
 	    (double) A->nnz * (double) K >= 268435456.0) {
-		svt_dev_pbc *P = svt_dev_pbc_build(A, 40, 16, 7);
+		int own_P = 1;
+		svt_dev_pbc *P = pbc_for(A, &own_P);
 		if (P == NULL)                 // e.g. more records than 32-bit stream offsets reach:
 			goto general;          // the general kernels take any size
 		const int kc = K < 512 ? (int) K : 512;
@@ -618,7 +810,7 @@ static int dev_crossprod_chunked(const svt_dev_csc *A, const void *Y_dev, int64_
 		}
 		if (rc == 0 && hipDeviceSynchronize() != hipSuccess)
 			rc = svt_set_error("device error in the panel-blocked crossprod");
-		svt_dev_pbc_release(P);
+		if (own_P) svt_dev_pbc_release(P);
 		return rc;
 	}
 general:
@@ -659,7 +851,7 @@ extern "C" int svt_crossprod2_SVT_mat(const svt_view *x, const void *y, int y_nr
 	memset(out, 0, out_n * sizeof(double));
 	if (x->svt_is_null || out_n == 0)     // :389-390
 		return 0;
-	CscGuard A(svt_upload(x));
+	CscGuard A(x);
 	if (A.h == NULL) return -1;
 	DevBuf Y, O;
 	if (Y.upload(y, (size_t) y_nrow * y_ncol * elt_size(y_Rtype)) ||
@@ -690,7 +882,7 @@ extern "C" int svt_crossprod2_mat_SVT(const void *x, int x_nrow, int x_ncol,
 	memset(out, 0, out_n * sizeof(double));
 	if (y->svt_is_null || out_n == 0)     // :439-440
 		return 0;
-	CscGuard A(svt_upload(y));
+	CscGuard A(y);
 	if (A.h == NULL) return -1;
 	DevBuf X, O;
 	if (X.upload(x, (size_t) x_nrow * x_ncol * elt_size(x_Rtype)) ||
@@ -718,9 +910,10 @@ static int dev_crossprod_pp(const svt_dev_csc *other, const svt_dev_csc *pp,
 	// large double products: panel-blocked layout of `other`, built once, against
 	// every densified chunk (same threshold and caveat as dev_crossprod_chunked)
 	svt_dev_pbc *P = NULL;
+	int own_P = 1;
 	if (other->Rtype == SVT_REALSXP && nrow >= 256 &&
 	    (double) other->nnz * (double) K >= 268435456.0) {
-		P = svt_dev_pbc_build(other, 40, 16, 7);
+		P = pbc_for(other, &own_P);
 		if (P != NULL && kc > 512) kc = 512;
 	}
 	DevBuf dense, ws;
@@ -744,7 +937,7 @@ static int dev_crossprod_pp(const svt_dev_csc *other, const svt_dev_csc *pp,
 	}
 	if (rc == 0 && hipDeviceSynchronize() != hipSuccess)
 		rc = svt_set_error("device error in the sparse x sparse crossprod");
-	if (P) svt_dev_pbc_release(P);
+	if (P && own_P) svt_dev_pbc_release(P);
 	return rc;
 }
 
@@ -775,7 +968,7 @@ extern "C" int svt_crossprod2_SVT_SVT(const svt_view *x, const svt_view *y, doub
 		return 0;
 	const int64_t Lpp_nops = view_nzcount(y) * out_nrow;   // :1077-1078
 	const int64_t Rpp_nops = view_nzcount(x) * out_ncol;
-	CscGuard X(svt_upload(x)), Y(svt_upload(y));
+	CscGuard X(x), Y(y);
 	if (X.h == NULL || Y.h == NULL) return -1;
 	DevBuf O;
 	if (O.alloc(out_n * 8) || O.zero())
@@ -817,6 +1010,37 @@ static svt_dev_csc *dev_transposed(const svt_dev_csc *A)
 	return T;
 }
 
+// t(A) of an operand: kept with a resident operand, else built for this call (*owned = 1).
+static svt_dev_csc *transposed_for(const CscGuard &A, int *owned)
+{
+	*owned = 1;
+	if (A.key != 0) {
+		std::lock_guard<std::mutex> lk(g_res_mu);
+		for (Resident &r : g_res)
+			if (r.key == A.key && r.tr != NULL) { *owned = 0; return r.tr; }
+	}
+	svt_dev_csc *T = dev_transposed(A.h);
+	if (T == NULL || A.key == 0) return T;
+	std::lock_guard<std::mutex> lk(g_res_mu);
+	for (Resident &r : g_res)
+		if (r.key == A.key) {
+			const size_t nb = csc_bytes(T);
+			resident_make_room(nb);
+			if (g_res_bytes + nb <= g_res_limit) {
+				r.tr = T; r.bytes += nb; g_res_bytes += nb;
+				*owned = 0;
+			}
+			break;
+		}
+	return T;
+}
+
+struct OwnedCsc {            // releases a handle only if this call built it
+	svt_dev_csc *t;
+	int own;
+	~OwnedCsc() { if (own) svt_release(t); }
+};
+
 // x %*% y, y an ordinary matrix: the R method (R/SparseMatrix-mult.R:195-215) is
 // .crossprod2_SparseMatrix_matrix(t(x), y), i.e. C_transpose_2D_SVT on the host
 // followed by C_crossprod2_SVT_mat.  Here the transposition happens on the device,
@@ -838,14 +1062,13 @@ extern "C" int svt_matmul_SVT_mat(const svt_view *x, const void *y, int y_nrow,
 	memset(out, 0, out_n * sizeof(double));
 	if (x->svt_is_null || out_n == 0)
 		return 0;
-	svt_dev_csc *T;
-	{
-		CscGuard A(svt_upload(x));
-		if (A.h == NULL) return -1;
-		T = dev_transposed(A.h);
-	}                                   // x's own device copy is released here
-	CscGuard TA(T);
+	CscGuard A(x);
+	if (A.h == NULL) return -1;
+	int own_T = 1;
+	svt_dev_csc *T = transposed_for(A, &own_T);
+	OwnedCsc TA = { T, own_T };
 	if (T == NULL) return -1;
+	A.drop();                           // a one-call operand: its untransposed copy can go now
 	DevBuf Y, O;
 	if (Y.upload(y, (size_t) y_nrow * y_ncol * elt_size(y_Rtype)) ||
 	    O.alloc(out_n * 8) || O.zero())
@@ -876,14 +1099,15 @@ extern "C" int svt_matmul_SVT_SVT(const svt_view *x, const svt_view *y, double *
 		return 0;
 	const int64_t Lpp_nops = view_nzcount(y) * out_nrow;
 	const int64_t Rpp_nops = view_nzcount(x) * out_ncol;
-	svt_dev_csc *T;
-	{
-		CscGuard X(svt_upload(x));
-		if (X.h == NULL) return -1;
-		T = dev_transposed(X.h);
-	}
-	CscGuard TX(T), Y(svt_upload(y));
-	if (T == NULL || Y.h == NULL) return -1;
+	CscGuard X(x);
+	if (X.h == NULL) return -1;
+	int own_T = 1;
+	svt_dev_csc *T = transposed_for(X, &own_T);
+	OwnedCsc TX = { T, own_T };
+	if (T == NULL) return -1;
+	X.drop();
+	CscGuard Y(y);
+	if (Y.h == NULL) return -1;
 	DevBuf O;
 	if (O.alloc(out_n * 8) || O.zero())
 		return -1;
@@ -907,7 +1131,7 @@ extern "C" int svt_crossprod1_SVT(const svt_view *x, double *out)
 	memset(out, 0, out_n * sizeof(double));
 	if (x->svt_is_null || out_n == 0)      // :880-881
 		return 0;
-	CscGuard X(svt_upload(x));
+	CscGuard X(x);
 	if (X.h == NULL) return -1;
 	DevBuf O;
 	if (O.alloc(out_n * 8) || O.zero())
@@ -957,7 +1181,7 @@ extern "C" int svt_colStats_SVT(const svt_view *x, int opcode, int na_rm, double
 	if (nout == 0)
 		return 0;
 	const int out_Rtype = svt_colStats_out_Rtype(opcode, x->Rtype);
-	CscGuard A(svt_upload(x));
+	CscGuard A(x);
 	if (A.h == NULL) return -1;
 	if (inner == 0) {
 		// zero-extent inner dims: every result summarizes an empty vector.
@@ -985,7 +1209,7 @@ extern "C" int svt_summarize_SVT(const svt_view *x, int opcode, int na_rm, doubl
 	*out_Rtype = rt;
 	out_d[0] = out_d[1] = 0.0;
 	out_i[0] = out_i[1] = 0;
-	CscGuard A(svt_upload(x));
+	CscGuard A(x);
 	if (A.h == NULL) return -1;
 	svt_dev_csc V = *A.h;      // the whole array as one generalized column
 	V.owned = 0;
@@ -1048,7 +1272,7 @@ extern "C" int svt_rowStats_SVT(const svt_view *x, int opcode, int na_rm,
 	}
 	if (nstrata > 0xFFFFFFFFLL)
 		return svt_set_error("too many strata for the device coverage counters");
-	CscGuard A(svt_upload(x));
+	CscGuard A(x);
 	if (A.h == NULL) return -1;
 	DevBuf O, C, S, W;
 	if (O.alloc((size_t) out_len * osz) ||
@@ -1156,7 +1380,7 @@ static int xsum_SVT(const svt_view *x, const int *group, int ngroup, int na_rm,
 				     "SVT_SparseMatrix objects of this type at the moment");
 	if (check_group(group, colsum ? x->dim[1] : x->dim[0], ngroup))
 		return -1;
-	CscGuard A(svt_upload(x));
+	CscGuard A(x);
 	if (A.h == NULL) return -1;
 	return groupsum_host(A.h, NULL, group, ngroup, na_rm, colsum, out, ovflow);
 }

@@ -355,3 +355,50 @@ def test_error_behaviour(hip):
         hip.any(x)
     with pytest.raises(SparseArrayError, match="group"):
         hip.SparseArray_Call("C_rowsum_SVT", x, np.full(100, 7, np.int32), 3, False)
+
+
+def test_resident_operands(hip, oracle):
+    """svt_resident_set_limit(): later calls on the same object find its device copy (and
+    its derived layouts); results are those of the uncached calls; LRU eviction; off again."""
+    x = _sprinkle(_svt(20000, 400, 0.02, 31), 31, SPECIAL_D)
+    x2 = _svt(20000, 300, 0.02, 32)
+    xi = _svt(5000, 64, 0.05, 33, "int")
+    rng = np.random.default_rng(34)
+    y = rng.uniform(-1, 1, (20000, 5))
+    z = rng.uniform(-1, 1, (400, 3))
+    want = [hip.colSums(x), hip.colVars(x), hip.rowSums(x), hip.crossprod(x, y),
+            hip.matmul(x, z), hip.matmul(x, z), hip.sum(x), hip.colSums(xi)]
+    base = hip.resident_stats()
+    assert base["entries"] == 0 and base["bytes"] == 0
+    try:
+        hip.resident_set_limit(1 << 30)
+        got = [hip.colSums(x), hip.colVars(x), hip.rowSums(x), hip.crossprod(x, y),
+               hip.matmul(x, z), hip.matmul(x, z), hip.sum(x), hip.colSums(xi)]
+        for g, w in zip(got, want):          # (rowSums adds in LDS-atomic order: not bit-reproducible)
+            assert_equal(np.asarray(g, dtype=np.float64), np.asarray(w, dtype=np.float64),
+                         tol=1e-12, atol=1e-13, strict_na=True)
+        st = hip.resident_stats()
+        assert st["entries"] == 2                           # x (with t(x)) and xi
+        assert st["hits"] - base["hits"] == 6 and st["misses"] - base["misses"] == 2
+        assert st["bytes"] >= 2 * 12 * 150_000             # x and t(x)
+        # a different object with equal shape is a different operand
+        assert_equal(hip.colSums(x2), oracle.colSums(x2), tol=1e-12)
+        assert hip.resident_stats()["entries"] == 3
+        # a modified copy of x (new leaf arrays) is not mistaken for x
+        leaves = list(x.leaves)
+        offs, vals = leaves[7]
+        leaves[7] = (offs.copy(), vals.copy() * 2.0)
+        xm = SVT_SparseArray(x.dim, x.type, leaves)
+        assert_equal(hip.colSums(xm), oracle.colSums(xm), tol=1e-12, strict_na=True)
+        # LRU: a limit that holds only the small operand drops the others
+        hip.resident_set_limit(200_000)
+        st = hip.resident_stats()
+        assert st["bytes"] <= 200_000
+        assert_identical(hip.colSums(x), want[0])             # too big to stay: one-call upload
+        assert hip.resident_stats()["bytes"] <= 200_000
+        hip.resident_clear()
+        assert hip.resident_stats()["entries"] == 0
+    finally:
+        hip.resident_set_limit(0)
+    assert hip.resident_stats()["bytes"] == 0
+    assert_identical(hip.colSums(x), want[0])

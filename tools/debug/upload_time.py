@@ -32,3 +32,26 @@ for rep in range(2):
     rc = fn(ctypes.addressof(view), y.ctypes.data, nrow, K, 14, 0, out.ctypes.data)
     dt = time.perf_counter() - t0
     print(f"C_crossprod2_SVT_mat host level: rc={rc} {dt*1e3:.1f} ms  ({len(ri)/dt/1e9:.2f} GNZ/s)")
+
+# resident operands: the same calls with the device copy (and its panel-blocked layout) kept
+lib.svt_resident_set_limit.argtypes = [ctypes.c_size_t]
+lib.svt_resident_set_limit(8 << 30)
+for rep in range(3):
+    t0 = time.perf_counter()
+    rc = fn(ctypes.addressof(view), y.ctypes.data, nrow, K, 14, 0, out.ctypes.data)
+    dt = time.perf_counter() - t0
+    print(f"C_crossprod2_SVT_mat, resident x: rc={rc} {dt*1e3:.1f} ms  ({len(ri)/dt/1e9:.2f} GNZ/s)")
+from sparsearray_amd._dispatch import CAbiDispatcher
+op_sum = CAbiDispatcher(lib, "svt_")._opcode("sum")
+cs = lib.svt_colStats_SVT
+cs.restype = ctypes.c_int
+cs.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+res = np.zeros(ncol)
+warn = ctypes.c_int(0)
+for lim in (8 << 30, 0):
+    lib.svt_resident_set_limit(lim)
+    for rep in range(3):
+        t0 = time.perf_counter()
+        rc = cs(ctypes.addressof(view), op_sum, 0, float("nan"), 1, res.ctypes.data, ctypes.addressof(warn))
+        dt = time.perf_counter() - t0
+        print(f"C_colStats_SVT(sum), resident limit {lim >> 30} GiB: rc={rc} {dt*1e3:.2f} ms")
