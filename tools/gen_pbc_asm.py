@@ -176,6 +176,14 @@ def gen(prof):
     ph = [f"{20 + i}" for i in range(NPH)]          # phase labels
     # ---------------------------------------------------------------- setup
     e("v_mov_b32 v10, 0x207")                      # class mask: sNaN | qNaN | -Inf | +Inf
+    if "ytouch" in EXP:                            # (experiment) v11 = L2-touch offsets into Y, 2 panels past the staged one
+        e("v_lshrrev_b32 v11, 7, v1")              # lane >> 3 = piece
+        e("s_sub_u32 vcc_lo, s22, s20")            # bytes between two dense columns (low word)
+        e("v_mul_lo_u32 v11, v11, vcc_lo")
+        e("v_bfe_u32 v5, v1, 4, 3")                # lane & 7 = 128-byte line of the piece
+        e("v_lshlrev_b32 v5, 7, v5")
+        e("v_add_u32 v11, v11, v5")
+        e("v_add_u32 v11, 0x800, v11")
     if "nosmem" in EXP:                            # constant, valid records (row j, column 5j, value 1.0)
         for r in BLK.values():
             for j in range(8):
@@ -200,7 +208,7 @@ def gen(prof):
     e(f"s_mov_b32 vcc_hi, {NPH}")
     e("s_branch 60f")
     e("17:")
-    e("s_waitcnt vmcnt(1)")                        # own pieces of this panel (the younger touch may fly)
+    e(f"s_waitcnt vmcnt({2 if 'ytouch' in EXP else 1})")   # own pieces of this panel (the younger touch may fly)
     stamp(1)                                       # own DMA pieces
     if "nobarrier" not in EXP:
         e("s_barrier")                             # everybody's pieces; everybody done with the previous panel
@@ -301,6 +309,11 @@ def gen(prof):
     for q in range(4):
         e(f"s_add_u32 s{20 + 2 * q}, s{20 + 2 * q}, 1024")
         e(f"s_addc_u32 s{21 + 2 * q}, s{21 + 2 * q}, 0")
+    if "ytouch" in EXP:
+        e("s_mov_b32 exec_lo, -1")
+        e("s_mov_b32 exec_hi, 0")
+        e("global_load_dword v5, v11, s[20:21]")
+        e("s_mov_b64 exec, -1")
     e("v_add_u32 v6, s10, v2")                     # records ~2 panels ahead towards L2
     e("s_mov_b32 exec_lo, s19")
     e("s_mov_b32 exec_hi, 0")
