@@ -226,6 +226,53 @@ rowpanel_table_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__rest
 		pt[q * ncol + j] = (int32_t) (end - beg);
 }
 
+// Same table, 16 leaves per workgroup (a wavefront each): the entries are collected in LDS
+// and every table row gets one 64-byte run instead of 16 scattered 4-byte stores (the
+// scattered form spends 222 us of a 0.65 ms rowSums at BASELINE config 2 on write
+// amplification).  LDS: (npan + 1) * 64 bytes.
+#define PT_LEAVES 16
+__global__ void __launch_bounds__(PT_LEAVES * 64)
+rowpanel_table16_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__ row_idx,
+			int64_t ncol, int64_t npan, int32_t *__restrict__ pt)
+{
+	extern __shared__ int32_t tab[];            // [npan + 1][PT_LEAVES]
+	const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int64_t j0 = (int64_t) blockIdx.x * PT_LEAVES, j = j0 + w;
+	if (j < ncol) {
+		const int64_t beg = col_ptr[j], end = col_ptr[j + 1];
+		int carry = -1;                         // panel of the element before this trip
+		for (int64_t k0 = beg; k0 < end; k0 += 4 * 64) {
+			int32_t r[4];
+#pragma unroll
+			for (int u = 0; u < 4; u++) {       // four coalesced loads in flight
+				const int64_t k = k0 + u * 64 + lane;
+				r[u] = k < end ? row_idx[k] : 0x7FFFFFFF;
+			}
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				const int64_t k = k0 + u * 64 + lane;
+				const int p = r[u] / ROWPANEL;
+				int prev = __shfl_up(p, 1, 64);
+				if (lane == 0) prev = carry;
+				carry = __shfl(p, 63, 64);
+				if (k < end)
+					for (int q = prev + 1; q <= p; q++)
+						tab[(int64_t) q * PT_LEAVES + w] = (int32_t) (k - beg);
+			}
+		}
+		const int64_t pl = end > beg ? row_idx[end - 1] / ROWPANEL : -1;
+		for (int64_t q = pl + 1 + lane; q <= npan; q += 64)
+			tab[q * PT_LEAVES + w] = (int32_t) (end - beg);
+	}
+	__syncthreads();
+	const int64_t n = (npan + 1) * PT_LEAVES;
+	for (int64_t t = threadIdx.x; t < n; t += PT_LEAVES * 64) {
+		const int64_t q = t / PT_LEAVES, l = t % PT_LEAVES;
+		if (j0 + l < ncol)
+			pt[q * ncol + j0 + l] = tab[t];
+	}
+}
+
 // G = lanes that share one leaf segment (power of two <= 64): the host picks
 // it from the mean segment length so that short segments still fill the wave.
 template <typename T>
@@ -388,7 +435,11 @@ int launch_rowstats_panel(const RowStatsArgs &a, void *ws, hipStream_t s)
 	int32_t *pt = (int32_t *) ws;
 	if (a.inner > 65535)
 		return svt_set_error("row stats: more than 65535 output columns per panel row");
-	if (a.ncol > 0) {
+	if (a.ncol > 0 && (size_t) (npan + 1) * PT_LEAVES * 4 <= 64 * 1024) {
+		hipLaunchKernelGGL(rowpanel_table16_kernel, dim3((unsigned) ((a.ncol + PT_LEAVES - 1) / PT_LEAVES)),
+				   dim3(PT_LEAVES * 64), (size_t) (npan + 1) * PT_LEAVES * 4, s,
+				   a.col_ptr, a.row_idx, a.ncol, npan, pt);
+	} else if (a.ncol > 0) {                    // very tall arrays: the table rows do not fit LDS
 		// (grid == ncol selects the workgroup-per-leaf form; never equal to (ncol+3)/4 for ncol > 1)
 		const bool wide = a.nnz_hint / a.ncol >= 1024 && a.ncol > 1;
 		hipLaunchKernelGGL(rowpanel_table_kernel, dim3((unsigned) (wide ? a.ncol : (a.ncol + 3) / 4)),
