@@ -178,6 +178,40 @@ static int staged_copy(void *dst, const void *src, size_t n)
 	return g_stager.drain();
 }
 
+// device -> contiguous host array: D2H into one pinned buffer while the thread team
+// copies the previous chunk out of the other (results can be large: the 1e6 x 128
+// product of BASELINE config 3 is 1 GB)
+static int staged_download(void *dst, const void *src, size_t n)
+{
+	if (n < ((size_t) 4 << 20)) {
+		if (n) HIP_TRY(hipMemcpy(dst, src, n, hipMemcpyDeviceToHost));
+		return 0;
+	}
+	if (g_stager.init() || g_stager.drain()) return -1;
+	HIP_TRY(hipDeviceSynchronize());            // the producer kernels ran on other streams
+	const size_t C = Stager::CHUNK;
+	const size_t nchunk = (n + C - 1) / C;
+	for (size_t c = 0; c <= nchunk; c++) {
+		if (c < nchunk) {                   // start chunk c into buffer c & 1
+			const size_t off = c * C, len = n - off < C ? n - off : C;
+			HIP_TRY(hipMemcpyAsync(g_stager.buf[c & 1], (const char *) src + off, len,
+					       hipMemcpyDeviceToHost, g_stager.stream));
+			HIP_TRY(hipEventRecord(g_stager.done[c & 1], g_stager.stream));
+		}
+		if (c > 0) {                        // chunk c - 1 has landed: copy it out
+			const size_t off = (c - 1) * C, len = n - off < C ? n - off : C;
+			HIP_TRY(hipEventSynchronize(g_stager.done[(c - 1) & 1]));
+			const char *b = g_stager.buf[(c - 1) & 1];
+			char *d0 = (char *) dst + off;
+			team_run(team_size(len), [&](int t, int nt) {
+				const size_t a = len * t / nt, e = len * (t + 1) / nt;
+				memcpy(d0 + a, b + a, e - a);
+			});
+		}
+	}
+	return 0;
+}
+
 // ---- small RAII device buffer --------------------------------------------------
 struct DevBuf {
 	void *p = nullptr;
@@ -732,8 +766,9 @@ extern "C" int svt_aperm_SVT(const svt_view *x, const int *perm, int64_t *out_co
 		return -1;
 	HIP_TRY(hipMemcpy(out_col_ptr, P.p, (size_t) (new_nl + 1) * 8, hipMemcpyDeviceToHost));
 	if (A.h->nnz) {
-		HIP_TRY(hipMemcpy(out_row_idx, I.p, (size_t) A.h->nnz * 4, hipMemcpyDeviceToHost));
-		HIP_TRY(hipMemcpy(out_val, V.p, (size_t) A.h->nnz * esz, hipMemcpyDeviceToHost));
+		if (staged_download(out_row_idx, I.p, (size_t) A.h->nnz * 4) ||
+		    staged_download(out_val, V.p, (size_t) A.h->nnz * esz))
+			return -1;
 	}
 	return 0;
 }
@@ -782,10 +817,46 @@ static int chunk_K(int64_t nrow, int64_t K)
 	return (int) kc;
 }
 
+static bool pbc_applies(const svt_dev_csc *A, int64_t K, int tr_y)
+{
+	return A->Rtype == SVT_REALSXP && !tr_y && A->nrow >= 256 && A->ncol > 0 &&
+	       (double) A->nnz * (double) K >= 268435456.0;
+}
+
+// The layout build is device work (a few ms at 1e8 nonzeros) and the upload of the dense
+// operand is PCIe + host threads: start the build on a helper thread, upload meanwhile.
+struct PbcAhead {
+	std::thread th;
+	svt_dev_pbc *P = NULL;
+	int own = 1;
+	bool started = false, taken = false;
+	void start(const svt_dev_csc *A, int64_t K, int tr_y)
+	{
+		if (!pbc_applies(A, K, tr_y)) return;
+		started = true;
+		th = std::thread([this, A] {
+			(void) hipSetDevice(g_device);
+			P = pbc_for(A, &own);
+		});
+	}
+	svt_dev_pbc *get(int *own_out)
+	{
+		if (th.joinable()) th.join();
+		taken = true;
+		*own_out = own;
+		return P;
+	}
+	~PbcAhead()
+	{
+		if (th.joinable()) th.join();
+		if (P && own && !taken) svt_dev_pbc_release(P);
+	}
+};
+
 // out (device) receives all K columns; the dense operand is already on the device.
 static int dev_crossprod_chunked(const svt_dev_csc *A, const void *Y_dev, int64_t ldY,
 				 int64_t K, int tr_y, double *out_dev,
-				 int64_t sc, int64_t sk)
+				 int64_t sc, int64_t sk, PbcAhead *ahead = NULL)
 {
 	if (K <= 0 || A->ncol <= 0)
 		return 0;
@@ -794,10 +865,9 @@ static int dev_crossprod_chunked(const svt_dev_csc *A, const void *Y_dev, int64_
 	// pays for itself within the call.  Below the threshold the general kernels run,
 	// whose sums are bit-identical to the reference's sequential ones; above it the
 	// row-split partial sums differ from those in the last bits (parity bar: 1e-6).
-	if (A->Rtype == SVT_REALSXP && !tr_y && A->nrow >= 256 &&
-	    (double) A->nnz * (double) K >= 268435456.0) {
+	if (pbc_applies(A, K, tr_y)) {
 		int own_P = 1;
-		svt_dev_pbc *P = pbc_for(A, &own_P);
+		svt_dev_pbc *P = (ahead && ahead->started) ? ahead->get(&own_P) : pbc_for(A, &own_P);
 		if (P == NULL)                 // e.g. more records than 32-bit stream offsets reach:
 			goto general;          // the general kernels take any size
 		const int kc = K < 512 ? (int) K : 512;
@@ -854,13 +924,15 @@ extern "C" int svt_crossprod2_SVT_mat(const svt_view *x, const void *y, int y_nr
 	CscGuard A(x);
 	if (A.h == NULL) return -1;
 	DevBuf Y, O;
+	PbcAhead ahead;
+	ahead.start(A.h, out_ncol, tr_y);
 	if (Y.upload(y, (size_t) y_nrow * y_ncol * elt_size(y_Rtype)) ||
 	    O.alloc(out_n * 8) || O.zero())
 		return -1;
 	if (dev_crossprod_chunked(A.h, Y.p, y_nrow, out_ncol, tr_y, O.as<double>(),
-				  1, out_nrow))
+				  1, out_nrow, &ahead))
 		return -1;
-	HIP_TRY(hipMemcpy(out, O.p, out_n * 8, hipMemcpyDeviceToHost));
+	if (staged_download(out, O.p, out_n * 8)) return -1;
 	return 0;
 }
 
@@ -885,14 +957,16 @@ extern "C" int svt_crossprod2_mat_SVT(const void *x, int x_nrow, int x_ncol,
 	CscGuard A(y);
 	if (A.h == NULL) return -1;
 	DevBuf X, O;
+	PbcAhead ahead;
+	ahead.start(A.h, out_nrow, tr_x);
 	if (X.upload(x, (size_t) x_nrow * x_ncol * elt_size(x_Rtype)) ||
 	    O.alloc(out_n * 8) || O.zero())
 		return -1;
 	// result cell (i = dense vector, j = leaf) lives at out[i + j*out_nrow]
 	if (dev_crossprod_chunked(A.h, X.p, x_nrow, out_nrow, tr_x, O.as<double>(),
-				  out_nrow, 1))
+				  out_nrow, 1, &ahead))
 		return -1;
-	HIP_TRY(hipMemcpy(out, O.p, out_n * 8, hipMemcpyDeviceToHost));
+	if (staged_download(out, O.p, out_n * 8)) return -1;
 	return 0;
 }
 
@@ -979,7 +1053,7 @@ extern "C" int svt_crossprod2_SVT_SVT(const svt_view *x, const svt_view *y, doub
 	else                       // expand the columns of y, walk the leaves of x
 		rc = dev_crossprod_pp(X.h, Y.h, O.as<double>(), 1, out_nrow);
 	if (rc) return -1;
-	HIP_TRY(hipMemcpy(out, O.p, out_n * 8, hipMemcpyDeviceToHost));
+	if (staged_download(out, O.p, out_n * 8)) return -1;
 	return 0;
 }
 
@@ -1070,12 +1144,14 @@ extern "C" int svt_matmul_SVT_mat(const svt_view *x, const void *y, int y_nrow,
 	if (T == NULL) return -1;
 	A.drop();                           // a one-call operand: its untransposed copy can go now
 	DevBuf Y, O;
+	PbcAhead ahead;
+	ahead.start(T, y_ncol, 0);
 	if (Y.upload(y, (size_t) y_nrow * y_ncol * elt_size(y_Rtype)) ||
 	    O.alloc(out_n * 8) || O.zero())
 		return -1;
-	if (dev_crossprod_chunked(T, Y.p, y_nrow, y_ncol, 0, O.as<double>(), 1, out_nrow))
+	if (dev_crossprod_chunked(T, Y.p, y_nrow, y_ncol, 0, O.as<double>(), 1, out_nrow, &ahead))
 		return -1;
-	HIP_TRY(hipMemcpy(out, O.p, out_n * 8, hipMemcpyDeviceToHost));
+	if (staged_download(out, O.p, out_n * 8)) return -1;
 	return 0;
 }
 
@@ -1117,7 +1193,7 @@ extern "C" int svt_matmul_SVT_SVT(const svt_view *x, const svt_view *y, double *
 	else
 		rc = dev_crossprod_pp(T, Y.h, O.as<double>(), 1, out_nrow);
 	if (rc) return -1;
-	HIP_TRY(hipMemcpy(out, O.p, out_n * 8, hipMemcpyDeviceToHost));
+	if (staged_download(out, O.p, out_n * 8)) return -1;
 	return 0;
 }
 
@@ -1140,7 +1216,7 @@ extern "C" int svt_crossprod1_SVT(const svt_view *x, double *out)
 		return -1;
 	if (launch_mirror_lower(O.as<double>(), n, 0))
 		return -1;
-	HIP_TRY(hipMemcpy(out, O.p, out_n * 8, hipMemcpyDeviceToHost));
+	if (staged_download(out, O.p, out_n * 8)) return -1;
 	return 0;
 }
 
@@ -1300,7 +1376,7 @@ extern "C" int svt_rowStats_SVT(const svt_view *x, int opcode, int na_rm,
 		return -1;
 	}
 	int w = 0;
-	HIP_TRY(hipMemcpy(out, O.p, (size_t) out_len * osz, hipMemcpyDeviceToHost));
+	if (staged_download(out, O.p, (size_t) out_len * osz)) return -1;
 	HIP_TRY(hipMemcpy(&w, W.p, 4, hipMemcpyDeviceToHost));
 	if (w) *warn = 1;
 	return 0;
@@ -1359,7 +1435,7 @@ static int groupsum_host(const svt_dev_csc *A, const int32_t *col_ptr32,
 		rc = launch_rowsum(a, 0);
 	if (rc) return -1;
 	int w = 0;
-	HIP_TRY(hipMemcpy(out, O.p, (size_t) out_len * osz, hipMemcpyDeviceToHost));
+	if (staged_download(out, O.p, (size_t) out_len * osz)) return -1;
 	HIP_TRY(hipMemcpy(&w, W.p, 4, hipMemcpyDeviceToHost));
 	if (ovflow && w) *ovflow = 1;
 	return 0;
@@ -1433,7 +1509,7 @@ static int xsum_dgC(int nrow, int ncol, const double *xx, const int *xi, const i
 	if (colsum ? launch_colsum(a, 0) : launch_rowsum(a, 0))
 		return -1;
 	(void) ov;
-	HIP_TRY(hipMemcpy(out, O.p, (size_t) out_len * 8, hipMemcpyDeviceToHost));
+	if (staged_download(out, O.p, (size_t) out_len * 8)) return -1;
 	return 0;
 }
 
