@@ -181,6 +181,16 @@ pbc_pass_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__
 #undef TILE_OF
 }
 
+// flag = 1 if some column group's record stream does not fit a 32-bit byte cursor
+__global__ void pbc_group_limit_kernel(const int64_t *__restrict__ tile_ptr, int64_t npanels,
+				       int64_t ngroups, int *__restrict__ flag)
+{
+	const int64_t g = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= ngroups) return;
+	const int64_t n = tile_ptr[(g + 1) * npanels] - tile_ptr[g * npanels];
+	if ((n + PBC_SLACK) * 16 >= ((int64_t) 1 << 32)) *flag = 1;
+}
+
 extern "C" void svt_dev_pbc_release(svt_dev_pbc *h)
 {
 	if (h == NULL) return;
@@ -252,13 +262,16 @@ extern "C" svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB
 		const size_t rbytes = h->fmt == 1 ? 12 : 16;
 		// the kernels walk one group's stream with a 32-bit byte cursor
 		bool too_big = false;
-		const int64_t ngroups = h->ngroups;
-		if (ok) {
-			std::vector<int64_t> gp((size_t) ngroups + 1);
-			ok = hipMemcpy2D(gp.data(), 8, h->tile_ptr, (size_t) h->npanels * 8, 8,
-					 (size_t) ngroups + 1, hipMemcpyDeviceToHost) == hipSuccess;
-			for (int64_t g = 0; ok && g < ngroups; g++)
-				if ((gp[g + 1] - gp[g] + PBC_SLACK) * 16 >= ((int64_t) 1 << 32)) too_big = true;
+		if (ok && (nrec + PBC_SLACK) * 16 >= ((int64_t) 1 << 32)) {      // (else no group can be)
+			int *flag = (int *) tmp;                 // scan scratch, >= 16 bytes, free again
+			int hflag = 0;
+			ok = hipMemset(flag, 0, 4) == hipSuccess;
+			if (ok) {
+				hipLaunchKernelGGL(pbc_group_limit_kernel, dim3((unsigned) ((h->ngroups + 255) / 256)),
+						   dim3(256), 0, 0, h->tile_ptr, h->npanels, h->ngroups, flag);
+				ok = hipMemcpy(&hflag, flag, 4, hipMemcpyDeviceToHost) == hipSuccess;
+			}
+			too_big = hflag != 0;
 		}
 		if (ok && too_big) {
 			svt_set_error("svt_dev_pbc_build: a column group too large for 32-bit record offsets");
