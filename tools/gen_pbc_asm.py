@@ -208,7 +208,7 @@ def gen(prof):
     e(f"s_mov_b32 vcc_hi, {NPH}")
     e("s_branch 60f")
     e("17:")
-    e(f"s_waitcnt vmcnt({2 if 'ytouch' in EXP else 1})")   # own pieces of this panel (the younger touch may fly)
+    e(f"s_waitcnt vmcnt({2 if 'ytouch' in EXP else 0 if 'notouch' in EXP else 1})")   # own pieces of this panel (the younger touch may fly)
     stamp(1)                                       # own DMA pieces
     if "nobarrier" not in EXP:
         e("s_barrier")                             # everybody's pieces; everybody done with the previous panel
@@ -238,6 +238,9 @@ def gen(prof):
         d8(i)
         e("s_branch 12f")
     e("12:")
+    if "nofinite" in EXP:
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_branch 13f")
     e("ds_read_b64 v[8:9], v6")
     e(f"v_add_u32 v6, {CHK}, v6")
     e("s_waitcnt lgkmcnt(0)")
@@ -248,6 +251,7 @@ def gen(prof):
     e("s_sub_u32 m0, m0, 1")
     e("s_cmp_lg_u32 m0, 0")
     e("s_cbranch_scc1 12b")
+    e("13:")
     stamp(6)                                       # resume stub + finiteness prescan
     dispatch("s15", [ph[(i + 1) % NPH] for i in range(NPH)], "f")
     # ---------------------------------------------------------------- the phases
@@ -317,7 +321,8 @@ def gen(prof):
     e("v_add_u32 v6, s10, v2")                     # records ~2 panels ahead towards L2
     e("s_mov_b32 exec_lo, s19")
     e("s_mov_b32 exec_hi, 0")
-    e("global_load_dword v5, v6, s[8:9]")
+    if "notouch" not in EXP:
+        e("global_load_dword v5, v6, s[8:9]")
     e("s_mov_b64 exec, -1")
     e("61:")
     stamp(3)                                       # DMA + touch issue
