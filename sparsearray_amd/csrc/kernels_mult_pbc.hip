@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(64)
 pbc_pass_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__ row_idx,
 		const double *__restrict__ val, int64_t ncol, int CBW, int logR,
 		int64_t npanels, int64_t *__restrict__ counts_or_ptr,
-		uint4 *__restrict__ rec, int *__restrict__ col_has_na)
+		uint4 *__restrict__ rec, int *__restrict__ col_has_na, int stag_mode)
 {
 	constexpr int BATCH = FMT == 1 ? 8 : PBC_BATCH;
 	__shared__ int64_t fill[PCH];
@@ -174,8 +174,19 @@ pbc_pass_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__
 				if (FMT == 1) pbc1_store(rec, q, 0u, 0.0);
 				else rec[q] = make_uint4(0, 0, 0, 0);
 			}
-			if (FMT == 1)                               // flag the tile's last batch
+			if (FMT == 1) {                             // flag the tile's last batch ...
 				atomicOr((unsigned int *) ((char *) rec + ((stop - 8) >> 3) * 96), 0x8000u);
+				// ... and the batch after which the wavefront issues the LDS-DMA of the
+				// next panel: staggered over the wavefronts of a workgroup, never past
+				// the end of the tile
+				const int64_t start = counts_or_ptr[TILE_OF(p0 + i)];
+				const int w = (int) (wv % 16);
+				int64_t bi = stag_mode == 0 ? 0 : stag_mode == 1 ? (w & 1) :
+					     stag_mode == 2 ? (w & 3) : ((w >> 2) & 1);
+				const int64_t nb = (stop - start) >> 3;
+				if (bi > nb - 1) bi = nb - 1;
+				atomicOr((unsigned int *) ((char *) rec + ((start >> 3) + bi) * 96), 0x4000u);
+			}
 		}
 	}
 #undef TILE_OF
@@ -240,11 +251,11 @@ extern "C" svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB
 		if (h->fmt == 1)
 			hipLaunchKernelGGL((pbc_pass_kernel<0, 1>), grid, dim3(64), 0, 0, A->col_ptr, A->row_idx,
 					   (const double *) A->val, A->ncol, CBW, logR, h->npanels,
-					   h->tile_ptr, (uint4 *) NULL, h->col_has_na);
+					   h->tile_ptr, (uint4 *) NULL, h->col_has_na, g_pbc_stagger);
 		else
 			hipLaunchKernelGGL((pbc_pass_kernel<0, 0>), grid, dim3(64), 0, 0, A->col_ptr, A->row_idx,
 					   (const double *) A->val, A->ncol, CBW, logR, h->npanels,
-					   h->tile_ptr, (uint4 *) NULL, h->col_has_na);
+					   h->tile_ptr, (uint4 *) NULL, h->col_has_na, g_pbc_stagger);
 		// exclusive scan in place over ntiles+1 entries (last entry = total)
 		ok = hipcub::DeviceScan::ExclusiveSum(NULL, tmp_bytes, h->tile_ptr, h->tile_ptr,
 						      (int) (ntiles + 1)) == hipSuccess &&
@@ -286,11 +297,11 @@ extern "C" svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB
 			if (h->fmt == 1)
 				hipLaunchKernelGGL((pbc_pass_kernel<1, 1>), grid, dim3(64), 0, 0, A->col_ptr,
 						   A->row_idx, (const double *) A->val, A->ncol, CBW, logR,
-						   h->npanels, h->tile_ptr, h->rec, h->col_has_na);
+						   h->npanels, h->tile_ptr, h->rec, h->col_has_na, g_pbc_stagger);
 			else
 				hipLaunchKernelGGL((pbc_pass_kernel<1, 0>), grid, dim3(64), 0, 0, A->col_ptr,
 						   A->row_idx, (const double *) A->val, A->ncol, CBW, logR,
-						   h->npanels, h->tile_ptr, h->rec, h->col_has_na);
+						   h->npanels, h->tile_ptr, h->rec, h->col_has_na, g_pbc_stagger);
 			ok = hipDeviceSynchronize() == hipSuccess;
 		}
 	}
@@ -749,7 +760,9 @@ crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restric
 		const int lane = tid & 63;
 		V0[0] = (uint32_t) lane * PBC_DMA_ROW;
 		V0[1] = (uint32_t) lane * 16u;
-		V0[2] = (lane < rt_lines ? (uint32_t) lane * 128u : 0u) + (uint32_t) rt_ahead;
+		// record touch: one 128-byte line per lane, the lanes past rt_lines repeat the last one
+		V0[2] = (uint32_t) (lane < rt_lines ? lane : rt_lines - 1) * 128u + (uint32_t) rt_ahead;
+		V0[11] = (uint32_t) lane * 16u;             // DMA lane offset + bytes staged so far
 		// finiteness prescan: this block's share of the 8192 doubles of a panel
 		const int chunk = (8192 + nblocks - 1) / nblocks;
 		const int nit = (chunk + 1023) / 1024;
@@ -888,7 +901,9 @@ __global__ void pbc_nafix_kernel(const int *__restrict__ col_has_na, int K, int6
 // Row splits: enough workgroups to fill the chip, every split non-empty.
 static bool pbc_dma_ok(const svt_dev_pbc *P, int tr_y)
 {
-	return !tr_y && P->fmt == 1;                // the layout was built for it
+	// the layout was built for it; the kernel stages a row split through 32-bit byte offsets
+	// (8 bytes per row per dense column), and a split is never longer than the matrix
+	return !tr_y && P->fmt == 1 && P->nrow < ((int64_t) 1 << 28);
 }
 
 static int pick_nsplit(const svt_dev_pbc *P, int K, bool dma, int64_t *pps_out)

@@ -29,7 +29,8 @@ Measured (tools/debug/exp_pbc.sh): what a phase costs is the round trips behind 
 single wait, not its instructions -- twice the work per phase ran 1.5 % slower --
 hence 8 records per phase (the SGPR file allows no more: 3 x 24).
 
-DMA issue: all 4 pieces of a wavefront at once, after s16 (= w & 3) phases.
+DMA issue: all 4 pieces of a wavefront at once, after the batch the layout flags with bit 14
+(batch w & 3 of the tile, or its last one), so that the phases pay one flag test, not two.
 Alternatives measured at config 2a: every piece on its own between phases 2.85 ms,
 in pairs 2.50 ms, staggered batches of four 2.14 ms (a lone piece stalls its
 wavefront ~260 cycles, four back to back ~130 each); all 64 at the barrier 2.32 ms.
@@ -40,9 +41,9 @@ Register map (fixed physical registers; the kernel pins C++ vectors to them):
         s11 next panel index         s12 end panel
         s13 LDS byte offset of the buffer holding the current panel (0 / BUF)
         s14 LDS byte address of this wavefront's first DMA piece in buffer 1
-        s15 phase to resume at       s16 DMA stagger (phases)   s17 its countdown (<0: issued)
-        s18 sticky "non-finite seen" s19 lane mask of the record touch
-        s[20:27] DMA source bases of the 4 pieces of the next panel to stage
+        s15 phase to resume at       s16, s17, s19 unused
+        s18 sticky "non-finite seen"
+        s[20:27] DMA source bases of the wavefront's 4 dense columns (row split start + 1 panel)
         vcc_lo scratch, vcc_hi return selector of the issue routine, m0 scratch
   VGPR  v0 lane*ROW (lane base, buffer 0)   v1 lane*16 (DMA lane offset)
         v2 record-touch lane offset (+ look-ahead distance)
@@ -50,7 +51,8 @@ Register map (fixed physical registers; the kernel pins C++ vectors to them):
         v5 touch destination (never read)   v6 scratch address
         v7 constants by lane: [0] finite-check iterations, [1] index of the partial
            last panel (or ~0), [2] byte shift of that panel's window
-        v[8:9] check value  v10 class mask  v11 spare
+        v[8:9] check value  v10 class mask
+        v11 DMA offset: lane*16 + bytes of the panels staged so far (32-bit: per row split)
         v[12:27] y set a, v[28:43] y set b (YSETS = 2)  /  v[12:19] addresses,
         v[20:35] y (YSETS = 1)
         v[ACC:...] partial sums (register-indexed: v[ACC + 2*column]), ACC = 44 / 36
@@ -176,14 +178,6 @@ def gen(prof):
     ph = [f"{20 + i}" for i in range(NPH)]          # phase labels
     # ---------------------------------------------------------------- setup
     e("v_mov_b32 v10, 0x207")                      # class mask: sNaN | qNaN | -Inf | +Inf
-    if "ytouch" in EXP:                            # (experiment) v11 = L2-touch offsets into Y, 2 panels past the staged one
-        e("v_lshrrev_b32 v11, 7, v1")              # lane >> 3 = piece
-        e("s_sub_u32 vcc_lo, s22, s20")            # bytes between two dense columns (low word)
-        e("v_mul_lo_u32 v11, v11, vcc_lo")
-        e("v_bfe_u32 v5, v1, 4, 3")                # lane & 7 = 128-byte line of the piece
-        e("v_lshlrev_b32 v5, 7, v5")
-        e("v_add_u32 v11, v11, v5")
-        e("v_add_u32 v11, 0x800, v11")
     if "nosmem" in EXP:                            # constant, valid records (row j, column 5j, value 1.0)
         for r in BLK.values():
             for j in range(8):
@@ -202,13 +196,8 @@ def gen(prof):
     e("s_waitcnt lgkmcnt(0)")
     e("s_cmp_ge_u32 s11, s12")
     e("s_cbranch_scc1 90f")
-    # pieces of this panel not issued yet (tile shorter than the stagger)? do it now
-    e("s_cmp_lt_i32 s17, 0")
-    e("s_cbranch_scc1 17f")
-    e(f"s_mov_b32 vcc_hi, {NPH}")
-    e("s_branch 60f")
-    e("17:")
-    e(f"s_waitcnt vmcnt({2 if 'ytouch' in EXP else 0 if 'notouch' in EXP else 1})")   # own pieces of this panel (the younger touch may fly)
+    # (the pieces of the next panel were issued inside the tile: the layout flags the batch)
+    e(f"s_waitcnt vmcnt({0 if 'notouch' in EXP else 1})")   # own pieces of this panel (the younger touch may fly)
     stamp(1)                                       # own DMA pieces
     if "nobarrier" not in EXP:
         e("s_barrier")                             # everybody's pieces; everybody done with the previous panel
@@ -222,7 +211,6 @@ def gen(prof):
     e("s_nop 3")                                   # (VALU-written SGPR read by a VALU)
     e("v_add_u32 v4, vcc_lo, v4")                  # to end at the last row; rows sit further in
     e("16:")
-    e("s_mov_b32 s17, s16")                        # arm the staggered issue of the next panel
     e("s_add_u32 s11, s11, 1")
     # finite check of this workgroup's share of the panel: the first read rides on
     # the resume stub's LDS wait, the rest (few column blocks only) loop at 12
@@ -271,37 +259,47 @@ def gen(prof):
         e("s_waitcnt lgkmcnt(0)")
         if i == NPH - 1:
             e(f"s_add_u32 s10, s10, {TRIP}")
-        if "nosmem" in EXP:
+        if "nosmem" in EXP:                        # (experiment: 7 batches per tile, issue after the third)
             e("s_sub_u32 s99, s99, 1")
+            e("s_cmp_eq_u32 s99, 4")
+            e(f"s_cbranch_scc1 {70 + i}f")
             e("s_cmp_eq_u32 s99, 0")
+            e(f"s_cbranch_scc1 {30 + i}f")
         else:
-            e(f"s_bitcmp1_b32 s{BLK[X0[i % 3]]}, 15")  # last batch of the tile?
-        e(f"s_cbranch_scc1 {30 + i}f")
-        e("s_sub_u32 s17, s17, 1")                 # stagger expired: issue the next panel's pieces
-        e(f"s_cbranch_scc1 {70 + i}f")
+            # bit 15 of the batch's first meta word: last batch of the tile; bit 14: issue the
+            # LDS-DMA of the next panel after this batch.  One test on the fast path.
+            e(f"s_and_b32 vcc_lo, s{BLK[X0[i % 3]]}, 0xc000")
+            e(f"s_cbranch_scc1 {70 + i}f")
     e(f"s_branch {ph[0]}b")
+    for i in range(NPH):
+        r0 = BLK[X0[i % 3]]
+        e(f"{70 + i}:")
+        if "nosmem" not in EXP:
+            e(f"s_bitcmp1_b32 s{r0}, 14")
+            e(f"s_cbranch_scc0 {30 + i}f")         # only the end-of-tile flag
+        e(f"s_mov_b32 vcc_hi, {i}")
+        e("s_branch 60f")
+        e(f"{80 + i}:")                            # back from the issue routine
+        if "nosmem" not in EXP:
+            e(f"s_bitcmp1_b32 s{r0}, 15")
+            e(f"s_cbranch_scc1 {30 + i}f")
+        e(f"s_branch {ph[(i + 1) % NPH]}b")
     for i in range(NPH):
         e(f"{30 + i}:")
         e(f"s_mov_b32 s15, {i}")
         e("s_branch 10b")
-    for i in range(NPH):
-        e(f"{70 + i}:")
-        e(f"s_mov_b32 vcc_hi, {i}")
-        e("s_branch 60f")
     # ---- issue the DMA pieces of panel s11 (the one after the current) + the
     # ---- record touch; returns to phase vcc_hi+1 or (vcc_hi = NPH) to the boundary
     e("60:")
     stamp(7)
-    e("s_mov_b32 s17, -1")
     e("s_cmp_ge_u32 s11, s12")
     e("s_cbranch_scc1 61f")
     e("v_readlane_b32 vcc_lo, v7, 1")
     e("s_cmp_lg_u32 s11, vcc_lo")
     e("s_cbranch_scc1 15f")
-    e("v_readlane_b32 vcc_lo, v7, 2")
-    for q in range(4):                             # partial last panel: its window ends at the
-        e(f"s_sub_u32 s{20 + 2 * q}, s{20 + 2 * q}, vcc_lo")   # last row (rows nrow-128 .. nrow-1)
-        e(f"s_subb_u32 s{21 + 2 * q}, s{21 + 2 * q}, 0")
+    e("v_readlane_b32 vcc_lo, v7, 2")              # partial last panel: its window ends at the
+    e("s_nop 3")                                   # last row (rows nrow-128 .. nrow-1)
+    e("v_subrev_u32 v11, vcc_lo, v11")
     e("15:")
     e("s_sub_u32 m0, s14, s13")                    # first piece, other buffer
     for q in range(4):
@@ -309,24 +307,15 @@ def gen(prof):
             e(f"s_add_u32 m0, m0, {ROW}")
         e("s_nop 0")
         if "nodma" not in EXP:
-            e(f"global_load_lds_dwordx4 v1, s[{20 + 2 * q}:{21 + 2 * q}]")
-    for q in range(4):
-        e(f"s_add_u32 s{20 + 2 * q}, s{20 + 2 * q}, 1024")
-        e(f"s_addc_u32 s{21 + 2 * q}, s{21 + 2 * q}, 0")
-    if "ytouch" in EXP:
-        e("s_mov_b32 exec_lo, -1")
-        e("s_mov_b32 exec_hi, 0")
-        e("global_load_dword v5, v11, s[20:21]")
-        e("s_mov_b64 exec, -1")
-    e("v_add_u32 v6, s10, v2")                     # records ~2 panels ahead towards L2
-    e("s_mov_b32 exec_lo, s19")
-    e("s_mov_b32 exec_hi, 0")
-    if "notouch" not in EXP:
+            e(f"global_load_lds_dwordx4 v11, s[{20 + 2 * q}:{21 + 2 * q}]")
+    e("s_nop 1")
+    e("v_add_u32 v11, 1024, v11")                  # next panel (the bases stay; 32-bit offsets per row split)
+    e("v_add_u32 v6, s10, v2")                     # records ~2 panels ahead towards L2 (all lanes:
+    if "notouch" not in EXP:                       # those past the tile repeat its last line)
         e("global_load_dword v5, v6, s[8:9]")
-    e("s_mov_b64 exec, -1")
     e("61:")
     stamp(3)                                       # DMA + touch issue
-    dispatch("vcc_hi", [ph[(i + 1) % NPH] for i in range(NPH)] + ["17"], "b")
+    dispatch("vcc_hi", [f"{80 + i}" for i in range(NPH)], "b")
     e("90:")
     e("s_waitcnt vmcnt(0) lgkmcnt(0)")
     return out
