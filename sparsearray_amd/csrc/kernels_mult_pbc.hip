@@ -739,12 +739,14 @@ crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restric
 		PB[1] = PBC_DMA_BUF;                            // toggles to 0 for the first panel
 		PB[2] = (uint32_t) (w * 4 * PBC_DMA_ROW + PBC_DMA_BUF);
 		PB[3] = 0;
-		// stagger of the DMA issue, in phases
-		PB[4] = stag_mode == 0 ? 0u : stag_mode == 1 ? (uint32_t) (w & 1) :
-			stag_mode == 2 ? (uint32_t) (w & 3) : (uint32_t) ((w >> 2) & 1);
-		PB[5] = 0xFFFFFFFFu;                       // "pieces of the first panel are issued"
+		// partial last panel (staged as rows nrow-128 .. nrow-1): its index, the byte shift
+		PB[4] = partial ? (uint32_t) (npanels - 1) : 0xFFFFFFFFu;
+		PB[5] = partial ? (uint32_t) ((128 - (nrow & 127)) * 8) : 0u;
 		PB[6] = 0;
-		PB[7] = (1u << rt_lines) - 1u;                  // lanes of the record touch (rt_lines <= 31)
+		{   // finiteness prescan: iterations - 1 over this block's share of a panel (see V0[3])
+			const int chunk = (8192 + nblocks - 1) / nblocks;
+			PB[7] = (uint32_t) ((chunk + 1023) / 1024 - 1);
+		}
 #pragma unroll
 		for (int q = 0; q < 4; q++) {
 			int kk = k0 + w * 4 + q;

@@ -187,61 +187,78 @@ def gen(prof):
     load("A", 0)
     load("B", BATCH)
     e(f"s_add_u32 s10, s10, {2 * BATCH}")
-    e(f"s_mov_b32 s15, {NPH - 1}")
-    # ---------------------------------------------------------------- panel boundary
-    e("10:")
-    if "nosmem" in EXP:
-        e("s_mov_b32 s99, 7")
-    stamp(7)                                       # phases
-    e("s_waitcnt lgkmcnt(0)")
-    e("s_cmp_ge_u32 s11, s12")
-    e("s_cbranch_scc1 90f")
-    # (the pieces of the next panel were issued inside the tile: the layout flags the batch)
-    e(f"s_waitcnt vmcnt({0 if 'notouch' in EXP else 1})")   # own pieces of this panel (the younger touch may fly)
-    stamp(1)                                       # own DMA pieces
-    if "nobarrier" not in EXP:
-        e("s_barrier")                             # everybody's pieces; everybody done with the previous panel
-    stamp(2)                                       # barrier
-    e(f"s_xor_b32 s13, s13, {BUF}")
-    e("v_add_u32 v4, s13, v0")
-    e("v_readlane_b32 vcc_lo, v7, 1")
-    e("s_cmp_lg_u32 s11, vcc_lo")
-    e("s_cbranch_scc1 16f")
-    e("v_readlane_b32 vcc_lo, v7, 2")              # partial last panel: its window was moved back
-    e("s_nop 3")                                   # (VALU-written SGPR read by a VALU)
-    e("v_add_u32 v4, vcc_lo, v4")                  # to end at the last row; rows sit further in
-    e("16:")
-    e("s_add_u32 s11, s11, 1")
-    # finite check of this workgroup's share of the panel: the first read rides on
-    # the resume stub's LDS wait, the rest (few column blocks only) loop at 12
-    e("v_readlane_b32 vcc_lo, v7, 0")
-    e("v_add_u32 v6, s13, v3")
-    e("s_mov_b32 m0, vcc_lo")
-    stamp(4)                                       # boundary bookkeeping
-    dispatch("s15", [f"{40 + i}" for i in range(NPH)], "f")
-    # ---------------------------------------------------------------- resume stubs
-    for i in range(NPH):
-        e(f"{40 + i}:")
-        stamp(5)                                   # dispatch
-        d8(i)
-        e("s_branch 12f")
-    e("12:")
-    if "nofinite" in EXP:
+    e(f"s_branch {30 + NPH - 1}f")                 # first panel: enter through the last phase's boundary
+
+    # ---- panel boundary after a tile that ended in phase i (one copy per phase: no
+    # ---- dispatch chains; the scalar unit is the busiest pipe of this kernel)
+    def boundary(i):
+        e(f"{30 + i}:")
+        if "nosmem" in EXP:
+            e("s_mov_b32 s99, 7")
+        stamp(7)                                   # phases
         e("s_waitcnt lgkmcnt(0)")
-        e("s_branch 13f")
-    e("ds_read_b64 v[8:9], v6")
-    e(f"v_add_u32 v6, {CHK}, v6")
-    e("s_waitcnt lgkmcnt(0)")
-    e("v_cmp_class_f64 vcc, v[8:9], v10")
-    if "nocheck" not in EXP:
-        e("s_or_b32 s18, s18, vcc_lo")
-        e("s_or_b32 s18, s18, vcc_hi")
-    e("s_sub_u32 m0, m0, 1")
-    e("s_cmp_lg_u32 m0, 0")
-    e("s_cbranch_scc1 12b")
-    e("13:")
-    stamp(6)                                       # resume stub + finiteness prescan
-    dispatch("s15", [ph[(i + 1) % NPH] for i in range(NPH)], "f")
+        e("s_cmp_ge_u32 s11, s12")
+        e("s_cbranch_scc1 90f")
+        # own pieces of this panel (issued inside the previous tile; the younger touch may fly)
+        e(f"s_waitcnt vmcnt({0 if 'notouch' in EXP else 1})")
+        stamp(1)                                   # own DMA pieces
+        if "nobarrier" not in EXP:
+            e("s_barrier")                         # everybody's pieces; everybody done with the previous panel
+        stamp(2)                                   # barrier
+        e(f"s_xor_b32 s13, s13, {BUF}")
+        e("v_add_u32 v4, s13, v0")
+        e("s_cmp_lg_u32 s11, s16")
+        e("s_cbranch_scc1 16f")
+        e("v_add_u32 v4, s17, v4")                 # partial last panel: its window was moved back to end
+        e("16:")                                   # at the last row; the rows sit further in
+        e("s_add_u32 s11, s11, 1")
+        # finite check of this workgroup's share of the panel: the first read rides on
+        # the LDS wait of the reads below, the rest (few column blocks only) loop at 12
+        e("v_add_u32 v6, s13, v3")
+        e("s_mov_b32 m0, s19")
+        stamp(4)                                   # boundary bookkeeping
+        d8(i)                                      # LDS reads of the batch the next phase multiplies
+        stamp(5)
+        if "nofinite" in EXP:
+            e("s_waitcnt lgkmcnt(0)")
+        else:
+            e("12:")
+            e("ds_read_b64 v[8:9], v6")
+            e(f"v_add_u32 v6, {CHK}, v6")
+            e("s_waitcnt lgkmcnt(0)")
+            e("v_cmp_class_f64 vcc, v[8:9], v10")
+            if "nocheck" not in EXP:
+                e("s_or_b32 s18, s18, vcc_lo")
+                e("s_or_b32 s18, s18, vcc_hi")
+            e("s_sub_u32 m0, m0, 1")               # m0 = iterations - 1: loop until it borrows
+            e("s_cbranch_scc0 12b")
+        stamp(6)                                   # resume reads + finiteness prescan
+        e(f"s_branch {ph[(i + 1) % NPH]}b")
+
+    # ---- DMA pieces of panel s11 (the one after the current) + the record touch
+    def issue():
+        stamp(7)
+        e("s_cmp_ge_u32 s11, s12")
+        e("s_cbranch_scc1 61f")
+        e("s_cmp_lg_u32 s11, s16")
+        e("s_cbranch_scc1 15f")
+        e("v_subrev_u32 v11, s17, v11")            # partial last panel: its window ends at the last row
+        e("15:")
+        e("s_sub_u32 m0, s14, s13")                # first piece, other buffer
+        for q in range(4):
+            if q:
+                e(f"s_add_u32 m0, m0, {ROW}")
+            e("s_nop 0")
+            if "nodma" not in EXP:
+                e(f"global_load_lds_dwordx4 v11, s[{20 + 2 * q}:{21 + 2 * q}]")
+        e("s_nop 1")
+        e("v_add_u32 v11, 1024, v11")              # next panel (the bases stay; 32-bit offsets per row split)
+        e("v_add_u32 v6, s10, v2")                 # records ~2 panels ahead towards L2 (all lanes:
+        if "notouch" not in EXP:                   # those past the tile repeat its last line)
+            e("global_load_dword v5, v6, s[8:9]")
+        e("61:")
+        stamp(3)                                   # DMA + touch issue
+
     # ---------------------------------------------------------------- the phases
     for i in range(NPH):
         if i == 0 and "align" in EXP:
@@ -271,51 +288,19 @@ def gen(prof):
             e(f"s_and_b32 vcc_lo, s{BLK[X0[i % 3]]}, 0xc000")
             e(f"s_cbranch_scc1 {70 + i}f")
     e(f"s_branch {ph[0]}b")
-    for i in range(NPH):
+    for i in range(NPH):                           # slow paths: a flagged batch
         r0 = BLK[X0[i % 3]]
         e(f"{70 + i}:")
         if "nosmem" not in EXP:
             e(f"s_bitcmp1_b32 s{r0}, 14")
             e(f"s_cbranch_scc0 {30 + i}f")         # only the end-of-tile flag
-        e(f"s_mov_b32 vcc_hi, {i}")
-        e("s_branch 60f")
-        e(f"{80 + i}:")                            # back from the issue routine
+        issue()
         if "nosmem" not in EXP:
             e(f"s_bitcmp1_b32 s{r0}, 15")
             e(f"s_cbranch_scc1 {30 + i}f")
         e(f"s_branch {ph[(i + 1) % NPH]}b")
     for i in range(NPH):
-        e(f"{30 + i}:")
-        e(f"s_mov_b32 s15, {i}")
-        e("s_branch 10b")
-    # ---- issue the DMA pieces of panel s11 (the one after the current) + the
-    # ---- record touch; returns to phase vcc_hi+1 or (vcc_hi = NPH) to the boundary
-    e("60:")
-    stamp(7)
-    e("s_cmp_ge_u32 s11, s12")
-    e("s_cbranch_scc1 61f")
-    e("v_readlane_b32 vcc_lo, v7, 1")
-    e("s_cmp_lg_u32 s11, vcc_lo")
-    e("s_cbranch_scc1 15f")
-    e("v_readlane_b32 vcc_lo, v7, 2")              # partial last panel: its window ends at the
-    e("s_nop 3")                                   # last row (rows nrow-128 .. nrow-1)
-    e("v_subrev_u32 v11, vcc_lo, v11")
-    e("15:")
-    e("s_sub_u32 m0, s14, s13")                    # first piece, other buffer
-    for q in range(4):
-        if q:
-            e(f"s_add_u32 m0, m0, {ROW}")
-        e("s_nop 0")
-        if "nodma" not in EXP:
-            e(f"global_load_lds_dwordx4 v11, s[{20 + 2 * q}:{21 + 2 * q}]")
-    e("s_nop 1")
-    e("v_add_u32 v11, 1024, v11")                  # next panel (the bases stay; 32-bit offsets per row split)
-    e("v_add_u32 v6, s10, v2")                     # records ~2 panels ahead towards L2 (all lanes:
-    if "notouch" not in EXP:                       # those past the tile repeat its last line)
-        e("global_load_dword v5, v6, s[8:9]")
-    e("61:")
-    stamp(3)                                       # DMA + touch issue
-    dispatch("vcc_hi", [f"{80 + i}" for i in range(NPH)], "b")
+        boundary(i)
     e("90:")
     e("s_waitcnt vmcnt(0) lgkmcnt(0)")
     return out
