@@ -65,7 +65,7 @@ struct svt_dev_pbc {
 #define PCH 256            // panels per build chunk
 static int g_pbc_debug = 0;
 static int g_pbc_nsplit = 0;
-static int g_pbc_stagger = 2;
+static int g_pbc_stagger = 7;     // DMA issue: wavefronts 4g..4g+3 after batch g of their tile (measured best of 12 patterns)
 static int g_pbc_ahead10 = 20;     // record touch: look-ahead in tenths of a tile
 
 // ---------------------------------------------------------------------------
@@ -181,9 +181,13 @@ pbc_pass_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__
 				// the end of the tile
 				const int64_t start = counts_or_ptr[TILE_OF(p0 + i)];
 				const int w = (int) (wv % 16);
-				int64_t bi = stag_mode == 0 ? 0 : stag_mode == 1 ? (w & 1) :
-					     stag_mode == 2 ? (w & 3) : ((w >> 2) & 1);
 				const int64_t nb = (stop - start) >> 3;
+				int64_t bi = stag_mode == 0 ? 0 : stag_mode == 1 ? (w & 1) :
+					     stag_mode == 2 ? (w & 3) : stag_mode == 3 ? ((w >> 2) & 1) :
+					     stag_mode == 4 ? (w & 7) : stag_mode == 5 ? ((w * nb) >> 4) :
+					     stag_mode == 6 ? ((w & 3) * 2) : stag_mode == 7 ? (w >> 2) :
+					     stag_mode == 8 ? ((w >> 2) * 2) : stag_mode == 9 ? (w >> 1) :
+					     stag_mode == 10 ? ((w >> 2) + 1) : (w >> 3);
 				if (bi > nb - 1) bi = nb - 1;
 				atomicOr((unsigned int *) ((char *) rec + ((start >> 3) + bi) * 96), 0x4000u);
 			}
