@@ -23,7 +23,7 @@ p.add_argument("--ablate", action="store_true")
 p.add_argument("--prof", action="store_true", help="per-section cycle counts of workgroup 0")
 p.add_argument("--reps", type=int, default=5)
 p.add_argument("--nsplits", default="0")
-p.add_argument("--staggers", default="2")
+p.add_argument("--staggers", default="7")
 p.add_argument("--aheads", default="20", help="record-touch look-ahead, tenths of a tile")
 p.add_argument("--ldy0", action="store_true", help="timing experiment: all dense columns alias column 0 (8 MB, cache resident)")
 a = p.parse_args()
