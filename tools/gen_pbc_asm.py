@@ -132,22 +132,20 @@ def sdwa_add(dst, src_s):
       f"src0_sel:WORD_1 src1_sel:DWORD")
 
 
-def d8(i):
-    """LDS reads of block X1(i) into y set sd(i) (two-set form and resume stubs)."""
+def d8(i, part="both"):
+    """LDS reads of block X1(i) into y set sd(i) (two-set form and resume code);
+    part = "addr": the address adds only, "read": the reads only."""
     r = BLK[X1[i % 3]]
     y = sd(i)
-    if YSETS == 2:
-        for j in range(8):
-            sdwa_add(y + 2 * j, r + j)
-        for j in range(8):
-            e(f"ds_read_b64 v[{y + 2 * j}:{y + 2 * j + 1}], v{y + 2 * j}")
-    else:
-        if "nolds" in EXP:
-            return
-        for j in range(8):
-            sdwa_add(ADDR + j, r + j)
-        for j in range(8):
-            e(f"ds_read_b64 v[{y + 2 * j}:{y + 2 * j + 1}], v{ADDR + j}")
+    if "nolds" in EXP:
+        return
+    for j in range(8):
+        if part != "read":
+            sdwa_add(y + 2 * j if YSETS == 2 else ADDR + j, r + j)
+    for j in range(8):
+        if part != "addr":
+            a = y + 2 * j if YSETS == 2 else ADDR + j
+            e(f"ds_read_b64 v[{y + 2 * j}:{y + 2 * j + 1}], v{a}")
 
 
 def f8(i, interleave):
@@ -199,12 +197,8 @@ def gen(prof):
         e("s_waitcnt lgkmcnt(0)")
         e("s_cmp_ge_u32 s11, s12")
         e("s_cbranch_scc1 90f")
-        # own pieces of this panel (issued inside the previous tile; the younger touch may fly)
-        e(f"s_waitcnt vmcnt({0 if 'notouch' in EXP else 1})")
-        stamp(1)                                   # own DMA pieces
-        if "nobarrier" not in EXP:
-            e("s_barrier")                         # everybody's pieces; everybody done with the previous panel
-        stamp(2)                                   # barrier
+        # bookkeeping and the LDS addresses of the next tile's first batch come before the
+        # barrier: wavefronts that arrive early do them while they would wait anyway
         e(f"s_xor_b32 s13, s13, {BUF}")
         e("v_add_u32 v4, s13, v0")
         e("s_cmp_lg_u32 s11, s16")
@@ -217,7 +211,14 @@ def gen(prof):
         e("v_add_u32 v6, s13, v3")
         e("s_mov_b32 m0, s19")
         stamp(4)                                   # boundary bookkeeping
-        d8(i)                                      # LDS reads of the batch the next phase multiplies
+        d8(i, "addr")
+        # own pieces of this panel (issued inside the previous tile; the younger touch may fly)
+        e(f"s_waitcnt vmcnt({0 if 'notouch' in EXP else 1})")
+        stamp(1)                                   # own DMA pieces
+        if "nobarrier" not in EXP:
+            e("s_barrier")                         # everybody's pieces; everybody done with the previous panel
+        stamp(2)                                   # barrier
+        d8(i, "read")                              # LDS reads of the batch the next phase multiplies
         stamp(5)
         if "nofinite" in EXP:
             e("s_waitcnt lgkmcnt(0)")
