@@ -1,0 +1,53 @@
+"""Differential fuzzing of the panel-blocked crossprod (LDS-DMA kernel, default layout) against the
+general gather kernel (whose sums follow the reference's order) on the GPU: random shapes,
+densities, skewed columns, dense operand widths, odd row counts.  Run on the GPU box:
+    python tools/debug/fuzz_pbc.py [ncases] [seed]"""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from sparsearray_amd.device import CrossprodPlan, DeviceCSC, PbcPlan
+
+ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+dev = torch.device("cuda", 0)
+worst = 0.0
+for case in range(ncases):
+    nrow = int(rng.choice([256, 257, 300, 383, 384, 385, 1000, 1279, 1280, 4097, 20000, 65537]))
+    ncol = int(rng.choice([1, 2, 39, 40, 41, 79, 640, 641, 1000, 1283, 2600]))
+    K = int(rng.choice([1, 2, 7, 63, 64, 65, 100, 128, 129, 200]))
+    kind = rng.integers(0, 5)
+    dens = float(rng.choice([0.0005, 0.003, 0.01, 0.05, 0.3]))
+    cols = []
+    for j in range(ncol):
+        d = dens
+        if kind == 1 and j % 7 == 0: d = 0.0                  # empty columns
+        if kind == 2 and j % 11 == 3: d = min(1.0, dens * 40)  # a few heavy columns (tiles of many batches)
+        if kind == 3: d = dens * (j + 1) / ncol                # ramp
+        if kind == 4 and j == ncol // 2: d = 1.0               # one fully dense column
+        n = rng.binomial(nrow, d)
+        cols.append(np.sort(rng.choice(nrow, size=n, replace=False)).astype(np.int32) if n else np.zeros(0, np.int32))
+    cp = np.zeros(ncol + 1, dtype=np.int64)
+    cp[1:] = np.cumsum([len(c) for c in cols])
+    ri = np.concatenate(cols) if cp[-1] else np.zeros(0, np.int32)
+    v = np.round(rng.normal(size=len(ri)), 3)
+    v[v == 0] = 0.5
+    A = DeviceCSC.from_host(nrow, cp, ri, v)
+    y = rng.uniform(-1, 1, (K, nrow))
+    Yd = torch.as_tensor(y, device=dev)
+    out_p = torch.full((K, ncol), 7.0, dtype=torch.float64, device=dev)
+    out_g = torch.full((K, ncol), 9.0, dtype=torch.float64, device=dev)
+    PbcPlan(A, K).run(Yd, nrow, out_p)
+    CrossprodPlan(A, K).run(Yd, nrow, out_g)
+    torch.cuda.synchronize()
+    # scale: sum of |a * y| per cell would be the honest one; the column's max |.| sum is a cheap bound
+    scale = max(1.0, float(out_g.abs().max()))
+    err = float((out_p - out_g).abs().max()) / scale
+    worst = max(worst, err)
+    flag = "" if err <= 1e-11 else "   <-- MISMATCH"
+    print(f"{case:4d} nrow {nrow:6d} ncol {ncol:5d} K {K:4d} kind {kind} dens {dens:<7g} nnz {len(ri):8d}  err {err:.2e}{flag}", flush=True)
+    if flag:
+        bad = (out_p - out_g).abs() / scale > 1e-11
+        idx = bad.nonzero()[:5].tolist()
+        print("   first bad (k, col):", idx)
+        sys.exit(1)
+print("worst relative error", worst)
