@@ -672,12 +672,17 @@ crossprod_pbc_kernel(const uint4 *__restrict__ rec,
 //     for the pieces does not wait for it: without it every scalar load of the
 //     record stream pays an HBM miss (7.6 ms instead of 5.2 at BASELINE config 2).
 //   * the DMA pieces of the next panel are issued from inside the record loop,
-//     staggered by wavefront, instead of all 64 at the barrier: the texture
-//     addresser takes ~20 cycles per piece and a burst blocks the issuing waves.
+//     after the batch the layout flags for this wavefront (wavefronts 4g .. 4g+3
+//     after batch g of their tile), instead of all 64 at the barrier: a piece
+//     blocks its wavefront for 100+ cycles and a burst blocks them all.
 //   * the whole panel loop is one asm statement (pbc_dma_asm.inc, generated by
 //     tools/gen_pbc_asm.py): the scalar-load pipeline of the record stream runs
 //     on across panel boundaries (only the LDS reads restart), loads use
-//     immediate offsets, the loop counter borrows instead of comparing.
+//     immediate offsets.  The CU's one scalar unit serves 16 wavefronts and is the
+//     busiest pipe of the kernel, so the loop is built to spend few scalar
+//     instructions: one flag test per batch, the boundary code once per resume
+//     phase (no dispatch chains), staging offsets in a VGPR, bookkeeping ahead of
+//     the barrier (DESIGN.md section 4 has the measurements).
 // The finiteness prescan of Y (src/SparseMatrix_mult.c:23-28) reads this
 // workgroup's 1/nblocks share of every landed panel back from LDS.
 // Grid: 1-D; when the number of row splits is a multiple of 8 the decode keeps
@@ -691,7 +696,6 @@ crossprod_pbc_kernel(const uint4 *__restrict__ rec,
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
-#define PBC_DMA_YAHEAD 3
 #define PBC_DMA_CLOBBERS "memory", "scc", "vcc", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99"
 
 template <int NV, bool PROF>
