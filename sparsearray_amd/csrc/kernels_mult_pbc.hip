@@ -799,7 +799,20 @@ crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restric
 			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) src,
 							 (__attribute__((address_space(3))) void *) dst, 16, 0, 0);
 		}
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		// cold start of the record stream: the in-loop touch runs two tiles ahead, so the
+		// first tiles' records would come from HBM one scalar load at a time (it shows with
+		// many short workgroups: A %*% Y runs 3126 of them at BASELINE config 2b).  One
+		// 128-byte line per lane, the first 4 KB of this wavefront's stream.
+		{
+			// (all lanes, no branch: lanes 32.. repeat line 31; the 4 KB stay inside the
+			// record array's slack even for the last wavefront)
+			uint32_t sink;
+			const char *ptr = (const char *) rec + tb[0] * 12 + (int64_t) (lane < 32 ? lane : 31) * 128;
+			// (load and wait in one statement: the register must not be handed to anything
+			// else while the load is in flight)
+			asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)"
+				     : "=v"(sink) : "v"(ptr) : "memory");
+		}
 	}
 #if PBC_DMA_YSETS == 2
 	u32x8 V3 = 0;
