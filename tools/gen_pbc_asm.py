@@ -185,6 +185,7 @@ def gen(prof):
     load("A", 0)
     load("B", BATCH)
     e(f"s_add_u32 s10, s10, {2 * BATCH}")
+    e("s_waitcnt lgkmcnt(0)")                      # (the boundary code itself never has a load in flight)
     e(f"s_branch {30 + NPH - 1}f")                 # first panel: enter through the last phase's boundary
 
     # ---- panel boundary after a tile that ended in phase i (one copy per phase: no
@@ -194,7 +195,6 @@ def gen(prof):
         if "nosmem" in EXP:
             e("s_mov_b32 s99, 7")
         stamp(7)                                   # phases
-        e("s_waitcnt lgkmcnt(0)")
         e("s_cmp_ge_u32 s11, s12")
         e("s_cbranch_scc1 90f")
         # bookkeeping and the LDS addresses of the next tile's first batch come before the
