@@ -58,3 +58,19 @@ def test_product_does_not_import_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 for needle in ("import oracle", "from oracle", "svt_oracle", "orc_"):
                     assert needle not in src, f"{f} references the oracle ({needle})"
+
+
+def test_generated_asm_is_in_sync(tmp_path):
+    """sparsearray_amd/csrc/pbc_dma_asm.inc is generated (tools/gen_pbc_asm.py) and committed:
+    the committed text must be what the generator writes with its defaults."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "pbc_dma_asm.inc"
+    env = {k: v for k, v in os.environ.items() if not k.startswith("PBC_")}
+    env["PBC_ASM_OUT"] = str(out)
+    subprocess.run([sys.executable, os.path.join(root, "tools", "gen_pbc_asm.py")], check=True, env=env,
+                   stdout=subprocess.DEVNULL)
+    committed = open(os.path.join(root, "sparsearray_amd", "csrc", "pbc_dma_asm.inc")).read()
+    assert out.read_text() == committed

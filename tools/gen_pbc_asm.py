@@ -307,8 +307,8 @@ def gen(prof):
     return out
 
 
-dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                   "sparsearray_amd", "csrc", "pbc_dma_asm.inc")
+dst = os.environ.get("PBC_ASM_OUT") or os.path.join(
+    os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sparsearray_amd", "csrc", "pbc_dma_asm.inc")
 with open(dst, "w") as f:
     f.write("// Generated by tools/gen_pbc_asm.py -- do not edit; see that file for the register map.\n")
     f.write(f"#define PBC_DMA_ROW {ROW}\n#define PBC_DMA_BUF {BUF}\n#define PBC_DMA_BATCH_BYTES {BATCH}\n")
