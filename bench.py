@@ -45,6 +45,10 @@ def parse():
     p.add_argument("--cbw", type=int, default=40)
     p.add_argument("--wpb", type=int, default=16)
     p.add_argument("--logr", type=int, default=7)
+    p.add_argument("--backend", default="nccl",
+                   help="nccl (= RCCL, the product path); gloo only to rehearse the N > 1 control flow on a one-GPU box")
+    p.add_argument("--same-device", action="store_true",
+                   help="rehearsal only: every rank uses GPU 0 (needs --backend gloo)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extras", action="store_true")
     return p.parse_args()
@@ -102,12 +106,18 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run")
+    if a.same_device:
+        local = 0
+        os.environ["LOCAL_RANK"] = "0"          # (the HIP library binds to LOCAL_RANK)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(a.backend)
 
     from sparsearray_amd import synth
     from sparsearray_amd.device import (CrossprodPlan, DeviceCSC, PbcPlan, colstats, rowsum,
