@@ -231,3 +231,31 @@ def test_device_stats(hip, oracle):
     got = rowsum(A, torch.as_tensor(grp, device="cuda"), 10).cpu().numpy().T
     want, _ = oracle.SparseArray_Call("C_rowsum_SVT", x, grp, 10, False)
     assert_equal(got, want, tol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("na_rm", [False, True])
+def test_device_rowsum_long_columns_16bit_group_table(hip, na_rm):
+    """nrow >= 65536 and < 65535 groups: the kernel gathers from a 16-bit copy of the group table
+    (kernels_rowstats.hip); NA groups land in the last slot (src/rowsum_methods.c:44-64)."""
+    from sparsearray_amd import NA_integer
+    from sparsearray_amd.device import rowsum
+    nrow, ncol, ngroup = 100_000, 60, 700
+    cp, ri, v = random_csc(nrow, ncol, 0.05, seed=41)
+    v = v.copy()
+    v[::97] = np.nan
+    A = _dev(cp, ri, v, nrow)
+    rng = np.random.default_rng(42)
+    grp = rng.integers(1, ngroup, nrow).astype(np.int32)       # 1 .. ngroup-1
+    grp[rng.integers(0, nrow, 500)] = NA_integer                # NA group = slot ngroup
+    out = rowsum(A, torch.as_tensor(grp, device="cuda"), ngroup, na_rm=na_rm)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()                                      # (ncol, ngroup)
+    g0 = np.where(grp == NA_integer, ngroup, grp) - 1
+    want = np.zeros((ncol, ngroup))
+    for j in range(ncol):
+        rows, vals = ri[cp[j]:cp[j + 1]], v[cp[j]:cp[j + 1]]
+        if na_rm:
+            keep = ~np.isnan(vals)
+            rows, vals = rows[keep], vals[keep]
+        np.add.at(want[j], g0[rows], vals)
+    assert_equal(got, want, tol=1e-12, atol=1e-12, what="rowsum g16")
