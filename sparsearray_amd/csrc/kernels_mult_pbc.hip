@@ -187,7 +187,9 @@ pbc_pass_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__
 					     stag_mode == 4 ? (w & 7) : stag_mode == 5 ? ((w * nb) >> 4) :
 					     stag_mode == 6 ? ((w & 3) * 2) : stag_mode == 7 ? (w >> 2) :
 					     stag_mode == 8 ? ((w >> 2) * 2) : stag_mode == 9 ? (w >> 1) :
-					     stag_mode == 10 ? ((w >> 2) + 1) : (w >> 3);
+					     stag_mode == 10 ? ((w >> 2) + 1) : stag_mode == 11 ? (w >> 3) :
+					     stag_mode == 12 ? ((w >> 2) < 2 ? (w >> 2) : 2) :
+					     stag_mode == 13 ? ((w >> 2) % 3) : ((w >> 2) * 3 / 4);
 				if (bi > nb - 1) bi = nb - 1;
 				atomicOr((unsigned int *) ((char *) rec + ((start >> 3) + bi) * 96), 0x4000u);
 			}
