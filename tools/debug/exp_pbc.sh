@@ -4,6 +4,7 @@
 #   nofma  no index switch / FMA          nolds    no address adds / LDS reads of Y
 #   nosmem no record loads (constant valid records, 7 batches per tile)
 #   nodma  no LDS-DMA of Y                nocheck  finiteness result ignored (use with nodma)
+#   nodmawait  no wait for the own DMA pieces   notouch, nofinite, noprio(removed), oldbound(removed)
 #   nobarrier, align
 # Experiment builds compute wrong results; the last line restores the real kernel.
 # NEVER run nosmem without constant records (garbage register indices) -- the generator

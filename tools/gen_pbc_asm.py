@@ -213,7 +213,8 @@ def gen(prof):
         stamp(4)                                   # boundary bookkeeping
         d8(i, "addr")
         # own pieces of this panel (issued inside the previous tile; the younger touch may fly)
-        e(f"s_waitcnt vmcnt({0 if 'notouch' in EXP else 1})")
+        if "nodmawait" not in EXP:                 # (experiment: pretend the pieces always landed in time)
+            e(f"s_waitcnt vmcnt({0 if 'notouch' in EXP else 1})")
         stamp(1)                                   # own DMA pieces
         if "nobarrier" not in EXP:
             e("s_barrier")                         # everybody's pieces; everybody done with the previous panel
