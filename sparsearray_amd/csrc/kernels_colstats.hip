@@ -511,6 +511,54 @@ __global__ void colstats_combine_kernel(StatsArgs a, int nchunk, ColState *__res
 	}
 }
 
+// Very short segments (fewer than ~4 nonzeros on average: arrays with a short first extent,
+// leaf-shattering permutations): one THREAD per segment, sequential like the reference; what
+// it streams is mostly col_ptr.  Same post-processing (colstats_final).
+template <typename T>
+__global__ void __launch_bounds__(256)
+colstats_thread_kernel(StatsArgs a)
+{
+	typedef ValTraits<T> VT;
+	const bool is_dbl = sizeof(T) == 8;
+	const int64_t g = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= a.nseg) return;
+	const T *__restrict__ val = (const T *) a.val;
+	const int64_t beg = a.col_ptr[g * a.inner], end = a.col_ptr[(g + 1) * a.inner];
+	const int oc = a.opcode;
+	const bool narm = a.na_rm != 0;
+	const bool is_minmax = oc == SVT_OP_MIN || oc == SVT_OP_MAX, is_min = oc == SVT_OP_MIN;
+	ColState st;
+	st.flags = 0; st.pad = 0; st.nacnt = 0;
+	st.acc = (oc == SVT_OP_PROD) ? 1.0 : 0.0;
+	st.mm = is_min ? INFINITY : -INFINITY;
+	for (int64_t k = beg; k < end; k++) {
+		const T v = val[k];
+		if (VT::is_missing(v)) {
+			st.nacnt++;
+			st.flags |= VT::is_na(v) ? F_NA : F_NAN;
+			if (narm || !is_dbl) continue;
+		} else {
+			st.flags |= (v != (T) 0) ? F_TRUE : F_ZERO;
+			st.flags |= F_HAVE;
+		}
+		const double d = VT::as_double(v);
+		if (oc == SVT_OP_PROD) st.acc *= d;
+		else if (is_minmax) { if (d == d) st.mm = is_min ? (d < st.mm ? d : st.mm) : (d > st.mm ? d : st.mm); }
+		else st.acc += d;
+	}
+	double c = 0.0, acc2 = 0.0;
+	if (oc == SVT_OP_CENTERED_X2_SUM || oc == SVT_OP_VAR1 || oc == SVT_OP_SD1) {
+		c = colstats_center(a, st, end - beg);
+		for (int64_t k = beg; k < end; k++) {
+			const T v = val[k];
+			if (VT::is_missing(v) && (narm || !is_dbl)) continue;
+			const double d = VT::as_double(v) - c;
+			acc2 += d * d;
+		}
+	}
+	colstats_final(a, g, st, end - beg, c, acc2, is_dbl);
+}
+
 static int launch_colstats_split(const StatsArgs &a, int nchunk, hipStream_t s)
 {
 	const bool is_dbl = a.Rtype == SVT_REALSXP;
@@ -564,7 +612,11 @@ int launch_colstats(const StatsArgs &a, int64_t nnz, hipStream_t s)
 		}
 	} else {
 		dim3 grid((unsigned) ((a.nseg + 3) / 4)), block(256);
-		if (avg < 160) {
+		if (avg < 4 && a.nseg >= 4096) {
+			dim3 gridt((unsigned) ((a.nseg + 255) / 256));
+			if (is_dbl) hipLaunchKernelGGL(colstats_thread_kernel<double>, gridt, block, 0, s, a);
+			else hipLaunchKernelGGL(colstats_thread_kernel<int>, gridt, block, 0, s, a);
+		} else if (avg < 160) {
 			// short leaves (config 1 / config 5, ~100 nonzeros): 16 lanes per segment
 			dim3 grid16((unsigned) ((a.nseg + 15) / 16));
 			if (is_dbl) hipLaunchKernelGGL((colstats_kernel<double, 16, 16>), grid16, block, 0, s, a);

@@ -402,3 +402,39 @@ def test_resident_operands(hip, oracle):
         hip.resident_set_limit(0)
     assert hip.resident_stats()["bytes"] == 0
     assert_identical(hip.colSums(x), want[0])
+
+
+@pytest.mark.parametrize("na_rm", [False, True])
+@pytest.mark.parametrize("type_", ["double", "integer", "NaArray"])
+def test_colstats_very_short_leaves(hip, oracle, type_, na_rm):
+    """Thousands of leaves with a handful of nonzeros each (short first extent): one thread per
+    generalized column on the device (kernels_colstats.hip, colstats_thread_kernel)."""
+    import warnings
+    rng = np.random.default_rng(29)
+    shape = (6, 90, 60)
+    if type_ == "integer":
+        a = rng.integers(-9, 10, shape).astype(np.int32)
+        a[rng.random(shape) < 0.7] = 0
+        a[2, 5, 7] = NA_integer
+        x = SVT_SparseArray.from_dense(np.asfortranarray(a), "integer")
+    else:
+        a = np.round(rng.normal(size=shape), 3)
+        if type_ == "NaArray":
+            a[rng.random(shape) < 0.7] = NA_real
+        else:
+            a[rng.random(shape) < 0.7] = 0.0
+            a[1, 4, 4] = NA_real
+        a[3, 8, 9] = np.nan
+        a[0, 1, 2] = np.inf
+        x = SVT_SparseArray.from_dense(np.asfortranarray(a), "double", na_background=type_ == "NaArray")
+    ops = OPS_COL + (["colAnys", "colAlls"] if type_ == "integer" else [])
+    for op in ops:
+        kw = {} if "AnyNAs" in op or "CountNAs" in op else {"na_rm": na_rm}
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            got = getattr(hip, op)(x, dims=1, **kw)
+            want = getattr(oracle, op)(x, dims=1, **kw)
+        if got.dtype == np.int32:
+            assert_identical(got, want, op)
+        else:
+            assert_equal(got, want, tol=1e-12, what=op, atol=1e-12, strict_na=op[3:] in ("Mins", "Maxs"))

@@ -31,3 +31,18 @@ for name, fn, nbytes in (
 ):
     ms = timed(fn)
     print(f"{name:32s} {ms:8.3f} ms  {nnz / ms / 1e6:7.1f} GNZ/s  {nbytes / ms / 1e6:7.0f} GB/s (algorithmic)")
+
+# aperm(x, c(3, 1, 2)): dim 3 becomes the leaf dimension; then "row stats along dim 3" are column
+# statistics of the permuted array (R/SparseArray-matrixStats.R:122-190 does exactly that on the host)
+import time
+for perm in ((3, 1, 2), (2, 1, 3)):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    P, pdim = A.aperm(D, perm)
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    P2, _ = A.aperm(D, perm)
+    torch.cuda.synchronize(); t2 = time.perf_counter()
+    print(f"aperm(x, c{perm}) -> {pdim}: first {1e3 * (t1 - t0):.1f} ms, again {1e3 * (t2 - t1):.1f} ms "
+          f"({nnz / (t2 - t1) / 1e9:.1f} GNZ/s)")
+    ms = timed(lambda: colstats(P, "sum"))
+    print(f"  colSums(dims=1) of the permuted array        {ms:8.3f} ms  {nnz / ms / 1e6:7.1f} GNZ/s")
+    del P, P2
