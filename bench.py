@@ -120,8 +120,8 @@ def main():
             dist.init_process_group(a.backend)
 
     from sparsearray_amd import synth
-    from sparsearray_amd.device import (CrossprodPlan, DeviceCSC, PbcPlan, colstats, rowsum,
-                                        rowsums)
+    from sparsearray_amd.device import (CrossprodPlan, DeviceCSC, PbcPlan, colmedians, colstats,
+                                        rowsum, rowsums)
 
     nrow, ncol, K = a.nrow, a.ncol, a.K
     # row-sharded global matrix: every rank owns an nrow x ncol block
@@ -268,10 +268,13 @@ def main():
         from sparsearray_amd.device import _lib as _devlib
         rs_out = torch.empty(nrow, dtype=torch.float64, device=dev)
         rs_ws = torch.empty(_devlib().svt_dev_rowstats_ws_bytes(nrow, ncol), dtype=torch.uint8, device=dev)
+        med_out = torch.empty(ncol, dtype=torch.float64, device=dev)
+        med_ws = torch.empty(_devlib().svt_dev_colmedians_ws_bytes(nnz, ncol), dtype=torch.uint8, device=dev)
         ex = {}
         for name, fn, nbytes in (
             ("colSums", lambda: colstats(A, "sum"), nnz * 8 + ncol * 16),
             ("colVars", lambda: colstats(A, "var1"), nnz * 8 + ncol * 16),
+            ("colMedians", lambda: colmedians(A, out=med_out, ws=med_ws), nnz * 8 + ncol * 16),
             ("rowSums", lambda: rowsums(A, out=rs_out, ws=rs_ws), nnz * 12 + nrow * 8),
             ("rowsum_1e3_groups", lambda: rowsum(A, grp, 1000), nnz * 12 + nrow * 4 + 1000 * ncol * 8),
         ):

@@ -138,6 +138,14 @@ int svt_matmul_SVT_mat(const svt_view *x, const void *y, int y_nrow, int y_ncol,
 		       int y_Rtype, double *out);
 int svt_matmul_SVT_SVT(const svt_view *x, const svt_view *y, double *out);
 
+/* colMedians(x, na.rm) of a 2-D SVT: .colMedians_SVT_SparseMatrix / .padded_median,
+   R/SparseArray-matrixStats.R:690-784 -- pure R in the reference (one sort per leaf; its TODO
+   at :690-691 asks for a .Call version).  Median of each column's nrow values, the implicit
+   zeros included; any NA/NaN among the nonzeros gives NA_real_ unless na_rm, an empty column
+   of a 0-row matrix NA_real_.  out: ncol(x) doubles.  rowMedians(x) is colMedians(t(x)) as
+   in the reference (:802-815). */
+int svt_colMedians_SVT(const svt_view *x, int na_rm, double *out);
+
 /* C_summarize_SVT, src/SparseArray_summarization.c:112-142.  The result is
    left in out_d[0..1] or out_i[0..1] according to *out_Rtype. */
 int svt_summarize_SVT(const svt_view *x, int opcode, int na_rm, double center,
@@ -283,6 +291,12 @@ int svt_dev_pbc_read_prof(const void *ws, unsigned long long *out);
 int svt_dev_colstats(const svt_dev_csc *A, int opcode, int na_rm,
 		     double center, int64_t inner, void *out, int *warn_flag,
 		     void *stream);
+
+/* colMedians on the device (see svt_colMedians_SVT): out = ncol doubles (device);
+   ws: svt_dev_colmedians_ws_bytes() bytes (two f64 key arrays + the sort's scratch). */
+size_t svt_dev_colmedians_ws_bytes(int64_t nnz, int64_t ncol);
+int svt_dev_colmedians(const svt_dev_csc *A, int na_rm, double *out, void *ws, size_t ws_bytes,
+		       void *stream);
 
 /* row sums: out[(j % inner) * nrow + r] = sum over the leaves j that map to
    that cell.  Every output cell is owned by one workgroup (LDS row panels, no

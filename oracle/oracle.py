@@ -37,9 +37,75 @@ def load_oracle() -> ctypes.CDLL:
     return _lib
 
 
+def _positive_padded_median(x, padding):
+    """.positive_padded_median(), R/SparseArray-matrixStats.R:695-708 (x >= 0, padding < len(x))."""
+    import numpy as np
+    n = len(x) + padding
+    xs = np.sort(x)                                  # sort(x, partial=k)[k] picks the same elements
+    if n % 2 == 1:
+        partial = (n + 1) // 2 - padding
+        return float(xs[partial - 1])
+    i1 = n // 2 - padding
+    return float(np.mean(xs[i1 - 1:i1 + 1]))
+
+
+def _padded_median(x, padding, na_rm):
+    """.padded_median(), R/SparseArray-matrixStats.R:712-758: median(c(x, integer(padding)))."""
+    import numpy as np
+    from sparsearray_amd import NA_real
+    x = np.asarray(x, dtype=np.float64)
+    if na_rm:
+        x = x[~np.isnan(x)]
+    elif np.isnan(x).any():
+        return NA_real
+    n = len(x) + padding
+    if n == 0:
+        return NA_real
+    if padding > len(x):
+        return 0.0
+    pos = x > 0
+    pos_count = int(pos.sum())
+    nonpos_count = n - pos_count
+    if pos_count > nonpos_count:
+        return _positive_padded_median(x[pos], nonpos_count)
+    neg_count = len(x) - pos_count
+    nonneg_count = n - neg_count
+    if neg_count > nonneg_count:
+        return -_positive_padded_median(-x[~pos], nonneg_count)
+    if n % 2 == 1:
+        return 0.0
+    half = n // 2
+    right = float(x[pos].min()) if pos_count == half else 0.0
+    left = float(x[~pos].max()) if neg_count == half else 0.0
+    return (left + right) * 0.5
+
+
 def oracle_dispatcher():
+    import numpy as np
+    from sparsearray_amd import NA_integer
     from sparsearray_amd._dispatch import CAbiDispatcher
-    return CAbiDispatcher(load_oracle(), "orc_")
+
+    class OracleDispatcher(CAbiDispatcher):
+        # .colMedians_SVT_SparseMatrix, R/SparseArray-matrixStats.R:761-784: pure R in the
+        # reference, restated leaf by leaf in Python
+        def C_colMedians_SVT(self, x, na_rm):
+            nrow, ncol = x.dim
+            ans = np.zeros(ncol)
+            for j, lf in enumerate(x.leaves):
+                if lf is None:
+                    continue
+                vals = lf[1]
+                if vals is None:                     # lacunar leaf: all ones
+                    vals = np.ones(len(lf[0]))
+                vals = np.asarray(vals)
+                if vals.dtype != np.float64:
+                    v = vals.astype(np.float64)
+                    v[vals == NA_integer] = np.nan
+                    vals = v
+                ans[j] = _padded_median(vals, nrow - len(vals), bool(na_rm))
+            return ans
+
+    return OracleDispatcher(load_oracle(), "orc_")
 
 
 def oracle_session():

@@ -59,6 +59,8 @@ class CAbiDispatcher:
             "rowsum_dgCMatrix": (I, [I, I, P, P, P, P, I, I, P]),
             "colsum_dgCMatrix": (I, [I, I, P, P, P, P, I, I, P]),
         }
+        if hasattr(self.lib, self.prefix + "colMedians_SVT"):      # HIP library (the oracle's is Python)
+            protos["colMedians_SVT"] = (I, [V, I, P])
         # x %*% y in one call (device-side transposition): HIP library only
         for name, sig in (("matmul_SVT_mat", (I, [V, P, I, I, I, P])),
                           ("matmul_SVT_SVT", (I, [V, V, P]))):
@@ -118,6 +120,13 @@ class CAbiDispatcher:
         out = np.zeros((x.dim[1], y.dim[1]), dtype=np.float64, order="F")
         xv, yv = make_view(x), make_view(y)
         self._check(self._fn("crossprod2_SVT_SVT")(byref(xv), byref(yv), _ptr(out)))
+        return out
+
+    # colMedians (R/SparseArray-matrixStats.R:761-784) --------------------------------
+    def C_colMedians_SVT(self, x: SVT_SparseArray, na_rm: bool):
+        out = np.zeros(x.dim[1] if x.ndim == 2 else 0, dtype=np.float64)
+        xv = make_view(x)
+        self._check(self._fn("colMedians_SVT")(byref(xv), int(bool(na_rm)), _ptr(out)))
         return out
 
     # resident operands (include/svt_hip.h; HIP library only) --------------------

@@ -251,6 +251,26 @@ class Session:
                           "infinite values to integers")
         return ans
 
+    def colMedians(self, x, na_rm=False):
+        """colMedians(x, na.rm) (R/SparseArray-matrixStats.R:786-800; 2-D objects only)."""
+        if x.ndim != 2:
+            raise SparseArrayError(
+                "the colMedians() method for SparseArray objects only supports 2D "
+                "objects (i.e. SparseMatrix objects) at the moment")
+        if not isinstance(na_rm, (bool, np.bool_)):
+            raise SparseArrayError("'na.rm' must be TRUE or FALSE")
+        if x.dim[0] == 0:
+            return np.full(x.dim[1], NA_real)            # :771-772
+        return self.SparseArray_Call("C_colMedians_SVT", x, bool(na_rm))
+
+    def rowMedians(self, x, na_rm=False):
+        """rowMedians(x) = colMedians(t(x)) (R/SparseArray-matrixStats.R:802-815)."""
+        if x.ndim != 2:
+            raise SparseArrayError(
+                "the rowMedians() method for SparseArray objects only supports 2D "
+                "objects (i.e. SparseMatrix objects) at the moment")
+        return self.colMedians(x.t(), na_rm=na_rm)
+
     def _rowStats(self, op, x, na_rm=False, center=None, dims=1):
         # .rowStats_SparseArray, R/SparseArray-matrixStats.R:197-259
         dims = int(dims)

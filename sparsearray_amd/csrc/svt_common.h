@@ -128,6 +128,9 @@ struct StatsArgs {
 	int na_bg;          // NaArray: implicit values are NAs (Rvector_summarization.c:1078-1106)
 };
 int launch_colstats(const StatsArgs &a, int64_t nnz, hipStream_t s);
+size_t colmedians_ws_bytes(int64_t nnz, int64_t ncol);
+int launch_colmedians(const int64_t *col_ptr, const void *val, int Rtype, int64_t nrow, int64_t ncol,
+		      int64_t nnz, int na_rm, double *out, void *ws, hipStream_t s);
 
 struct RowStatsArgs {
 	const int64_t *col_ptr;

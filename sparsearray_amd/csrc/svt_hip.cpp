@@ -670,6 +670,22 @@ extern "C" int svt_dev_colstats(const svt_dev_csc *A, int opcode, int na_rm,
 	return launch_colstats(a, A->nnz, (hipStream_t) stream);
 }
 
+extern "C" size_t svt_dev_colmedians_ws_bytes(int64_t nnz, int64_t ncol)
+{
+	return colmedians_ws_bytes(nnz, ncol);
+}
+
+extern "C" int svt_dev_colmedians(const svt_dev_csc *A, int na_rm, double *out, void *ws,
+				  size_t ws_bytes, void *stream)
+{
+	if (A->na_background)
+		return svt_set_error("colMedians() is not supported on NaArray objects");
+	if (ws_bytes < colmedians_ws_bytes(A->nnz, A->ncol))
+		return svt_set_error("svt_dev_colmedians: workspace too small");
+	return launch_colmedians(A->col_ptr, A->val, A->Rtype, A->nrow, A->ncol, A->nnz, na_rm, out, ws,
+				 (hipStream_t) stream);
+}
+
 extern "C" size_t svt_dev_rowstats_ws_bytes(int64_t nrow, int64_t ncol)
 {
 	return rowstats_panel_ws_bytes(nrow, ncol);
@@ -1270,6 +1286,34 @@ extern "C" int svt_colStats_SVT(const svt_view *x, int opcode, int na_rm, double
 		return run_colstats(&E, opcode, na_rm, center, 1, out, out_Rtype, warn);
 	}
 	return run_colstats(A.h, opcode, na_rm, center, inner, out, out_Rtype, warn);
+}
+
+// colMedians(): .colMedians_SVT_SparseMatrix, R/SparseArray-matrixStats.R:761-784 (pure R in the
+// reference, with a TODO asking for a .Call version).  out: ncol(x) doubles.
+extern "C" int svt_colMedians_SVT(const svt_view *x, int na_rm, double *out)
+{
+	if (ensure_init() || check_view(x))
+		return -1;
+	if (x->ndim != 2)       // stopifnot_2D_object(), R/SparseArray-matrixStats.R:51-57
+		return svt_set_error("the colMedians() method for SparseArray objects only supports 2D "
+				     "objects (i.e. SparseMatrix objects) at the moment");
+	if (x->Rtype != SVT_REALSXP && x->Rtype != SVT_INTSXP && x->Rtype != SVT_LGLSXP)
+		return svt_set_error("colMedians(): unsupported type");
+	if (x->na_background)
+		return svt_set_error("colMedians() is not supported on NaArray objects");
+	const int64_t ncol = x->dim[1];
+	if (ncol == 0)
+		return 0;
+	CscGuard A(x);
+	if (A.h == NULL) return -1;
+	DevBuf O, W;
+	if (O.alloc((size_t) ncol * 8) || W.alloc(colmedians_ws_bytes(A.h->nnz, ncol)))
+		return -1;
+	if (launch_colmedians(A.h->col_ptr, A.h->val, A.h->Rtype, A.h->nrow, ncol, A.h->nnz, na_rm,
+			      O.as<double>(), W.p, 0))
+		return -1;
+	HIP_TRY(hipDeviceSynchronize());
+	return staged_download(out, O.p, (size_t) ncol * 8);
 }
 
 // C_summarize_SVT, src/SparseArray_summarization.c:112-142

@@ -51,6 +51,9 @@ def _lib():
                                                     c_size_t, c_void_p, c_int]
         lib.svt_dev_colstats.argtypes = [c_void_p, c_int, c_int, c_double, c_int64,
                                          c_void_p, c_void_p, c_void_p]
+        lib.svt_dev_colmedians_ws_bytes.restype = c_size_t
+        lib.svt_dev_colmedians_ws_bytes.argtypes = [c_int64, c_int64]
+        lib.svt_dev_colmedians.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
         lib.svt_dev_rowstats_ws_bytes.restype = c_size_t
         lib.svt_dev_rowstats_ws_bytes.argtypes = [c_int64, c_int64]
         lib.svt_dev_rowsums.argtypes = [c_void_p, c_int, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]
@@ -226,6 +229,18 @@ def colstats(A: DeviceCSC, op: str, na_rm=False, center=float("nan"), inner=1):
     _check(_lib().svt_dev_colstats(A.handle, oc, int(na_rm), float(center), inner,
                                    out.data_ptr(), warn.data_ptr(), _stream()))
     return out, warn
+
+
+def colmedians(A: DeviceCSC, na_rm=False, out=None, ws=None):
+    """colMedians() of a resident 2-D operand (include/svt_hip.h, svt_dev_colmedians)."""
+    if out is None:
+        out = torch.empty(A.ncol, dtype=torch.float64, device=A.val.device)
+    if ws is None:
+        ws = torch.empty(_lib().svt_dev_colmedians_ws_bytes(A.nnz, A.ncol), dtype=torch.uint8,
+                         device=A.val.device)
+    _check(_lib().svt_dev_colmedians(A.handle, int(na_rm), out.data_ptr(), ws.data_ptr(),
+                                     ws.numel(), _stream()))
+    return out
 
 
 def rowsums(A: DeviceCSC, na_rm=False, inner=1, out=None, ws=None):

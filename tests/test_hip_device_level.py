@@ -259,3 +259,17 @@ def test_device_rowsum_long_columns_16bit_group_table(hip, na_rm):
             rows, vals = rows[keep], vals[keep]
         np.add.at(want[j], g0[rows], vals)
     assert_equal(got, want, tol=1e-12, atol=1e-12, what="rowsum g16")
+
+
+def test_device_colmedians(hip):
+    from sparsearray_amd.device import colmedians
+    nrow, ncol = 30_000, 200
+    cp, ri, v = random_csc(nrow, ncol, 0.6, seed=51)          # dense enough for non-zero medians
+    A = _dev(cp, ri, v, nrow)
+    got = colmedians(A).cpu().numpy()
+    want = np.empty(ncol)
+    for j in range(ncol):
+        col = np.zeros(nrow)
+        col[ri[cp[j]:cp[j + 1]]] = v[cp[j]:cp[j + 1]]
+        want[j] = np.median(col)
+    assert_equal(got, want, tol=1e-15, what="colmedians")
