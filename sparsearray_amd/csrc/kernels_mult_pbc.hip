@@ -761,7 +761,9 @@ crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restric
 		for (int q = 0; q < 4; q++) {
 			int kk = k0 + w * 4 + q;
 			if (kk > K - 1) kk = K - 1;                 // tail of K: a valid column, never stored
-			const uint64_t src = (uint64_t) (uintptr_t) (Y + (int64_t) kk * ldY + (pa + 1) * 128);
+			// (bases one panel back, the offset register starts one panel in: the shift of a
+			// partial last panel must not take the unsigned 32-bit offset below zero)
+			const uint64_t src = (uint64_t) (uintptr_t) (Y + (int64_t) kk * ldY + pa * 128);
 			PB[8 + 2 * q] = (uint32_t) src; PB[9 + 2 * q] = (uint32_t) (src >> 32);
 		}
 	}
@@ -774,7 +776,7 @@ crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restric
 		V0[1] = (uint32_t) lane * 16u;
 		// record touch: one 128-byte line per lane, the lanes past rt_lines repeat the last one
 		V0[2] = (uint32_t) (lane < rt_lines ? lane : rt_lines - 1) * 128u + (uint32_t) rt_ahead;
-		V0[11] = (uint32_t) lane * 16u;             // DMA lane offset + bytes staged so far
+		V0[11] = (uint32_t) lane * 16u + 1024u;     // DMA lane offset + bytes from the split's first panel
 		// finiteness prescan: this block's share of the 8192 doubles of a panel
 		const int chunk = (8192 + nblocks - 1) / nblocks;
 		const int nit = (chunk + 1023) / 1024;

@@ -273,3 +273,29 @@ def test_device_colmedians(hip):
         col[ri[cp[j]:cp[j + 1]]] = v[cp[j]:cp[j + 1]]
         want[j] = np.median(col)
     assert_equal(got, want, tol=1e-15, what="colmedians")
+
+
+@pytest.mark.parametrize("nsplit", [8, 16, 5])
+def test_pbc_dma_partial_last_panel_first_in_a_split(hip, oracle, nsplit):
+    """Row splits of two panels (or one) whose in-loop staging starts with the partial last panel:
+    its window is moved back by less than one panel, and the kernel's staging offset register is
+    unsigned -- a fault at 300000 columns x 2000 rows once (svt_matmul_SVT_SVT)."""
+    from sparsearray_amd import _hip
+    from sparsearray_amd.device import PbcPlan
+    lib = _hip.init()
+    nrow, ncol, K = 2000, 900, 50                      # 16 panels, the last of 80 rows
+    cp, ri, v = random_csc(nrow, ncol, 0.02, seed=61)
+    x = SVT_SparseArray.from_csc((nrow, ncol), "double", cp, ri, v)
+    y = np.random.default_rng(62).uniform(-1, 1, (nrow, K))
+    want = oracle.crossprod(x, y)
+    A = _dev(cp, ri, v, nrow)
+    Yd = torch.as_tensor(np.ascontiguousarray(y.T), device="cuda")
+    try:
+        lib.svt_dev_pbc_set_debug(100 + nsplit)        # tuning override of the split count
+        plan = PbcPlan(A, K)
+        out = torch.zeros((K, ncol), dtype=torch.float64, device="cuda")
+        plan.run(Yd, nrow, out)
+        torch.cuda.synchronize()
+    finally:
+        lib.svt_dev_pbc_set_debug(100)
+    assert_equal(out.cpu().numpy().T, want, tol=1e-9, atol=1e-11, what=f"nsplit {nsplit}")

@@ -5,7 +5,9 @@ densities, skewed columns, dense operand widths, odd row counts.  Run on the GPU
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from sparsearray_amd import _hip
 from sparsearray_amd.device import CrossprodPlan, DeviceCSC, PbcPlan
+lib = _hip.init()
 
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -34,6 +36,8 @@ for case in range(ncases):
     A = DeviceCSC.from_host(nrow, cp, ri, v)
     y = rng.uniform(-1, 1, (K, nrow))
     Yd = torch.as_tensor(y, device=dev)
+    ns = int(rng.choice([0, 0, 2, 3, 5, 8, 16]))        # 0: automatic; else forced row-split count
+    lib.svt_dev_pbc_set_debug(100 + ns)
     out_p = torch.full((K, ncol), 7.0, dtype=torch.float64, device=dev)
     out_g = torch.full((K, ncol), 9.0, dtype=torch.float64, device=dev)
     PbcPlan(A, K).run(Yd, nrow, out_p)
@@ -44,10 +48,11 @@ for case in range(ncases):
     err = float((out_p - out_g).abs().max()) / scale
     worst = max(worst, err)
     flag = "" if err <= 1e-11 else "   <-- MISMATCH"
-    print(f"{case:4d} nrow {nrow:6d} ncol {ncol:5d} K {K:4d} kind {kind} dens {dens:<7g} nnz {len(ri):8d}  err {err:.2e}{flag}", flush=True)
+    print(f"{case:4d} nrow {nrow:6d} ncol {ncol:5d} K {K:4d} kind {kind} dens {dens:<7g} nsplit {ns:2d} nnz {len(ri):8d}  err {err:.2e}{flag}", flush=True)
     if flag:
         bad = (out_p - out_g).abs() / scale > 1e-11
         idx = bad.nonzero()[:5].tolist()
         print("   first bad (k, col):", idx)
         sys.exit(1)
+lib.svt_dev_pbc_set_debug(100)
 print("worst relative error", worst)

@@ -43,7 +43,7 @@ Register map (fixed physical registers; the kernel pins C++ vectors to them):
         s14 LDS byte address of this wavefront's first DMA piece in buffer 1
         s15 phase to resume at       s16, s17, s19 unused
         s18 sticky "non-finite seen"
-        s[20:27] DMA source bases of the wavefront's 4 dense columns (row split start + 1 panel)
+        s[20:27] DMA source bases of the wavefront's 4 dense columns (start of the row split)
         vcc_lo scratch, vcc_hi return selector of the issue routine, m0 scratch
   VGPR  v0 lane*ROW (lane base, buffer 0)   v1 lane*16 (DMA lane offset)
         v2 record-touch lane offset (+ look-ahead distance)
@@ -52,7 +52,9 @@ Register map (fixed physical registers; the kernel pins C++ vectors to them):
         v7 constants by lane: [0] finite-check iterations, [1] index of the partial
            last panel (or ~0), [2] byte shift of that panel's window
         v[8:9] check value  v10 class mask
-        v11 DMA offset: lane*16 + bytes of the panels staged so far (32-bit: per row split)
+        v11 DMA offset: lane*16 + bytes from the split's first panel to the one to stage (>= 1024, so
+            that the backward shift of a partial last panel, < 1024, keeps it non-negative: the
+            global saddr form takes the VGPR offset as unsigned)
         v[12:27] y set a, v[28:43] y set b (YSETS = 2)  /  v[12:19] addresses,
         v[20:35] y (YSETS = 1)
         v[ACC:...] partial sums (register-indexed: v[ACC + 2*column]), ACC = 44 / 36
