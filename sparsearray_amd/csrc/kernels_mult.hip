@@ -274,6 +274,27 @@ int launch_densify(const int64_t *col_ptr, const int32_t *row_idx,
 	return 0;
 }
 
+// int32 -> f64 (NA_integer_ -> NA_real_): integer operands of large products take the f64
+// panel kernels.  The reference multiplies and adds integer operands in double anyway
+// (_dotprod_intSV_*, src/SparseVec_dotprod.c:73-114), and an NA becomes the one non-finite
+// value that sends a product down the general path, where "NA anywhere in the dense column
+// or the leaf -> NA_real_" is the rule for both types.
+__global__ void int_to_f64_kernel(const int *__restrict__ in, int64_t n, double *__restrict__ out)
+{
+	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const int v = in[i];
+	out[i] = v == NA_INT ? svt_na_real() : (double) v;
+}
+
+int launch_int_to_f64(const int *in, int64_t n, double *out, hipStream_t s)
+{
+	if (n <= 0) return 0;
+	hipLaunchKernelGGL(int_to_f64_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, in, n, out);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
 // compute_sym_dotprods_* write out[k] and out[k*n] from one dot product
 // (src/SparseMatrix_mult.c:263-296): keep the (i > j) value, mirror it.
 __global__ void mirror_lower_kernel(double *out, int64_t n)

@@ -876,6 +876,21 @@ static int dev_crossprod_chunked(const svt_dev_csc *A, const void *Y_dev, int64_
 {
 	if (K <= 0 || A->ncol <= 0)
 		return 0;
+	// Large integer products: the same panel-blocked kernels on f64 copies of the values and
+	// of the dense operand (count matrices are integer; see int_to_f64_kernel for why the
+	// results, NA rules included, are those of the integer path -- bit for bit while the sums
+	// stay below 2^53).
+	if (A->Rtype == SVT_INTSXP && !tr_y && ldY == A->nrow && A->nrow >= 256 &&
+	    (double) A->nnz * (double) K >= 268435456.0) {
+		DevBuf V, Yf;
+		if (V.alloc((size_t) (A->nnz > 0 ? A->nnz : 1) * 8) || Yf.alloc((size_t) A->nrow * K * 8) ||
+		    launch_int_to_f64((const int *) A->val, A->nnz, V.as<double>(), 0) ||
+		    launch_int_to_f64((const int *) Y_dev, A->nrow * K, Yf.as<double>(), 0))
+			return -1;
+		svt_dev_csc Af = *A;
+		Af.Rtype = SVT_REALSXP; Af.val = V.p; Af.owned = 0;
+		return dev_crossprod_chunked(&Af, Yf.p, ldY, K, 0, out_dev, sc, sk, NULL);
+	}
 	// Large double products with a column-major dense operand take the panel-blocked
 	// kernels: the one-off layout build (a few ms at 1e8 nonzeros)
 	// pays for itself within the call.  Below the threshold the general kernels run,
@@ -995,6 +1010,19 @@ static int dev_crossprod_pp(const svt_dev_csc *other, const svt_dev_csc *pp,
 	const int64_t K = pp->ncol, nrow = pp->nrow;
 	if (K <= 0 || other->ncol <= 0)
 		return 0;
+	if (other->Rtype == SVT_INTSXP && nrow >= 256 &&
+	    (double) other->nnz * (double) K >= 268435456.0) {          // as in dev_crossprod_chunked
+		DevBuf V1, V2;
+		if (V1.alloc((size_t) (other->nnz > 0 ? other->nnz : 1) * 8) ||
+		    V2.alloc((size_t) (pp->nnz > 0 ? pp->nnz : 1) * 8) ||
+		    launch_int_to_f64((const int *) other->val, other->nnz, V1.as<double>(), 0) ||
+		    launch_int_to_f64((const int *) pp->val, pp->nnz, V2.as<double>(), 0))
+			return -1;
+		svt_dev_csc of = *other, pf = *pp;
+		of.Rtype = pf.Rtype = SVT_REALSXP; of.owned = pf.owned = 0;
+		of.val = V1.p; pf.val = V2.p;
+		return dev_crossprod_pp(&of, other == pp ? &of : &pf, out_dev, sc, sk);
+	}
 	int kc = chunk_K(nrow, K);
 	const size_t esz = elt_size(pp->Rtype);
 	// large double products: panel-blocked layout of `other`, built once, against

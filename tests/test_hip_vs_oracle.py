@@ -438,3 +438,20 @@ def test_colstats_very_short_leaves(hip, oracle, type_, na_rm):
             assert_identical(got, want, op)
         else:
             assert_equal(got, want, tol=1e-12, what=op, atol=1e-12, strict_na=op[3:] in ("Mins", "Maxs"))
+
+
+def test_crossprod_int_large_takes_panel_kernels(hip, oracle):
+    """Integer operands with nnz * K >= 2^28 run on the f64 panel kernels through f64 copies made on
+    the device (svt_hip.cpp, dev_crossprod_chunked / dev_crossprod_pp): integer arithmetic in double
+    is what the reference does (src/SparseVec_dotprod.c:73-114), so the results are identical, the
+    NA rules included."""
+    x = _svt(200_000, 1500, 0.01, 71, "int")                       # 3e6 nonzeros
+    rng = np.random.default_rng(72)
+    y = rng.integers(-9, 10, (200_000, 96)).astype(np.int32)
+    assert_identical(hip.crossprod(x, y), oracle.crossprod(x, y))
+    xn = _sprinkle(x, 73, [NA_integer])                            # NA in some leaves
+    assert_identical(hip.crossprod(xn, y), oracle.crossprod(xn, y))
+    y[12_345, 7] = NA_integer                                      # NA in the dense operand
+    assert_identical(hip.crossprod(xn, y), oracle.crossprod(xn, y))
+    z = _svt(200_000, 100, 0.02, 74, "int")
+    assert_identical(hip.crossprod(x, z), oracle.crossprod(x, z))
