@@ -118,7 +118,11 @@ void svt_resident_stats(size_t *bytes, int64_t *entries, int64_t *hits, int64_t 
 /* ---------------------------------------------------------------------- */
 
 /* C_crossprod2_SVT_mat, src/SparseMatrix_mult.c:931-982.
-   out: ncol(x) x (tr_y ? y_nrow : y_ncol) doubles. */
+   out: ncol(x) x (tr_y ? y_nrow : y_ncol) doubles.
+   Types: the reference's entry point requires type(x) == typeof(y) and its R method coerces the
+   integer operand of a mixed pair on the host first; svt_crossprod2_SVT_mat, _mat_SVT and
+   svt_matmul_SVT_mat also take an integer operand next to a double one and widen it on the device
+   (NA_integer_ -> NA_real_, as as.double() does). */
 int svt_crossprod2_SVT_mat(const svt_view *x, const void *y, int y_nrow,
 			   int y_ncol, int y_Rtype, int tr_y, double *out);
 /* C_crossprod2_mat_SVT, src/SparseMatrix_mult.c:985-1034.

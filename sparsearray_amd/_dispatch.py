@@ -148,6 +148,12 @@ class CAbiDispatcher:
         f(byref(b), byref(e), byref(h), byref(m))
         return {"bytes": b.value, "entries": e.value, "hits": h.value, "misses": m.value}
 
+    @property
+    def accepts_mixed_types(self) -> bool:
+        """The HIP library widens an integer operand of a mixed integer/double product on the
+        device (include/svt_hip.h); the oracle keeps the reference's "same type" rule."""
+        return self.prefix == "svt_"
+
     def has_entry(self, name: str) -> bool:
         return hasattr(self.lib, self.prefix + name[2:])
 

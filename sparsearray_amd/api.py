@@ -105,8 +105,9 @@ class Session:
         else:
             xy = _common_type(x.type, ytype)
             _check_crossprod_input_type(xy)
-            x = x.with_type(xy)
-            y = _dense_to_double(y)
+            if not self._device_coerces(x.type, ytype):
+                x = x.with_type(xy)
+                y = _dense_to_double(y)
         return self.SparseArray_Call("C_crossprod2_SVT_mat", x, y,
                                      bool(transpose_y))
 
@@ -125,10 +126,17 @@ class Session:
         else:
             xy = _common_type(xtype, y.type)
             _check_crossprod_input_type(xy)
-            y = y.with_type(xy)
-            x = _dense_to_double(x)
+            if not self._device_coerces(xtype, y.type):
+                y = y.with_type(xy)
+                x = _dense_to_double(x)
         return self.SparseArray_Call("C_crossprod2_mat_SVT", x, y,
                                      bool(transpose_x))
+
+    def _device_coerces(self, t1, t2) -> bool:
+        # integer x double: the R methods coerce the integer operand first (type(x) <- "double");
+        # the HIP library takes the pair as it is and widens on the device
+        return getattr(self._call, "accepts_mixed_types", False) and \
+            {t1, t2} == {"integer", "double"}
 
     def _crossprod2_SparseMatrix_SparseMatrix(self, x, y):
         if x.ndim != 2 or y.ndim != 2:
@@ -163,8 +171,9 @@ class Session:
         else:
             xy = _common_type(x.type, ytype)
             _check_crossprod_input_type(xy)
-            x = x.with_type(xy)
-            y = y.with_type(xy) if isinstance(y, SVT_SparseArray) else _dense_to_double(y)
+            if isinstance(y, SVT_SparseArray) or not self._device_coerces(x.type, ytype):
+                x = x.with_type(xy)
+                y = y.with_type(xy) if isinstance(y, SVT_SparseArray) else _dense_to_double(y)
         if isinstance(y, SVT_SparseArray):
             return self.SparseArray_Call("C_matmul_SVT_SVT", x, y)
         return self.SparseArray_Call("C_matmul_SVT_mat", x, y)

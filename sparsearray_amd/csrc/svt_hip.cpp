@@ -933,6 +933,43 @@ general:
 	return 0;
 }
 
+// Mixed integer / double operands.  The reference's entry points refuse them ("not supported
+// yet") and its R methods coerce the integer operand on the host first (type(x) <- "double",
+// R/SparseMatrix-mult.R:75-120) -- a copy of the whole tree.  Here the integer side is uploaded
+// as it is (4 bytes per value over PCIe) and widened on the device; as.double(NA_integer_) is
+// NA_real_, which is what int_to_f64_kernel writes.
+struct Promoted {
+	svt_dev_csc view;
+	DevBuf val, dense;
+	const svt_dev_csc *A;
+	const void *Y;
+	int promote(const svt_dev_csc *A_in, const void *Y_dev, int y_Rtype, size_t y_elems)
+	{
+		A = A_in; Y = Y_dev;
+		if (A_in->Rtype == y_Rtype)
+			return 0;
+		if (A_in->Rtype == SVT_INTSXP) {                 // sparse int, dense double
+			if (val.alloc((size_t) (A_in->nnz > 0 ? A_in->nnz : 1) * 8) ||
+			    launch_int_to_f64((const int *) A_in->val, A_in->nnz, val.as<double>(), 0))
+				return -1;
+			view = *A_in;
+			view.Rtype = SVT_REALSXP; view.val = val.p; view.owned = 0;
+			A = &view;
+		} else {                                          // sparse double, dense int
+			if (dense.alloc((y_elems > 0 ? y_elems : 1) * 8) ||
+			    launch_int_to_f64((const int *) Y_dev, (int64_t) y_elems, dense.as<double>(), 0))
+				return -1;
+			Y = dense.p;
+		}
+		return 0;
+	}
+};
+
+static bool mult_types_ok(int a, int b)
+{
+	return (a == SVT_REALSXP || a == SVT_INTSXP) && (b == SVT_REALSXP || b == SVT_INTSXP);
+}
+
 // C_crossprod2_SVT_mat, src/SparseMatrix_mult.c:931-982
 extern "C" int svt_crossprod2_SVT_mat(const svt_view *x, const void *y, int y_nrow,
 				      int y_ncol, int y_Rtype, int tr_y, double *out)
@@ -943,7 +980,7 @@ extern "C" int svt_crossprod2_SVT_mat(const svt_view *x, const void *y, int y_nr
 	if (in_nrow != (tr_y ? y_ncol : y_nrow))
 		return svt_set_error("input objects are non-conformable");
 	if (y_Rtype == SVT_LGLSXP) y_Rtype = SVT_INTSXP;
-	if (x->Rtype != y_Rtype)
+	if (!mult_types_ok(x->Rtype, y_Rtype))
 		return svt_set_error("SparseArray internal error in "
 				     "C_crossprod2_SVT_mat():\n"
 				     "    'x_Rtype != TYPEOF(y)' not supported yet");
@@ -960,8 +997,11 @@ extern "C" int svt_crossprod2_SVT_mat(const svt_view *x, const void *y, int y_nr
 	if (Y.upload(y, (size_t) y_nrow * y_ncol * elt_size(y_Rtype)) ||
 	    O.alloc(out_n * 8) || O.zero())
 		return -1;
-	if (dev_crossprod_chunked(A.h, Y.p, y_nrow, out_ncol, tr_y, O.as<double>(),
-				  1, out_nrow, &ahead))
+	Promoted pr;
+	if (pr.promote(A.h, Y.p, y_Rtype, (size_t) y_nrow * y_ncol))
+		return -1;
+	if (dev_crossprod_chunked(pr.A, pr.Y, y_nrow, out_ncol, tr_y, O.as<double>(),
+				  1, out_nrow, pr.A == A.h ? &ahead : NULL))
 		return -1;
 	if (staged_download(out, O.p, out_n * 8)) return -1;
 	return 0;
@@ -978,7 +1018,7 @@ extern "C" int svt_crossprod2_mat_SVT(const void *x, int x_nrow, int x_ncol,
 	if ((tr_x ? x_ncol : x_nrow) != in_nrow)
 		return svt_set_error("input objects are non-conformable");
 	if (x_Rtype == SVT_LGLSXP) x_Rtype = SVT_INTSXP;
-	if (x_Rtype != y->Rtype)
+	if (!mult_types_ok(x_Rtype, y->Rtype))
 		return svt_set_error("input objects must have the same type() for now");
 	const int out_nrow = tr_x ? x_nrow : x_ncol;
 	const size_t out_n = (size_t) out_nrow * out_ncol;
@@ -994,8 +1034,11 @@ extern "C" int svt_crossprod2_mat_SVT(const void *x, int x_nrow, int x_ncol,
 	    O.alloc(out_n * 8) || O.zero())
 		return -1;
 	// result cell (i = dense vector, j = leaf) lives at out[i + j*out_nrow]
-	if (dev_crossprod_chunked(A.h, X.p, x_nrow, out_nrow, tr_x, O.as<double>(),
-				  out_nrow, 1, &ahead))
+	Promoted pr;
+	if (pr.promote(A.h, X.p, x_Rtype, (size_t) x_nrow * x_ncol))
+		return -1;
+	if (dev_crossprod_chunked(pr.A, pr.Y, x_nrow, out_nrow, tr_x, O.as<double>(),
+				  out_nrow, 1, pr.A == A.h ? &ahead : NULL))
 		return -1;
 	if (staged_download(out, O.p, out_n * 8)) return -1;
 	return 0;
@@ -1172,7 +1215,7 @@ extern "C" int svt_matmul_SVT_mat(const svt_view *x, const void *y, int y_nrow,
 	if (in_nrow != y_nrow)
 		return svt_set_error("input objects are non-conformable");
 	if (y_Rtype == SVT_LGLSXP) y_Rtype = SVT_INTSXP;
-	if (x->Rtype != y_Rtype)
+	if (!mult_types_ok(x->Rtype, y_Rtype))
 		return svt_set_error("SparseArray internal error in "
 				     "C_crossprod2_SVT_mat():\n"
 				     "    'x_Rtype != TYPEOF(y)' not supported yet");
@@ -1193,7 +1236,11 @@ extern "C" int svt_matmul_SVT_mat(const svt_view *x, const void *y, int y_nrow,
 	if (Y.upload(y, (size_t) y_nrow * y_ncol * elt_size(y_Rtype)) ||
 	    O.alloc(out_n * 8) || O.zero())
 		return -1;
-	if (dev_crossprod_chunked(T, Y.p, y_nrow, y_ncol, 0, O.as<double>(), 1, out_nrow, &ahead))
+	Promoted pr;
+	if (pr.promote(T, Y.p, y_Rtype, (size_t) y_nrow * y_ncol))
+		return -1;
+	if (dev_crossprod_chunked(pr.A, pr.Y, y_nrow, y_ncol, 0, O.as<double>(), 1, out_nrow,
+				  pr.A == T ? &ahead : NULL))
 		return -1;
 	if (staged_download(out, O.p, out_n * 8)) return -1;
 	return 0;

@@ -455,3 +455,26 @@ def test_crossprod_int_large_takes_panel_kernels(hip, oracle):
     assert_identical(hip.crossprod(xn, y), oracle.crossprod(xn, y))
     z = _svt(200_000, 100, 0.02, 74, "int")
     assert_identical(hip.crossprod(x, z), oracle.crossprod(x, z))
+
+
+def test_crossprod_mixed_integer_double(hip, oracle):
+    """Integer x double pairs: the R methods coerce the integer operand on the host first; the HIP
+    library takes the pair as it is and widens on the device (include/svt_hip.h).  Same results as
+    the coerced call, small (general kernels) and large (panel kernels)."""
+    rng = np.random.default_rng(81)
+    for nrow, ncol, K in ((900, 70, 9), (60_000, 1000, 224)):
+        xi = _svt(nrow, ncol, 0.02, 82, "int")          # large case: 1.2e6 nonzeros x 224 >= 2^28
+        xd = _svt(nrow, ncol, 0.02, 84)
+        yd = rng.uniform(-1, 1, (nrow, K))
+        yi = rng.integers(-5, 6, (nrow, K)).astype(np.int32)
+        if nrow < 1000:       # (NAs make the oracle walk whole columns: small case only)
+            xi = _sprinkle(xi, 83, [NA_integer])
+            yi[7, 2] = NA_integer
+        tol = dict(tol=1e-9, atol=1e-10, strict_na=True)
+        assert_equal(hip.crossprod(xi, yd), oracle.crossprod(xi, yd), **tol)
+        assert_equal(hip.crossprod(yd, xi), oracle.crossprod(yd, xi), **tol)
+        assert_equal(hip.crossprod(xd, yi), oracle.crossprod(xd, yi), **tol)
+        assert_equal(hip.crossprod(yi, xd), oracle.crossprod(yi, xd), **tol)
+    zi = _svt(70, 900, 0.05, 85, "int")
+    w = rng.uniform(-1, 1, (900, 4))
+    assert_equal(hip.matmul(zi, w), oracle.matmul(zi, w), tol=1e-12, strict_na=True)
