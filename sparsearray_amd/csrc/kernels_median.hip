@@ -13,7 +13,12 @@
 // one canonical positive NaN (sorts last), sorted per column by hipcub's segmented
 // radix sort, and one thread per column picks the order statistics by three
 // binary searches (first key >= 0, first key > 0, first NaN).
-// Roofline: HBM; algorithmic bytes = 8 per nonzero read + 8 written per sort pass.
+// Most columns of a sparse matrix never get that far: when the middle ranks fall among the
+// zeros (fewer than half of the column's values positive, fewer than half negative) the
+// median is 0, which a counting pass over the values decides (median_count_kernel); only
+// the other columns keep a non-empty segment for the sort.
+// Roofline: HBM; algorithmic bytes = 8 per nonzero for the count pass, 8 + 8 for the key
+// copy, and 16 per sort pass for the columns that need one.
 #include "svt_common.h"
 #include <hipcub/hipcub.hpp>
 
@@ -33,12 +38,52 @@ __global__ void median_key_kernel(const T *__restrict__ val, int64_t nnz, double
 	keys[k] = d;
 }
 
+// One wavefront per column: negatives, positives, NA/NaN among the stored values.  Writes the
+// result where no order statistic of the nonzeros is needed (NA rule, empty column, both middle
+// ranks among the zeros) and gives every other column its sort segment [seg_b, seg_e).
+template <typename T>
+__global__ void __launch_bounds__(256)
+median_count_kernel(const int64_t *__restrict__ col_ptr, const T *__restrict__ val, int64_t nrow,
+		    int64_t ncol, int na_rm, double *__restrict__ out,
+		    int64_t *__restrict__ seg_b, int64_t *__restrict__ seg_e)
+{
+	const int lane = threadIdx.x & 63;
+	const int64_t j = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (j >= ncol) return;
+	const int64_t beg = col_ptr[j], end = col_ptr[j + 1];
+	long long neg = 0, pos = 0, nan = 0;
+	for (int64_t k = beg + lane; k < end; k += 64) {
+		double d;
+		if (sizeof(T) == 8) d = (double) val[k];
+		else { const int v = (int) val[k]; d = v == NA_INT ? NAN : (double) v; }
+		if (d != d) nan++;
+		else if (d < 0.0) neg++;
+		else if (d > 0.0) pos++;
+	}
+	neg = wave_sum_ll(neg); pos = wave_sum_ll(pos); nan = wave_sum_ll(nan);
+	neg = __shfl(neg, 0, 64); pos = __shfl(pos, 0, 64); nan = __shfl(nan, 0, 64);
+	if (lane != 0) return;
+	const int64_t len = end - beg, v = len - nan, padding = nrow - len, n = v + padding;
+	int64_t b = beg, e = beg;                        // empty segment: nothing to sort
+	if ((!na_rm && nan > 0) || n == 0) {
+		out[j] = svt_na_real();
+	} else {
+		const int64_t z = v - neg - pos + padding;   // stored + implicit zeros
+		const int64_t lo = (n - 1) >> 1, hi = n >> 1;
+		if (lo >= neg && hi < neg + z) out[j] = 0.0;
+		else { out[j] = -1.0; e = end; }             // decided by median_pick_kernel
+	}
+	seg_b[j] = b; seg_e[j] = e;
+}
+
 __global__ void median_pick_kernel(const int64_t *__restrict__ col_ptr, const double *__restrict__ keys,
-				   int64_t nrow, int64_t ncol, int na_rm, double *__restrict__ out)
+				   int64_t nrow, int64_t ncol, int na_rm, double *__restrict__ out,
+				   const int64_t *__restrict__ seg_e)
 {
 	const int64_t j = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
 	if (j >= ncol) return;
 	const int64_t beg = col_ptr[j], end = col_ptr[j + 1];
+	if (seg_e[j] != end || end == beg) return;       // decided by the counting pass
 	const double *__restrict__ s = keys + beg;
 	const int64_t len = end - beg;
 	// first NaN, first key >= 0, first key > 0
@@ -71,7 +116,7 @@ size_t colmedians_ws_bytes(int64_t nnz, int64_t ncol)
 	(void) hipcub::DeviceSegmentedRadixSort::SortKeys(NULL, tmp, (const double *) NULL, (double *) NULL,
 							  (int) n, (int) (ncol > 0 ? ncol : 1),
 							  (const int64_t *) NULL, (const int64_t *) NULL);
-	return (size_t) n * 16 + tmp + 512;
+	return (size_t) n * 16 + tmp + (size_t) (ncol > 0 ? ncol : 1) * 16 + 1024;
 }
 
 int launch_colmedians(const int64_t *col_ptr, const void *val, int Rtype, int64_t nrow, int64_t ncol,
@@ -83,7 +128,18 @@ int launch_colmedians(const int64_t *col_ptr, const void *val, int Rtype, int64_
 		return svt_set_error("colMedians: more than 2^31-1 nonzeros or columns");
 	double *k_in = (double *) ws;
 	double *k_out = k_in + (nnz > 0 ? nnz : 1);
-	void *tmp = (void *) (((uintptr_t) (k_out + (nnz > 0 ? nnz : 1)) + 255) & ~(uintptr_t) 255);
+	int64_t *seg_b = (int64_t *) (((uintptr_t) (k_out + (nnz > 0 ? nnz : 1)) + 255) & ~(uintptr_t) 255);
+	int64_t *seg_e = seg_b + ncol;
+	void *tmp = (void *) (((uintptr_t) (seg_e + ncol) + 255) & ~(uintptr_t) 255);
+	{
+		const unsigned nbc = (unsigned) ((ncol + 3) / 4);
+		if (Rtype == SVT_REALSXP)
+			hipLaunchKernelGGL(median_count_kernel<double>, dim3(nbc), dim3(256), 0, s, col_ptr,
+					   (const double *) val, nrow, ncol, na_rm, out, seg_b, seg_e);
+		else
+			hipLaunchKernelGGL(median_count_kernel<int>, dim3(nbc), dim3(256), 0, s, col_ptr,
+					   (const int *) val, nrow, ncol, na_rm, out, seg_b, seg_e);
+	}
 	if (nnz > 0) {
 		const unsigned nb = (unsigned) ((nnz + 255) / 256);
 		if (Rtype == SVT_REALSXP)
@@ -92,12 +148,12 @@ int launch_colmedians(const int64_t *col_ptr, const void *val, int Rtype, int64_
 			hipLaunchKernelGGL(median_key_kernel<int>, dim3(nb), dim3(256), 0, s, (const int *) val, nnz, k_in);
 		size_t tmp_bytes = 0;
 		HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(NULL, tmp_bytes, k_in, k_out, (int) nnz, (int) ncol,
-								   col_ptr, col_ptr + 1));
+								   seg_b, seg_e));
 		HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(tmp, tmp_bytes, k_in, k_out, (int) nnz, (int) ncol,
-								   col_ptr, col_ptr + 1, 0, 64, s));
+								   seg_b, seg_e, 0, 64, s));
 	}
 	hipLaunchKernelGGL(median_pick_kernel, dim3((unsigned) ((ncol + 255) / 256)), dim3(256), 0, s,
-			   col_ptr, k_out, nrow, ncol, na_rm, out);
+			   col_ptr, k_out, nrow, ncol, na_rm, out, seg_e);
 	HIP_TRY(hipGetLastError());
 	return 0;
 }
