@@ -149,6 +149,8 @@ int svt_matmul_SVT_SVT(const svt_view *x, const svt_view *y, double *out);
    of a 0-row matrix NA_real_.  out: ncol(x) doubles.  rowMedians(x) is colMedians(t(x)) as
    in the reference (:802-815). */
 int svt_colMedians_SVT(const svt_view *x, int na_rm, double *out);
+/* rowMedians(x): the same on t(x), transposed on the device.  out: nrow(x) doubles. */
+int svt_rowMedians_SVT(const svt_view *x, int na_rm, double *out);
 
 /* C_summarize_SVT, src/SparseArray_summarization.c:112-142.  The result is
    left in out_d[0..1] or out_i[0..1] according to *out_Rtype. */

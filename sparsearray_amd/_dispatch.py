@@ -61,6 +61,7 @@ class CAbiDispatcher:
         }
         if hasattr(self.lib, self.prefix + "colMedians_SVT"):      # HIP library (the oracle's is Python)
             protos["colMedians_SVT"] = (I, [V, I, P])
+            protos["rowMedians_SVT"] = (I, [V, I, P])
         # x %*% y in one call (device-side transposition): HIP library only
         for name, sig in (("matmul_SVT_mat", (I, [V, P, I, I, I, P])),
                           ("matmul_SVT_SVT", (I, [V, V, P]))):
@@ -127,6 +128,12 @@ class CAbiDispatcher:
         out = np.zeros(x.dim[1] if x.ndim == 2 else 0, dtype=np.float64)
         xv = make_view(x)
         self._check(self._fn("colMedians_SVT")(byref(xv), int(bool(na_rm)), _ptr(out)))
+        return out
+
+    def C_rowMedians_SVT(self, x: SVT_SparseArray, na_rm: bool):
+        out = np.zeros(x.dim[0] if x.ndim == 2 else 0, dtype=np.float64)
+        xv = make_view(x)
+        self._check(self._fn("rowMedians_SVT")(byref(xv), int(bool(na_rm)), _ptr(out)))
         return out
 
     # resident operands (include/svt_hip.h; HIP library only) --------------------

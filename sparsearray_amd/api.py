@@ -278,6 +278,11 @@ class Session:
             raise SparseArrayError(
                 "the rowMedians() method for SparseArray objects only supports 2D "
                 "objects (i.e. SparseMatrix objects) at the moment")
+        if not isinstance(na_rm, (bool, np.bool_)):
+            raise SparseArrayError("'na.rm' must be TRUE or FALSE")
+        has = getattr(self._call, "has_entry", lambda name: False)
+        if has("C_rowMedians_SVT") and x.dim[1] > 0 and x.dim[0] > 0:
+            return self.SparseArray_Call("C_rowMedians_SVT", x, bool(na_rm))   # t(x) on the device
         return self.colMedians(x.t(), na_rm=na_rm)
 
     def _rowStats(self, op, x, na_rm=False, center=None, dims=1):

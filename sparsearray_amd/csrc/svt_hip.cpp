@@ -1365,30 +1365,50 @@ extern "C" int svt_colStats_SVT(const svt_view *x, int opcode, int na_rm, double
 
 // colMedians(): .colMedians_SVT_SparseMatrix, R/SparseArray-matrixStats.R:761-784 (pure R in the
 // reference, with a TODO asking for a .Call version).  out: ncol(x) doubles.
-extern "C" int svt_colMedians_SVT(const svt_view *x, int na_rm, double *out)
+static int medians_SVT(const svt_view *x, int na_rm, int by_row, double *out)
 {
 	if (ensure_init() || check_view(x))
 		return -1;
 	if (x->ndim != 2)       // stopifnot_2D_object(), R/SparseArray-matrixStats.R:51-57
-		return svt_set_error("the colMedians() method for SparseArray objects only supports 2D "
-				     "objects (i.e. SparseMatrix objects) at the moment");
+		return svt_set_error("the %s() method for SparseArray objects only supports 2D "
+				     "objects (i.e. SparseMatrix objects) at the moment",
+				     by_row ? "rowMedians" : "colMedians");
 	if (x->Rtype != SVT_REALSXP && x->Rtype != SVT_INTSXP && x->Rtype != SVT_LGLSXP)
 		return svt_set_error("colMedians(): unsupported type");
 	if (x->na_background)
 		return svt_set_error("colMedians() is not supported on NaArray objects");
-	const int64_t ncol = x->dim[1];
-	if (ncol == 0)
+	const int64_t nout = x->dim[by_row ? 0 : 1];
+	if (nout == 0)
 		return 0;
 	CscGuard A(x);
 	if (A.h == NULL) return -1;
+	const svt_dev_csc *M = A.h;
+	int own_T = 0;
+	svt_dev_csc *T = NULL;
+	if (by_row) {           // rowMedians(x) = colMedians(t(x)), :802-815; t() on the device
+		T = transposed_for(A, &own_T);
+		if (T == NULL) return -1;
+		M = T;
+	}
+	OwnedCsc TG = { T, own_T };
 	DevBuf O, W;
-	if (O.alloc((size_t) ncol * 8) || W.alloc(colmedians_ws_bytes(A.h->nnz, ncol)))
+	if (O.alloc((size_t) nout * 8) || W.alloc(colmedians_ws_bytes(M->nnz, nout)))
 		return -1;
-	if (launch_colmedians(A.h->col_ptr, A.h->val, A.h->Rtype, A.h->nrow, ncol, A.h->nnz, na_rm,
+	if (launch_colmedians(M->col_ptr, M->val, M->Rtype, M->nrow, nout, M->nnz, na_rm,
 			      O.as<double>(), W.p, 0))
 		return -1;
 	HIP_TRY(hipDeviceSynchronize());
-	return staged_download(out, O.p, (size_t) ncol * 8);
+	return staged_download(out, O.p, (size_t) nout * 8);
+}
+
+extern "C" int svt_colMedians_SVT(const svt_view *x, int na_rm, double *out)
+{
+	return medians_SVT(x, na_rm, 0, out);
+}
+
+extern "C" int svt_rowMedians_SVT(const svt_view *x, int na_rm, double *out)
+{
+	return medians_SVT(x, na_rm, 1, out);
 }
 
 // C_summarize_SVT, src/SparseArray_summarization.c:112-142
