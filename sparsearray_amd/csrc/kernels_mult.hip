@@ -62,10 +62,13 @@ prep_dense_kernel(const T *__restrict__ Y, int64_t ldY, int64_t nrow, int K,
 	__shared__ double tile[64][65];
 	if (run_flag != NULL && *run_flag == 0)
 		return;   // fast path already produced the result
-	const int64_t r0 = (int64_t) blockIdx.x * 64;
 	const int k0 = blockIdx.y * 64;
 	const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
 	const bool is_dbl = sizeof(T) == 8;
+	// (row tiles in a grid-stride loop: the grid stays small, so that the launch that finds
+	// run_flag == 0 -- every product on the fast path -- costs ~1 us instead of ~8)
+	for (int64_t r0 = (int64_t) blockIdx.x * 64; r0 < nrow; r0 += (int64_t) gridDim.x * 64) {
+	if (r0 != (int64_t) blockIdx.x * 64) __syncthreads();        // tile[] is reused
 	if (!tr_y) {
 		// element (r, k) at Y[r + k*ldY]: lanes run along r
 		for (int kk = ty; kk < 64; kk += 4) {
@@ -105,6 +108,7 @@ prep_dense_kernel(const T *__restrict__ Y, int64_t ldY, int64_t nrow, int K,
 			if (r < nrow)
 				Yt[r * Kp + k] = d;
 		}
+	}
 	}
 }
 
@@ -198,7 +202,8 @@ static int dense_prepare(const CrossprodArgs &a, const int *run_flag, hipStream_
 	ColFlags fl = flags_of(a.ws, a.nrow, Kp);
 	HIP_TRY(hipMemsetAsync(fl.nonfinite, 0, (size_t) Kp * 8, s));
 	if (a.nrow > 0) {
-		dim3 grid((unsigned) ((a.nrow + 63) / 64), (unsigned) (Kp / 64));
+		const int64_t ntile = (a.nrow + 63) / 64;
+		dim3 grid((unsigned) (ntile < 2048 ? ntile : 2048), (unsigned) (Kp / 64));
 		if (a.Rtype == SVT_REALSXP)
 			hipLaunchKernelGGL(prep_dense_kernel<double>, grid, dim3(256), 0, s,
 					   (const double *) a.Y, a.ldY, a.nrow, a.K, a.tr_y, Yt, Kp, fl, run_flag);
