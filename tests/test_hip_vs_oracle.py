@@ -478,3 +478,13 @@ def test_crossprod_mixed_integer_double(hip, oracle):
     zi = _svt(70, 900, 0.05, 85, "int")
     w = rng.uniform(-1, 1, (900, 4))
     assert_equal(hip.matmul(zi, w), oracle.matmul(zi, w), tol=1e-12, strict_na=True)
+
+
+def test_crossprod_wide_dense_operand_is_chunked(hip, oracle):
+    """More than 512 dense columns: the host entry point runs the panel kernels chunk by chunk
+    (svt_hip.cpp, dev_crossprod_chunked); both orientations."""
+    x = _svt(60_000, 1000, 0.01, 91)
+    y = np.random.default_rng(92).uniform(-1, 1, (60_000, 600))
+    want = oracle.crossprod(x, y)
+    assert_equal(hip.crossprod(x, y), want, tol=1e-9, atol=1e-11)
+    assert_equal(hip.crossprod(y, x), want.T, tol=1e-9, atol=1e-11)
