@@ -15,6 +15,14 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle_session
+    from oracle.oracle import load_oracle
+    # The oracle's OpenMP loops take every core they see; on a shared GPU box the process owns
+    # a share of them (16 for one GPU) and oversubscription makes the large cases crawl.
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    load_oracle().orc_set_max_threads(max(1, min(ncpu, 16)))
     return oracle_session()
 
 
