@@ -4,14 +4,19 @@
 Workload (BASELINE.json configs[1], reading 2a of SURVEY.md section 8d):
     A = SVT_SparseMatrix 1e6 x 1e4 @ 1% density (randomSparseArray()-style),
     Y = dense double 1e6 x 128,  step = crossprod(A, Y) -> 1e4 x 128.
-One step = one pass of the hot path (stage Y + sparse x dense product) over
-operands already resident in HBM.  Metric: GNZ/s = nonzeros of A streamed per
-second (whole job, all ranks).
+One step = one pass of the hot path over operands already resident in HBM.
+Metric: GNZ/s = nonzeros of A streamed per second (whole job, all ranks).
 
-    python bench.py --gpus N --steps K --warmup W
-N > 1 is launched by torch.distributed.run (one rank per GPU): A and Y are
-row-sharded (every rank owns a full-size row block, weak scaling) and the
-small ncol x K result is all-reduced over RCCL inside the timed step.
+    python bench.py --gpus N --steps K --warmup W [--scaling strong|weak] [--config 2|4]
+
+N > 1 is launched by torch.distributed.run, one rank per GPU (RCCL).  Default `--scaling strong`:
+the SAME 1e6 x 1e4 problem at every N -- the matrix is defined as 8 row blocks
+(sparsearray_amd/synth.py, random_device_csc_blocked), rank r owns blocks r*8/N .. (r+1)*8/N-1 of A
+and of Y (rows = the contracted dimension, sparsearray_amd/parallel.py), and the 10 MB ncol x K
+result is all-reduced inside every step, overlapped with the next step's product.
+`--scaling weak` gives every rank a full-size block of its own (an N times larger problem).
+`--config 4`: BASELINE.json configs[3], 1e7 x 5e4 @ 0.1%, step = crossprod(A, Y 1e7 x 128) + colSums(A),
+sharded the same way (all-reduce of the 51 MB product and of the 5e4 column sums).
 """
 from __future__ import annotations
 
@@ -30,18 +35,27 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+CONFIGS = {
+    2: dict(nrow=1_000_000, ncol=10_000, density=0.01, K=128,
+            name="BASELINE.json configs[1] (reading 2a)"),
+    4: dict(nrow=10_000_000, ncol=50_000, density=0.001, K=128,
+            name="BASELINE.json configs[3] (crossprod + colSums)"),
+}
+
 
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--nrow", type=int, default=1_000_000)
-    p.add_argument("--ncol", type=int, default=10_000)
-    p.add_argument("--density", type=float, default=0.01)
-    p.add_argument("--K", type=int, default=128)
+    p.add_argument("--config", type=int, choices=sorted(CONFIGS), default=2)
+    p.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    p.add_argument("--nrow", type=int, default=None)
+    p.add_argument("--ncol", type=int, default=None)
+    p.add_argument("--density", type=float, default=None)
+    p.add_argument("--K", type=int, default=None)
     p.add_argument("--path", choices=["pbc", "v1"], default="pbc",
-                   help="pbc: panel-blocked LDS kernel (default); v1: gather kernel")
+                   help="pbc: panel-blocked LDS kernel (default); v1: gather kernel (1 GPU only)")
     p.add_argument("--cbw", type=int, default=40)
     p.add_argument("--wpb", type=int, default=16)
     p.add_argument("--logr", type=int, default=7)
@@ -51,7 +65,12 @@ def parse():
                    help="rehearsal only: every rank uses GPU 0 (needs --backend gloo)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extras", action="store_true")
-    return p.parse_args()
+    a = p.parse_args()
+    c = CONFIGS[a.config]
+    for k in ("nrow", "ncol", "density", "K"):
+        if getattr(a, k) is None:
+            setattr(a, k, c[k])
+    return a
 
 
 def host_cores() -> int:
@@ -103,91 +122,91 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run")
+    if world != a.gpus and world == 1 and a.gpus > 1:
+        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run")
     if a.same_device:
         local = 0
         os.environ["LOCAL_RANK"] = "0"          # (the HIP library binds to LOCAL_RANK)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    import torch.distributed as dist
     if world > 1:
-        import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if a.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(a.backend)
 
+    from sparsearray_amd import parallel as par
     from sparsearray_amd import synth
     from sparsearray_amd.device import (CrossprodPlan, DeviceCSC, PbcPlan, colmedians, colstats,
                                         rowsum, rowsums)
 
     nrow, ncol, K = a.nrow, a.ncol, a.K
-    # row-sharded global matrix: every rank owns an nrow x ncol block
-    col_ptr, row_idx, val = synth.random_device_csc(nrow, ncol, a.density, seed=1 + rank, device=dev)
-    Y = synth.random_dense(nrow, K, seed=101 + rank, device=dev)
-    A = DeviceCSC(nrow, col_ptr, row_idx, val)
+    strong = a.scaling == "strong"
+    if strong:
+        # one global problem, cut into row blocks that do not depend on the number of ranks
+        nblocks = 8 if 8 % world == 0 else world
+        per = nblocks // world
+        col_ptr, row_idx, val, (r0, r1) = synth.random_device_csc_blocked(
+            nrow, ncol, a.density, seed=1, device=dev, nblocks=nblocks, first=rank * per, last=(rank + 1) * per)
+        Y = synth.random_dense_blocked(nrow, K, seed=101, device=dev, nblocks=nblocks,
+                                       first=rank * per, last=(rank + 1) * per)
+    else:
+        # every rank owns a full-size block of an N times taller matrix
+        col_ptr, row_idx, val = synth.random_device_csc(nrow, ncol, a.density, seed=1 + rank, device=dev)
+        Y = synth.random_dense(nrow, K, seed=101 + rank, device=dev)
+        r0, r1 = rank * nrow, (rank + 1) * nrow
+    lrow = r1 - r0
+    A = DeviceCSC(lrow, col_ptr, row_idx, val)
     nnz = A.nnz
-    out = torch.zeros((K, ncol), dtype=torch.float64, device=dev)
-    # N > 1: two result buffers, so that the all-reduce of step i runs under the
-    # product of step i+1 (RCCL stream); step i+2 waits for it before reusing the buffer
-    outs = [out, torch.zeros_like(out)] if world > 1 else [out]
-    pending = [None, None]
-    stepno = [0]
-
-    def reduce_async(buf_i):
-        pending[buf_i] = dist.all_reduce(outs[buf_i], async_op=True)
-
-    def pick_out():
-        i = stepno[0] % len(outs)
-        stepno[0] += 1
-        if pending[i] is not None:
-            pending[i].wait()           # stream-level wait: buffer i is free again
-            pending[i] = None
-        return i
+    with_colsums = a.config == 4
     layout_ms = None
+    csum = [None]
     if a.path == "pbc":
         # one-off re-layout of the sparse operand (reported, not part of a step:
         # it depends on A only and is reused by every product with that A)
         torch.cuda.synchronize()
         t_l = time.perf_counter()
-        plan = PbcPlan(A, K, a.cbw, a.wpb, a.logr)
+        sc = par.ShardedCrossprod(A, K, None, a.cbw, a.wpb, a.logr)
         torch.cuda.synchronize()
         layout_ms = (time.perf_counter() - t_l) * 1e3
         kernel_name = "crossprod_pbc_dma_kernel"
 
         def step(ev=None):
-            i = pick_out()
-            if ev is not None:
-                ev[0].record()
-            plan.run_phase(1, Y, nrow, outs[i])   # the dominant kernel
-            if ev is not None:
-                ev[1].record()
-            plan.run_phase(2, Y, nrow, outs[i])   # partial sums -> out
-            if world > 1:
-                reduce_async(i)
+            sc.step(Y, ev)
+            if with_colsums:
+                csum[0] = par.sharded_colsums_rows(A)
+
+        def finish():
+            sc.wait()
+
+        def result():
+            return sc.result()
     else:
+        if world > 1:
+            raise SystemExit("--path v1 is a one-GPU diagnostic")
         plan = CrossprodPlan(A, K)
+        out = torch.zeros((K, ncol), dtype=torch.float64, device=dev)
         kernel_name = "crossprod_gather_kernel<double>"
 
         def step(ev=None):
-            i = pick_out()
-            plan.prepare(Y, nrow)
+            plan.prepare(Y, lrow)
             if ev is not None:
                 ev[0].record()
-            plan.multiply(outs[i], 1, ncol)
+            plan.multiply(out, 1, ncol)
             if ev is not None:
                 ev[1].record()
-            if world > 1:
-                reduce_async(i)
+
+        def finish():
+            pass
+
+        def result():
+            return out
 
     for _ in range(a.warmup):
         step()
-    for i_, w_ in enumerate(pending):
-        if w_ is not None:
-            w_.wait()
-            pending[i_] = None
+    finish()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -197,9 +216,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(evs[i])
-    for w_ in pending:
-        if w_ is not None:
-            w_.wait()
+    finish()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -215,47 +232,64 @@ def main():
     else:
         total_nnz = nnz
     kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs]))
+    res_t = result()
+    checksum = [float(res_t.sum().item()), float(res_t.abs().sum().item())]
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
-    # roofline of the dominant kernel (the sparse x dense product), per launch
-    alg_bytes = nnz * 12 + 8 * (ncol + 1) + nrow * K * 8 + ncol * K * 8
+    # roofline of the dominant kernel (the sparse x dense product) on this rank, per launch
+    alg_bytes = nnz * 12 + 8 * (ncol + 1) + lrow * K * 8 + ncol * K * 8
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-    traffic = None
+    traffic, traffic_source = None, None
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tfile):
+    if os.path.exists(tfile) and world == 1:
         try:
             tj = json.load(open(tfile))
             same_load = tj.get("workload_nnz_nominal") == int(nrow * ncol * a.density)
             if same_load and str(tj.get("kernel", "")).startswith(kernel_name.split("<")[0]):
                 traffic = tj.get("hbm_bytes_per_launch")
+                traffic_source = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this " \
+                                 "command, corrected as profiles/README says; not measured in this run)"
         except Exception:
             traffic = None
+    if world == 1:
+        para = "1 GPU"
+    elif strong:
+        para = (f"strong scaling: the one {nrow}x{ncol} problem, rows (contracted dimension) of A and Y sharded over "
+                f"{world} ranks; all-reduce of the ncol x K result inside every step, overlapped with the next "
+                "step's product (sparsearray_amd/parallel.py)")
+    else:
+        para = (f"weak scaling: every rank owns its own {nrow}x{ncol} block of a {world}x taller matrix; all-reduce "
+                "of the ncol x K result inside every step")
+    what = "crossprod(A, Y)" + (" + colSums(A)" if with_colsums else "")
     res = {
-        "metric": "GNZ/s, SVT crossprod(svt, dense) 1e6x1e4 @1% nnz",
+        "metric": "GNZ/s, SVT crossprod(svt, dense) 1e6x1e4 @1% nnz" if a.config == 2 else
+                  "GNZ/s, SVT crossprod(svt, dense) + colSums 1e7x5e4 @0.1% nnz",
         "value": total_nnz * a.steps / elapsed / 1e9,
         "unit": "GNZ/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": elapsed / a.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": a.scaling if world > 1 else "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"crossprod(A[{nrow}x{ncol} SVT @{a.density}], Y[{nrow}x{K} dense f64]) "
-                               f"-> {ncol}x{K}; BASELINE.json configs[1] (reading 2a)",
-                   "nnz_per_gpu": nnz, "parallelism": "rows sharded; all-reduce of the ncol x K result inside every step, "
-                                  "overlapped with the next step's product" if world > 1 else "1 GPU"},
+        "config": {"workload": f"{what}: A[{nrow if strong else nrow * world}x{ncol} SVT @{a.density}], "
+                               f"Y[{nrow if strong else nrow * world}x{K} dense f64] -> {ncol}x{K}; "
+                               f"{CONFIGS[a.config]['name']}; {a.scaling} scaling",
+                   "nnz_total": total_nnz, "nnz_rank0": nnz, "rows_rank0": lrow,
+                   "parallelism": para,
+                   "result_checksum": {"sum": checksum[0], "abs_sum": checksum[1]}},
         "roofline": {"bound": "hbm", "kernel": kernel_name,
                      "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                     "frac": achieved / 8000.0, "traffic": traffic,
+                     "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_source,
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "kernel_ms": kern_ms},
     }
     if layout_ms is not None:
         res["config"]["layout"] = f"PBC cbw={a.cbw} wpb={a.wpb} logR={a.logr}"
         res["config"]["layout_build_ms_once_per_operand"] = layout_ms
-    if world == 1 and not a.no_extras:
+    if world == 1 and not a.no_extras and a.config == 2:
         def timed(fn, reps=5):
             fn(); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -264,10 +298,10 @@ def main():
                 fn()
             e1.record(); torch.cuda.synchronize()
             return e0.elapsed_time(e1) / reps
-        grp = torch.randint(1, 1001, (nrow,), device=dev, dtype=torch.int32)
+        grp = torch.randint(1, 1001, (lrow,), device=dev, dtype=torch.int32)
         from sparsearray_amd.device import _lib as _devlib
-        rs_out = torch.empty(nrow, dtype=torch.float64, device=dev)
-        rs_ws = torch.empty(_devlib().svt_dev_rowstats_ws_bytes(nrow, ncol), dtype=torch.uint8, device=dev)
+        rs_out = torch.empty(lrow, dtype=torch.float64, device=dev)
+        rs_ws = torch.empty(_devlib().svt_dev_rowstats_ws_bytes(lrow, ncol), dtype=torch.uint8, device=dev)
         med_out = torch.empty(ncol, dtype=torch.float64, device=dev)
         med_ws = torch.empty(_devlib().svt_dev_colmedians_ws_bytes(nnz, ncol), dtype=torch.uint8, device=dev)
         ex = {}
@@ -275,8 +309,8 @@ def main():
             ("colSums", lambda: colstats(A, "sum"), nnz * 8 + ncol * 16),
             ("colVars", lambda: colstats(A, "var1"), nnz * 8 + ncol * 16),
             ("colMedians", lambda: colmedians(A, out=med_out, ws=med_ws), nnz * 8 + ncol * 16),
-            ("rowSums", lambda: rowsums(A, out=rs_out, ws=rs_ws), nnz * 12 + nrow * 8),
-            ("rowsum_1e3_groups", lambda: rowsum(A, grp, 1000), nnz * 12 + nrow * 4 + 1000 * ncol * 8),
+            ("rowSums", lambda: rowsums(A, out=rs_out, ws=rs_ws), nnz * 12 + lrow * 8),
+            ("rowsum_1e3_groups", lambda: rowsum(A, grp, 1000), nnz * 12 + lrow * 4 + 1000 * ncol * 8),
         ):
             ms = timed(fn)
             ex[name] = {"ms": ms, "GNZ/s": nnz / ms / 1e6, "GB/s": nbytes / ms / 1e6}
@@ -284,20 +318,22 @@ def main():
         torch.cuda.synchronize(); t_t = time.perf_counter()
         T = A.t()
         torch.cuda.synchronize(); tr_ms = (time.perf_counter() - t_t) * 1e3
+        torch.cuda.synchronize(); t_t = time.perf_counter()
         plan_t = PbcPlan(T, K, a.cbw, a.wpb, a.logr)
+        torch.cuda.synchronize(); lay_ms = (time.perf_counter() - t_t) * 1e3
         Y2 = synth.random_dense(ncol, K, seed=202, device=dev)
-        out2 = torch.empty((K, nrow), dtype=torch.float64, device=dev)
+        out2 = torch.empty((K, lrow), dtype=torch.float64, device=dev)
         ms = timed(lambda: plan_t.run(Y2, ncol, out2))
         ex["matmul_A_Y(2b)"] = {"ms": ms, "GNZ/s": nnz / ms / 1e6,
-                                "GB/s": (nnz * 12 + ncol * K * 8 + nrow * K * 8) / ms / 1e6,
-                                "transpose_ms_once": tr_ms}
+                                "GB/s": (nnz * 12 + ncol * K * 8 + lrow * K * 8) / ms / 1e6,
+                                "transpose_ms_once": tr_ms, "layout_ms_once": lay_ms}
         del plan_t, T, out2
         res["extras"] = ex
     if world == 1 and not a.no_cpu_baseline:
         ns = max(1, min(ncol, int(1e8 / max(nnz / ncol, 1))))   # <= 1e8 nz x K: 10-30 core-seconds
-        cb, ref_out, ns = cpu_baseline(col_ptr, row_idx, val, Y, nrow, K, ns)
+        cb, ref_out, ns = cpu_baseline(col_ptr, row_idx, val, Y, lrow, K, ns)
         # the timed GPU result must agree with the CPU oracle on the sample
-        got = outs[(stepno[0] - 1) % len(outs)][:, :ns].cpu().numpy()
+        got = result()[:, :ns].cpu().numpy()
         err = np.max(np.abs(got - ref_out) / np.maximum(np.abs(ref_out), 1e-12))
         cb["max_rel_err_vs_gpu"] = float(err)
         res["cpu_baseline"] = cb

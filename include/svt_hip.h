@@ -104,7 +104,7 @@ const char *svt_device_arch(void);
  * (plus what they derive from it: the panel-blocked layout, t(x)) up to that many bytes,
  * least recently used first out, and recognise the operand of a later call by a
  * fingerprint of its view: dims, type, and per leaf the host pointers, the count and
- * three sampled (offset, value) pairs.  R vectors are not modified once shared; callers
+ * eight sampled (offset, value) pairs.  R vectors are not modified once shared; callers
  * that overwrite leaves in place must call svt_resident_clear().  This is the device-side
  * counterpart of the reference operating in place on host memory
  * (src/SVT_SparseArray_class.c:598-633 walks the leaves on every call, at no cost).

@@ -246,6 +246,12 @@ extern "C" svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB
 	h->npanels = (A->nrow + (1LL << logR) - 1) >> logR;
 	if (h->npanels < 1) h->npanels = 1;
 	const int64_t ntiles = h->ngroups * h->npanels;
+	if (ntiles + 1 + PBC_TP_PAD >= (int64_t) 2147483647) {       // the scan below counts in int
+		svt_set_error("svt_dev_pbc_build: too many tiles (%lld) for the panel-blocked layout",
+			      (long long) ntiles);
+		free(h);
+		return NULL;
+	}
 	void *tmp = NULL;
 	size_t tmp_bytes = 0;
 	bool ok = hipMalloc((void **) &h->tile_ptr, (size_t) (ntiles + 1 + PBC_TP_PAD) * 8) == hipSuccess &&

@@ -486,20 +486,33 @@ int launch_rowstats(const RowStatsArgs &a, int64_t nnz, hipStream_t s)
 // --------------------------------------------------------------------------
 // rowsum / colsum
 // --------------------------------------------------------------------------
+// int32 results.  The reference adds one value at a time with safe_int_add() /
+// add_sparse_vec_to_ints() (src/rowsum_methods.c:66-84, 166-199): a cell becomes NA at the first
+// NA value (na.rm = FALSE) or at the first running sum outside [-INT_MAX, INT_MAX] -- only the
+// latter raises the overflow warning -- and stays NA.  On the device every cell gets its exact
+// total (i64), the sum of |values| and an "NA seen" flag in one parallel pass.  If the sum of
+// |values| fits, no running sum can leave the range whatever the order, and the total is the
+// reference's result.  Otherwise the cell's output column is redone by one thread in the
+// reference's order (groupsum_int_exact_kernel): rare (the data sit at the edge of int32), exact.
 struct IntSumScratch {
 	long long *sum;
+	unsigned long long *abs;
 	int *na;
+	int *redo;               // [number of output columns]
 };
 __host__ __device__ inline IntSumScratch split_int_scratch(void *p, int64_t n)
 {
 	IntSumScratch s;
 	s.sum = (long long *) p;
-	s.na = (int *) (s.sum + n);
+	s.abs = (unsigned long long *) (s.sum + n);
+	s.na = (int *) (s.abs + n);
+	s.redo = s.na + n;
 	return s;
 }
 size_t groupsum_scratch_bytes(int Rtype, int64_t out_len)
 {
-	return Rtype == SVT_REALSXP ? 16 : (size_t) out_len * 12 + 16;
+	// (at most out_len output columns)
+	return Rtype == SVT_REALSXP ? 16 : (size_t) out_len * 24 + 16;
 }
 
 __device__ inline int64_t col_beg(const GroupSumArgs &a, int64_t j)
@@ -575,32 +588,76 @@ groupsum_atomic_kernel(GroupSumArgs a, int64_t out_len)
 		} else if (miss) {
 			atomicOr(is.na + i, 1);
 		} else {
-			atomicAdd((unsigned long long *) is.sum + i,
-				  (unsigned long long) (long long) (int) v);
+			const long long x = (long long) (int) v;
+			atomicAdd((unsigned long long *) is.sum + i, (unsigned long long) x);
+			atomicAdd(is.abs + i, (unsigned long long) (x < 0 ? -x : x));
 		}
 	}
 }
 
-// int32 results: NA is sticky, a sum outside [-INT_MAX, INT_MAX] becomes NA
-// and raises the overflow flag (safe_int_add semantics applied to the total;
-// src/rowsum_methods.c:66-84, 166-199).
-__global__ void groupsum_int_finish_kernel(GroupSumArgs a, int64_t out_len)
+// int32 results from the parallel pass; cells whose running sums could have left the range
+// flag their output column for groupsum_int_exact_kernel.
+__global__ void groupsum_int_finish_kernel(GroupSumArgs a, int64_t out_len, int64_t col_len)
 {
 	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= out_len)
 		return;
 	IntSumScratch is = split_int_scratch(a.scratch, out_len);
-	const long long sum = is.sum[i];
-	int r;
-	if (is.na[i]) {
-		r = NA_INT;
-	} else if (sum > 2147483647LL || sum < -2147483647LL) {
-		r = NA_INT;
-		if (a.ovflow_flag) *a.ovflow_flag = 1;
-	} else {
-		r = (int) sum;
+	if (is.abs[i] > 2147483647ULL) {
+		is.redo[i / col_len] = 1;
+		return;
 	}
-	((int *) a.out)[i] = r;
+	((int *) a.out)[i] = is.na[i] ? NA_INT : (int) is.sum[i];
+}
+
+// One thread per flagged output column, the reference's loops as they are:
+// TARGET 0 rowsum (compute_rowsum_ints, src/rowsum_methods.c:66-84): output column j = leaf j;
+// TARGET 1 colsum (add_sparse_vec_to_ints, :166-199): output column g = the leaves of group g in
+// ascending order.
+template <int TARGET>
+__global__ void groupsum_int_exact_kernel(GroupSumArgs a, int64_t out_len, int64_t ncols_out,
+					  int64_t col_len)
+{
+	const int64_t c = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= ncols_out)
+		return;
+	IntSumScratch is = split_int_scratch(a.scratch, out_len);
+	if (!is.redo[c])
+		return;
+	int *__restrict__ out = (int *) a.out + c * col_len;
+	const int *__restrict__ val = (const int *) a.val;
+	for (int64_t r = 0; r < col_len; r++) out[r] = 0;
+	int ov = 0;
+	const int64_t j0 = TARGET == 0 ? c : 0, j1 = TARGET == 0 ? c + 1 : a.ncol;
+	for (int64_t j = j0; j < j1; j++) {
+		if (TARGET == 1) {
+			int g = a.group[j];
+			if (g == NA_INT) g = a.ngroup;
+			if (g - 1 != c) continue;
+		}
+		const int64_t beg = col_beg(a, j), end = col_beg(a, j + 1);
+		for (int64_t k = beg; k < end; k++) {
+			int64_t r;
+			if (TARGET == 0) {
+				int g = a.group[a.row_idx[k]];
+				if (g == NA_INT) g = a.ngroup;
+				r = g - 1;
+			} else {
+				r = a.row_idx[k];
+			}
+			const int cur = out[r], v = val[k];
+			if (v == NA_INT) {
+				if (!a.na_rm) out[r] = NA_INT;
+				continue;
+			}
+			if (cur == NA_INT)
+				continue;
+			const long long y = (long long) cur + v;
+			if (y > 2147483647LL || y < -2147483647LL) { out[r] = NA_INT; ov = 1; }
+			else out[r] = (int) y;
+		}
+	}
+	if (ov && a.ovflow_flag) *a.ovflow_flag = 1;
 }
 
 static int groupsum_common(const GroupSumArgs &a, int64_t out_len, bool colsum,
@@ -612,7 +669,7 @@ static int groupsum_common(const GroupSumArgs &a, int64_t out_len, bool colsum,
 	if (is_dbl)
 		HIP_TRY(hipMemsetAsync(a.out, 0, (size_t) out_len * 8, s));
 	else
-		HIP_TRY(hipMemsetAsync(a.scratch, 0, (size_t) out_len * 12, s));
+		HIP_TRY(hipMemsetAsync(a.scratch, 0, groupsum_scratch_bytes(a.Rtype, out_len), s));
 	if (a.ncol > 0) {
 		const unsigned nb = (unsigned) ((a.ncol + 3) / 4);
 		if (colsum) {
@@ -624,8 +681,13 @@ static int groupsum_common(const GroupSumArgs &a, int64_t out_len, bool colsum,
 		}
 	}
 	if (!is_dbl) {
+		const int64_t col_len = colsum ? a.nrow : a.ngroup;
+		const int64_t ncols_out = colsum ? a.ngroup : a.ncol;
 		const unsigned nbo = (unsigned) ((out_len + 255) / 256);
-		hipLaunchKernelGGL(groupsum_int_finish_kernel, dim3(nbo), dim3(256), 0, s, a, out_len);
+		const unsigned nbc = (unsigned) ((ncols_out + 63) / 64);
+		hipLaunchKernelGGL(groupsum_int_finish_kernel, dim3(nbo), dim3(256), 0, s, a, out_len, col_len);
+		if (colsum) hipLaunchKernelGGL(groupsum_int_exact_kernel<1>, dim3(nbc), dim3(64), 0, s, a, out_len, ncols_out, col_len);
+		else hipLaunchKernelGGL(groupsum_int_exact_kernel<0>, dim3(nbc), dim3(64), 0, s, a, out_len, ncols_out, col_len);
 	}
 	HIP_TRY(hipGetLastError());
 	return 0;

@@ -84,6 +84,7 @@ static int ensure_init()
 // the R heap) into one buffer while the previous one is in flight on a copy stream
 // (the reference's counterpart is the leaf walk of
 // src/SVT_SparseArray_class.c:598-633, which never leaves the host).
+#include <algorithm>
 #include <functional>
 #include <mutex>
 #include <vector>
@@ -139,6 +140,23 @@ struct Stager {
 	}
 };
 static Stager g_stager;
+
+// Bytes of a pinned buffer used per trip.  SVT_STAGING_CHUNK (bytes, read once) lowers it so
+// that a test can drive the multi-chunk paths -- a leaf longer than a chunk among them --
+// with small inputs.
+static size_t g_stager_chunk()
+{
+	static size_t v = 0;
+	if (v == 0) {
+		v = Stager::CHUNK;
+		const char *e = getenv("SVT_STAGING_CHUNK");
+		if (e != NULL) {
+			const long long t = atoll(e);
+			if (t >= 4096 && (size_t) t < Stager::CHUNK) v = (size_t) t / 4096 * 4096;
+		}
+	}
+	return v;
+}
 
 // run fn(t, nt) on a small team (the calling thread is one of them)
 static void team_run(int nt, const std::function<void(int, int)> &fn)
@@ -257,6 +275,21 @@ static int check_view(const svt_view *x)
 	return 0;
 }
 
+// counts within [0, dim0], no NULL offsets behind a positive count
+static int check_leaves(const svt_view *x)
+{
+	if (x->svt_is_null) return 0;
+	const int dim0 = x->dim[0];
+	for (int64_t j = 0; j < x->nleaves; j++) {
+		const int c = x->nzcount[j];
+		if (c < 0 || c > dim0)
+			return svt_set_error("invalid SVT leaf (nzcount %d, dim %d)", c, dim0);
+		if (c > 0 && x->nzoffs[j] == NULL)
+			return svt_set_error("invalid SVT leaf (NULL nzoffs)");
+	}
+	return 0;
+}
+
 extern "C" svt_dev_csc *svt_upload(const svt_view *x)
 {
 	if (ensure_init() || check_view(x))
@@ -295,44 +328,46 @@ extern "C" svt_dev_csc *svt_upload(const svt_view *x)
 	}
 	bool ok = hipMemcpy(d->col_ptr, col_ptr.data(), (size_t) (d->ncol + 1) * 8,
 			    hipMemcpyHostToDevice) == hipSuccess;
-	// leaves j0 .. j1-1 per trip: as many as fit one pinned buffer
-	// ([offsets of the chunk][values of the chunk], 4 + esz bytes per nonzero)
-	const int64_t cap = (int64_t) (Stager::CHUNK / (4 + esz));
-	int64_t j0 = 0;
-	while (ok && j0 < n) {
-		int64_t j1 = j0;
-		while (j1 < n && col_ptr[j1 + 1] - col_ptr[j0] <= cap) j1++;
-		if (j1 == j0) j1 = j0 + 1;                  // (a leaf never exceeds cap: dim0 < 2^31)
-		const int64_t k0 = col_ptr[j0], cnt = col_ptr[j1] - k0;
-		if (cnt > 0) {
-			char *b; int slot;
-			if (g_stager.acquire(&b, &slot)) { ok = false; break; }
-			int32_t *so = (int32_t *) b;
-			char *sv = b + (size_t) cnt * 4;
-			team_run(team_size((size_t) cnt * (4 + esz)), [&](int t, int nt) {
-				const int64_t ja = j0 + (j1 - j0) * t / nt, jb = j0 + (j1 - j0) * (t + 1) / nt;
-				for (int64_t j = ja; j < jb; j++) {
-					const int64_t s = col_ptr[j] - k0, c = col_ptr[j + 1] - col_ptr[j];
-					if (c == 0) continue;
-					memcpy(so + s, x->nzoffs[j], (size_t) c * 4);
-					const void *v = x->nzvals[j];
-					if (v != NULL) {
-						memcpy(sv + (size_t) s * esz, v, (size_t) c * esz);
-					} else if (esz == 8) {      // lacunar leaf: all ones
-						double *o = (double *) sv + s;
-						for (int64_t k = 0; k < c; k++) o[k] = 1.0;
-					} else {
-						int *o = (int *) sv + s;
-						for (int64_t k = 0; k < c; k++) o[k] = 1;
-					}
+	// nonzeros k0 .. k0+cnt-1 per trip: as many as fit one pinned buffer
+	// ([offsets of the chunk][values of the chunk], 4 + esz bytes per nonzero).  Chunks are
+	// cut in nonzeros, not in leaves: one leaf may be longer than a buffer (dim0 only has to
+	// exceed CHUNK / 12), and the team splits a chunk evenly whatever the leaf lengths are.
+	const int64_t cap = (int64_t) (g_stager_chunk() / (4 + esz));
+	const int64_t nnz = d->nnz;
+	for (int64_t k0 = 0; ok && k0 < nnz; k0 += cap) {
+		const int64_t cnt = nnz - k0 < cap ? nnz - k0 : cap;
+		char *b; int slot;
+		if (g_stager.acquire(&b, &slot)) { ok = false; break; }
+		int32_t *so = (int32_t *) b;
+		char *sv = b + (size_t) cnt * 4;
+		team_run(team_size((size_t) cnt * (4 + esz)), [&](int t, int nt) {
+			const int64_t ka = k0 + cnt * t / nt, kb = k0 + cnt * (t + 1) / nt;
+			if (ka >= kb) return;
+			// first leaf that reaches past ka
+			int64_t j = std::upper_bound(col_ptr.begin(), col_ptr.end(), ka) - col_ptr.begin() - 1;
+			for (; j < n && col_ptr[j] < kb; j++) {
+				const int64_t a = col_ptr[j] > ka ? col_ptr[j] : ka;
+				const int64_t e = col_ptr[j + 1] < kb ? col_ptr[j + 1] : kb;
+				if (e <= a) continue;
+				const int64_t in_leaf = a - col_ptr[j], s = a - k0, c = e - a;
+				memcpy(so + s, x->nzoffs[j] + in_leaf, (size_t) c * 4);
+				const void *v = x->nzvals[j];
+				if (v != NULL) {
+					memcpy(sv + (size_t) s * esz, (const char *) v + (size_t) in_leaf * esz,
+					       (size_t) c * esz);
+				} else if (esz == 8) {      // lacunar leaf: all ones
+					double *o = (double *) sv + s;
+					for (int64_t k = 0; k < c; k++) o[k] = 1.0;
+				} else {
+					int *o = (int *) sv + s;
+					for (int64_t k = 0; k < c; k++) o[k] = 1;
 				}
-			});
-			ok = g_stager.send(slot, d->row_idx + k0, 0, (size_t) cnt * 4) == 0 &&
-			     g_stager.send(slot, (char *) d->val + (size_t) k0 * esz, (size_t) cnt * 4,
-					   (size_t) cnt * esz) == 0 &&
-			     g_stager.commit(slot) == 0;
-		}
-		j0 = j1;
+			}
+		});
+		ok = g_stager.send(slot, d->row_idx + k0, 0, (size_t) cnt * 4) == 0 &&
+		     g_stager.send(slot, (char *) d->val + (size_t) k0 * esz, (size_t) cnt * 4,
+				   (size_t) cnt * esz) == 0 &&
+		     g_stager.commit(slot) == 0;
 	}
 	if (ok) ok = g_stager.drain() == 0;
 	if (!ok) {
@@ -378,7 +413,7 @@ extern "C" void svt_release(svt_dev_csc *h)
 // (svt_resident_set_limit), the host-level entry points keep the device copy of an
 // operand -- and the layouts derived from it: panel-blocked records, t(x) -- and find it
 // again through a fingerprint of the view: dims, type, and per leaf the two host
-// pointers, the count and the first / middle / last (offset, value).  R vectors are
+// pointers, the count and eight evenly spread (offset, value) samples.  R vectors are
 // immutable once shared, so equal pointers + counts + samples mean equal contents for
 // well-behaved callers; code that overwrites leaves in place must call
 // svt_resident_clear().  Off by default.  
@@ -475,8 +510,9 @@ static uint64_t view_fingerprint(const svt_view *x)
 		if (n <= 0) continue;
 		h = fp_mix(h, (uint64_t) (uintptr_t) x->nzoffs[j]);
 		h = fp_mix(h, (uint64_t) (uintptr_t) x->nzvals[j]);
-		const int at[3] = { 0, n / 2, n - 1 };
-		for (int t = 0; t < 3; t++) {
+		int at[8];
+		for (int t = 0; t < 8; t++) at[t] = (int) ((int64_t) (n - 1) * t / 7);
+		for (int t = 0; t < 8; t++) {
 			uint64_t v = (uint64_t) (uint32_t) x->nzoffs[j][at[t]];
 			if (x->nzvals[j] != NULL) {               // (NULL: lacunar leaf, all ones)
 				uint64_t bits = 0;
@@ -498,6 +534,7 @@ struct CscGuard {
 	explicit CscGuard(const svt_view *x) : h(NULL), key(0)
 	{
 		if (g_res_limit == 0) { h = svt_upload(x); return; }
+		if (check_view(x) || check_leaves(x)) return;      // (the fingerprint reads the leaves)
 		const uint64_t k = view_fingerprint(x) | 1;
 		{
 			std::lock_guard<std::mutex> lk(g_res_mu);
@@ -535,6 +572,15 @@ struct CscGuard {
 	CscGuard &operator=(const CscGuard &) = delete;
 };
 
+// index of the resident entry that owns the device handle A (as its operand or as its
+// transposed copy), or -1; call with g_res_mu held
+static int resident_find(const svt_dev_csc *A)
+{
+	for (size_t i = 0; i < g_res.size(); i++)
+		if (g_res[i].csc == A || g_res[i].tr == A) return (int) i;
+	return -1;
+}
+
 // The panel-blocked layout of a resident operand lives with it; for a one-call operand it
 // is built and released by the caller.  *owned tells which.
 static svt_dev_pbc *pbc_for(const svt_dev_csc *A, int *owned)
@@ -552,17 +598,18 @@ static svt_dev_pbc *pbc_for(const svt_dev_csc *A, int *owned)
 	svt_dev_pbc *P = svt_dev_pbc_build(A, 40, 16, 7);
 	if (P == NULL) return NULL;
 	std::lock_guard<std::mutex> lk(g_res_mu);
-	for (Resident &r : g_res)
-		if (r.csc == A || r.tr == A) {
-			const size_t nb = pbc_bytes(P);
-			resident_make_room(nb);                   // (the entry itself is pinned by its guard)
-			if (g_res_bytes + nb <= g_res_limit) {
-				(r.csc == A ? r.pbc : r.tr_pbc) = P;
-				r.bytes += nb; g_res_bytes += nb;
-				*owned = 0;
-			}
-			break;
+	if (resident_find(A) >= 0) {
+		const size_t nb = pbc_bytes(P);
+		resident_make_room(nb);                   // (the entry itself is pinned by its guard)
+		// make_room() erases entries: look the operand up again, never keep a reference across it
+		const int i = resident_find(A);
+		if (i >= 0 && g_res_bytes + nb <= g_res_limit) {
+			Resident &r = g_res[(size_t) i];
+			(r.csc == A ? r.pbc : r.tr_pbc) = P;
+			r.bytes += nb; g_res_bytes += nb;
+			*owned = 0;
 		}
+	}
 	return P;
 }
 
@@ -833,10 +880,22 @@ static int chunk_K(int64_t nrow, int64_t K)
 	return (int) kc;
 }
 
+// The panel-blocked layout stores every (column group, 128-row panel) tile as whole batches of
+// 8 records (96 bytes, at least one per tile) plus 8 bytes of tile table: a hypersparse operand
+// (1e6 x 1e6 with 3e7 nonzeros: 20 GB of records for 0.36 GB of CSC) would be streamed at a
+// fraction of the general kernels' speed, and the tile count must fit the 32-bit scan.
+static bool pbc_shape_ok(int64_t nrow, int64_t ncol, int64_t nnz)
+{
+	const double ngroups = (double) ((ncol + 639) / 640) * 16.0;
+	const double npanels = (double) ((nrow + 127) / 128);
+	const double ntiles = ngroups * npanels;
+	return ntiles + 1.0 < 2147483647.0 && (double) nnz >= 4.0 * ntiles;
+}
+
 static bool pbc_applies(const svt_dev_csc *A, int64_t K, int tr_y)
 {
 	return A->Rtype == SVT_REALSXP && !tr_y && A->nrow >= 256 && A->ncol > 0 &&
-	       (double) A->nnz * (double) K >= 268435456.0;
+	       (double) A->nnz * (double) K >= 268435456.0 && pbc_shape_ok(A->nrow, A->ncol, A->nnz);
 }
 
 // The layout build is device work (a few ms at 1e8 nonzeros) and the upload of the dense
@@ -881,7 +940,7 @@ static int dev_crossprod_chunked(const svt_dev_csc *A, const void *Y_dev, int64_
 	// results, NA rules included, are those of the integer path -- bit for bit while the sums
 	// stay below 2^53).
 	if (A->Rtype == SVT_INTSXP && !tr_y && ldY == A->nrow && A->nrow >= 256 &&
-	    (double) A->nnz * (double) K >= 268435456.0) {
+	    (double) A->nnz * (double) K >= 268435456.0 && pbc_shape_ok(A->nrow, A->ncol, A->nnz)) {
 		DevBuf V, Yf;
 		if (V.alloc((size_t) (A->nnz > 0 ? A->nnz : 1) * 8) || Yf.alloc((size_t) A->nrow * K * 8) ||
 		    launch_int_to_f64((const int *) A->val, A->nnz, V.as<double>(), 0) ||
@@ -1053,8 +1112,9 @@ static int dev_crossprod_pp(const svt_dev_csc *other, const svt_dev_csc *pp,
 	const int64_t K = pp->ncol, nrow = pp->nrow;
 	if (K <= 0 || other->ncol <= 0)
 		return 0;
-	if (other->Rtype == SVT_INTSXP && nrow >= 256 &&
-	    (double) other->nnz * (double) K >= 268435456.0) {          // as in dev_crossprod_chunked
+	const bool big = nrow >= 256 && (double) other->nnz * (double) K >= 268435456.0 &&
+			 pbc_shape_ok(other->nrow, other->ncol, other->nnz);
+	if (other->Rtype == SVT_INTSXP && big) {                         // as in dev_crossprod_chunked
 		DevBuf V1, V2;
 		if (V1.alloc((size_t) (other->nnz > 0 ? other->nnz : 1) * 8) ||
 		    V2.alloc((size_t) (pp->nnz > 0 ? pp->nnz : 1) * 8) ||
@@ -1072,8 +1132,7 @@ static int dev_crossprod_pp(const svt_dev_csc *other, const svt_dev_csc *pp,
 	// every densified chunk (same threshold and caveat as dev_crossprod_chunked)
 	svt_dev_pbc *P = NULL;
 	int own_P = 1;
-	if (other->Rtype == SVT_REALSXP && nrow >= 256 &&
-	    (double) other->nnz * (double) K >= 268435456.0) {
+	if (other->Rtype == SVT_REALSXP && big) {
 		P = pbc_for(other, &own_P);
 		if (P != NULL && kc > 512) kc = 512;
 	}
@@ -1183,16 +1242,15 @@ static svt_dev_csc *transposed_for(const CscGuard &A, int *owned)
 	svt_dev_csc *T = dev_transposed(A.h);
 	if (T == NULL || A.key == 0) return T;
 	std::lock_guard<std::mutex> lk(g_res_mu);
-	for (Resident &r : g_res)
-		if (r.key == A.key) {
-			const size_t nb = csc_bytes(T);
-			resident_make_room(nb);
-			if (g_res_bytes + nb <= g_res_limit) {
+	const size_t nb = csc_bytes(T);
+	resident_make_room(nb);                           // may erase entries: search afterwards
+	if (g_res_bytes + nb <= g_res_limit)
+		for (Resident &r : g_res)
+			if (r.key == A.key) {
 				r.tr = T; r.bytes += nb; g_res_bytes += nb;
 				*owned = 0;
+				break;
 			}
-			break;
-		}
 	return T;
 }
 

@@ -1,31 +1,45 @@
 """Multi-GPU sharding of the hot path.
 
-One process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI on
-the GPU box, "gloo" in the CPU tests).  The rule: split the largest operand,
-move the smallest tensor.
+One process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI on the GPU box,
+"gloo" in the CPU tests and in the same-device rehearsal).  The reference has no multi-device
+path ("Collective call sites: none"); the rule used here: split the
+largest operand, move the smallest tensor.
 
-* crossprod(A, Y) with a tall dense Y: shard the CONTRACTED dimension (rows).
-  Rank g owns rows [r0, r1) of A (row-filtered leaves) and of Y, computes a
-  full ncol x K partial, and the partials are all-reduced (ncol*K doubles).
-* col stats / rowsum: shard leaves (columns) by nnz; results are gathered.
+=====================================  ==========================  ===========================
+op                                     partition                   collective
+=====================================  ==========================  ===========================
+crossprod(A, Y), Y tall and dense      rows (contracted dim) of    all-reduce of the ncol x K
+                                       A and of Y                  result
+colSums/colVars/... (col stats)        leaves (columns) by nnz     all-gather of the scalars
+colSums on a ROW-sharded operand       rows                        all-reduce of ncol scalars
+rowsum(A, group)                       leaves (columns) by nnz     all-gather of ngroup x ncol/N
+A %*% Y (tall result)                  rows of A = rows of result  none (each rank owns rows)
+=====================================  ==========================  ===========================
 
-The local compute is passed in as a callable so the same sharding logic runs
-on the HIP path (bench.py) and under the CPU tests.
+Everything here works on device-resident operands (`DeviceCSC`) and calls the HIP library for
+the local compute; `local=` hooks let the CPU tests plug the oracle in under the same sharding
+and collective logic.  bench.py drives `ShardedCrossprod` for its N > 1 runs.
 """
 from __future__ import annotations
 
-from typing import Callable, Tuple
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
 import torch.distributed as dist
 
 
-def row_block(nrow: int, rank: int, world: int) -> Tuple[int, int]:
-    """Contiguous row block of `rank` (sizes differ by at most one)."""
-    base, rem = divmod(nrow, world)
-    r0 = rank * base + min(rank, rem)
-    return r0, r0 + base + (1 if rank < rem else 0)
+# --------------------------------------------------------------------------------------------
+# partitions
+# --------------------------------------------------------------------------------------------
+def row_block(nrow: int, rank: int, world: int, align: int = 1) -> Tuple[int, int]:
+    """Contiguous row block of `rank`.  Sizes differ by at most `align` rows; with align > 1
+    every boundary but the last is a multiple of it (128 = the row panels of the product kernel)."""
+    units = (nrow + align - 1) // align
+    base, rem = divmod(units, world)
+    u0 = rank * base + min(rank, rem)
+    u1 = u0 + base + (1 if rank < rem else 0)
+    return min(u0 * align, nrow), min(u1 * align, nrow)
 
 
 def row_shard_csc(col_ptr, row_idx, val, r0: int, r1: int):
@@ -44,7 +58,7 @@ def row_shard_csc(col_ptr, row_idx, val, r0: int, r1: int):
     return csum[np.asarray(col_ptr)], (row_idx[keep] - r0).astype(np.int32), val[keep]
 
 
-def col_blocks_by_nnz(col_ptr, world: int):
+def col_blocks_by_nnz(col_ptr, world: int) -> List[Tuple[int, int]]:
     """Leaf ranges [c0, c1) per rank with ~equal nnz (prefix sums of col_ptr)."""
     cp = col_ptr.cpu().numpy() if isinstance(col_ptr, torch.Tensor) else np.asarray(col_ptr)
     ncol, nnz = len(cp) - 1, int(cp[-1])
@@ -56,29 +70,177 @@ def col_blocks_by_nnz(col_ptr, world: int):
     return [(int(cuts[g]), int(cuts[g + 1])) for g in range(world)]
 
 
+def col_shard_csc(col_ptr, row_idx, val, c0: int, c1: int):
+    """Leaves [c0, c1) as a CSC of their own (col_ptr rebased); views, no copy of the payload."""
+    k0, k1 = int(col_ptr[c0]), int(col_ptr[c1])
+    return col_ptr[c0:c1 + 1] - k0, row_idx[k0:k1], val[k0:k1]
+
+
+# --------------------------------------------------------------------------------------------
+# collectives
+# --------------------------------------------------------------------------------------------
+def _world(group=None) -> int:
+    return dist.get_world_size(group) if dist.is_initialized() else 1
+
+
+def _rank(group=None) -> int:
+    return dist.get_rank(group) if dist.is_initialized() else 0
+
+
 def sharded_crossprod(local_crossprod: Callable[[], torch.Tensor], group=None) -> torch.Tensor:
     """`local_crossprod()` returns this rank's ncol x K partial (any layout, the
     same on every rank); the sum over ranks is returned on every rank."""
     part = local_crossprod()
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _world(group) > 1:
         dist.all_reduce(part, op=dist.ReduceOp.SUM, group=group)
     return part
 
 
-def gather_columns(local: torch.Tensor, sizes, group=None) -> torch.Tensor:
-    """Concatenate per-rank result slices (col stats: one scalar per leaf)."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+def gather_columns(local: torch.Tensor, sizes: Sequence[int], group=None) -> torch.Tensor:
+    """Concatenate per-rank result slices along dim 0 (col stats: one scalar per leaf; rowsum: one
+    row of `ngroup` sums per leaf).  `sizes[r]` = leading extent of rank r's slice."""
+    if _world(group) == 1:
         return local
-    outs = [torch.empty(n, dtype=local.dtype, device=local.device) for n in sizes]
-    dist.all_gather(outs, local, group=group) if len(set(sizes)) == 1 else \
-        _all_gather_ragged(outs, local, group)
+    tail = tuple(local.shape[1:])
+    outs = [torch.empty((int(n),) + tail, dtype=local.dtype, device=local.device) for n in sizes]
+    if len(set(int(n) for n in sizes)) == 1:
+        dist.all_gather(outs, local.contiguous(), group=group)
+    else:
+        _all_gather_ragged(outs, local.contiguous(), group)
     return torch.cat(outs)
 
 
 def _all_gather_ragged(outs, local, group):
+    """Ragged all-gather as one broadcast per member.  `dist.broadcast(src=)` takes a GLOBAL
+    rank: inside a sub-group the member index must be translated."""
     world = dist.get_world_size(group)
-    for src in range(world):
-        buf = outs[src]
-        if dist.get_rank(group) == src:
+    me = dist.get_rank(group)
+    for member in range(world):
+        buf = outs[member]
+        if me == member:
             buf.copy_(local)
+        src = dist.get_global_rank(group, member) if group is not None else member
         dist.broadcast(buf, src=src, group=group)
+
+
+# --------------------------------------------------------------------------------------------
+# device-resident sharded operands (HIP path)
+# --------------------------------------------------------------------------------------------
+def shard_rows_device(A, rank: int, world: int, align: int = 128):
+    """Row block `rank` of a resident operand as a DeviceCSC of its own (device-side filter)."""
+    from .device import DeviceCSC
+    r0, r1 = row_block(A.nrow, rank, world, align)
+    cp, ri, v = row_shard_csc(A.col_ptr, A.row_idx, A.val, r0, r1)
+    return DeviceCSC(r1 - r0, cp, ri, v), (r0, r1)
+
+
+def shard_cols_device(A, rank: int, world: int):
+    """Leaf block `rank` (balanced by nnz) of a resident operand; returns (shard, blocks)."""
+    from .device import DeviceCSC
+    blocks = col_blocks_by_nnz(A.col_ptr, world)
+    c0, c1 = blocks[rank]
+    cp, ri, v = col_shard_csc(A.col_ptr, A.row_idx, A.val, c0, c1)
+    return DeviceCSC(A.nrow, cp.contiguous(), ri, v), blocks
+
+
+class ShardedCrossprod:
+    """crossprod(A, Y) with A and Y sharded on rows.  Every rank holds its row block of A (with
+    the panel-blocked layout of that block, built once) and of Y; a step computes the rank's
+    ncol x K partial with the product kernels and all-reduces it.
+
+    Two result buffers: the all-reduce of step i runs on the collective's stream while the
+    product of step i + 1 runs on the compute stream; step i + 2 waits for it before it reuses
+    the buffer.  `result()` returns the last finished buffer, laid out (K, ncol) C-contiguous =
+    the column-major ncol x K matrix R would get.
+    """
+
+    def __init__(self, A_local, K: int, group=None, cbw: int = 40, wpb: int = 16, logr: int = 7):
+        from .device import PbcPlan
+        self.A, self.K, self.group = A_local, int(K), group
+        self.plan = PbcPlan(A_local, K, cbw, wpb, logr)
+        dev = A_local.val.device
+        nbuf = 2 if _world(group) > 1 else 1
+        self.outs = [torch.zeros((self.K, A_local.ncol), dtype=torch.float64, device=dev) for _ in range(nbuf)]
+        self.pending = [None] * nbuf
+        self.stepno = 0
+
+    def _pick(self) -> int:
+        i = self.stepno % len(self.outs)
+        self.stepno += 1
+        if self.pending[i] is not None:
+            self.pending[i].wait()           # stream-level wait: buffer i is free again
+            self.pending[i] = None
+        return i
+
+    def step(self, Y_local: torch.Tensor, events=None) -> int:
+        """One product + reduction; Y_local is this rank's (K, rows) block.  `events` = a pair of
+        torch events recorded around the dominant kernel."""
+        i = self._pick()
+        ld = Y_local.shape[1]
+        if events is not None:
+            events[0].record()
+        self.plan.run_phase(1, Y_local, ld, self.outs[i])
+        if events is not None:
+            events[1].record()
+        self.plan.run_phase(2, Y_local, ld, self.outs[i])
+        if _world(self.group) > 1:
+            self.pending[i] = dist.all_reduce(self.outs[i], op=dist.ReduceOp.SUM, group=self.group,
+                                              async_op=True)
+        return i
+
+    def wait(self):
+        for i, w in enumerate(self.pending):
+            if w is not None:
+                w.wait()
+                self.pending[i] = None
+
+    def result(self) -> torch.Tensor:
+        self.wait()
+        return self.outs[(self.stepno - 1) % len(self.outs)]
+
+
+def sharded_colsums_rows(A_local, group=None, local: Optional[Callable] = None) -> torch.Tensor:
+    """colSums of a ROW-sharded operand: per-rank partial sums of every column, all-reduced
+    (ncol doubles on the wire; BASELINE config 4 runs it beside the row-sharded crossprod)."""
+    if local is not None:
+        part = local()
+    else:
+        from .device import colstats
+        part, _ = colstats(A_local, "sum")
+    if _world(group) > 1:
+        dist.all_reduce(part, op=dist.ReduceOp.SUM, group=group)
+    return part
+
+
+def sharded_colstats(A_cols, blocks, op: str, na_rm=False, group=None,
+                     local: Optional[Callable] = None) -> torch.Tensor:
+    """A column statistic of a LEAF-sharded operand: every leaf is whole on one rank, so the
+    values are the single-GPU ones; the scalars are all-gathered."""
+    if local is not None:
+        loc = local()
+    else:
+        from .device import colstats
+        loc, _ = colstats(A_cols, op, na_rm)
+    return gather_columns(loc, [b[1] - b[0] for b in blocks], group)
+
+
+def sharded_rowsum(A_cols, blocks, grp: torch.Tensor, ngroup: int, na_rm=False, group=None,
+                   local: Optional[Callable] = None) -> torch.Tensor:
+    """rowsum(A, group) of a LEAF-sharded operand (columns are independent:
+    src/rowsum_methods.c:86-103): every rank computes the ngroup sums of its own leaves, the
+    (ncol_local, ngroup) slabs are all-gathered into the (ncol, ngroup) result = column-major
+    ngroup x ncol.  `grp` (one int per row) is replicated."""
+    if local is not None:
+        loc = local()
+    else:
+        from .device import rowsum
+        loc = rowsum(A_cols, grp, ngroup, na_rm)
+    return gather_columns(loc, [b[1] - b[0] for b in blocks], group)
+
+
+def sharded_matmul(A_rows_t_plan, Y2: torch.Tensor, out_local: torch.Tensor):
+    """A %*% Y2 with A sharded on rows: rank g owns rows [r0, r1) of the result, computed as
+    crossprod(t(A_g), Y2) with the panel-blocked layout of t(A_g); Y2 is replicated and there is
+    no collective."""
+    A_rows_t_plan.run(Y2, Y2.shape[1], out_local)
+    return out_local

@@ -51,7 +51,16 @@ def _worker(rank, world, port, q):
                                          torch.from_numpy(v), r0, r1)
         ok3 = np.array_equal(tcp.numpy(), scp) and np.array_equal(tri.numpy(), sri) \
             and np.array_equal(tv.numpy(), sv)
-        q.put((rank, ok1, ok2, ok3))
+        # rowsum: leaves sharded by nnz, (ncol_local, ngroup) slabs gathered (ragged blocks)
+        grp = list(np.random.default_rng(7).integers(1, 6, nrow))
+        loc_rs = np.ascontiguousarray(np.asarray(S.rowsum(sub, grp)[0], dtype=np.float64).T)   # (c1-c0, ngroup)
+        allrs = par.sharded_rowsum(None, blocks, None, 5, local=lambda: torch.from_numpy(loc_rs))
+        ok4 = np.array_equal(allrs.numpy().T, np.asarray(S.rowsum(full, grp)[0]))
+        # colSums of the ROW shards: partial sums all-reduced
+        part = par.sharded_colsums_rows(None, local=lambda: torch.from_numpy(
+            np.asarray(S.colSums(shard), dtype=np.float64).copy()))
+        ok5 = np.allclose(part.numpy(), S.colSums(full), rtol=1e-12, atol=1e-12)
+        q.put((rank, ok1, ok2, ok3, ok4, ok5))
     finally:
         dist.destroy_process_group()
 
@@ -68,16 +77,79 @@ def test_row_sharded_crossprod_and_column_sharded_colsums_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, ok1, ok2, ok3 in res:
+    for rank, ok1, ok2, ok3, ok4, ok5 in res:
         assert ok1, f"rank {rank}: sharded crossprod differs"
         assert ok2, f"rank {rank}: sharded colSums differs"
         assert ok3, f"rank {rank}: torch/numpy row filter differ"
+        assert ok4, f"rank {rank}: sharded rowsum differs"
+        assert ok5, f"rank {rank}: row-sharded colSums differ"
+
+
+def _subgroup_worker(rank, world, port, q):
+    """Ragged gather inside a sub-group whose member indices are not global ranks
+    (advisor finding, round 1: broadcast(src=) takes a global rank)."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sparsearray_amd import parallel as par
+        g = dist.new_group([1, 2])                    # every rank must take part in new_group
+        ok = True
+        if rank in (1, 2):
+            me = rank - 1
+            sizes = [3, 5]
+            loc = torch.arange(sizes[me], dtype=torch.float64) + 100.0 * rank
+            got = par.gather_columns(loc, sizes, group=g)
+            want = torch.cat([torch.arange(3, dtype=torch.float64) + 100.0,
+                              torch.arange(5, dtype=torch.float64) + 200.0])
+            ok = bool(torch.equal(got, want))
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ragged_gather_in_subgroup_gloo():
+    world = 3
+    port = 31500 + os.getpid() % 2000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_subgroup_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res
 
 
 def test_row_blocks_cover():
     sys.path.insert(0, ROOT)
     from sparsearray_amd.parallel import row_block
     for n, w in ((10, 3), (7, 8), (1_000_000, 8)):
-        blocks = [row_block(n, r, w) for r in range(w)]
-        assert blocks[0][0] == 0 and blocks[-1][1] == n
-        assert all(blocks[i][1] == blocks[i + 1][0] for i in range(w - 1))
+        for align in (1, 128):
+            blocks = [row_block(n, r, w, align) for r in range(w)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            assert all(blocks[i][1] == blocks[i + 1][0] for i in range(w - 1))
+            assert all(b[0] % align == 0 or b[0] == n for b in blocks)
+
+
+def test_blocked_generator_is_rank_count_invariant():
+    """The benchmark's global matrix is the same at every N: the union of the row blocks that the
+    ranks of an N-way run generate equals the one-rank matrix (sparsearray_amd/synth.py)."""
+    sys.path.insert(0, ROOT)
+    from sparsearray_amd import synth
+    from sparsearray_amd.parallel import row_shard_csc
+    cp, ri, v, (r0, r1) = synth.random_device_csc_blocked(20000, 30, 0.01, 3, device="cpu")
+    assert (r0, r1) == (0, 20000) and int(cp[-1]) == int(20000 * 30 * 0.01)
+    Y = synth.random_dense_blocked(20000, 3, 9, "cpu")
+    for world in (2, 4, 8):
+        per = 8 // world
+        for rank in range(world):
+            cpa, ria, va, (a0, a1) = synth.random_device_csc_blocked(
+                20000, 30, 0.01, 3, device="cpu", first=rank * per, last=(rank + 1) * per)
+            scp, sri, sv = row_shard_csc(cp, ri, v, a0, a1)
+            assert torch.equal(scp, cpa) and torch.equal(sri, ria) and torch.equal(sv, va)
+            Ya = synth.random_dense_blocked(20000, 3, 9, "cpu", first=rank * per, last=(rank + 1) * per)
+            assert torch.equal(Y[:, a0:a1], Ya)

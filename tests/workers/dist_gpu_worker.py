@@ -1,0 +1,85 @@
+"""Child process of tests/test_hip_configs.py::test_two_ranks_same_device_*: one rank of a 2-rank
+`gloo` job whose ranks both compute on GPU 0 with the HIP library (the one-GPU rehearsal of the
+multi-GPU path; the RCCL run on 8 GPUs is the driver's).  Runs the sharded operations of
+sparsearray_amd/parallel.py on a slice of BASELINE configs 2a and 4 and compares every reduced /
+gathered result with the one-rank result computed from the unsharded operand.  Rank 0 writes a JSON
+verdict to argv[1]."""
+import json
+import os
+import sys
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ["LOCAL_RANK"] = "0"                       # both ranks bind the HIP library to GPU 0
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+
+def main():
+    out_path = sys.argv[1]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo")
+    from sparsearray_amd import parallel as par
+    from sparsearray_amd import synth
+    from sparsearray_amd.device import DeviceCSC, PbcPlan, colstats, rowsum
+    verdict = {}
+    for name, (nrow, ncol, dens, K) in {
+        "config2a_slice": (256_000, 10_000, 0.01, 128),       # 2.56e7 nonzeros
+        "config4_slice": (1_280_000, 50_000, 0.001, 64),      # 6.4e7 nonzeros, 5-record tiles
+    }.items():
+        # the global operand, identical on both ranks (same seeds), and this rank's row blocks
+        cp, ri, v, _ = synth.random_device_csc_blocked(nrow, ncol, dens, seed=11, device=dev)
+        Y = synth.random_dense_blocked(nrow, K, seed=111, device=dev)
+        A = DeviceCSC(nrow, cp, ri, v)
+        per = 8 // world
+        cpl, ril, vl, (r0, r1) = synth.random_device_csc_blocked(nrow, ncol, dens, seed=11, device=dev,
+                                                                 first=rank * per, last=(rank + 1) * per)
+        Al = DeviceCSC(r1 - r0, cpl, ril, vl)
+        Yl = Y[:, r0:r1].contiguous()
+        # the device-side row filter gives the same shard as generating the blocks directly
+        As, (s0, s1) = par.shard_rows_device(A, rank, world, align=128)
+        same_shard = (s0, s1) == (r0, r1) and torch.equal(As.col_ptr, Al.col_ptr) and \
+            torch.equal(As.row_idx, Al.row_idx) and torch.equal(As.val, Al.val)
+        # crossprod: row-sharded product + all-reduce vs the one-rank product
+        sc = par.ShardedCrossprod(Al, K)
+        sc.step(Yl)
+        sc.step(Yl)                                       # second step: the other buffer, waits on the first
+        got = sc.result().clone()
+        ref = torch.zeros((K, ncol), dtype=torch.float64, device=dev)
+        PbcPlan(A, K).run(Y, nrow, ref)
+        torch.cuda.synchronize()
+        scale = float(ref.abs().max())
+        err_cp = float((got - ref).abs().max()) / scale
+        # colSums of the row shards, all-reduced, vs the one-rank colSums
+        cs = par.sharded_colsums_rows(Al)
+        cs_ref, _ = colstats(A, "sum")
+        err_cs = float((cs - cs_ref).abs().max()) / float(cs_ref.abs().max())
+        # leaf-sharded colVars (gathered scalars) and rowsum (gathered slabs): bit-identical
+        Ac, blocks = par.shard_cols_device(A, rank, world)
+        cv = par.sharded_colstats(Ac, blocks, "var1")
+        cv_ref, _ = colstats(A, "var1")
+        ng = 1000
+        g = torch.Generator(device=dev); g.manual_seed(5)
+        grp = torch.randint(1, ng + 1, (nrow,), generator=g, device=dev, dtype=torch.int32)
+        rs = par.sharded_rowsum(Ac, blocks, grp, ng)
+        rs_ref = rowsum(A, grp, ng)
+        torch.cuda.synchronize()
+        err_rs = float((rs - rs_ref).abs().max()) / max(float(rs_ref.abs().max()), 1e-300)
+        verdict[name] = {"same_shard": bool(same_shard), "crossprod_rel_err": err_cp, "colsums_rel_err": err_cs,
+                         "colvars_identical": bool(torch.equal(cv, cv_ref)), "rowsum_rel_err": err_rs,
+                         "nnz": A.nnz, "rows_rank": r1 - r0, "blocks": blocks}
+        del sc, A, Al, As, Ac, Y, Yl, got, ref
+        torch.cuda.empty_cache()
+    dist.barrier()
+    if rank == 0:
+        with open(out_path, "w") as f:
+            json.dump(verdict, f)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
