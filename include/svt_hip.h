@@ -283,13 +283,6 @@ int svt_dev_crossprod_pbc_phase(const svt_dev_pbc *P, const svt_dev_csc *A,
 				int64_t out_stride_k, void *ws, size_t ws_bytes,
 				void *stream, int phase);
 
-/* Diagnostic only (tools/tune_pbc.py): 0 = normal; 2 = timing-only build of the
-   PBC kernel without the record loop (results wrong by construction); 3 = normal
-   results + per-section cycle counts of workgroup 0, read back with
-   svt_dev_pbc_read_prof (16 wavefronts x 8 counters); 100 + n = force n row splits. */
-void svt_dev_pbc_set_debug(int mode);
-int svt_dev_pbc_read_prof(const void *ws, unsigned long long *out);
-
 /* col stats over segments of `inner` consecutive leaves each
    (dims > 1 => inner = prod(dim[1..dims-1])); out has ncol/inner elements of
    svt_colStats_out_Rtype().  warn_flag: device int, set to 1 on the

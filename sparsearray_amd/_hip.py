@@ -9,7 +9,10 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsvt_hip.so")
+# SVT_HIP_TUNING=1: the tuning build (make -C sparsearray_amd/csrc TUNING=1) with the knobs of
+# tools/tune_pbc.py compiled in; never what the product, the tests or the bench load.
+LIB_PATH = os.path.join(_HERE, "libsvt_hip_tuning.so" if os.environ.get("SVT_HIP_TUNING") == "1"
+                        else "libsvt_hip.so")
 
 # Every symbol include/svt_hip.h declares (checked by tests/test_abi.py).
 EXPORTS = [
@@ -26,7 +29,7 @@ EXPORTS = [
     "svt_dev_crossprod_ws_bytes", "svt_dev_crossprod_csc_dense",
     "svt_dev_dense_prepare", "svt_dev_crossprod_prepared",
     "svt_dev_pbc_build", "svt_dev_pbc_release",
-    "svt_dev_crossprod_pbc_ws_bytes", "svt_dev_crossprod_pbc", "svt_dev_crossprod_pbc_phase", "svt_dev_pbc_set_debug", "svt_dev_pbc_read_prof",
+    "svt_dev_crossprod_pbc_ws_bytes", "svt_dev_crossprod_pbc", "svt_dev_crossprod_pbc_phase",
     "svt_get_num_procs", "svt_get_max_threads", "svt_set_max_threads", "svt_dev_aperm_ws_bytes", "svt_dev_aperm", "svt_aperm_SVT", "svt_dev_transpose_ws_bytes", "svt_dev_transpose", "svt_dev_colstats", "svt_dev_rowstats_ws_bytes", "svt_dev_rowsums", "svt_dev_rowsum",
 ]
 

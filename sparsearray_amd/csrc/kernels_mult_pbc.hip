@@ -63,10 +63,19 @@ struct svt_dev_pbc {
 };
 
 #define PCH 256            // panels per build chunk
+// Tuning builds only (make TUNING=1 -> -DSVT_TUNING; build() does not produce one): knobs of
+// tools/tune_pbc.py.  The product library has constants here and exports none of the setters.
+#ifdef SVT_TUNING
 static int g_pbc_debug = 0;
 static int g_pbc_nsplit = 0;
-static int g_pbc_stagger = 7;     // DMA issue: wavefronts 4g..4g+3 after batch g of their tile (measured best of 12 patterns)
-static int g_pbc_ahead10 = 20;     // record touch: look-ahead in tenths of a tile
+static int g_pbc_stagger = 7;
+static int g_pbc_ahead10 = 20;
+#else
+static constexpr int g_pbc_debug = 0;
+static constexpr int g_pbc_nsplit = 0;
+static constexpr int g_pbc_stagger = 7;   // DMA issue: wavefronts 4g..4g+3 after batch g of their tile (measured best of 12 patterns)
+static constexpr int g_pbc_ahead10 = 20;  // record touch: look-ahead in tenths of a tile
+#endif
 
 // ---------------------------------------------------------------------------
 // layout build
@@ -329,13 +338,18 @@ extern "C" svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB
 // ---------------------------------------------------------------------------
 // main kernel
 // ---------------------------------------------------------------------------
+#ifdef SVT_TUNING
+// 0 = normal; 2 = timing-only build without the record loop (results wrong by construction);
+// 3 = normal results + per-section cycle counts of workgroup 0 (svt_dev_pbc_read_prof);
+// 100 + n = force n row splits; 200 + m = DMA issue stagger mode; 300 + t = record-touch look-ahead
 extern "C" void svt_dev_pbc_set_debug(int mode)
 {
-	if (mode >= 300) g_pbc_ahead10 = mode - 300;  // 300 + t: record-touch look-ahead, tenths of a tile (tuning)
-	else if (mode >= 200) g_pbc_stagger = mode - 200;  // 200 + m: DMA issue stagger mode (tuning)
-	else if (mode >= 100) g_pbc_nsplit = mode - 100;   // 100 + n: force n row splits (tuning)
+	if (mode >= 300) g_pbc_ahead10 = mode - 300;
+	else if (mode >= 200) g_pbc_stagger = mode - 200;
+	else if (mode >= 100) g_pbc_nsplit = mode - 100;
 	else g_pbc_debug = mode;
 }
+#endif
 
 struct PbcFlags {
 	int *y_nonfinite;    // [1] any NaN/Inf/NA in the dense operand
@@ -344,14 +358,16 @@ struct PbcFlags {
 // DBG == 3 (tuning only): cycles per section, per wavefront of workgroup (0,0,0):
 // [w][0] fetch issue, [1] record loop, [2] barrier after the loop, [3] commit,
 // [4] barrier after commit, [5] panels
-// (kept in the flag block at the head of the workspace, bytes 256 .. 1279)
-#define PBC_FLAG_BYTES 2048
+// (kept in the flag block at the head of the workspace, its last 1024 bytes)
+#define PBC_FLAG_BYTES 8192      // [0, 256) flags; [256, ...) per-column counters of the dirty-column fix-up when they fit
+#ifdef SVT_TUNING
 extern "C" int svt_dev_pbc_read_prof(const void *ws, unsigned long long *out)
 {
 	HIP_TRY(hipDeviceSynchronize());
-	HIP_TRY(hipMemcpy(out, (const char *) ws + 256, 16 * 8 * 8, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(out, (const char *) ws + 7168, 16 * 8 * 8, hipMemcpyDeviceToHost));
 	return 0;
 }
+#endif
 
 // A batch of PBC_BATCH (= 4) records = 16 dwords, held in a block of 16 SGPRs
 // that is pinned to fixed physical registers (s[32:47] / s[48:63]) so that the
@@ -471,15 +487,9 @@ struct Stager {
 	"s_set_gpr_idx_off\n\t"
 // block A = s[36:51], B = s[52:67], C = s[68:83]  (s32-s35 are the stack/frame
 // pointer registers of the calling convention and are left alone)
-#ifdef PBC_EXPERIMENT_CACHED   /* timing experiment only: every load hits a 1 KB window */
-#define PBC_LOAD_A "s_and_b32 s84, %[lo], 0x3c0\n\ts_load_dwordx16 s[36:51], %[base], s84\n\t"
-#define PBC_LOAD_B "s_and_b32 s84, %[lo], 0x3c0\n\ts_load_dwordx16 s[52:67], %[base], s84\n\t"
-#define PBC_LOAD_C "s_and_b32 s84, %[lo], 0x3c0\n\ts_load_dwordx16 s[68:83], %[base], s84\n\t"
-#else
 #define PBC_LOAD_A "s_load_dwordx16 s[36:51], %[base], %[lo]\n\t"
 #define PBC_LOAD_B "s_load_dwordx16 s[52:67], %[base], %[lo]\n\t"
 #define PBC_LOAD_C "s_load_dwordx16 s[68:83], %[base], %[lo]\n\t"
-#endif
 #define PBC_D_A(YS) PBC_D4(36, 40, 44, 48, YS)
 #define PBC_D_B(YS) PBC_D4(52, 56, 60, 64, YS)
 #define PBC_D_C(YS) PBC_D4(68, 72, 76, 80, YS)
@@ -639,7 +649,7 @@ crossprod_pbc_kernel(const uint4 *__restrict__ rec,
 		if (DBG == 3) pr[5]++;
 	}
 	if (DBG == 3 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0)
-		for (int i = 0; i < 6; i++) ((unsigned long long *) (fl.y_nonfinite + 64))[w * 8 + i] = pr[i];
+		for (int i = 0; i < 6; i++) ((unsigned long long *) (fl.y_nonfinite + 1792))[w * 8 + i] = pr[i];
 	if (b == 0 && __any(bad) && lane == 0)
 		*fl.y_nonfinite = 1;
 	touch ^= tv;
@@ -836,6 +846,7 @@ crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restric
 #define PBC_ACC1 "+{v[68:99]}"
 #define PBC_ACC2 "+{v[100:115]}"
 #endif
+#ifdef SVT_TUNING
 	if constexpr (PROF) {
 		// tuning build (NV <= 2): cycles per section in v[116:123], see gen_pbc_asm.py
 		u32x16 PV = 0;
@@ -844,11 +855,13 @@ crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restric
 			       "+{v[112:127]}"(PV)
 			     : : PBC_DMA_CLOBBERS, "s100", "s101");
 		if (blockIdx.x == 0 && (tid & 63) == 0) {
-			unsigned long long *o = (unsigned long long *) (fl.y_nonfinite + 64) + w * 8;
+			unsigned long long *o = (unsigned long long *) (fl.y_nonfinite + 1792) + w * 8;
 			// [-, dma wait, barrier, issue, prescan, dispatch, stub, phases]
 			for (int i = 0; i < 8; i++) o[i] = PV[4 + i];
 		}
-	} else if constexpr (NV == 1) {
+	} else
+#endif
+	if constexpr (NV == 1) {
 		asm volatile(PBC_DMA_ASM_TEXT
 			     : PBC_ACC0(acc[0]), PBC_DMA_STATE
 			     : : PBC_DMA_CLOBBERS);
@@ -929,6 +942,210 @@ __global__ void pbc_nafix_kernel(const int *__restrict__ col_has_na, int K, int6
 }
 
 // ---------------------------------------------------------------------------
+// Dense operand given by rows (tr_y: element (r, k) at Y[k + r * ldY], the tcrossprod() /
+// transpose.x orientation of src/SparseMatrix_mult.c:411-421, which copies one row at a time
+// into a column buffer): one tiled pass turns it into the column-major panel source of the
+// product kernel.  1 GB in, 1 GB out at BASELINE config 2.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+pbc_transpose_dense_kernel(const double *__restrict__ Yin, int64_t ldY, int64_t nrow, int K,
+			   double *__restrict__ Yc)
+{
+	__shared__ double tile[64][65];
+	const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+	const int k0 = blockIdx.y * 64;
+	for (int64_t r0 = (int64_t) blockIdx.x * 64; r0 < nrow; r0 += (int64_t) gridDim.x * 64) {
+		if (r0 != (int64_t) blockIdx.x * 64) __syncthreads();
+		for (int rr = ty; rr < 64; rr += 4) {        // lanes along k: contiguous in Yin
+			const int64_t r = r0 + rr;
+			const int k = k0 + tx;
+			tile[rr][tx] = (r < nrow && k < K) ? Yin[k + r * ldY] : 0.0;
+		}
+		__syncthreads();
+		for (int kk = ty; kk < 64; kk += 4) {        // lanes along r: contiguous in Yc
+			const int64_t r = r0 + tx;
+			const int k = k0 + kk;
+			if (r < nrow && k < K) Yc[r + (int64_t) k * nrow] = tile[tx][kk];
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------
+// Dense columns that hold NaN / Inf / NA.  The reference switches to
+// _dotprod_doubleSV_doubles (src/SparseVec_dotprod.c:48-65) for exactly those columns
+// (src/SparseMatrix_mult.c:193-207): it multiplies the implicit zeros too, so per (leaf c, dirty
+// column k):
+//     the column or the leaf holds an R NA                 -> NA_real_
+//     some non-finite y sits on a row where c has no entry -> NaN   (0 * Inf, 0 * NaN)
+//     every non-finite y sits on a nonzero of c            -> the IEEE sum over the nonzeros, in
+//                                                             ascending offset order
+// The product kernel raises one flag when any staged entry is not finite.  Then (and only then:
+// every kernel below returns at once while the flag is clear) one pass over Y counts the
+// non-finite entries per column and lists their (row, column) positions; a leaf "hits" an entry
+// if the row is among its offsets (binary search, offsets ascend inside a leaf); the fix-up
+// rewrites the cells of the dirty columns by the rule above.  The clean columns are never
+// touched.  More than PBC_DIRTY_CAP entries or PBC_DIRTY_COLS dirty columns: the general kernels
+// redo the whole product as before (a column of NAs is the typical case; correct, just slow).
+// ---------------------------------------------------------------------------
+#define PBC_DIRTY_CAP 8192
+#define PBC_DIRTY_COLS 16
+#define PBC_DIRTY_WORK 16384
+struct DirtyWs {
+	int *flags;          // the flag block: [0] product kernel saw a non-finite y, [2] run the general
+	                     // kernels, [3] number of non-finite entries, [4] number of dirty columns, [5] cells to redo
+	int *col_nf;         // [Kp] non-finite entries per dense column
+	int *has_na;         // [Kp] the column holds an R NA
+	int *slot;           // [Kp] rank of the column among the dirty ones
+	uint2 *list;         // [PBC_DIRTY_CAP] (row, column)
+	uint2 *work;         // [PBC_DIRTY_WORK] (leaf, column) cells to be summed again ([5] counts them)
+	int *hit;            // [ncol * PBC_DIRTY_COLS] entries of dirty column `slot` on nonzeros of leaf c
+};
+
+static size_t dirty_ws_bytes(int64_t ncol, int64_t Kp)
+{
+	return (size_t) Kp * 12 + (size_t) (PBC_DIRTY_CAP + PBC_DIRTY_WORK) * 8 + (size_t) (ncol > 0 ? ncol : 1) * PBC_DIRTY_COLS * 4 + 256;
+}
+
+static DirtyWs dirty_ws_of(void *flag_block, void *tail, int64_t ncol, int64_t Kp)
+{
+	DirtyWs d;
+	(void) ncol;
+	d.flags = (int *) flag_block;
+	const bool in_block = 256 + Kp * 12 <= PBC_FLAG_BYTES - 1024;   // (the last KB: tuning builds' cycle counters)      // then phase 1 clears them with the flags
+	d.col_nf = in_block ? (int *) ((char *) flag_block + 256) : (int *) tail;
+	if (in_block) {
+		d.has_na = d.col_nf + Kp;
+		d.slot = d.has_na + Kp;
+		d.list = (uint2 *) (((uintptr_t) tail + 15) & ~(uintptr_t) 15);
+		d.work = d.list + PBC_DIRTY_CAP;
+		d.hit = (int *) (d.work + PBC_DIRTY_WORK);
+		return d;
+	}
+	d.has_na = d.col_nf + Kp;
+	d.slot = d.has_na + Kp;
+	d.list = (uint2 *) (((uintptr_t) (d.slot + Kp) + 15) & ~(uintptr_t) 15);
+	d.work = d.list + PBC_DIRTY_CAP;
+	d.hit = (int *) (d.work + PBC_DIRTY_WORK);
+	return d;
+}
+
+__global__ void __launch_bounds__(256)
+pbc_dirty_scan_kernel(const double *__restrict__ Y, int64_t ldY, int64_t nrow, int K, int64_t ncol, DirtyWs d)
+{
+	if (d.flags[0] == 0)
+		return;
+	const int k = blockIdx.y;
+	{       // hit counters (read by the hits kernel two launches later)
+		const int64_t nthr = (int64_t) gridDim.x * gridDim.y * blockDim.x;
+		const int64_t me = ((int64_t) blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+		for (int64_t i = me; i < ncol * PBC_DIRTY_COLS; i += nthr) d.hit[i] = 0;
+	}
+	const double *__restrict__ col = Y + (int64_t) k * ldY;
+	for (int64_t r = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; r < nrow;
+	     r += (int64_t) gridDim.x * blockDim.x) {
+		const double y = col[r];
+		if (svt_is_finite(y))
+			continue;
+		atomicAdd(d.col_nf + k, 1);
+		if (svt_is_na(y)) d.has_na[k] = 1;
+		const int at = atomicAdd(d.flags + 3, 1);
+		if (at < PBC_DIRTY_CAP) d.list[at] = make_uint2((unsigned) r, (unsigned) k);
+	}
+}
+
+// one thread: ranks the dirty columns and decides between the fix-up and the general kernels
+__global__ void pbc_dirty_plan_kernel(int K, DirtyWs d)
+{
+	if (d.flags[0] == 0 || threadIdx.x != 0)
+		return;
+	int n = 0;
+	for (int k = 0; k < K; k++)
+		if (d.col_nf[k] > 0) d.slot[k] = n++;
+	d.flags[4] = n;
+	d.flags[2] = (d.flags[3] > PBC_DIRTY_CAP || n > PBC_DIRTY_COLS) ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256)
+pbc_dirty_hits_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__ row_idx,
+		      int64_t ncol, DirtyWs d)
+{
+	if (d.flags[0] == 0 || d.flags[2] != 0)
+		return;
+	const int64_t c = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= ncol)
+		return;
+	const int n = d.flags[3];
+	const int64_t beg = col_ptr[c], end = col_ptr[c + 1];
+	for (int e = blockIdx.y; e < n; e += gridDim.y) {
+		const uint2 rk = d.list[e];
+		int64_t lo = beg, hi = end;
+		while (lo < hi) {
+			const int64_t mid = (lo + hi) >> 1;
+			if ((uint32_t) row_idx[mid] < rk.x) lo = mid + 1; else hi = mid;
+		}
+		if (lo < end && (uint32_t) row_idx[lo] == rk.x)
+			atomicAdd(d.hit + c * PBC_DIRTY_COLS + d.slot[rk.y], 1);
+	}
+}
+
+__global__ void __launch_bounds__(256)
+pbc_dirty_fix_kernel(const int *__restrict__ col_has_na, int K, int64_t ncol, DirtyWs d,
+		     double *__restrict__ out, int64_t sc, int64_t sk)
+{
+	if (d.flags[0] == 0 || d.flags[2] != 0)
+		return;
+	const int64_t c = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= ncol)
+		return;
+	const bool leaf_na = col_has_na[c] != 0;
+	for (int k = 0; k < K; k++) {
+		const int nf = d.col_nf[k];
+		if (nf == 0)
+			continue;
+		double *cell = out + c * sc + (int64_t) k * sk;
+		if (d.has_na[k] || leaf_na) {
+			*cell = svt_na_real();
+		} else if (d.hit[c * PBC_DIRTY_COLS + d.slot[k]] < nf) {
+			*cell = *cell + NAN;
+		} else {
+			// every non-finite entry of the column sits on a nonzero of this leaf: the IEEE sum
+			// over the nonzeros.  The product kernel's own value cannot be kept (the zero records
+			// that pad its tiles multiply row 0 of their panel, and 0 * Inf is NaN): the cell
+			// goes on the list of pbc_dirty_redo_kernel.
+			const int at = atomicAdd(d.flags + 5, 1);
+			if (at < PBC_DIRTY_WORK) d.work[at] = make_uint2((unsigned) c, (unsigned) k);
+			else d.flags[2] = 1;            // too many: the general kernels redo the product
+		}
+	}
+}
+
+// one wavefront per listed cell: sum of a_i * y_i over the leaf's nonzeros (lane-strided partial
+// sums, then a fixed-order butterfly: NaN / Inf class as in the sequential sum, finite parts within
+// rounding)
+__global__ void __launch_bounds__(256)
+pbc_dirty_redo_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__ row_idx,
+		      const double *__restrict__ val, const double *__restrict__ Y, int64_t ldY,
+		      DirtyWs d, double *__restrict__ out, int64_t sc, int64_t sk)
+{
+	if (d.flags[0] == 0 || d.flags[2] != 0)
+		return;
+	const int lane = threadIdx.x & 63;
+	const int nw = gridDim.x * (blockDim.x >> 6);
+	int n = d.flags[5];
+	if (n > PBC_DIRTY_WORK) n = PBC_DIRTY_WORK;
+	for (int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); w < n; w += nw) {
+		const uint2 ck = d.work[w];
+		const double *__restrict__ y = Y + (int64_t) ck.y * ldY;
+		double acc = 0.0;
+		for (int64_t i = col_ptr[ck.x] + lane; i < col_ptr[ck.x + 1]; i += 64)
+			acc += val[i] * y[row_idx[i]];
+		for (int off = 32; off > 0; off >>= 1)
+			acc += __shfl_xor(acc, off, 64);
+		if (lane == 0) out[(int64_t) ck.x * sc + (int64_t) ck.y * sk] = acc;
+	}
+}
+
+// ---------------------------------------------------------------------------
 // launch
 // ---------------------------------------------------------------------------
 // Row splits: enough workgroups to fill the chip, every split non-empty.
@@ -979,9 +1196,10 @@ extern "C" size_t svt_dev_crossprod_pbc_ws_bytes(const svt_dev_pbc *P, int K)
 		const int nd = pick_nsplit(P, K, true, NULL);
 		if (nd > ns) ns = nd;
 	}
-	// [flags][partials][general-path workspace]
+	// [flags][partials][general-path workspace; a row-major Y is transposed into it first]
+	// [dirty-column scratch]
 	return PBC_FLAG_BYTES + (size_t) ns * Kp * (P->ncol > 0 ? P->ncol : 1) * 8 +
-	       crossprod_ws_bytes(P->nrow, P->ncol, K);
+	       crossprod_ws_bytes(P->nrow, P->ncol, K) + dirty_ws_bytes(P->ncol, Kp);
 }
 
 template <int NV, int WPB, int LOGR>
@@ -997,9 +1215,13 @@ static void launch_main(const svt_dev_pbc *P, const double *Y, int64_t ldY, int 
 	if (tr_y)
 		kern = crossprod_pbc_kernel<NV, WPB, LOGR, true, 0>;
 	else
+#ifdef SVT_TUNING
 		kern = g_pbc_debug == 2 ? crossprod_pbc_kernel<NV, WPB, LOGR, false, 2> :
 		       g_pbc_debug == 3 ? crossprod_pbc_kernel<NV, WPB, LOGR, false, 3> :
 					  crossprod_pbc_kernel<NV, WPB, LOGR, false, 0>;
+#else
+		kern = crossprod_pbc_kernel<NV, WPB, LOGR, false, 0>;
+#endif
 	(void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
 	hipLaunchKernelGGL(kern, grid, dim3(WPB * 64), lds, s, P->rec, P->tile_ptr, P->npanels,
 			   Y, ldY, P->nrow, K, P->ncol, pps, part, Kp, fl, P->CBW);
@@ -1021,8 +1243,12 @@ static void launch_dma(const svt_dev_pbc *P, const double *Y, int64_t ldY, int K
 	int rt_ahead = ((int) (g_pbc_ahead10 * 0.1 * tile_bytes) + 127) / 128 * 128;
 	if (rt_ahead + rt_lines * 128 > 4608) rt_ahead = 4608 - rt_lines * 128;
 	if (rt_ahead < 0) rt_ahead = 0;
+#ifdef SVT_TUNING
 	auto kern = (g_pbc_debug == 3 && NV <= 2) ? crossprod_pbc_dma_kernel<(NV <= 2 ? NV : 2), true>
 						  : crossprod_pbc_dma_kernel<NV, false>;
+#else
+	auto kern = crossprod_pbc_dma_kernel<NV, false>;
+#endif
 	(void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
 	hipLaunchKernelGGL(kern, dim3((unsigned) ((int64_t) nsplit * kt * P->nblocks)), dim3(1024), lds, s,
 			   P->rec, P->tile_ptr, P->npanels, Y, ldY, P->nrow, K, P->ncol, P->CBW, nsplit,
@@ -1046,29 +1272,47 @@ extern "C" int svt_dev_crossprod_pbc_phase(const svt_dev_pbc *P, const svt_dev_c
 		return svt_set_error("svt_dev_crossprod_pbc: workspace too small");
 	const int64_t Kp = ((int64_t) K + 63) / 64 * 64;
 	int64_t pps = 1;
-	const bool dma = pbc_dma_ok(P, tr_y);
+	// a dense operand given by rows is transposed on the device first (phase 1) and the product
+	// runs on the column-major copy: same kernel, same speed + one 2 x |Y| pass
+	const bool dma = pbc_dma_ok(P, 0);
+	const bool via_copy = tr_y && dma;
 	const int nsplit = pick_nsplit(P, K, dma, &pps);
 	PbcFlags fl;
 	fl.y_nonfinite = (int *) ws;
 	double *part = (double *) ((char *) ws + PBC_FLAG_BYTES);
 	void *gen_ws = (char *) part + (size_t) nsplit * Kp * P->ncol * 8;
+	const size_t gen_bytes = crossprod_ws_bytes(P->nrow, P->ncol, K);
+	DirtyWs dw = dirty_ws_of(ws, (char *) gen_ws + gen_bytes, P->ncol, Kp);
+	const double *Yc = via_copy ? (const double *) gen_ws : Y;     // what the product kernel stages
+	const int64_t ldc = via_copy ? P->nrow : ldY;
 	// one split, whole 64-wide dense tiles, result laid out like the partials:
 	// the product kernel writes `out` directly
 	const bool direct = nsplit == 1 && Kp == K && out_stride_c == 1 && out_stride_k == P->ncol;
 	if (direct) part = out;
 	if (phase == 1) {
-		HIP_TRY(hipMemsetAsync(ws, 0, 256, s));
+		if ((char *) dw.col_nf == (char *) ws + 256) {
+			HIP_TRY(hipMemsetAsync(ws, 0, 256 + (size_t) Kp * 12, s));
+		} else {
+			HIP_TRY(hipMemsetAsync(ws, 0, 256, s));
+			HIP_TRY(hipMemsetAsync(dw.col_nf, 0, (size_t) Kp * 12, s));
+		}
 		if (P->rec == NULL) {
 			// no nonzero at all (no record stream was built): the general kernels
 			// produce the zeros -- or the NaNs, if Y is not finite
-			HIP_TRY(hipMemsetAsync(ws, 1, 4, s));
+			HIP_TRY(hipMemsetAsync(ws, 1, 12, s));        // flags [0] and [2]
 			return 0;
 		}
 		const int nv = (P->CBW + 15) / 16;
 		if (dma) {
-			if (nv == 1) launch_dma<1>(P, Y, ldY, K, nsplit, pps, part, Kp, fl, s);
-			else if (nv == 2) launch_dma<2>(P, Y, ldY, K, nsplit, pps, part, Kp, fl, s);
-			else launch_dma<3>(P, Y, ldY, K, nsplit, pps, part, Kp, fl, s);
+			if (via_copy && P->nrow > 0) {
+				const int64_t ntile = (P->nrow + 63) / 64;
+				dim3 tg((unsigned) (ntile < 8192 ? ntile : 8192), (unsigned) (Kp / 64));
+				hipLaunchKernelGGL(pbc_transpose_dense_kernel, tg, dim3(256), 0, s, Y, ldY, P->nrow, K,
+						   (double *) gen_ws);
+			}
+			if (nv == 1) launch_dma<1>(P, Yc, ldc, K, nsplit, pps, part, Kp, fl, s);
+			else if (nv == 2) launch_dma<2>(P, Yc, ldc, K, nsplit, pps, part, Kp, fl, s);
+			else launch_dma<3>(P, Yc, ldc, K, nsplit, pps, part, Kp, fl, s);
 			HIP_TRY(hipGetLastError());
 			return 0;
 		}
@@ -1083,10 +1327,9 @@ extern "C" int svt_dev_crossprod_pbc_phase(const svt_dev_pbc *P, const svt_dev_c
 		PBC_CASE(2, 8, 7) PBC_CASE(3, 8, 7) PBC_CASE(4, 8, 7)
 		PBC_CASE(2, 8, 6) PBC_CASE(4, 4, 5)
 		default:
-			// no panel kernel for this layout / orientation (e.g. row-major Y with
-			// 40 columns per wavefront): raise the flag that sends the whole
+			// no panel kernel for this layout: raise the flags that send the whole
 			// product through the general kernels in phase 2
-			HIP_TRY(hipMemsetAsync(ws, 1, 4, s));
+			HIP_TRY(hipMemsetAsync(ws, 1, 12, s));
 		}
 #undef PBC_CASE
 		HIP_TRY(hipGetLastError());
@@ -1101,14 +1344,33 @@ extern "C" int svt_dev_crossprod_pbc_phase(const svt_dev_pbc *P, const svt_dev_c
 				   P->col_has_na, out, out_stride_c, out_stride_k);
 	}
 	HIP_TRY(hipGetLastError());
-	// General (slow-path) semantics if the dense operand is not finite.
+	// Dense columns with NaN / Inf / NA (all four kernels return at once while the product
+	// kernel's flag is clear).  The register-staged kernels read the dense operand as it was given:
+	// their dirty columns always take the general kernels.
+	if (dma && P->rec != NULL) {
+		// (small grids: while the flag is clear -- every product with a finite operand -- these
+		// launches cost their blocks' start-up and nothing else)
+		const int64_t rb = (P->nrow + 255) / 256;
+		dim3 sg((unsigned) (rb < 128 ? (rb > 0 ? rb : 1) : 128), (unsigned) K);
+		hipLaunchKernelGGL(pbc_dirty_scan_kernel, sg, dim3(256), 0, s, Yc, ldc, P->nrow, K, P->ncol, dw);
+		hipLaunchKernelGGL(pbc_dirty_plan_kernel, dim3(1), dim3(64), 0, s, K, dw);
+		dim3 hg((unsigned) ((P->ncol + 255) / 256), 16);
+		hipLaunchKernelGGL(pbc_dirty_hits_kernel, hg, dim3(256), 0, s, A->col_ptr, A->row_idx, P->ncol, dw);
+		dim3 fg((unsigned) ((P->ncol + 255) / 256));
+		hipLaunchKernelGGL(pbc_dirty_fix_kernel, fg, dim3(256), 0, s, P->col_has_na, K, P->ncol, dw,
+				   out, out_stride_c, out_stride_k);
+		hipLaunchKernelGGL(pbc_dirty_redo_kernel, dim3(64), dim3(256), 0, s, A->col_ptr, A->row_idx,
+				   (const double *) A->val, Yc, ldc, dw, out, out_stride_c, out_stride_k);
+		HIP_TRY(hipGetLastError());
+	}
+	// General (slow-path) semantics for everything else that is not finite.
 	CrossprodArgs a;
 	memset(&a, 0, sizeof(a));
 	a.col_ptr = A->col_ptr; a.row_idx = A->row_idx; a.val = A->val; a.Rtype = SVT_REALSXP;
 	a.nrow = A->nrow; a.ncol = A->ncol; a.Y = Y; a.ldY = ldY; a.K = K; a.tr_y = tr_y;
 	a.out = out; a.out_stride_c = out_stride_c; a.out_stride_k = out_stride_k;
-	a.ws = gen_ws; a.ws_bytes = crossprod_ws_bytes(P->nrow, P->ncol, K);
-	return launch_crossprod_general_if(a, fl.y_nonfinite, s);
+	a.ws = gen_ws; a.ws_bytes = gen_bytes;
+	return launch_crossprod_general_if(a, dma && P->rec != NULL ? dw.flags + 2 : fl.y_nonfinite, s);
 }
 
 extern "C" int svt_dev_crossprod_pbc(const svt_dev_pbc *P, const svt_dev_csc *A, const double *Y,

@@ -894,7 +894,8 @@ static bool pbc_shape_ok(int64_t nrow, int64_t ncol, int64_t nnz)
 
 static bool pbc_applies(const svt_dev_csc *A, int64_t K, int tr_y)
 {
-	return A->Rtype == SVT_REALSXP && !tr_y && A->nrow >= 256 && A->ncol > 0 &&
+	(void) tr_y;       // a dense operand given by rows is transposed on the device (kernels_mult_pbc.hip)
+	return A->Rtype == SVT_REALSXP && A->nrow >= 256 && A->ncol > 0 &&
 	       (double) A->nnz * (double) K >= 268435456.0 && pbc_shape_ok(A->nrow, A->ncol, A->nnz);
 }
 
@@ -965,8 +966,8 @@ static int dev_crossprod_chunked(const svt_dev_csc *A, const void *Y_dev, int64_
 		int rc = ws.alloc(svt_dev_crossprod_pbc_ws_bytes(P, kc));
 		for (int64_t k0 = 0; rc == 0 && k0 < K; k0 += kc) {
 			const int kn = (int) (K - k0 < kc ? K - k0 : kc);
-			rc = svt_dev_crossprod_pbc(P, A, (const double *) Y_dev + k0 * ldY, ldY, kn, 0,
-						   out_dev + k0 * sk, sc, sk, ws.p, ws.bytes, 0);
+			rc = svt_dev_crossprod_pbc(P, A, (const double *) Y_dev + (tr_y ? k0 : k0 * ldY), ldY, kn,
+						   tr_y, out_dev + k0 * sk, sc, sk, ws.p, ws.bytes, 0);
 		}
 		if (rc == 0 && hipDeviceSynchronize() != hipSuccess)
 			rc = svt_set_error("device error in the panel-blocked crossprod");

@@ -275,27 +275,103 @@ def test_device_colmedians(hip):
     assert_equal(got, want, tol=1e-15, what="colmedians")
 
 
-@pytest.mark.parametrize("nsplit", [8, 16, 5])
-def test_pbc_dma_partial_last_panel_first_in_a_split(hip, oracle, nsplit):
-    """Row splits of two panels (or one) whose in-loop staging starts with the partial last panel:
-    its window is moved back by less than one panel, and the kernel's staging offset register is
-    unsigned -- a fault at 300000 columns x 2000 rows once (svt_matmul_SVT_SVT)."""
-    from sparsearray_amd import _hip
+@pytest.mark.parametrize("nrow", [2000, 38480, 65 * 128 + 3])
+def test_pbc_dma_partial_last_panel_first_in_a_split(hip, oracle, nrow):
+    """Row splits whose in-loop staging starts with the partial last panel: its window is moved back
+    by less than one panel, and the kernel's staging offset register is unsigned -- a fault at 300000
+    columns x 2000 rows once (svt_matmul_SVT_SVT).  Shapes for which the launcher's own choice of
+    row splits puts the partial panel first in its split: 2000 rows = 16 splits of one panel (the last
+    of 80 rows); 38480 rows = 301 panels in splits of 3 (the last split is the 80-row panel alone);
+    8323 rows = 66 panels, the last of 3 rows."""
     from sparsearray_amd.device import PbcPlan
-    lib = _hip.init()
-    nrow, ncol, K = 2000, 900, 50                      # 16 panels, the last of 80 rows
-    cp, ri, v = random_csc(nrow, ncol, 0.02, seed=61)
+    ncol, K = 900, 50
+    cp, ri, v = random_csc(nrow, ncol, 0.02 if nrow < 10000 else 0.004, seed=61)
     x = SVT_SparseArray.from_csc((nrow, ncol), "double", cp, ri, v)
     y = np.random.default_rng(62).uniform(-1, 1, (nrow, K))
     want = oracle.crossprod(x, y)
     A = _dev(cp, ri, v, nrow)
     Yd = torch.as_tensor(np.ascontiguousarray(y.T), device="cuda")
-    try:
-        lib.svt_dev_pbc_set_debug(100 + nsplit)        # tuning override of the split count
-        plan = PbcPlan(A, K)
-        out = torch.zeros((K, ncol), dtype=torch.float64, device="cuda")
-        plan.run(Yd, nrow, out)
+    plan = PbcPlan(A, K)
+    out = torch.zeros((K, ncol), dtype=torch.float64, device="cuda")
+    plan.run(Yd, nrow, out)
+    torch.cuda.synchronize()
+    assert_equal(out.cpu().numpy().T, want, tol=1e-9, atol=1e-11, what=f"nrow {nrow}")
+
+
+def test_pbc_dirty_columns_fixed_up_per_column(hip, oracle):
+    """Non-finite entries of the dense operand: only their columns are rewritten (the reference's
+    per-column switch to the slow dot product, src/SparseMatrix_mult.c:193-207).  Entries on rows
+    where some leaves have a nonzero (those leaves keep the IEEE sum: Inf, or NaN from Inf - Inf)
+    and on rows where they have none (NaN from 0 * Inf), an R NA (the whole column NA), leaves that
+    hold an NA themselves, several entries in one column, and the clean columns bit for bit."""
+    from sparsearray_amd.device import PbcPlan
+    nrow, ncol, K = 30000 + 50, 1500, 70
+    cp, ri, v = random_csc(nrow, ncol, 0.01, seed=71)
+    v = v.copy()
+    v[cp[17] + 3] = NA_real                              # leaf 17 holds an R NA
+    x = SVT_SparseArray.from_csc((nrow, ncol), "double", cp, ri, v)
+    A = _dev(cp, ri, v, nrow)
+    plan = PbcPlan(A, K)
+    rng = np.random.default_rng(72)
+    y0 = rng.uniform(-1, 1, (nrow, K))
+    out = torch.zeros((K, ncol), dtype=torch.float64, device="cuda")
+
+    def run(y):
+        plan.run(torch.as_tensor(np.ascontiguousarray(y.T), device="cuda"), nrow, out)
         torch.cuda.synchronize()
-    finally:
-        lib.svt_dev_pbc_set_debug(100)
-    assert_equal(out.cpu().numpy().T, want, tol=1e-9, atol=1e-11, what=f"nsplit {nsplit}")
+        return out.cpu().numpy().T.copy()
+
+    clean = run(y0)
+    y = y0.copy()
+    r_hit = int(ri[cp[5] + 2])                          # a row where leaf 5 has a nonzero
+    r_hit2 = int(ri[cp[5] + 7])
+    y[r_hit, 3] = np.inf                                # column 3: one entry, hit by leaf 5 (and others)
+    y[r_hit, 9] = np.inf; y[r_hit2, 9] = -np.inf        # column 9: two entries, both hit by leaf 5
+    y[12345, 20] = np.nan                               # column 20: a NaN
+    y[nrow - 1, 69] = NA_real                           # column 69: an R NA in the last partial panel
+    y[0, 0] = -np.inf
+    got = run(y)
+    want = oracle.crossprod(x, y)
+    assert_equal(got, want, tol=1e-9, atol=1e-11, strict_na=True, what="dirty columns")
+    assert np.isinf(got[5, 3]) and (np.isnan(got[6, 3]) or np.isinf(got[6, 3]))
+    dirty = [0, 3, 9, 20, 69]
+    keep = [k for k in range(K) if k not in dirty]
+    assert np.array_equal(got[:, keep], clean[:, keep], equal_nan=True)     # untouched, bit for bit
+    # a clean operand afterwards: nothing sticks
+    assert np.array_equal(run(y0), clean, equal_nan=True)
+    # a whole column of NaN (more entries than the fix-up lists): the general kernels take over
+    y = y0.copy()
+    y[:, 11] = np.nan
+    y[77, 12] = np.inf
+    assert_equal(run(y), oracle.crossprod(x, y), tol=1e-9, atol=1e-11, strict_na=True, what="NaN column")
+    # more dirty columns than the fix-up handles
+    y = y0.copy()
+    y[100, ::3] = np.inf
+    assert_equal(run(y), oracle.crossprod(x, y), tol=1e-9, atol=1e-11, strict_na=True, what="many dirty columns")
+
+
+@pytest.mark.parametrize("shape", [(20000 + 77, 2100, 70), (4096, 700, 64), (1282, 90, 130)])
+def test_pbc_dense_operand_given_by_rows(hip, oracle, shape):
+    """tr_y (tcrossprod / transpose.x, src/SparseMatrix_mult.c:411-421): the K x nrow operand is
+    transposed on the device and takes the same product kernel: bit-identical to the column-major
+    call, and equal to the oracle; with a non-finite entry too."""
+    from sparsearray_amd.device import PbcPlan
+    nrow, ncol, K = shape
+    cp, ri, v = random_csc(nrow, ncol, 0.01, seed=81)
+    x = SVT_SparseArray.from_csc((nrow, ncol), "double", cp, ri, v)
+    A = _dev(cp, ri, v, nrow)
+    plan = PbcPlan(A, K)
+    y = np.random.default_rng(82).uniform(-1, 1, (nrow, K))
+    for poison in (False, True):
+        if poison:
+            y[nrow // 2, K - 1] = np.inf
+        Ycm = torch.as_tensor(np.ascontiguousarray(y.T), device="cuda")     # (K, nrow) = column-major nrow x K
+        Yrm = torch.as_tensor(np.ascontiguousarray(y), device="cuda")       # (nrow, K) = column-major K x nrow
+        o1 = torch.zeros((K, ncol), dtype=torch.float64, device="cuda")
+        o2 = torch.zeros((K, ncol), dtype=torch.float64, device="cuda")
+        plan.run(Ycm, nrow, o1)
+        plan.run(Yrm, K, o2, tr_y=True)
+        torch.cuda.synchronize()
+        assert torch.equal(torch.nan_to_num(o1, nan=7.0), torch.nan_to_num(o2, nan=7.0))
+        assert_equal(o2.cpu().numpy().T, oracle.crossprod(x, y), tol=1e-9, atol=1e-11, strict_na=True,
+                     what=f"tr_y poison={poison}")

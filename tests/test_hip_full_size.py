@@ -88,6 +88,18 @@ def test_full_size_poisoned_dense_entry_switches_semantics(operands):
     assert float((got[keep] - clean[keep]).abs().max()) <= 1e-9 * float(clean.abs().max())
 
 
+def test_full_size_dense_operand_given_by_rows(operands):
+    """tcrossprod orientation at full size: the 128 x 1e6 operand is transposed on the device and
+    takes the product kernel; results identical to the column-major call."""
+    A, plan, Y = operands
+    want = _crossprod(plan, Y)
+    Yrm = Y.t().contiguous()                                  # (nrow, K) C-contiguous = column-major K x nrow
+    out = torch.zeros((K, NCOL), dtype=torch.float64, device=Y.device)
+    plan.run(Yrm, K, out, tr_y=True)
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+
+
 # ---------------------------------------------------------------------------
 # BASELINE.json config 5: 2e4 x 2e4 x 64 @ 0.5 % (1.28e8 nonzeros, 1.28e6 leaves)
 # ---------------------------------------------------------------------------

@@ -1,7 +1,10 @@
 """Differential fuzzing of the panel-blocked crossprod (LDS-DMA kernel, default layout) against the
-general gather kernel (whose sums follow the reference's order) on the GPU: random shapes,
-densities, skewed columns, dense operand widths, odd row counts.  Run on the GPU box:
-    python tools/debug/fuzz_pbc.py [ncases] [seed]"""
+general gather kernel (whose sums follow the reference's order and which implements the reference's
+NaN / Inf / NA rules in full) on the GPU: random shapes, densities, skewed columns, dense operand
+widths, odd row counts, the dense operand given by columns or by rows, and a few non-finite entries
+in it (the per-column fix-up).  Run on the GPU box:
+    python tools/debug/fuzz_pbc.py [ncases] [seed]
+With SVT_HIP_TUNING=1 (a tuning build of the library) the row-split count is forced as well."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -35,24 +38,42 @@ for case in range(ncases):
     v[v == 0] = 0.5
     A = DeviceCSC.from_host(nrow, cp, ri, v)
     y = rng.uniform(-1, 1, (K, nrow))
-    Yd = torch.as_tensor(y, device=dev)
     ns = int(rng.choice([0, 0, 2, 3, 5, 8, 16]))        # 0: automatic; else forced row-split count
-    lib.svt_dev_pbc_set_debug(100 + ns)
+    if hasattr(lib, "svt_dev_pbc_set_debug"):
+        lib.svt_dev_pbc_set_debug(100 + ns)
+    else:
+        ns = 0
+    npoison = int(rng.choice([0, 0, 0, 1, 2, 5]))
+    for _ in range(npoison):
+        r = int(rng.integers(0, nrow)) if rng.random() < 0.5 or len(ri) == 0 else int(ri[rng.integers(0, len(ri))])
+        y[rng.integers(0, K), r] = rng.choice([np.inf, -np.inf, np.nan])
+    Yd = torch.as_tensor(y, device=dev)
+    by_rows = bool(rng.integers(0, 2))
     out_p = torch.full((K, ncol), 7.0, dtype=torch.float64, device=dev)
     out_g = torch.full((K, ncol), 9.0, dtype=torch.float64, device=dev)
-    PbcPlan(A, K).run(Yd, nrow, out_p)
+    if by_rows:
+        PbcPlan(A, K).run(Yd.t().contiguous(), K, out_p, tr_y=True)
+    else:
+        PbcPlan(A, K).run(Yd, nrow, out_p)
     CrossprodPlan(A, K).run(Yd, nrow, out_g)
     torch.cuda.synchronize()
+    same_class = bool((torch.isnan(out_p) == torch.isnan(out_g)).all()) and \
+        bool(((out_p == float("inf")) == (out_g == float("inf"))).all()) and \
+        bool(((out_p == float("-inf")) == (out_g == float("-inf"))).all())
+    fin = torch.isfinite(out_g) & torch.isfinite(out_p)
     # scale: sum of |a * y| per cell would be the honest one; the column's max |.| sum is a cheap bound
-    scale = max(1.0, float(out_g.abs().max()))
-    err = float((out_p - out_g).abs().max()) / scale
+    scale = max(1.0, float(out_g[fin].abs().max())) if bool(fin.any()) else 1.0
+    err = float((out_p - out_g)[fin].abs().max()) / scale if bool(fin.any()) else 0.0
+    if not same_class:
+        err = float("inf")
     worst = max(worst, err)
     flag = "" if err <= 1e-11 else "   <-- MISMATCH"
-    print(f"{case:4d} nrow {nrow:6d} ncol {ncol:5d} K {K:4d} kind {kind} dens {dens:<7g} nsplit {ns:2d} nnz {len(ri):8d}  err {err:.2e}{flag}", flush=True)
+    print(f"{case:4d} nrow {nrow:6d} ncol {ncol:5d} K {K:4d} kind {kind} dens {dens:<7g} nsplit {ns:2d} poison {npoison} by_rows {int(by_rows)} nnz {len(ri):8d}  err {err:.2e}{flag}", flush=True)
     if flag:
-        bad = (out_p - out_g).abs() / scale > 1e-11
+        bad = ~(((out_p - out_g).abs() / scale <= 1e-11) | (torch.isnan(out_p) & torch.isnan(out_g)) | (out_p == out_g))
         idx = bad.nonzero()[:5].tolist()
         print("   first bad (k, col):", idx)
         sys.exit(1)
-lib.svt_dev_pbc_set_debug(100)
+if hasattr(lib, "svt_dev_pbc_set_debug"):
+    lib.svt_dev_pbc_set_debug(100)
 print("worst relative error", worst)

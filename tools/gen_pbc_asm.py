@@ -310,6 +310,9 @@ def gen(prof):
     return out
 
 
+if EXP and not os.environ.get("PBC_ASM_OUT"):
+    raise SystemExit("PBC_EXP builds compute wrong results: write them to PBC_ASM_OUT (a tuning build's include), "
+                     "never over the product's pbc_dma_asm.inc")
 dst = os.environ.get("PBC_ASM_OUT") or os.path.join(
     os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sparsearray_amd", "csrc", "pbc_dma_asm.inc")
 with open(dst, "w") as f:
@@ -318,9 +321,13 @@ with open(dst, "w") as f:
     f.write(f"#define PBC_DMA_YSETS {YSETS}\n")
     for name, prof in (("PBC_DMA_ASM_TEXT", False), ("PBC_DMA_ASM_TEXT_PROF", True)):
         lines = gen(prof)
+        if prof:
+            f.write("#ifdef SVT_TUNING\n")
         f.write(f"#define {name} \\\n")
         for ln in lines:
             sep = "\\n" if ln.endswith(":") else "\\n\\t"
             f.write(f'\t"{ln}{sep}" \\\n')
         f.write('\t""\n')
+        if prof:
+            f.write("#endif\n")
         print("wrote", name, len(lines), "lines")

@@ -9,6 +9,8 @@ import time
 
 import torch
 
+os.environ["SVT_HIP_TUNING"] = "1"   # needs `make -C sparsearray_amd/csrc TUNING=1` (svt_dev_pbc_set_debug)
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sparsearray_amd import synth  # noqa: E402
 from sparsearray_amd.device import DeviceCSC, PbcPlan, _lib  # noqa: E402
