@@ -273,6 +273,16 @@ int svt_dev_crossprod_pbc(const svt_dev_pbc *P, const svt_dev_csc *A,
 			  int64_t out_stride_k, void *ws, size_t ws_bytes,
 			  void *stream);
 
+/* The same, restricted to the leaves from `first_col` on (rounded down to the kernel's block of
+   16 * CBW columns): cells of earlier leaves are not written.  What the unary crossprod(x) needs:
+   of dense column k only the leaves c >= k (compute_sym_dotprods_*, src/SparseMatrix_mult.c:
+   263-296, computes ncol^2 / 2 dot products and mirrors them). */
+int svt_dev_crossprod_pbc_from(const svt_dev_pbc *P, const svt_dev_csc *A,
+			       const double *Y, int64_t ldY, int K, int tr_y,
+			       double *out, int64_t out_stride_c,
+			       int64_t out_stride_k, void *ws, size_t ws_bytes,
+			       void *stream, int64_t first_col);
+
 /* The two phases of svt_dev_crossprod_pbc() separately (so that each can be
    timed): phase 1 = the LDS-panel product kernel (partial sums into ws),
    phase 2 = deterministic sum of the partials into `out` + the general path

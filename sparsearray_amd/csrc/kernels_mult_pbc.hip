@@ -720,7 +720,7 @@ template <int NV, bool PROF>
 __global__ void __launch_bounds__(1024)
 crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restrict__ tile_ptr,
 			 int64_t npanels, const double *__restrict__ Y, int64_t ldY, int64_t nrow,
-			 int K, int64_t ncol, int CBW, int nsplit, int nblocks,
+			 int K, int64_t ncol, int CBW, int nsplit, int nblocks, int block0,
 			 int64_t panels_per_split, double *__restrict__ part, int64_t Kp,
 			 PbcFlags fl, int rt_lines, int rt_ahead, int stag_mode)
 {
@@ -729,14 +729,17 @@ crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restric
 	const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int kt = (int) (Kp / 64);
 	const int L = blockIdx.x;
-	int b, kh, split;
+	// nblocks column blocks are launched, the first of them is block0 of the layout (a symmetric
+	// product only needs the blocks from its dense chunk's first column on); bl counts from 0
+	int bl, kh, split;
 	if ((nsplit & 7) == 0) {
 		const int xcd = L & 7, j = L >> 3, u = j / nblocks;
-		b = j % nblocks; kh = u % kt; split = (u / kt) * 8 + xcd;
+		bl = j % nblocks; kh = u % kt; split = (u / kt) * 8 + xcd;
 	} else {
 		const int u = L / nblocks;
-		b = L % nblocks; kh = u % kt; split = u / kt;
+		bl = L % nblocks; kh = u % kt; split = u / kt;
 	}
+	const int b = bl + block0;
 	const int64_t pa = (int64_t) split * panels_per_split;
 	const int64_t pb = pa + panels_per_split < npanels ? pa + panels_per_split : npanels;
 	if (pa >= pb)
@@ -796,7 +799,7 @@ crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restric
 		// finiteness prescan: this block's share of the 8192 doubles of a panel
 		const int chunk = (8192 + nblocks - 1) / nblocks;
 		const int nit = (chunk + 1023) / 1024;
-		int e0 = b * chunk;
+		int e0 = bl * chunk;
 		if (e0 > 8192 - nit * 1024) e0 = 8192 - nit * 1024;
 		const int e = e0 + tid;
 		V0[3] = (uint32_t) ((e >> 7) * PBC_DMA_ROW + (e & 127) * 8);
@@ -919,9 +922,9 @@ crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restric
 // out[c, k] = sum over splits (fixed order) ; NA_real_ for leaves holding an NA
 __global__ void pbc_reduce_kernel(const double *__restrict__ part, int nsplit, int64_t Kp,
 				  int K, int64_t ncol, const int *__restrict__ col_has_na,
-				  double *__restrict__ out, int64_t sc, int64_t sk)
+				  double *__restrict__ out, int64_t sc, int64_t sk, int64_t c_begin)
 {
-	const int64_t c = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	const int64_t c = c_begin + (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
 	const int k = blockIdx.y;
 	if (c >= ncol || k >= K) return;
 	double s = 0.0;
@@ -934,9 +937,9 @@ __global__ void pbc_reduce_kernel(const double *__restrict__ part, int nsplit, i
 // Single row split: the product kernel wrote `out` itself; only the leaves
 // holding an R NA remain to be patched.
 __global__ void pbc_nafix_kernel(const int *__restrict__ col_has_na, int K, int64_t ncol,
-				 double *__restrict__ out, int64_t sc, int64_t sk)
+				 double *__restrict__ out, int64_t sc, int64_t sk, int64_t c_begin)
 {
-	const int64_t c = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	const int64_t c = c_begin + (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
 	if (c >= ncol || !col_has_na[c]) return;
 	for (int k = 0; k < K; k++) out[c * sc + (int64_t) k * sk] = svt_na_real();
 }
@@ -1229,7 +1232,7 @@ static void launch_main(const svt_dev_pbc *P, const double *Y, int64_t ldY, int 
 
 template <int NV>
 static void launch_dma(const svt_dev_pbc *P, const double *Y, int64_t ldY, int K, int nsplit,
-		       int64_t pps, double *part, int64_t Kp, PbcFlags fl, hipStream_t s)
+		       int64_t pps, double *part, int64_t Kp, PbcFlags fl, hipStream_t s, int block0)
 {
 	const size_t lds = (size_t) 2 * PBC_DMA_BUF;
 	const int kt = (int) (Kp / 64);
@@ -1250,20 +1253,25 @@ static void launch_dma(const svt_dev_pbc *P, const double *Y, int64_t ldY, int K
 	auto kern = crossprod_pbc_dma_kernel<NV, false>;
 #endif
 	(void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-	hipLaunchKernelGGL(kern, dim3((unsigned) ((int64_t) nsplit * kt * P->nblocks)), dim3(1024), lds, s,
+	const int nb = (int) P->nblocks - block0;
+	hipLaunchKernelGGL(kern, dim3((unsigned) ((int64_t) nsplit * kt * nb)), dim3(1024), lds, s,
 			   P->rec, P->tile_ptr, P->npanels, Y, ldY, P->nrow, K, P->ncol, P->CBW, nsplit,
-			   (int) P->nblocks, pps, part, Kp, fl, rt_lines, rt_ahead, g_pbc_stagger);
+			   nb, block0, pps, part, Kp, fl, rt_lines, rt_ahead, g_pbc_stagger);
 }
 
 int launch_crossprod_general_if(const CrossprodArgs &a, const int *flag, hipStream_t s);
 
 // phase 1: the LDS-panel product kernel (partials into ws); phase 2: sum the
 // partials into `out`, then the general kernels if Y was not finite.
-extern "C" int svt_dev_crossprod_pbc_phase(const svt_dev_pbc *P, const svt_dev_csc *A,
-					   const double *Y, int64_t ldY, int K, int tr_y,
-					   double *out, int64_t out_stride_c,
-					   int64_t out_stride_k, void *ws, size_t ws_bytes,
-					   void *stream, int phase)
+// first_col > 0: only the leaves of the workgroup column block that holds first_col and of the
+// later ones are computed (their cells of `out` written); the cells of earlier leaves are left
+// alone.  Unary crossprod(x) needs only the leaves c >= k of dense column k (the reference's
+// compute_sym_dotprods_*, src/SparseMatrix_mult.c:263-296, computes ncol^2 / 2 dot products).
+static int pbc_phase(const svt_dev_pbc *P, const svt_dev_csc *A,
+		     const double *Y, int64_t ldY, int K, int tr_y,
+		     double *out, int64_t out_stride_c,
+		     int64_t out_stride_k, void *ws, size_t ws_bytes,
+		     void *stream, int phase, int64_t first_col)
 {
 	hipStream_t s = (hipStream_t) stream;
 	if (P->ncol <= 0 || K <= 0)
@@ -1276,6 +1284,12 @@ extern "C" int svt_dev_crossprod_pbc_phase(const svt_dev_pbc *P, const svt_dev_c
 	// runs on the column-major copy: same kernel, same speed + one 2 x |Y| pass
 	const bool dma = pbc_dma_ok(P, 0);
 	const bool via_copy = tr_y && dma;
+	int block0 = 0;
+	if (dma && first_col > 0) {
+		block0 = (int) (first_col / ((int64_t) 16 * P->CBW));
+		if (block0 > P->nblocks - 1) block0 = (int) P->nblocks - 1;
+	}
+	const int64_t c_begin = (int64_t) block0 * 16 * P->CBW;
 	const int nsplit = pick_nsplit(P, K, dma, &pps);
 	PbcFlags fl;
 	fl.y_nonfinite = (int *) ws;
@@ -1310,9 +1324,9 @@ extern "C" int svt_dev_crossprod_pbc_phase(const svt_dev_pbc *P, const svt_dev_c
 				hipLaunchKernelGGL(pbc_transpose_dense_kernel, tg, dim3(256), 0, s, Y, ldY, P->nrow, K,
 						   (double *) gen_ws);
 			}
-			if (nv == 1) launch_dma<1>(P, Yc, ldc, K, nsplit, pps, part, Kp, fl, s);
-			else if (nv == 2) launch_dma<2>(P, Yc, ldc, K, nsplit, pps, part, Kp, fl, s);
-			else launch_dma<3>(P, Yc, ldc, K, nsplit, pps, part, Kp, fl, s);
+			if (nv == 1) launch_dma<1>(P, Yc, ldc, K, nsplit, pps, part, Kp, fl, s, block0);
+			else if (nv == 2) launch_dma<2>(P, Yc, ldc, K, nsplit, pps, part, Kp, fl, s, block0);
+			else launch_dma<3>(P, Yc, ldc, K, nsplit, pps, part, Kp, fl, s, block0);
 			HIP_TRY(hipGetLastError());
 			return 0;
 		}
@@ -1336,12 +1350,12 @@ extern "C" int svt_dev_crossprod_pbc_phase(const svt_dev_pbc *P, const svt_dev_c
 		return 0;
 	}
 	if (direct) {
-		hipLaunchKernelGGL(pbc_nafix_kernel, dim3((unsigned) ((P->ncol + 255) / 256)), dim3(256), 0, s,
-				   P->col_has_na, K, P->ncol, out, out_stride_c, out_stride_k);
+		hipLaunchKernelGGL(pbc_nafix_kernel, dim3((unsigned) ((P->ncol - c_begin + 255) / 256)), dim3(256), 0, s,
+				   P->col_has_na, K, P->ncol, out, out_stride_c, out_stride_k, c_begin);
 	} else {
-		dim3 rgrid((unsigned) ((P->ncol + 255) / 256), (unsigned) K);
+		dim3 rgrid((unsigned) ((P->ncol - c_begin + 255) / 256), (unsigned) K);
 		hipLaunchKernelGGL(pbc_reduce_kernel, rgrid, dim3(256), 0, s, part, nsplit, Kp, K, P->ncol,
-				   P->col_has_na, out, out_stride_c, out_stride_k);
+				   P->col_has_na, out, out_stride_c, out_stride_k, c_begin);
 	}
 	HIP_TRY(hipGetLastError());
 	// Dense columns with NaN / Inf / NA (all four kernels return at once while the product
@@ -1373,14 +1387,30 @@ extern "C" int svt_dev_crossprod_pbc_phase(const svt_dev_pbc *P, const svt_dev_c
 	return launch_crossprod_general_if(a, dma && P->rec != NULL ? dw.flags + 2 : fl.y_nonfinite, s);
 }
 
+extern "C" int svt_dev_crossprod_pbc_phase(const svt_dev_pbc *P, const svt_dev_csc *A,
+					   const double *Y, int64_t ldY, int K, int tr_y,
+					   double *out, int64_t out_stride_c,
+					   int64_t out_stride_k, void *ws, size_t ws_bytes,
+					   void *stream, int phase)
+{
+	return pbc_phase(P, A, Y, ldY, K, tr_y, out, out_stride_c, out_stride_k, ws, ws_bytes, stream, phase, 0);
+}
+
 extern "C" int svt_dev_crossprod_pbc(const svt_dev_pbc *P, const svt_dev_csc *A, const double *Y,
 				     int64_t ldY, int K, int tr_y, double *out,
 				     int64_t out_stride_c, int64_t out_stride_k, void *ws,
 				     size_t ws_bytes, void *stream)
 {
-	if (svt_dev_crossprod_pbc_phase(P, A, Y, ldY, K, tr_y, out, out_stride_c, out_stride_k,
-					ws, ws_bytes, stream, 1))
+	return svt_dev_crossprod_pbc_from(P, A, Y, ldY, K, tr_y, out, out_stride_c, out_stride_k,
+					  ws, ws_bytes, stream, 0);
+}
+
+extern "C" int svt_dev_crossprod_pbc_from(const svt_dev_pbc *P, const svt_dev_csc *A, const double *Y,
+					  int64_t ldY, int K, int tr_y, double *out,
+					  int64_t out_stride_c, int64_t out_stride_k, void *ws,
+					  size_t ws_bytes, void *stream, int64_t first_col)
+{
+	if (pbc_phase(P, A, Y, ldY, K, tr_y, out, out_stride_c, out_stride_k, ws, ws_bytes, stream, 1, first_col))
 		return -1;
-	return svt_dev_crossprod_pbc_phase(P, A, Y, ldY, K, tr_y, out, out_stride_c, out_stride_k,
-					   ws, ws_bytes, stream, 2);
+	return pbc_phase(P, A, Y, ldY, K, tr_y, out, out_stride_c, out_stride_k, ws, ws_bytes, stream, 2, first_col);
 }

@@ -1143,18 +1143,30 @@ static int dev_crossprod_pp(const svt_dev_csc *other, const svt_dev_csc *pp,
 	    ws.alloc(P ? svt_dev_crossprod_pbc_ws_bytes(P, kc)
 		       : crossprod_ws_bytes(nrow, other->ncol, kc)))
 		rc = -1;
+	// crossprod(x) (other == pp): of the dense chunk [k0, k0 + kn) only the leaves c >= k0 are
+	// needed -- the cells with c >= k, which the caller mirrors -- as in compute_sym_dotprods_*
+	// (src/SparseMatrix_mult.c:263-296: ncol^2 / 2 dot products).
+	const bool sym = other == pp;
 	for (int64_t k0 = 0; rc == 0 && k0 < K; k0 += kc) {
 		const int kn = (int) (K - k0 < kc ? K - k0 : kc);
 		if (launch_densify(pp->col_ptr, pp->row_idx, pp->val, pp->Rtype, nrow,
-				   k0, kn, dense.p, 0))
+				   k0, kn, dense.p, 0)) {
 			rc = -1;
-		else if (P)
-			rc = svt_dev_crossprod_pbc(P, other, (const double *) dense.p, nrow, kn, 0,
-						   out_dev + k0 * sk, sc, sk, ws.p, ws.bytes, 0);
-		else
+		} else if (P) {
+			rc = svt_dev_crossprod_pbc_from(P, other, (const double *) dense.p, nrow, kn, 0,
+							out_dev + k0 * sk, sc, sk, ws.p, ws.bytes, 0,
+							sym ? k0 : 0);
+		} else if (sym && k0 > 0) {
+			svt_dev_csc tail = *other;                 // leaves k0 .. ncol-1 (col_ptr entries stay absolute)
+			tail.col_ptr += k0; tail.ncol -= k0; tail.owned = 0;
+			rc = svt_dev_crossprod_csc_dense(&tail, dense.p, nrow, kn, 0,
+							 out_dev + k0 * sk + k0 * sc, sc, sk,
+							 ws.p, ws.bytes, 0);
+		} else {
 			rc = svt_dev_crossprod_csc_dense(other, dense.p, nrow, kn, 0,
 							 out_dev + k0 * sk, sc, sk,
 							 ws.p, ws.bytes, 0);
+		}
 	}
 	if (rc == 0 && hipDeviceSynchronize() != hipSuccess)
 		rc = svt_set_error("device error in the sparse x sparse crossprod");

@@ -488,3 +488,24 @@ def test_crossprod_wide_dense_operand_is_chunked(hip, oracle):
     want = oracle.crossprod(x, y)
     assert_equal(hip.crossprod(x, y), want, tol=1e-9, atol=1e-11)
     assert_equal(hip.crossprod(y, x), want.T, tol=1e-9, atol=1e-11)
+
+
+def test_crossprod1_large_is_triangular_and_symmetric(hip, oracle):
+    """Unary crossprod(x) above the panel-kernel threshold: every dense chunk of x's own columns is
+    multiplied with the leaves from its first column on only (src/SparseMatrix_mult.c:263-296) and
+    the result is mirrored.  An NA in one leaf, an Inf in another (a dirty dense column in its own
+    chunk) and a second chunk (ncol > 512)."""
+    x = _svt(150_000, 1300, 0.01, 91)
+    leaves = list(x.leaves)
+    offs, vals = leaves[700]
+    vals = vals.copy(); vals[5] = np.inf
+    leaves[700] = (offs, vals)
+    offs, vals = leaves[3]
+    vals = vals.copy(); vals[0] = NA_real
+    leaves[3] = (offs, vals)
+    x = SVT_SparseArray(x.dim, x.type, leaves)
+    got = hip.crossprod(x)
+    want = oracle.crossprod(x)
+    assert_equal(got, want, tol=1e-9, atol=1e-11, strict_na=True, what="crossprod(x)")
+    g = np.asarray(got)
+    assert np.array_equal(g, g.T, equal_nan=True)
