@@ -207,6 +207,152 @@ pbc_pass_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__
 #undef TILE_OF
 }
 
+// ---------------------------------------------------------------------------
+// Scatter pass of the format-1 layout through LDS.  pbc_pass_kernel<1, 1> writes every record
+// with two scattered stores (4 + 8 bytes into 96-byte batches of some other tile each time):
+// 4.8 GB leave the chip for 1.3 GB of records at BASELINE config 2
+// (profiles/r01_dma_summary.txt).  Here a workgroup owns (column group g, PBC_SUBP consecutive
+// panels): their tiles are contiguous in the record array, so the workgroup assembles the byte
+// image of that stretch in LDS -- padding zeros and batch flags included -- and writes it out with
+// 16-byte stores, every byte once.
+//   1. lanes 0 .. nc-1 find their column's nonzeros inside the row range (two binary searches)
+//   2. all threads walk the flattened list of those nonzeros: count per (panel, column), and the
+//      first position of each (panel, column) run (rows ascend inside a column)
+//   3. one thread per panel turns the counts into offsets inside the tile, columns in order:
+//      the tile keeps the CSC order of the old builder, whatever the thread timing
+//   4. second walk: every record goes to its final slot of the image
+//   5. batch flags, copy-out
+// A stretch larger than the LDS image (a very dense column group) falls back to global stores.
+// ---------------------------------------------------------------------------
+#define PBC_IMG_BYTES 24576
+
+__device__ inline void pbc1_put(char *img, int64_t ridx, uint32_t meta, double x)
+{
+	char *b = img + (ridx >> 3) * 96;
+	((uint32_t *) b)[ridx & 7] = meta;
+	((double *) (b + 32))[ridx & 7] = x;
+}
+
+// bounds[c * (nchunks + 1) + q] = number of nonzeros of column c above row q * subp * R: where the
+// stretches of `subp` panels start inside every column.  One independent binary search per entry
+// (millions in flight), so that the scatter workgroups below start from two table reads instead of
+// a chain of 2 x 14 dependent loads each (38 -> ~8 us per workgroup).
+__global__ void pbc_bounds_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__ row_idx,
+				  int64_t ncol, int64_t nchunks, int64_t rows_per_chunk,
+				  int32_t *__restrict__ bounds)
+{
+	const int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= ncol * (nchunks + 1)) return;
+	const int64_t c = t / (nchunks + 1), q = t - c * (nchunks + 1);
+	const int64_t beg = col_ptr[c], end = col_ptr[c + 1];
+	bounds[t] = (int32_t) (lower_bound_row(row_idx, beg, end, q * rows_per_chunk) - beg);
+}
+
+// dynamic LDS: [image PBC_IMG_BYTES][cnt subp * nc ints][first subp * nc ints]
+__global__ void __launch_bounds__(256)
+pbc_scatter_lds_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__ row_idx,
+		       const double *__restrict__ val, int64_t ncol, int CBW, int logR, int64_t npanels,
+		       const int64_t *__restrict__ tile_ptr, char *__restrict__ rec,
+		       int *__restrict__ col_has_na, int stag_mode, int subp,
+		       const int32_t *__restrict__ bounds, int64_t nchunks)
+{
+	extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+	char *img = lds_raw;
+	int *s_cnt = (int *) (lds_raw + PBC_IMG_BYTES);         // counts, then offsets inside the image
+	int *s_first = s_cnt + subp * CBW;                      // first flattened index of the (panel, column) run
+	__shared__ int64_t s_lo[64];
+	__shared__ int s_cum[65];
+	__shared__ int s_tile0[257];                            // first record of each tile, relative to the stretch
+	const int tid = threadIdx.x;
+	const int64_t g = blockIdx.x;
+	const int64_t ps = (int64_t) blockIdx.y * subp;
+	const int np = (int) (ps + subp <= npanels ? subp : npanels - ps);
+	const int64_t c0 = g * CBW;
+	// (the last workgroup's trailing groups may lie past the last column: nc = 0, tiles of padding only)
+	const int nc = (int) (c0 + CBW <= ncol ? CBW : (c0 < ncol ? ncol - c0 : 0));
+	const int64_t base = tile_ptr[g * npanels + ps];
+	const int64_t nr = tile_ptr[g * npanels + ps + np] - base;            // records, a multiple of 8
+	const int64_t nbytes = (nr >> 3) * 96;
+	const bool in_lds = nbytes <= PBC_IMG_BYTES;
+	char *dst = in_lds ? img : rec + (base >> 3) * 96;
+	// ---- 1
+	if (tid < nc) {
+		const int64_t c = c0 + tid;
+		const int32_t *bc = bounds + c * (nchunks + 1) + blockIdx.y;
+		s_lo[tid] = col_ptr[c] + bc[0];
+		s_cum[tid + 1] = bc[1] - bc[0];
+	}
+	if (tid <= np) s_tile0[tid] = (int) (tile_ptr[g * npanels + ps + tid] - base);
+	for (int i = tid; i < np * nc; i += 256) { s_cnt[i] = 0; s_first[i] = 0x7fffffff; }
+	if (in_lds)
+		for (int64_t i = tid; i < nbytes / 16; i += 256) ((uint4 *) img)[i] = make_uint4(0, 0, 0, 0);
+	__syncthreads();
+	if (tid == 0) {
+		s_cum[0] = 0;
+		for (int j = 0; j < nc; j++) s_cum[j + 1] += s_cum[j];
+	}
+	__syncthreads();
+	const int total = s_cum[nc];
+	// ---- 2
+	for (int i = tid; i < total; i += 256) {
+		int a = 0, b = nc;                                  // column j with cum[j] <= i < cum[j + 1]
+		while (b - a > 1) { const int m = (a + b) >> 1; if (s_cum[m] <= i) a = m; else b = m; }
+		const int r = row_idx[s_lo[a] + (i - s_cum[a])];
+		const int p = (int) (((int64_t) r >> logR) - ps);
+		atomicAdd(&s_cnt[p * nc + a], 1);
+		atomicMin(&s_first[p * nc + a], i);
+	}
+	__syncthreads();
+	// ---- 3
+	if (tid < np) {
+		int run = s_tile0[tid];
+		for (int j = 0; j < nc; j++) { const int n = s_cnt[tid * nc + j]; s_cnt[tid * nc + j] = run; run += n; }
+		if (!in_lds) {                                      // global fallback: the padding is written here
+			for (int q = run; q < s_tile0[tid + 1]; q++) pbc1_put(dst, q, 0u, 0.0);
+		}
+	}
+	__syncthreads();
+	// ---- 4
+	for (int i = tid; i < total; i += 256) {
+		int a = 0, b = nc;
+		while (b - a > 1) { const int m = (a + b) >> 1; if (s_cum[m] <= i) a = m; else b = m; }
+		const int64_t k = s_lo[a] + (i - s_cum[a]);
+		const int r = row_idx[k];
+		const double x = val[k];
+		const int p = (int) (((int64_t) r >> logR) - ps);
+		const int pos = s_cnt[p * nc + a] + (i - s_first[p * nc + a]);
+		const uint32_t ro = (uint32_t) (r - (int32_t) ((p + ps) << logR)) * 8u;
+		pbc1_put(dst, pos, (ro << 16) | (uint32_t) a * 2u, x);
+		if (svt_is_na(x)) col_has_na[c0 + a] = 1;
+	}
+	__syncthreads();
+	// ---- 5: flag the tile's last batch, and the batch after which the wavefront issues the
+	// LDS-DMA of the next panel (staggered over the wavefronts of a workgroup, as pbc_pass_kernel)
+	if (tid < np) {
+		const int start = s_tile0[tid], stop = s_tile0[tid + 1];
+		uint32_t *last = (uint32_t *) (dst + ((stop - 8) >> 3) * 96);
+		*last |= 0x8000u;
+		const int w = (int) (g % 16);
+		const int nb = (stop - start) >> 3;
+		int bi = stag_mode == 0 ? 0 : stag_mode == 1 ? (w & 1) :
+			 stag_mode == 2 ? (w & 3) : stag_mode == 3 ? ((w >> 2) & 1) :
+			 stag_mode == 4 ? (w & 7) : stag_mode == 5 ? ((w * nb) >> 4) :
+			 stag_mode == 6 ? ((w & 3) * 2) : stag_mode == 7 ? (w >> 2) :
+			 stag_mode == 8 ? ((w >> 2) * 2) : stag_mode == 9 ? (w >> 1) :
+			 stag_mode == 10 ? ((w >> 2) + 1) : stag_mode == 11 ? (w >> 3) :
+			 stag_mode == 12 ? ((w >> 2) < 2 ? (w >> 2) : 2) :
+			 stag_mode == 13 ? ((w >> 2) % 3) : ((w >> 2) * 3 / 4);
+		if (bi > nb - 1) bi = nb - 1;
+		uint32_t *issue = (uint32_t *) (dst + ((start >> 3) + bi) * 96);
+		*issue |= 0x4000u;
+	}
+	if (!in_lds)
+		return;
+	__syncthreads();
+	uint4 *out = (uint4 *) (rec + (base >> 3) * 96);
+	for (int64_t i = tid; i < nbytes / 16; i += 256) out[i] = ((const uint4 *) img)[i];
+}
+
 // flag = 1 if some column group's record stream does not fit a 32-bit byte cursor
 __global__ void pbc_group_limit_kernel(const int64_t *__restrict__ tile_ptr, int64_t npanels,
 				       int64_t ngroups, int *__restrict__ flag)
@@ -262,12 +408,19 @@ extern "C" svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB
 		return NULL;
 	}
 	void *tmp = NULL;
+	int32_t *bounds = NULL;
 	size_t tmp_bytes = 0;
 	bool ok = hipMalloc((void **) &h->tile_ptr, (size_t) (ntiles + 1 + PBC_TP_PAD) * 8) == hipSuccess &&
 		  hipMalloc((void **) &h->col_has_na, (size_t) (A->ncol > 0 ? A->ncol : 1) * 4) == hipSuccess;
-	if (ok) ok = hipMemset(h->tile_ptr, 0, (size_t) (ntiles + 1 + PBC_TP_PAD) * 8) == hipSuccess &&
-		     hipMemset(h->col_has_na, 0, (size_t) (A->ncol > 0 ? A->ncol : 1) * 4) == hipSuccess;
+	if (ok) ok = hipMemsetAsync(h->tile_ptr, 0, (size_t) (ntiles + 1 + PBC_TP_PAD) * 8, 0) == hipSuccess &&
+		     hipMemsetAsync(h->col_has_na, 0, (size_t) (A->ncol > 0 ? A->ncol : 1) * 4, 0) == hipSuccess;
 	if (ok && A->ncol > 0 && A->nnz > 0) {
+		const int BATCH = h->fmt == 1 ? 8 : PBC_BATCH;
+		const size_t rbytes = h->fmt == 1 ? 12 : 16;
+		// Every tile is padded to whole batches (format 1: at least one): at most BATCH - 1 (BATCH)
+		// records of padding per tile.  Allocating for that bound spares the build a round trip to
+		// the host between its count and scatter passes; the exact count is read back at the end.
+		const int64_t nrec_max = A->nnz + ntiles * (int64_t) (h->fmt == 1 ? BATCH : BATCH - 1);
 		dim3 grid((unsigned) h->ngroups, (unsigned) ((h->npanels + PCH - 1) / PCH));
 		if (h->fmt == 1)
 			hipLaunchKernelGGL((pbc_pass_kernel<0, 1>), grid, dim3(64), 0, 0, A->col_ptr, A->row_idx,
@@ -283,15 +436,46 @@ extern "C" svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB
 		     hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16) == hipSuccess &&
 		     hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, h->tile_ptr, h->tile_ptr,
 						      (int) (ntiles + 1)) == hipSuccess;
+		if (ok) ok = hipMalloc((void **) &h->rec, (size_t) nrec_max * rbytes + PBC_SLACK * 16) == hipSuccess;
+		if (ok) {
+			if (h->fmt == 1) {
+				// panels per scatter workgroup: the fewest (>= 16) that give a column ~8 nonzeros per
+				// stretch on average (very sparse operands: fewer, larger stretches; the table of
+				// stretch bounds then stays smaller than the operand)
+				int subp = 16;
+				while (subp < 128 && (double) A->nnz * subp < 8.0 * (double) A->ncol * (double) h->npanels)
+					subp *= 2;
+				const int64_t nchunks = (h->npanels + subp - 1) / subp;
+				const int64_t nb_entries = A->ncol * (nchunks + 1);
+				ok = hipMalloc((void **) &bounds, (size_t) nb_entries * 4) == hipSuccess;
+				if (ok) {
+					hipLaunchKernelGGL(pbc_bounds_kernel, dim3((unsigned) ((nb_entries + 255) / 256)), dim3(256), 0, 0,
+							   A->col_ptr, A->row_idx, A->ncol, nchunks, (int64_t) subp << logR, bounds);
+					const size_t lds = PBC_IMG_BYTES + (size_t) 2 * subp * CBW * 4;
+					(void) hipFuncSetAttribute((const void *) pbc_scatter_lds_kernel,
+								   hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+					dim3 sgrid((unsigned) h->ngroups, (unsigned) nchunks);
+					hipLaunchKernelGGL(pbc_scatter_lds_kernel, sgrid, dim3(256), lds, 0, A->col_ptr, A->row_idx,
+							   (const double *) A->val, A->ncol, CBW, logR, h->npanels,
+							   h->tile_ptr, (char *) h->rec, h->col_has_na, g_pbc_stagger, subp,
+							   bounds, nchunks);
+				}
+			} else {
+				hipLaunchKernelGGL((pbc_pass_kernel<1, 0>), grid, dim3(64), 0, 0, A->col_ptr,
+						   A->row_idx, (const double *) A->val, A->ncol, CBW, logR,
+						   h->npanels, h->tile_ptr, h->rec, h->col_has_na, g_pbc_stagger);
+			}
+		}
 		int64_t nrec = 0;
-		if (ok) ok = hipMemcpy(&nrec, h->tile_ptr + ntiles, 8, hipMemcpyDeviceToHost) == hipSuccess;
+		if (ok) ok = hipMemcpy(&nrec, h->tile_ptr + ntiles, 8, hipMemcpyDeviceToHost) == hipSuccess;   // (synchronises)
 		h->nrec = nrec;
 		if (ok) {
 			int64_t pad[PBC_TP_PAD];
 			for (int i = 0; i < PBC_TP_PAD; i++) pad[i] = nrec;
-			ok = hipMemcpy(h->tile_ptr + ntiles + 1, pad, sizeof(pad), hipMemcpyHostToDevice) == hipSuccess;
+			// the look-ahead stages of the kernels read up to 3 batches past the end
+			ok = hipMemcpy(h->tile_ptr + ntiles + 1, pad, sizeof(pad), hipMemcpyHostToDevice) == hipSuccess &&
+			     hipMemset((char *) h->rec + (size_t) nrec * rbytes, 0, (size_t) PBC_SLACK * 16) == hipSuccess;
 		}
-		const size_t rbytes = h->fmt == 1 ? 12 : 16;
 		// the kernels walk one group's stream with a 32-bit byte cursor
 		bool too_big = false;
 		if (ok && (nrec + PBC_SLACK) * 16 >= ((int64_t) 1 << 32)) {      // (else no group can be)
@@ -308,25 +492,14 @@ extern "C" svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB
 		if (ok && too_big) {
 			svt_set_error("svt_dev_pbc_build: a column group too large for 32-bit record offsets");
 			if (tmp) (void) hipFree(tmp);
+			if (bounds) (void) hipFree(bounds);
 			svt_dev_pbc_release(h);
 			return NULL;
 		}
-		if (ok) ok = hipMalloc((void **) &h->rec, (size_t) nrec * rbytes + PBC_SLACK * 16) == hipSuccess &&
-			     // the look-ahead stages of the kernels read up to 3 batches past the end
-			     hipMemset((char *) h->rec + (size_t) nrec * rbytes, 0, (size_t) PBC_SLACK * 16) == hipSuccess;
-		if (ok) {
-			if (h->fmt == 1)
-				hipLaunchKernelGGL((pbc_pass_kernel<1, 1>), grid, dim3(64), 0, 0, A->col_ptr,
-						   A->row_idx, (const double *) A->val, A->ncol, CBW, logR,
-						   h->npanels, h->tile_ptr, h->rec, h->col_has_na, g_pbc_stagger);
-			else
-				hipLaunchKernelGGL((pbc_pass_kernel<1, 0>), grid, dim3(64), 0, 0, A->col_ptr,
-						   A->row_idx, (const double *) A->val, A->ncol, CBW, logR,
-						   h->npanels, h->tile_ptr, h->rec, h->col_has_na, g_pbc_stagger);
-			ok = hipDeviceSynchronize() == hipSuccess;
-		}
+		if (ok) ok = hipDeviceSynchronize() == hipSuccess;
 	}
 	if (tmp) (void) hipFree(tmp);
+	if (bounds) (void) hipFree(bounds);
 	if (!ok) {
 		svt_set_error("svt_dev_pbc_build failed: %s", hipGetErrorString(hipGetLastError()));
 		svt_dev_pbc_release(h);

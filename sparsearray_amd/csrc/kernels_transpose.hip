@@ -30,16 +30,51 @@ __global__ void row_bounds_kernel(const int32_t *__restrict__ sorted_rows, int64
 	out_ptr[r] = lo;
 }
 
+// Which chunk of 256 outputs a workgroup takes.  Workgroups are dealt round-robin over the 8 XCDs
+// (MI355X_MICROARCH.md, Workgroup dispatch): with chunk = blockIdx the 8 entries of one 64-byte
+// sector of `val` -- 8 consecutive nonzeros of a column, i.e. 8 output rows ~100 rows apart -- are
+// gathered by workgroups of 8 different XCDs and every XCD's L2 fetches the sector for itself.
+// Here XCD x walks the x-th eighth of the output in order, so a sector is fetched by one L2 and
+// its other entries hit it (2.9 -> ~1 ms for the gather of t(A) at 1e8 nonzeros).
+__device__ inline int64_t xcd_chunk(int64_t nchunks)
+{
+	const int64_t b = blockIdx.x, per = (nchunks + 7) / 8;
+	return (b & 7) * per + (b >> 3);
+}
+
+// Column of source position k without a search over all of col_ptr: hint[b] = the column that
+// holds position b << HINT_SHIFT.  A full binary search per output costs ~8 L2 requests on the same
+// few col_ptr lines from every CU (the gather ran at the L2's request rate: 5.6e8 requests in 3 ms,
+// 97 % hits, profiles/r02_transpose_*); with the hint the search runs over the handful of columns
+// that start inside one block of 256 positions.
+#define HINT_SHIFT 8
+__global__ void col_hint_kernel(const int64_t *__restrict__ col_ptr, int64_t ncol, int64_t nblk,
+				uint32_t *__restrict__ hint)
+{
+	const int64_t b = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if (b > nblk) return;
+	const int64_t k = b << HINT_SHIFT;
+	int64_t lo = 0, hi = ncol;                  // last c with col_ptr[c] <= k (ncol if k is past the end)
+	while (lo < hi) {
+		const int64_t mid = (lo + hi + 1) >> 1;
+		if (col_ptr[mid] <= k) lo = mid; else hi = mid - 1;
+	}
+	hint[b] = (uint32_t) lo;
+}
+
+// (4 outputs per thread with streamed loads / stores: 2.0 ms against 1.5 ms for this form)
 template <typename T>
 __global__ void transpose_gather_kernel(const int64_t *__restrict__ col_ptr, int64_t ncol,
 					const T *__restrict__ val, const uint32_t *__restrict__ perm,
+					const uint32_t *__restrict__ hint,
 					int64_t nnz, int32_t *__restrict__ out_idx, T *__restrict__ out_val)
 {
-	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	const int64_t i = xcd_chunk((nnz + blockDim.x - 1) / blockDim.x) * blockDim.x + threadIdx.x;
 	if (i >= nnz) return;
 	const int64_t k = perm[i];
-	// column of position k: last c with col_ptr[c] <= k
-	int64_t lo = 0, hi = ncol;
+	// column of position k: last c with col_ptr[c] <= k, between the hints of k's block and the next
+	int64_t lo = hint[k >> HINT_SHIFT], hi = hint[(k >> HINT_SHIFT) + 1];
+	if (hi > ncol - 1) hi = ncol - 1;
 	while (lo < hi) {
 		const int64_t mid = (lo + hi + 1) >> 1;
 		if (col_ptr[mid] <= k) lo = mid; else hi = mid - 1;
@@ -64,11 +99,16 @@ static int key_bits(int64_t nrow)
 	return b;
 }
 
-// [sorted rows nnz*4][positions nnz*4][sorted positions nnz*4][radix-sort temp]
+static size_t hint_bytes(int64_t nnz)
+{
+	return ((size_t) ((nnz >> HINT_SHIFT) + 2) * 4 + 255) / 256 * 256;
+}
+
+// [sorted rows nnz*4][positions nnz*4][sorted positions nnz*4][column hints][radix-sort temp]
 size_t transpose_ws_bytes(int64_t nrow, int64_t nnz)
 {
 	const size_t a = ((size_t) (nnz > 0 ? nnz : 1) * 4 + 255) / 256 * 256;
-	return 3 * a + sort_tmp_bytes(nnz, key_bits(nrow)) + 256;
+	return 3 * a + hint_bytes(nnz) + sort_tmp_bytes(nnz, key_bits(nrow)) + 256;
 }
 
 int launch_transpose(const int64_t *col_ptr, const int32_t *row_idx, const void *val, int Rtype,
@@ -86,19 +126,23 @@ int launch_transpose(const int64_t *col_ptr, const int32_t *row_idx, const void 
 	int32_t *srows = (int32_t *) ws;
 	uint32_t *pos = (uint32_t *) ((char *) ws + a);
 	uint32_t *perm = (uint32_t *) ((char *) ws + 2 * a);
-	void *tmp = (char *) ws + 3 * a;
+	uint32_t *hint = (uint32_t *) ((char *) ws + 3 * a);
+	void *tmp = (char *) ws + 3 * a + hint_bytes(nnz);
 	const int bits = key_bits(nrow);
 	size_t tb = sort_tmp_bytes(nnz, bits);
 	const unsigned nb = (unsigned) ((nnz + 255) / 256);
+	const unsigned nb8 = (unsigned) (((nnz + 255) / 256 + 7) / 8 * 8);      // whole rounds over the 8 XCDs (xcd_chunk)
 	hipLaunchKernelGGL(iota_u32_kernel, dim3(nb), dim3(256), 0, s, pos, nnz);
+	const int64_t nblk = (nnz >> HINT_SHIFT) + 1;
+	hipLaunchKernelGGL(col_hint_kernel, dim3((unsigned) ((nblk + 1 + 255) / 256)), dim3(256), 0, s, col_ptr, ncol, nblk, hint);
 	HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tb, row_idx, srows, pos, perm, (int) nnz, 0, bits, s));
 	hipLaunchKernelGGL(row_bounds_kernel, dim3(nbr), dim3(256), 0, s, srows, nnz, nrow, out_ptr);
 	if (Rtype == SVT_REALSXP)
-		hipLaunchKernelGGL(transpose_gather_kernel<double>, dim3(nb), dim3(256), 0, s, col_ptr, ncol,
-				   (const double *) val, perm, nnz, out_idx, (double *) out_val);
+		hipLaunchKernelGGL(transpose_gather_kernel<double>, dim3(nb8), dim3(256), 0, s, col_ptr, ncol,
+				   (const double *) val, perm, hint, nnz, out_idx, (double *) out_val);
 	else
-		hipLaunchKernelGGL(transpose_gather_kernel<int32_t>, dim3(nb), dim3(256), 0, s, col_ptr, ncol,
-				   (const int32_t *) val, perm, nnz, out_idx, (int32_t *) out_val);
+		hipLaunchKernelGGL(transpose_gather_kernel<int32_t>, dim3(nb8), dim3(256), 0, s, col_ptr, ncol,
+				   (const int32_t *) val, perm, hint, nnz, out_idx, (int32_t *) out_val);
 	HIP_TRY(hipGetLastError());
 	return 0;
 }
@@ -163,7 +207,7 @@ __global__ void aperm_gather_kernel(const unsigned long long *__restrict__ skeys
 				    int64_t nnz, int64_t dim0, int32_t *__restrict__ out_idx,
 				    T *__restrict__ out_val)
 {
-	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	const int64_t i = xcd_chunk((nnz + blockDim.x - 1) / blockDim.x) * blockDim.x + threadIdx.x;
 	if (i >= nnz) return;
 	out_idx[i] = (int32_t) (skeys[i] % (unsigned long long) dim0);
 	out_val[i] = val[perm[i]];
@@ -241,14 +285,15 @@ int launch_aperm(const int64_t *col_ptr, const int32_t *row_idx, const void *val
 	const int bits = aperm_bits(dim, ndim);
 	size_t tb = aperm_sort_tmp(nnz, bits);
 	const unsigned nb = (unsigned) ((nnz + 255) / 256);
+	const unsigned nb8 = (unsigned) (((nnz + 255) / 256 + 7) / 8 * 8);
 	hipLaunchKernelGGL(aperm_key_kernel, dim3(nb), dim3(256), 0, s, col_ptr, row_idx, ncol, nnz, d, keys, pos);
 	HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tb, keys, skeys, pos, spos, (int) nnz, 0, bits, s));
 	hipLaunchKernelGGL(aperm_bounds_kernel, dim3(nbl), dim3(256), 0, s, skeys, nnz, new_nleaves, new_dim0, out_ptr);
 	if (Rtype == SVT_REALSXP)
-		hipLaunchKernelGGL(aperm_gather_kernel<double>, dim3(nb), dim3(256), 0, s, skeys, spos,
+		hipLaunchKernelGGL(aperm_gather_kernel<double>, dim3(nb8), dim3(256), 0, s, skeys, spos,
 				   (const double *) val, nnz, new_dim0, out_idx, (double *) out_val);
 	else
-		hipLaunchKernelGGL(aperm_gather_kernel<int32_t>, dim3(nb), dim3(256), 0, s, skeys, spos,
+		hipLaunchKernelGGL(aperm_gather_kernel<int32_t>, dim3(nb8), dim3(256), 0, s, skeys, spos,
 				   (const int32_t *) val, nnz, new_dim0, out_idx, (int32_t *) out_val);
 	HIP_TRY(hipGetLastError());
 	return 0;
