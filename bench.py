@@ -56,9 +56,9 @@ def parse():
     p.add_argument("--K", type=int, default=None)
     p.add_argument("--path", choices=["pbc", "v1"], default="pbc",
                    help="pbc: panel-blocked LDS kernel (default); v1: gather kernel (1 GPU only)")
-    p.add_argument("--cbw", type=int, default=40)
-    p.add_argument("--wpb", type=int, default=16)
-    p.add_argument("--logr", type=int, default=7)
+    p.add_argument("--cbw", type=int, default=0, help="0 0 0: layout chosen by density (LDS-DMA or gather kernel)")
+    p.add_argument("--wpb", type=int, default=0)
+    p.add_argument("--logr", type=int, default=0)
     p.add_argument("--backend", default="nccl",
                    help="nccl (= RCCL, the product path); gloo only to rehearse the N > 1 control flow on a one-GPU box")
     p.add_argument("--same-device", action="store_true",
@@ -171,7 +171,9 @@ def main():
         sc = par.ShardedCrossprod(A, K, None, a.cbw, a.wpb, a.logr)
         torch.cuda.synchronize()
         layout_ms = (time.perf_counter() - t_l) * 1e3
-        kernel_name = "crossprod_pbc_dma_kernel"
+        auto_gather = (a.cbw, a.wpb, a.logr) == (0, 0, 0) and a.density * 40 * 128 < 12 and lrow >= 4096
+        kernel_name = "crossprod_pbc_gather_kernel" if auto_gather or (a.wpb == 4 and a.logr >= 9) \
+            else "crossprod_pbc_dma_kernel"
 
         def step(ev=None):
             sc.step(Y, ev)
@@ -287,7 +289,9 @@ def main():
                      "kernel_ms": kern_ms},
     }
     if layout_ms is not None:
-        res["config"]["layout"] = f"PBC cbw={a.cbw} wpb={a.wpb} logR={a.logr}"
+        res["config"]["layout"] = ("PBC cbw=40 wpb=4 logR=10 (gather kernel)" if kernel_name.startswith("crossprod_pbc_gather")
+                                   else "PBC cbw=40 wpb=16 logR=7 (LDS-DMA kernel)") if a.cbw == 0 else \
+            f"PBC cbw={a.cbw} wpb={a.wpb} logR={a.logr}"
         res["config"]["layout_build_ms_once_per_operand"] = layout_ms
     if world == 1 and not a.no_extras and a.config == 2:
         def timed(fn, reps=5):

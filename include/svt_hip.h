@@ -254,8 +254,9 @@ int svt_dev_crossprod_csc_dense(const svt_dev_csc *A, const void *Y,
  * sparse operand -- the device analogue of the reference's per-call leaf
  * "preprocessing" (src/SparseMatrix_mult.c:632-724) -- and a kernel that keeps
  * row panels of Y in LDS and per-column partial sums in registers.
- *   CBW   columns per wavefront (16, 32, 48 or 64), WPB wavefronts per
- *         workgroup, logR = log2(rows per panel).
+ *   CBW   columns per wavefront (<= 64), WPB wavefronts per workgroup, logR = log2(rows per
+ *         panel).  (0, 0, 0) = chosen by the operand's density: (40, 16, 7), the LDS-DMA kernel,
+ *         or, below ~0.25 % density, (40, 4, 10), the gather kernel (rows of Y straight from L2).
  * svt_dev_pbc_build() allocates and synchronises (not for the launch path).
  * svt_dev_crossprod_pbc() has the semantics and the out-indexing of
  * svt_dev_crossprod_csc_dense() (A is needed for the general path that

@@ -179,6 +179,26 @@ static int dense_prepare(const CrossprodArgs &a, const int *run_flag, hipStream_
 static int crossprod_prepared(const CrossprodArgs &a, const int *run_flag, hipStream_t s);
 
 int launch_dense_prepare(const CrossprodArgs &a, hipStream_t s) { return dense_prepare(a, NULL, s); }
+
+// *any = 1 if some dense column holds a non-finite entry (per-column counters of the staging pass)
+__global__ void any_nonfinite_kernel(const int *__restrict__ nonfinite, int K, int *__restrict__ any)
+{
+	for (int k = threadIdx.x; k < K; k += blockDim.x)
+		if (nonfinite[k] > 0) *any = 1;
+}
+
+// staging pass + the "dense operand is not finite" flag the panel kernels' phase 2 looks at
+int launch_dense_prepare_flag(const CrossprodArgs &a, int *any, hipStream_t s)
+{
+	if (dense_prepare(a, NULL, s))
+		return -1;
+	if (a.K > 0) {
+		ColFlags fl = flags_of(a.ws, a.nrow, pad_k(a.K));
+		hipLaunchKernelGGL(any_nonfinite_kernel, dim3(1), dim3(64), 0, s, fl.nonfinite, a.K, any);
+		HIP_TRY(hipGetLastError());
+	}
+	return 0;
+}
 int launch_crossprod_prepared(const CrossprodArgs &a, hipStream_t s) { return crossprod_prepared(a, NULL, s); }
 
 // Both phases, skipped on the device when *flag == 0 (see kernels_mult_pbc.hip).

@@ -56,6 +56,7 @@ struct svt_dev_pbc {
 	int CBW, WPB, logR;
 	int fmt;               // record format: 0 = 16-byte records, batches of 4 (register-staged
 	                       // kernel); 1 = 12-byte records, batches of 8 (LDS-DMA kernel)
+	int gather;            // format 0 with tall panels, read by crossprod_pbc_gather_kernel (very sparse operands)
 	int64_t ngroups, nblocks, npanels;
 	uint4 *rec;            // [nrec] 16-byte records
 	int64_t *tile_ptr;     // [ngroups*npanels + 1]
@@ -379,6 +380,19 @@ extern "C" size_t svt_dev_pbc_bytes(const svt_dev_pbc *h)
 	       (size_t) (h->ngroups * h->npanels + 1 + PBC_TP_PAD) * 8 + (size_t) h->ncol * 4;
 }
 
+// The layout svt_dev_pbc_build(A, 0, 0, 0) picks.  The LDS-DMA kernel stages whole 128-row panels of
+// Y for every block of 640 columns; below ~12 nonzeros per (40-column group, panel) tile -- density
+// < 0.25 % -- most staged rows are never used and the gather kernel (rows of Y straight from L2,
+// panels of 1024 rows) moves less.
+void pbc_auto_layout(int64_t nrow, int64_t ncol, int64_t nnz, int *CBW, int *WPB, int *logR)
+{
+	*CBW = 40;
+	const double per_tile = (double) nnz * 40.0 * 128.0 /
+				((double) (nrow > 0 ? nrow : 1) * (double) (ncol > 0 ? ncol : 1));
+	if (per_tile < 12.0 && nrow >= 4096) { *WPB = 4; *logR = 10; }
+	else { *WPB = 16; *logR = 7; }
+}
+
 // Not on the launch path: allocates, synchronises.
 extern "C" svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB, int logR)
 {
@@ -386,6 +400,8 @@ extern "C" svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB
 		svt_set_error("svt_dev_pbc_build: f64 operands only");
 		return NULL;
 	}
+	if (CBW == 0 && WPB == 0 && logR == 0)
+		pbc_auto_layout(A->nrow, A->ncol, A->nnz, &CBW, &WPB, &logR);
 	if (CBW <= 0 || CBW > 64 || WPB <= 0 || WPB > 16 || logR < 4 || logR > 15) {
 		svt_set_error("svt_dev_pbc_build: bad parameters");
 		return NULL;
@@ -395,6 +411,7 @@ extern "C" svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB
 	h->CBW = CBW; h->WPB = WPB; h->logR = logR;
 	// the LDS-DMA kernel wants 16 wavefronts, 128-row panels, <= 40 columns each
 	h->fmt = (WPB == 16 && logR == 7 && CBW <= 40 && A->nrow >= 256 && g_pbc_debug != 9) ? 1 : 0;
+	h->gather = (h->fmt == 0 && WPB == 4 && logR >= 9) ? 1 : 0;
 	const int64_t CB = (int64_t) CBW * WPB;
 	h->nblocks = (A->ncol + CB - 1) / CB;
 	h->ngroups = h->nblocks * WPB;                // one group per wavefront
@@ -847,6 +864,158 @@ crossprod_pbc_kernel(const uint4 *__restrict__ rec,
 }
 
 // ---------------------------------------------------------------------------
+// Gather kernel: very sparse operands (BASELINE config 4: 0.1 %, 5 nonzeros per (40-column group,
+// 128-row panel) tile).  Staging whole panels of Y for every block of columns moves 64 KB into LDS
+// per ~80 nonzeros there; here every nonzero fetches the 512 bytes it needs -- row r of the
+// row-major, K-padded copy Yt that prep_dense_kernel makes (kernels_mult.hip), 64 dense columns,
+// lane = dense column -- straight from L2 into registers.  No LDS, no barrier: a wavefront streams
+// the records of its column group (format 0, panels of 2^logR >= 512 rows, padded to batches of 4)
+// through the same 3-stage pipeline as crossprod_pbc_kernel, with the LDS reads replaced by
+// global loads (two batches = 8 loads in flight per wavefront, counted by vmcnt, which the scalar
+// record loads do not share).  All wavefronts of a row split walk the rows in the same order, so
+// a row of Yt is fetched from HBM once per XCD and hit in L2 by the other column groups.
+// Traffic: 512 B per (nonzero, 64 dense columns) L2 -> CU, i.e. nnz * K * 8 bytes: the floor of an
+// out-stationary product when a column block holds less than one nonzero per row.
+// ---------------------------------------------------------------------------
+#define PBG_D4(B0, B1, B2, B3, YS)                                                    \
+	"v_mad_u32_u24 %[t0], s" #B0 ", %[kp], %[l8]\n\t"                               \
+	"v_mad_u32_u24 %[t1], s" #B1 ", %[kp], %[l8]\n\t"                               \
+	"v_mad_u32_u24 %[t2], s" #B2 ", %[kp], %[l8]\n\t"                               \
+	"v_mad_u32_u24 %[t3], s" #B3 ", %[kp], %[l8]\n\t"                               \
+	"global_load_dwordx2 %[" #YS "0], %[t0], %[pb]\n\t"                             \
+	"global_load_dwordx2 %[" #YS "1], %[t1], %[pb]\n\t"                             \
+	"global_load_dwordx2 %[" #YS "2], %[t2], %[pb]\n\t"                             \
+	"global_load_dwordx2 %[" #YS "3], %[t3], %[pb]\n\t"
+// accumulators pinned to v[64:143]: 144 VGPRs, 12 wavefronts per CU.  (Pinned to v[40:119] the kernel
+// runs 16 per CU and takes 60 ms instead of 53 at BASELINE config 4: more wavefronts spread over more
+// rows of Yt than the L2 holds.)
+#define PBG_F4(I0, A0L, A0H, I1, A1L, A1H, I2, A2L, A2H, I3, A3L, A3H, YS)              \
+	"s_set_gpr_idx_on s" #I0 ", gpr_idx(SRC2,DST)\n\t"                              \
+	"v_fma_f64 v[64:65], s[" #A0L ":" #A0H "], %[" #YS "0], v[64:65]\n\t"            \
+	"s_set_gpr_idx_idx s" #I1 "\n\t"                                                \
+	"v_fma_f64 v[64:65], s[" #A1L ":" #A1H "], %[" #YS "1], v[64:65]\n\t"            \
+	"s_set_gpr_idx_idx s" #I2 "\n\t"                                                \
+	"v_fma_f64 v[64:65], s[" #A2L ":" #A2H "], %[" #YS "2], v[64:65]\n\t"            \
+	"s_set_gpr_idx_idx s" #I3 "\n\t"                                                \
+	"v_fma_f64 v[64:65], s[" #A3L ":" #A3H "], %[" #YS "3], v[64:65]\n\t"            \
+	"s_set_gpr_idx_off\n\t"
+#define PBG_F_A(YS) PBG_F4(37, 38, 39, 41, 42, 43, 45, 46, 47, 49, 50, 51, YS)
+#define PBG_F_B(YS) PBG_F4(53, 54, 55, 57, 58, 59, 61, 62, 63, 65, 66, 67, YS)
+#define PBG_F_C(YS) PBG_F4(69, 70, 71, 73, 74, 75, 77, 78, 79, 81, 82, 83, YS)
+#define PBG_D_A(YS) PBG_D4(36, 40, 44, 48, YS)
+#define PBG_D_B(YS) PBG_D4(52, 56, 60, 64, YS)
+#define PBG_D_C(YS) PBG_D4(68, 72, 76, 80, YS)
+// one phase: record load into LB, Y loads for DB into set YD, FMAs of FB with set YF (whose loads
+// are the 4 older of the 8 in flight)
+#define PBG_PHASE(LOADTXT, DTXT, FTXT)                                                 \
+	"s_add_u32 %[lo], %[lo], 64\n\t"                                               \
+	LOADTXT DTXT                                                                   \
+	"s_waitcnt vmcnt(4)\n\t"                                                       \
+	FTXT                                                                           \
+	"s_waitcnt lgkmcnt(0)\n\t"                                                     \
+	"s_sub_u32 %[nb], %[nb], 1\n\t"                                                \
+	"s_cmp_eq_u32 %[nb], 0\n\t"                                                    \
+	"s_cbranch_scc1 9f\n\t"
+#define PBG_PANEL_TXT                                                                  \
+	"s_mov_b32 s85, m0\n\t"                                                        \
+	"s_cmp_eq_u32 %[nb], 0\n\t"                                                    \
+	"s_cbranch_scc1 9f\n\t"                                                        \
+	PBC_LOAD_A                                                                     \
+	"s_waitcnt lgkmcnt(0)\n\t"                                                     \
+	"s_add_u32 %[lo], %[lo], 64\n\t"                                               \
+	PBC_LOAD_B PBG_D_A(ya)                                                         \
+	"s_waitcnt lgkmcnt(0)\n"                                                       \
+	"1:\n\t"                                                                       \
+	PBG_PHASE(PBC_LOAD_C, PBG_D_B(yb), PBG_F_A(ya))                                \
+	PBG_PHASE(PBC_LOAD_A, PBG_D_C(ya), PBG_F_B(yb))                                \
+	PBG_PHASE(PBC_LOAD_B, PBG_D_A(yb), PBG_F_C(ya))                                \
+	PBG_PHASE(PBC_LOAD_C, PBG_D_B(ya), PBG_F_A(yb))                                \
+	PBG_PHASE(PBC_LOAD_A, PBG_D_C(yb), PBG_F_B(ya))                                \
+	PBG_PHASE(PBC_LOAD_B, PBG_D_A(ya), PBG_F_C(yb))                                \
+	"s_branch 1b\n"                                                                \
+	"9:\n\t"                                                                       \
+	"s_waitcnt vmcnt(0)\n\t"                                                       \
+	"s_mov_b32 m0, s85\n\t"
+#define PBG_PANEL_OPS                                                                  \
+	[lo] "+s"(lo_), [nb] "+s"(nb_),                                                \
+	[t0] "=&v"(t0_), [t1] "=&v"(t1_), [t2] "=&v"(t2_), [t3] "=&v"(t3_),              \
+	[ya0] "=&v"(ya0_), [ya1] "=&v"(ya1_), [ya2] "=&v"(ya2_), [ya3] "=&v"(ya3_),      \
+	[yb0] "=&v"(yb0_), [yb1] "=&v"(yb1_), [yb2] "=&v"(yb2_), [yb3] "=&v"(yb3_)
+#define PBG_CHUNK_PANELS 256     // panels per row split and launch (16: 88 ms, 64: 59, 256: 53, all: 78-87 at config 4)
+#define PBG_PANEL_IN [base] "s"(rec_w), [pb] "s"(pbase), [kp] "v"(kp_v), [l8] "v"(lane8)
+
+template <int NV>
+__global__ void __launch_bounds__(256)
+crossprod_pbc_gather_kernel(const uint4 *__restrict__ rec, const int64_t *__restrict__ tile_ptr,
+			    int64_t npanels, const double *__restrict__ Yt, int64_t Ktp, int K,
+			    int64_t ncol, int64_t panels_per_split, double *__restrict__ part, int64_t Kp,
+			    int CBW, int logR, int64_t p_first, int64_t p_last, int accumulate)
+{
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int split = blockIdx.x, kt = blockIdx.y;
+	const int64_t wv = (int64_t) blockIdx.z * 4 + w;          // column group of this wavefront
+	// this launch: panels [p_first, p_last) of the operand, cut into gridDim.x row splits
+	const int64_t pa = p_first + (int64_t) split * panels_per_split;
+	const int64_t pb = pa + panels_per_split < p_last ? pa + panels_per_split : p_last;
+	if (pa >= pb)
+		return;
+	const int k0 = kt * 64;
+	// NV == 3 keeps 40 columns (16 + 16 + 8)
+	d16 acc[NV > 2 ? 2 : NV];
+	d8 acc8 = 0.0;
+#pragma unroll
+	for (int i = 0; i < (NV > 2 ? 2 : NV); i++) acc[i] = 0.0;
+	const uint32_t lane8 = (uint32_t) lane * 8u;
+	const uint32_t kp_v = (uint32_t) Ktp;                    // (row offset in bytes = 8 * row * Ktp)
+	const int64_t *__restrict__ tb = tile_ptr + (wv * npanels + pa);
+	const uint4 *__restrict__ rec_w = rec + tb[0];
+	uint32_t off = 0;
+	for (int64_t p = pa; p < pb; p++, tb += 1) {
+		const int64_t tbeg = tb[0], tend = tb[1];
+		uint32_t nb_ = (uint32_t) ((tend - tbeg) / PBC_BATCH);
+		uint32_t lo_ = off;
+		off += nb_ * (PBC_BATCH * 16u);
+		// first row of the panel, this wavefront's 64 dense columns (wave-uniform: an SGPR pair)
+		const double *pbase = Yt + (p << logR) * Ktp + k0;
+		uint32_t t0_, t1_, t2_, t3_;
+		double ya0_, ya1_, ya2_, ya3_, yb0_, yb1_, yb2_, yb3_;
+		if constexpr (NV == 1) {
+			asm volatile(PBG_PANEL_TXT
+				     : "+{v[64:95]}"(acc[0]), PBG_PANEL_OPS
+				     : PBG_PANEL_IN
+				     : PBC_PANEL_CLOBBERS);
+		} else if constexpr (NV == 2) {
+			asm volatile(PBG_PANEL_TXT
+				     : "+{v[64:95]}"(acc[0]), "+{v[96:127]}"(acc[NV > 1 ? 1 : 0]), PBG_PANEL_OPS
+				     : PBG_PANEL_IN
+				     : PBC_PANEL_CLOBBERS);
+		} else {
+			asm volatile(PBG_PANEL_TXT
+				     : "+{v[64:95]}"(acc[0]), "+{v[96:127]}"(acc[NV > 1 ? 1 : 0]),
+				       "+{v[128:143]}"(acc8), PBG_PANEL_OPS
+				     : PBG_PANEL_IN
+				     : PBC_PANEL_CLOBBERS);
+		}
+	}
+	// ---- partial results: part[(split*Kp + k) * ncol + c] -----------------
+	const int64_t c0 = wv * CBW;
+	double *__restrict__ dst = part + ((int64_t) split * Kp + k0 + lane) * ncol + c0;
+#pragma unroll
+	for (int ii = 0; ii < (NV > 2 ? 2 : NV); ii++)
+#pragma unroll
+		for (int jj = 0; jj < 16; jj++)
+			if (ii * 16 + jj < CBW && c0 + ii * 16 + jj < ncol)
+				dst[ii * 16 + jj] = accumulate ? dst[ii * 16 + jj] + acc[ii][jj] : acc[ii][jj];
+	if constexpr (NV > 2) {
+#pragma unroll
+		for (int jj = 0; jj < 8; jj++)
+			if (32 + jj < CBW && c0 + 32 + jj < ncol)
+				dst[32 + jj] = accumulate ? dst[32 + jj] + acc8[jj] : acc8[jj];
+	}
+}
+
+// ---------------------------------------------------------------------------
 // DMA kernel: the same product on the same layout, restructured around the three
 // things the register-staged kernel above spends its time on (measured with
 // s_memtime per section, tools/tune_pbc.py --prof: per 128-row panel ~3000
@@ -1206,7 +1375,7 @@ static DirtyWs dirty_ws_of(void *flag_block, void *tail, int64_t ncol, int64_t K
 }
 
 __global__ void __launch_bounds__(256)
-pbc_dirty_scan_kernel(const double *__restrict__ Y, int64_t ldY, int64_t nrow, int K, int64_t ncol, DirtyWs d)
+pbc_dirty_scan_kernel(const double *__restrict__ Y, int64_t rs, int64_t cs, int64_t nrow, int K, int64_t ncol, DirtyWs d)
 {
 	if (d.flags[0] == 0)
 		return;
@@ -1216,10 +1385,10 @@ pbc_dirty_scan_kernel(const double *__restrict__ Y, int64_t ldY, int64_t nrow, i
 		const int64_t me = ((int64_t) blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
 		for (int64_t i = me; i < ncol * PBC_DIRTY_COLS; i += nthr) d.hit[i] = 0;
 	}
-	const double *__restrict__ col = Y + (int64_t) k * ldY;
+	const double *__restrict__ col = Y + (int64_t) k * cs;            // element (r, k) at Y[r * rs + k * cs]
 	for (int64_t r = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; r < nrow;
 	     r += (int64_t) gridDim.x * blockDim.x) {
-		const double y = col[r];
+		const double y = col[r * rs];
 		if (svt_is_finite(y))
 			continue;
 		atomicAdd(d.col_nf + k, 1);
@@ -1300,7 +1469,7 @@ pbc_dirty_fix_kernel(const int *__restrict__ col_has_na, int K, int64_t ncol, Di
 // rounding)
 __global__ void __launch_bounds__(256)
 pbc_dirty_redo_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__ row_idx,
-		      const double *__restrict__ val, const double *__restrict__ Y, int64_t ldY,
+		      const double *__restrict__ val, const double *__restrict__ Y, int64_t rs, int64_t cs,
 		      DirtyWs d, double *__restrict__ out, int64_t sc, int64_t sk)
 {
 	if (d.flags[0] == 0 || d.flags[2] != 0)
@@ -1311,10 +1480,10 @@ pbc_dirty_redo_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__rest
 	if (n > PBC_DIRTY_WORK) n = PBC_DIRTY_WORK;
 	for (int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); w < n; w += nw) {
 		const uint2 ck = d.work[w];
-		const double *__restrict__ y = Y + (int64_t) ck.y * ldY;
+		const double *__restrict__ y = Y + (int64_t) ck.y * cs;
 		double acc = 0.0;
 		for (int64_t i = col_ptr[ck.x] + lane; i < col_ptr[ck.x + 1]; i += 64)
-			acc += val[i] * y[row_idx[i]];
+			acc += val[i] * y[(int64_t) row_idx[i] * rs];
 		for (int off = 32; off > 0; off >>= 1)
 			acc += __shfl_xor(acc, off, 64);
 		if (lane == 0) out[(int64_t) ck.x * sc + (int64_t) ck.y * sk] = acc;
@@ -1330,6 +1499,31 @@ static bool pbc_dma_ok(const svt_dev_pbc *P, int tr_y)
 	// the layout was built for it; the kernel stages a row split through 32-bit byte offsets
 	// (8 bytes per row per dense column), and a split is never longer than the matrix
 	return !tr_y && P->fmt == 1 && P->nrow < ((int64_t) 1 << 28);
+}
+
+// rows of the staged dense operand the gather kernel may touch: its look-ahead loads run on into the
+// records of the next tile, whose row offsets are relative to a panel that may be the last, partial one
+static int64_t pbc_padded_rows(const svt_dev_pbc *P)
+{
+	return P->gather ? (P->npanels << P->logR) : P->nrow;
+}
+
+// gather kernel: no staging to share, so splits only have to fill the chip (~8192 wavefronts)
+static int pick_nsplit_gather(const svt_dev_pbc *P, int K, int64_t *pps_out)
+{
+	const int64_t kt = ((int64_t) K + 63) / 64;
+	const int64_t waves = P->ngroups * kt;
+	int64_t target = 4096;                               // one round of resident wavefronts (16 per CU)
+#ifdef SVT_TUNING
+	if (getenv("SVT_PBG_WAVES")) target = atoll(getenv("SVT_PBG_WAVES"));
+#endif
+	int64_t s = waves >= target ? 1 : (target + waves - 1) / waves;
+	if (s > P->npanels) s = P->npanels;
+	if (s < 1) s = 1;
+	const int64_t pps = (P->npanels + s - 1) / s;
+	s = (P->npanels + pps - 1) / pps;
+	if (pps_out) *pps_out = pps;
+	return (int) s;
 }
 
 static int pick_nsplit(const svt_dev_pbc *P, int K, bool dma, int64_t *pps_out)
@@ -1372,10 +1566,14 @@ extern "C" size_t svt_dev_crossprod_pbc_ws_bytes(const svt_dev_pbc *P, int K)
 		const int nd = pick_nsplit(P, K, true, NULL);
 		if (nd > ns) ns = nd;
 	}
+	if (P->gather) {
+		const int ng = pick_nsplit_gather(P, K, NULL);
+		if (ng > ns) ns = ng;
+	}
 	// [flags][partials][general-path workspace; a row-major Y is transposed into it first]
 	// [dirty-column scratch]
 	return PBC_FLAG_BYTES + (size_t) ns * Kp * (P->ncol > 0 ? P->ncol : 1) * 8 +
-	       crossprod_ws_bytes(P->nrow, P->ncol, K) + dirty_ws_bytes(P->ncol, Kp);
+	       crossprod_ws_bytes(pbc_padded_rows(P), P->ncol, K) + dirty_ws_bytes(P->ncol, Kp);
 }
 
 template <int NV, int WPB, int LOGR>
@@ -1433,6 +1631,7 @@ static void launch_dma(const svt_dev_pbc *P, const double *Y, int64_t ldY, int K
 }
 
 int launch_crossprod_general_if(const CrossprodArgs &a, const int *flag, hipStream_t s);
+int launch_dense_prepare_flag(const CrossprodArgs &a, int *any, hipStream_t s);
 
 // phase 1: the LDS-panel product kernel (partials into ws); phase 2: sum the
 // partials into `out`, then the general kernels if Y was not finite.
@@ -1456,6 +1655,7 @@ static int pbc_phase(const svt_dev_pbc *P, const svt_dev_csc *A,
 	// a dense operand given by rows is transposed on the device first (phase 1) and the product
 	// runs on the column-major copy: same kernel, same speed + one 2 x |Y| pass
 	const bool dma = pbc_dma_ok(P, 0);
+	const bool gath = P->gather != 0;
 	const bool via_copy = tr_y && dma;
 	int block0 = 0;
 	if (dma && first_col > 0) {
@@ -1463,12 +1663,12 @@ static int pbc_phase(const svt_dev_pbc *P, const svt_dev_csc *A,
 		if (block0 > P->nblocks - 1) block0 = (int) P->nblocks - 1;
 	}
 	const int64_t c_begin = (int64_t) block0 * 16 * P->CBW;
-	const int nsplit = pick_nsplit(P, K, dma, &pps);
+	const int nsplit = gath ? pick_nsplit_gather(P, K, &pps) : pick_nsplit(P, K, dma, &pps);
 	PbcFlags fl;
 	fl.y_nonfinite = (int *) ws;
 	double *part = (double *) ((char *) ws + PBC_FLAG_BYTES);
 	void *gen_ws = (char *) part + (size_t) nsplit * Kp * P->ncol * 8;
-	const size_t gen_bytes = crossprod_ws_bytes(P->nrow, P->ncol, K);
+	const size_t gen_bytes = crossprod_ws_bytes(pbc_padded_rows(P), P->ncol, K);
 	DirtyWs dw = dirty_ws_of(ws, (char *) gen_ws + gen_bytes, P->ncol, Kp);
 	const double *Yc = via_copy ? (const double *) gen_ws : Y;     // what the product kernel stages
 	const int64_t ldc = via_copy ? P->nrow : ldY;
@@ -1490,6 +1690,38 @@ static int pbc_phase(const svt_dev_pbc *P, const svt_dev_csc *A,
 			return 0;
 		}
 		const int nv = (P->CBW + 15) / 16;
+		if (gath) {
+			// row-major, K-padded copy of the dense operand (either orientation) + "not finite" flag,
+			// then every nonzero gathers its row from it
+			CrossprodArgs pa;
+			memset(&pa, 0, sizeof(pa));
+			pa.Rtype = SVT_REALSXP; pa.nrow = P->nrow; pa.ncol = P->ncol; pa.Y = Y; pa.ldY = ldY; pa.K = K;
+			pa.tr_y = tr_y; pa.ws = gen_ws; pa.ws_bytes = gen_bytes;
+			if (launch_dense_prepare_flag(pa, fl.y_nonfinite, s))
+				return -1;
+			dim3 grid((unsigned) nsplit, (unsigned) (Kp / 64), (unsigned) P->nblocks);
+			auto kern = nv == 1 ? crossprod_pbc_gather_kernel<1> : nv == 2 ? crossprod_pbc_gather_kernel<2>
+									     : crossprod_pbc_gather_kernel<3>;
+			// Row chunks as consecutive launches (the partial sums go through memory in between):
+			// inside one launch the wavefronts of all column groups walk the same rows at about the
+			// same pace, so a row of Yt fetched for one group is still in L2 for the others; over a
+			// whole operand they drift apart by more rows than the L2 holds and every record's 512
+			// bytes come from the Infinity Cache or HBM (81.8 ms at BASELINE config 4, i.e. HBM speed).
+			int64_t cpanels = PBG_CHUNK_PANELS;
+#ifdef SVT_TUNING
+			if (getenv("SVT_PBG_CHUNK")) cpanels = atoll(getenv("SVT_PBG_CHUNK"));
+#endif
+			const int64_t chunk = (int64_t) nsplit * cpanels;
+			for (int64_t p0 = 0; p0 < P->npanels; p0 += chunk) {
+				const int64_t p1 = p0 + chunk < P->npanels ? p0 + chunk : P->npanels;
+				const int64_t cpps = (p1 - p0 + nsplit - 1) / nsplit;
+				hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, P->rec, P->tile_ptr, P->npanels,
+						   (const double *) gen_ws, Kp, K, P->ncol, cpps, part, Kp, P->CBW, P->logR,
+						   p0, p1, p0 > 0 ? 1 : 0);
+			}
+			HIP_TRY(hipGetLastError());
+			return 0;
+		}
 		if (dma) {
 			if (via_copy && P->nrow > 0) {
 				const int64_t ntile = (P->nrow + 63) / 64;
@@ -1534,12 +1766,16 @@ static int pbc_phase(const svt_dev_pbc *P, const svt_dev_csc *A,
 	// Dense columns with NaN / Inf / NA (all four kernels return at once while the product
 	// kernel's flag is clear).  The register-staged kernels read the dense operand as it was given:
 	// their dirty columns always take the general kernels.
-	if (dma && P->rec != NULL) {
+	const bool fast = dma || gath;
+	// where the fix-up reads the dense operand: element (r, k) at Yd[r * yrs + k * ycs]
+	const double *Yd = gath ? (const double *) gen_ws : Yc;
+	const int64_t yrs = gath ? Kp : 1, ycs = gath ? 1 : ldc;
+	if (fast && P->rec != NULL) {
 		// (small grids: while the flag is clear -- every product with a finite operand -- these
 		// launches cost their blocks' start-up and nothing else)
 		const int64_t rb = (P->nrow + 255) / 256;
 		dim3 sg((unsigned) (rb < 128 ? (rb > 0 ? rb : 1) : 128), (unsigned) K);
-		hipLaunchKernelGGL(pbc_dirty_scan_kernel, sg, dim3(256), 0, s, Yc, ldc, P->nrow, K, P->ncol, dw);
+		hipLaunchKernelGGL(pbc_dirty_scan_kernel, sg, dim3(256), 0, s, Yd, yrs, ycs, P->nrow, K, P->ncol, dw);
 		hipLaunchKernelGGL(pbc_dirty_plan_kernel, dim3(1), dim3(64), 0, s, K, dw);
 		dim3 hg((unsigned) ((P->ncol + 255) / 256), 16);
 		hipLaunchKernelGGL(pbc_dirty_hits_kernel, hg, dim3(256), 0, s, A->col_ptr, A->row_idx, P->ncol, dw);
@@ -1547,7 +1783,7 @@ static int pbc_phase(const svt_dev_pbc *P, const svt_dev_csc *A,
 		hipLaunchKernelGGL(pbc_dirty_fix_kernel, fg, dim3(256), 0, s, P->col_has_na, K, P->ncol, dw,
 				   out, out_stride_c, out_stride_k);
 		hipLaunchKernelGGL(pbc_dirty_redo_kernel, dim3(64), dim3(256), 0, s, A->col_ptr, A->row_idx,
-				   (const double *) A->val, Yc, ldc, dw, out, out_stride_c, out_stride_k);
+				   (const double *) A->val, Yd, yrs, ycs, dw, out, out_stride_c, out_stride_k);
 		HIP_TRY(hipGetLastError());
 	}
 	// General (slow-path) semantics for everything else that is not finite.
@@ -1557,7 +1793,7 @@ static int pbc_phase(const svt_dev_pbc *P, const svt_dev_csc *A,
 	a.nrow = A->nrow; a.ncol = A->ncol; a.Y = Y; a.ldY = ldY; a.K = K; a.tr_y = tr_y;
 	a.out = out; a.out_stride_c = out_stride_c; a.out_stride_k = out_stride_k;
 	a.ws = gen_ws; a.ws_bytes = gen_bytes;
-	return launch_crossprod_general_if(a, dma && P->rec != NULL ? dw.flags + 2 : fl.y_nonfinite, s);
+	return launch_crossprod_general_if(a, fast && P->rec != NULL ? dw.flags + 2 : fl.y_nonfinite, s);
 }
 
 extern "C" int svt_dev_crossprod_pbc_phase(const svt_dev_pbc *P, const svt_dev_csc *A,

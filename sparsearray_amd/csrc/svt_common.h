@@ -211,4 +211,5 @@ int launch_densify(const int64_t *col_ptr, const int32_t *row_idx,
 		   int64_t nc, void *dense, hipStream_t s);
 // out[j, i] = out[i, j] for i > j (n x n, column-major)
 int launch_mirror_lower(double *out, int64_t n, hipStream_t s);
+void pbc_auto_layout(int64_t nrow, int64_t ncol, int64_t nnz, int *CBW, int *WPB, int *logR);
 int launch_int_to_f64(const int *in, int64_t n, double *out, hipStream_t s);

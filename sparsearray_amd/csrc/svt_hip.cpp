@@ -595,7 +595,7 @@ static svt_dev_pbc *pbc_for(const svt_dev_csc *A, int *owned)
 				break;
 			}
 	}
-	svt_dev_pbc *P = svt_dev_pbc_build(A, 40, 16, 7);
+	svt_dev_pbc *P = svt_dev_pbc_build(A, 0, 0, 0);        // layout by density (pbc_auto_layout)
 	if (P == NULL) return NULL;
 	std::lock_guard<std::mutex> lk(g_res_mu);
 	if (resident_find(A) >= 0) {
@@ -886,8 +886,11 @@ static int chunk_K(int64_t nrow, int64_t K)
 // fraction of the general kernels' speed, and the tile count must fit the 32-bit scan.
 static bool pbc_shape_ok(int64_t nrow, int64_t ncol, int64_t nnz)
 {
-	const double ngroups = (double) ((ncol + 639) / 640) * 16.0;
-	const double npanels = (double) ((nrow + 127) / 128);
+	int cbw, wpb, logr;
+	pbc_auto_layout(nrow, ncol, nnz, &cbw, &wpb, &logr);      // (very sparse operands: panels of 1024 rows)
+	const int64_t cb = (int64_t) cbw * wpb;
+	const double ngroups = (double) ((ncol + cb - 1) / cb) * (double) wpb;
+	const double npanels = (double) ((nrow + ((int64_t) 1 << logr) - 1) >> logr);
 	const double ntiles = ngroups * npanels;
 	return ntiles + 1.0 < 2147483647.0 && (double) nnz >= 4.0 * ntiles;
 }

@@ -176,6 +176,7 @@ class PbcPlan:
     once, here) + workspace for K dense columns."""
 
     def __init__(self, A: DeviceCSC, K: int, CBW: int = 40, WPB: int = 16, logR: int = 7):
+        # (0, 0, 0): the library picks the layout by density (LDS-DMA kernel or gather kernel)
         assert A.Rtype == REALSXP
         self.A, self.K = A, int(K)
         self._p = _lib().svt_dev_pbc_build(A.handle, CBW, WPB, logR)

@@ -154,7 +154,7 @@ class ShardedCrossprod:
     the column-major ncol x K matrix R would get.
     """
 
-    def __init__(self, A_local, K: int, group=None, cbw: int = 40, wpb: int = 16, logr: int = 7):
+    def __init__(self, A_local, K: int, group=None, cbw: int = 0, wpb: int = 0, logr: int = 0):
         from .device import PbcPlan
         self.A, self.K, self.group = A_local, int(K), group
         self.plan = PbcPlan(A_local, K, cbw, wpb, logr)

@@ -375,3 +375,51 @@ def test_pbc_dense_operand_given_by_rows(hip, oracle, shape):
         assert torch.equal(torch.nan_to_num(o1, nan=7.0), torch.nan_to_num(o2, nan=7.0))
         assert_equal(o2.cpu().numpy().T, oracle.crossprod(x, y), tol=1e-9, atol=1e-11, strict_na=True,
                      what=f"tr_y poison={poison}")
+
+
+@pytest.mark.parametrize("shape", [(200_000, 3000, 128, 0.001), (70_000 + 31, 1100, 70, 0.002), (5000, 170, 64, 0.004)])
+def test_pbc_gather_kernel_matches_oracle(hip, oracle, shape):
+    """Very sparse operands: layout (40, 4, 10) and crossprod_pbc_gather_kernel (rows of the
+    row-major copy of Y straight from L2, no LDS staging).  Both orientations of the dense operand,
+    an NA in a leaf, non-finite entries in Y (per-column fix-up on the row-major copy)."""
+    from sparsearray_amd.device import PbcPlan
+    nrow, ncol, K, dens = shape
+    cp, ri, v = random_csc(nrow, ncol, dens, seed=91)
+    v = v.copy()
+    v[cp[ncol // 2] if cp[ncol // 2] < len(v) else 0] = NA_real
+    x = SVT_SparseArray.from_csc((nrow, ncol), "double", cp, ri, v)
+    A = _dev(cp, ri, v, nrow)
+    plan = PbcPlan(A, K, 40, 4, 10)
+    y = np.random.default_rng(92).uniform(-1, 1, (nrow, K))
+    out = torch.zeros((K, ncol), dtype=torch.float64, device="cuda")
+    for poison in (0, 1, 2):
+        if poison == 1:
+            y[int(ri[cp[3]]) if cp[4] > cp[3] else 5, K - 1] = np.inf     # on a nonzero of leaf 3
+            y[nrow - 1, 0] = np.nan
+        if poison == 2:
+            y[:, 2] = np.nan                                               # general kernels take over
+        want = oracle.crossprod(x, y)
+        plan.run(torch.as_tensor(np.ascontiguousarray(y.T), device="cuda"), nrow, out)
+        torch.cuda.synchronize()
+        assert_equal(out.cpu().numpy().T, want, tol=1e-9, atol=1e-11, strict_na=True, what=f"poison {poison}")
+        out.fill_(5.0)
+        plan.run(torch.as_tensor(np.ascontiguousarray(y), device="cuda"), K, out, tr_y=True)
+        torch.cuda.synchronize()
+        assert_equal(out.cpu().numpy().T, want, tol=1e-9, atol=1e-11, strict_na=True, what=f"by rows, poison {poison}")
+
+
+def test_pbc_auto_layout_picks_by_density(hip, oracle):
+    """svt_dev_pbc_build(A, 0, 0, 0): the gather layout below ~0.25 % density, the LDS-DMA layout
+    above; same results either way."""
+    from sparsearray_amd.device import PbcPlan
+    for dens in (0.0008, 0.01):
+        nrow, ncol, K = 60_000, 900, 64
+        cp, ri, v = random_csc(nrow, ncol, dens, seed=95)
+        x = SVT_SparseArray.from_csc((nrow, ncol), "double", cp, ri, v)
+        A = _dev(cp, ri, v, nrow)
+        y = np.random.default_rng(96).uniform(-1, 1, (nrow, K))
+        Yd = torch.as_tensor(np.ascontiguousarray(y.T), device="cuda")
+        o_auto = torch.zeros((K, ncol), dtype=torch.float64, device="cuda")
+        PbcPlan(A, K, 0, 0, 0).run(Yd, nrow, o_auto)
+        torch.cuda.synchronize()
+        assert_equal(o_auto.cpu().numpy().T, oracle.crossprod(x, y), tol=1e-9, atol=1e-11, what=f"density {dens}")

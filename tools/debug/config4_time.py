@@ -1,18 +1,23 @@
-"""BASELINE config 4 at full size on ONE GPU (1e7 x 5e4 @ 0.1 %, 5e8 nonzeros): crossprod with a
-dense 1e7 x 128 operand and colSums.  (The 8-GPU run shards this by columns; bench.py --gpus 8.)"""
+"""BASELINE config 4 on ONE GPU (1e7 x 5e4 @ 0.1 %, Y 1e7 x 128): crossprod with the LDS-DMA layout
+(40, 16, 7) and with the gather layout (40, 4, 10) that svt_dev_pbc_build(A, 0, 0, 0) picks at this
+density, and colSums."""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
 from sparsearray_amd import synth
 from sparsearray_amd.device import DeviceCSC, PbcPlan, colstats
+
 nrow, ncol, K = 10_000_000, 50_000, 128
 dev = torch.device("cuda", 0)
 cp, ri, v = synth.random_device_csc(nrow, ncol, 0.001, seed=4, device=dev)
 A = DeviceCSC(nrow, cp, ri, v)
-nnz = A.nnz
+Y = synth.random_dense(nrow, K, seed=104, device=dev)
+out = torch.zeros((K, ncol), dtype=torch.float64, device=dev)
+alg = A.nnz * 12 + nrow * K * 8 + ncol * K * 8
 
 
-def timed(fn, reps=5):
+def timed(fn, reps=3):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -22,12 +27,21 @@ def timed(fn, reps=5):
     return e0.elapsed_time(e1) / reps
 
 
-t0 = time.perf_counter(); plan = PbcPlan(A, K); torch.cuda.synchronize()
-print(f"layout build {(time.perf_counter() - t0) * 1e3:.1f} ms, nnz {nnz:.3e}")
-Y = synth.random_dense(nrow, K, seed=104, device=dev)
-out = torch.zeros((K, ncol), dtype=torch.float64, device=dev)
-ms = timed(lambda: plan.run(Y, nrow, out))
-alg = nnz * 12 + nrow * K * 8 + ncol * K * 8
-print(f"crossprod(A, Y 1e7 x 128)  {ms:8.3f} ms  {nnz / ms / 1e6:6.1f} GNZ/s  {alg / ms / 1e6:6.0f} GB/s (algorithmic)")
-ms = timed(lambda: colstats(A, "sum"))
-print(f"colSums                    {ms:8.3f} ms  {nnz / ms / 1e6:6.1f} GNZ/s  {nnz * 8 / ms / 1e6:6.0f} GB/s (algorithmic)")
+ref = None
+only = sys.argv[1] if len(sys.argv) > 1 else ""
+for name, cfg in (("gather (40,4,10)", (40, 4, 10)), ("LDS-DMA (40,16,7)", (40, 16, 7))):
+    if only and not name.startswith(only):
+        continue
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    plan = PbcPlan(A, K, *cfg)
+    torch.cuda.synchronize(); tb = (time.perf_counter() - t0) * 1e3
+    ms = timed(lambda: plan.run(Y, nrow, out))
+    print(f"crossprod {name}: layout {tb:.1f} ms, product {ms:.2f} ms, {A.nnz / ms / 1e6:.1f} GNZ/s, "
+          f"{alg / ms / 1e6:.0f} GB/s = {alg / ms / 1e6 / 8000 * 100:.1f} % of 8 TB/s", flush=True)
+    if ref is None:
+        ref = out.clone()
+    else:
+        print("max |gather - dma| / max|.| =", float((out - ref).abs().max() / ref.abs().max()))
+    del plan
+ms = timed(lambda: colstats(A, "sum"), 5)
+print(f"colSums: {ms:.3f} ms, {A.nnz * 8 / ms / 1e6:.0f} GB/s")
