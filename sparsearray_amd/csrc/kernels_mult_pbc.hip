@@ -1337,10 +1337,10 @@ pbc_transpose_dense_kernel(const double *__restrict__ Yin, int64_t ldY, int64_t 
 #define PBC_DIRTY_WORK 16384
 struct DirtyWs {
 	int *flags;          // the flag block: [0] product kernel saw a non-finite y, [2] run the general
-	                     // kernels, [3] number of non-finite entries, [4] number of dirty columns, [5] cells to redo
+	                     // kernels, [3] number of non-finite entries, [5] cells to redo
 	int *col_nf;         // [Kp] non-finite entries per dense column
 	int *has_na;         // [Kp] the column holds an R NA
-	int *slot;           // [Kp] rank of the column among the dirty ones
+	int *slot;           // [Kp] (unused since the plan moved into the hits / fix kernels)
 	uint2 *list;         // [PBC_DIRTY_CAP] (row, column)
 	uint2 *work;         // [PBC_DIRTY_WORK] (leaf, column) cells to be summed again ([5] counts them)
 	int *hit;            // [ncol * PBC_DIRTY_COLS] entries of dirty column `slot` on nonzeros of leaf c
@@ -1398,23 +1398,33 @@ pbc_dirty_scan_kernel(const double *__restrict__ Y, int64_t rs, int64_t cs, int6
 	}
 }
 
-// one thread: ranks the dirty columns and decides between the fix-up and the general kernels
-__global__ void pbc_dirty_plan_kernel(int K, DirtyWs d)
+// Rank of every dirty column among the dirty ones (slot[k], in LDS) and the decision between the
+// fix-up and the general kernels: recomputed by every workgroup of the two kernels below from the
+// scan's counters (K <= a few hundred entries) rather than by a launch of its own -- every launch
+// costs ~5 us per product even when the dense operand is clean.  Returns true for "general kernels".
+__device__ inline bool pbc_dirty_plan(int K, const DirtyWs &d, int *slot_lds)
 {
-	if (d.flags[0] == 0 || threadIdx.x != 0)
-		return;
-	int n = 0;
-	for (int k = 0; k < K; k++)
-		if (d.col_nf[k] > 0) d.slot[k] = n++;
-	d.flags[4] = n;
-	d.flags[2] = (d.flags[3] > PBC_DIRTY_CAP || n > PBC_DIRTY_COLS) ? 1 : 0;
+	__shared__ int s_general;
+	if (threadIdx.x == 0) {
+		int n = 0;
+		for (int k = 0; k < K; k++) {
+			slot_lds[k] = n;
+			if (d.col_nf[k] > 0) n++;
+		}
+		s_general = (d.flags[3] > PBC_DIRTY_CAP || n > PBC_DIRTY_COLS) ? 1 : 0;
+	}
+	__syncthreads();
+	return s_general != 0;
 }
 
 __global__ void __launch_bounds__(256)
 pbc_dirty_hits_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__ row_idx,
-		      int64_t ncol, DirtyWs d)
+		      int64_t ncol, int K, DirtyWs d)
 {
-	if (d.flags[0] == 0 || d.flags[2] != 0)
+	extern __shared__ int slot_lds[];                       // [K]
+	if (d.flags[0] == 0)
+		return;
+	if (pbc_dirty_plan(K, d, slot_lds))
 		return;
 	const int64_t c = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
 	if (c >= ncol)
@@ -1429,7 +1439,7 @@ pbc_dirty_hits_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__rest
 			if ((uint32_t) row_idx[mid] < rk.x) lo = mid + 1; else hi = mid;
 		}
 		if (lo < end && (uint32_t) row_idx[lo] == rk.x)
-			atomicAdd(d.hit + c * PBC_DIRTY_COLS + d.slot[rk.y], 1);
+			atomicAdd(d.hit + c * PBC_DIRTY_COLS + slot_lds[rk.y], 1);
 	}
 }
 
@@ -1437,8 +1447,14 @@ __global__ void __launch_bounds__(256)
 pbc_dirty_fix_kernel(const int *__restrict__ col_has_na, int K, int64_t ncol, DirtyWs d,
 		     double *__restrict__ out, int64_t sc, int64_t sk)
 {
-	if (d.flags[0] == 0 || d.flags[2] != 0)
+	extern __shared__ int slot_lds[];                       // [K]
+	if (d.flags[0] == 0)
 		return;
+	const bool general = pbc_dirty_plan(K, d, slot_lds);
+	if (general) {
+		if (blockIdx.x == 0 && threadIdx.x == 0) d.flags[2] = 1;    // read by the general kernels' gate
+		return;
+	}
 	const int64_t c = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
 	if (c >= ncol)
 		return;
@@ -1450,7 +1466,7 @@ pbc_dirty_fix_kernel(const int *__restrict__ col_has_na, int K, int64_t ncol, Di
 		double *cell = out + c * sc + (int64_t) k * sk;
 		if (d.has_na[k] || leaf_na) {
 			*cell = svt_na_real();
-		} else if (d.hit[c * PBC_DIRTY_COLS + d.slot[k]] < nf) {
+		} else if (d.hit[c * PBC_DIRTY_COLS + slot_lds[k]] < nf) {
 			*cell = *cell + NAN;
 		} else {
 			// every non-finite entry of the column sits on a nonzero of this leaf: the IEEE sum
@@ -1472,7 +1488,7 @@ pbc_dirty_redo_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__rest
 		      const double *__restrict__ val, const double *__restrict__ Y, int64_t rs, int64_t cs,
 		      DirtyWs d, double *__restrict__ out, int64_t sc, int64_t sk)
 {
-	if (d.flags[0] == 0 || d.flags[2] != 0)
+	if (d.flags[0] == 0 || d.flags[2] != 0)       // ([2]: set by the fix kernel, which ran before)
 		return;
 	const int lane = threadIdx.x & 63;
 	const int nw = gridDim.x * (blockDim.x >> 6);
@@ -1548,6 +1564,23 @@ static int pick_nsplit(const svt_dev_pbc *P, int K, bool dma, int64_t *pps_out)
 	} else {
 		s = (512 + units - 1) / units;          // aim for >= 512 workgroups
 		s = (s + 7) / 8 * 8;                    // whole XCD rounds
+	}
+	// Multi-GPU runs overlap the all-reduce of one product with the next product.  A workgroup of this
+	// kernel takes a whole CU (16 wavefronts x 128 VGPRs, 132 KB of LDS): a CU that hosts one of RCCL's
+	// workgroups cannot start one, and a grid of exactly 256 would run its last workgroups in a second
+	// round behind the collective.  SVT_RESERVED_CUS (bench.py sets it when N > 1) keeps that many CUs
+	// out of the split count.
+	if (dma && units < 512 && s > 1) {
+		static int reserved = -1;
+		if (reserved < 0) {
+			const char *e = getenv("SVT_RESERVED_CUS");
+			reserved = e ? atoi(e) : 0;
+			if (reserved < 0 || reserved > 128) reserved = 0;
+		}
+		if (reserved > 0 && units * s > 256 - reserved) {
+			s = (256 - reserved) / units;
+			if (s < 1) s = 1;
+		}
 	}
 	if (g_pbc_nsplit > 0 && units < 512) s = g_pbc_nsplit;   // tuning override
 	if (s > P->npanels) s = P->npanels;
@@ -1776,11 +1809,10 @@ static int pbc_phase(const svt_dev_pbc *P, const svt_dev_csc *A,
 		const int64_t rb = (P->nrow + 255) / 256;
 		dim3 sg((unsigned) (rb < 128 ? (rb > 0 ? rb : 1) : 128), (unsigned) K);
 		hipLaunchKernelGGL(pbc_dirty_scan_kernel, sg, dim3(256), 0, s, Yd, yrs, ycs, P->nrow, K, P->ncol, dw);
-		hipLaunchKernelGGL(pbc_dirty_plan_kernel, dim3(1), dim3(64), 0, s, K, dw);
 		dim3 hg((unsigned) ((P->ncol + 255) / 256), 16);
-		hipLaunchKernelGGL(pbc_dirty_hits_kernel, hg, dim3(256), 0, s, A->col_ptr, A->row_idx, P->ncol, dw);
+		hipLaunchKernelGGL(pbc_dirty_hits_kernel, hg, dim3(256), (size_t) K * 4, s, A->col_ptr, A->row_idx, P->ncol, K, dw);
 		dim3 fg((unsigned) ((P->ncol + 255) / 256));
-		hipLaunchKernelGGL(pbc_dirty_fix_kernel, fg, dim3(256), 0, s, P->col_has_na, K, P->ncol, dw,
+		hipLaunchKernelGGL(pbc_dirty_fix_kernel, fg, dim3(256), (size_t) K * 4, s, P->col_has_na, K, P->ncol, dw,
 				   out, out_stride_c, out_stride_k);
 		hipLaunchKernelGGL(pbc_dirty_redo_kernel, dim3(64), dim3(256), 0, s, A->col_ptr, A->row_idx,
 				   (const double *) A->val, Yd, yrs, ycs, dw, out, out_stride_c, out_stride_k);
