@@ -132,9 +132,6 @@ def main():
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # the product kernel's workgroups take whole CUs; leave some to the collective that runs beside the
-        # next product (kernels_mult_pbc.hip, pick_nsplit)
-        os.environ.setdefault("SVT_RESERVED_CUS", "32")
         if a.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:

@@ -1565,23 +1565,6 @@ static int pick_nsplit(const svt_dev_pbc *P, int K, bool dma, int64_t *pps_out)
 		s = (512 + units - 1) / units;          // aim for >= 512 workgroups
 		s = (s + 7) / 8 * 8;                    // whole XCD rounds
 	}
-	// Multi-GPU runs overlap the all-reduce of one product with the next product.  A workgroup of this
-	// kernel takes a whole CU (16 wavefronts x 128 VGPRs, 132 KB of LDS): a CU that hosts one of RCCL's
-	// workgroups cannot start one, and a grid of exactly 256 would run its last workgroups in a second
-	// round behind the collective.  SVT_RESERVED_CUS (bench.py sets it when N > 1) keeps that many CUs
-	// out of the split count.
-	if (dma && units < 512 && s > 1) {
-		static int reserved = -1;
-		if (reserved < 0) {
-			const char *e = getenv("SVT_RESERVED_CUS");
-			reserved = e ? atoi(e) : 0;
-			if (reserved < 0 || reserved > 128) reserved = 0;
-		}
-		if (reserved > 0 && units * s > 256 - reserved) {
-			s = (256 - reserved) / units;
-			if (s < 1) s = 1;
-		}
-	}
 	if (g_pbc_nsplit > 0 && units < 512) s = g_pbc_nsplit;   // tuning override
 	if (s > P->npanels) s = P->npanels;
 	if (s < 1) s = 1;

@@ -10,7 +10,6 @@ import sys
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 os.environ["LOCAL_RANK"] = "0"                       # both ranks bind the HIP library to GPU 0
-os.environ.setdefault("SVT_RESERVED_CUS", "32")      # as bench.py does for N > 1: 7 row splits instead of 8
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
