@@ -1071,6 +1071,10 @@ crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restric
 	const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int kt = (int) (Kp / 64);
 	const int L = blockIdx.x;
+#ifdef SVT_TUNING
+	unsigned long long t_entry = 0, t_loop = 0, t_epi = 0;
+	if (PROF) t_entry = __builtin_readcyclecounter();
+#endif
 	// nblocks column blocks are launched, the first of them is block0 of the layout (a symmetric
 	// product only needs the blocks from its dense chunk's first column on); bl counts from 0
 	int bl, kh, split;
@@ -1179,6 +1183,9 @@ crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restric
 				     : "=v"(sink) : "v"(ptr) : "memory");
 		}
 	}
+#ifdef SVT_TUNING
+	if (PROF) t_loop = __builtin_readcyclecounter();
+#endif
 #if PBC_DMA_YSETS == 2
 	u32x8 V3 = 0;
 #define PBC_DMA_STATE "+{v[0:15]}"(V0), "+{v[16:31]}"(V1), "+{v[32:39]}"(V3), "+{v[40:43]}"(V2), "+{s[8:11]}"(PA), "+{s[12:27]}"(PB)
@@ -1226,6 +1233,9 @@ crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restric
 #undef PBC_DMA_STATE
 	if (PB[6] != 0 && (tid & 63) == 0)
 		*fl.y_nonfinite = 1;
+#ifdef SVT_TUNING
+	if (PROF) t_epi = __builtin_readcyclecounter();
+#endif
 	// ---- partial results: part[(split*Kp + k) * ncol + c] ------------------------
 	// A lane holds one dense column k of its wavefront's CBW sparse columns: stored
 	// straight from registers that is 64 eight-byte writes ncol*8 bytes apart per
@@ -1233,8 +1243,11 @@ crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restric
 	// LDS as [k][16*CBW (+1)] and leave as whole rows of the workgroup's 16*CBW
 	// columns (matters when the result is large: x %*% y writes nrow x K).
 	const int lane2 = (int) __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-	const int CWG = 16 * CBW, LS = CWG + 1;
+	// (row stride even: the rows leave as 16-byte stores; 16 lanes writing one column of 16 rows still
+	// hit 16 different bank groups: 2 * LS mod 64 = 4 for CBW = 40)
+	const int CWG = 16 * CBW, LS = CWG + 2;
 	const int64_t cwg0 = (int64_t) b * CWG;
+	const int nvalid = (int) (ncol - cwg0 < CWG ? ncol - cwg0 : CWG);     // columns of this block inside the matrix
 	__syncthreads();
 #pragma unroll 1
 	for (int q = 0; q < 4; q++) {
@@ -1252,13 +1265,29 @@ crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restric
 			}
 		}
 		__syncthreads();
-		for (int idx = tid; idx < 16 * CWG; idx += 1024) {
-			const int kk = idx / CWG, cc = idx - kk * CWG;
-			if (cwg0 + cc < ncol)
-				part[((int64_t) split * Kp + k0 + q * 16 + kk) * ncol + cwg0 + cc] = ylds[kk * LS + cc];
+		{       // wavefront w stores row w of the 16: one contiguous run, 16 bytes per lane where the row
+			// is aligned (the epilogue took 35k cycles per workgroup with 8-byte stores and an integer
+			// division per element: a tenth of a 79-panel workgroup of A %*% Y)
+			double *__restrict__ dstrow = part + ((int64_t) split * Kp + k0 + q * 16 + w) * ncol + cwg0;
+			const double *__restrict__ src = ylds + w * LS;
+			if ((((uintptr_t) dstrow) & 15) == 0) {
+				for (int cc = lane2 * 2; cc < nvalid; cc += 128) {
+					if (cc + 1 < nvalid) *(double2 *) (dstrow + cc) = *(const double2 *) (src + cc);
+					else dstrow[cc] = src[cc];
+				}
+			} else {
+				for (int cc = lane2; cc < nvalid; cc += 64) dstrow[cc] = src[cc];
+			}
 		}
 		__syncthreads();
 	}
+#ifdef SVT_TUNING
+	if (PROF && tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1 || blockIdx.x == gridDim.x / 2)) {
+		const unsigned long long t_end = __builtin_readcyclecounter();
+		printf("wg %d: prologue %llu, panel loop %llu, epilogue %llu cycles\n", (int) blockIdx.x,
+		       t_loop - t_entry, t_epi - t_loop, t_end - t_epi);
+	}
+#endif
 }
 
 // out[c, k] = sum over splits (fixed order) ; NA_real_ for leaves holding an NA
