@@ -51,10 +51,12 @@ for case in range(ncases):
     by_rows = bool(rng.integers(0, 2))
     out_p = torch.full((K, ncol), 7.0, dtype=torch.float64, device=dev)
     out_g = torch.full((K, ncol), 9.0, dtype=torch.float64, device=dev)
+    # layout: the default LDS-DMA one, the gather one (needs >= 512-row panels to make sense), or by density
+    lay = [(40, 16, 7), (40, 4, 10), (0, 0, 0), (40, 4, 9)][int(rng.integers(0, 4))]
     if by_rows:
-        PbcPlan(A, K).run(Yd.t().contiguous(), K, out_p, tr_y=True)
+        PbcPlan(A, K, *lay).run(Yd.t().contiguous(), K, out_p, tr_y=True)
     else:
-        PbcPlan(A, K).run(Yd, nrow, out_p)
+        PbcPlan(A, K, *lay).run(Yd, nrow, out_p)
     CrossprodPlan(A, K).run(Yd, nrow, out_g)
     torch.cuda.synchronize()
     same_class = bool((torch.isnan(out_p) == torch.isnan(out_g)).all()) and \
@@ -68,7 +70,7 @@ for case in range(ncases):
         err = float("inf")
     worst = max(worst, err)
     flag = "" if err <= 1e-11 else "   <-- MISMATCH"
-    print(f"{case:4d} nrow {nrow:6d} ncol {ncol:5d} K {K:4d} kind {kind} dens {dens:<7g} nsplit {ns:2d} poison {npoison} by_rows {int(by_rows)} nnz {len(ri):8d}  err {err:.2e}{flag}", flush=True)
+    print(f"{case:4d} nrow {nrow:6d} ncol {ncol:5d} K {K:4d} kind {kind} dens {dens:<7g} nsplit {ns:2d} poison {npoison} by_rows {int(by_rows)} layout {lay} nnz {len(ri):8d}  err {err:.2e}{flag}", flush=True)
     if flag:
         bad = ~(((out_p - out_g).abs() / scale <= 1e-11) | (torch.isnan(out_p) & torch.isnan(out_g)) | (out_p == out_g))
         idx = bad.nonzero()[:5].tolist()
