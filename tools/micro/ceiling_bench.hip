@@ -576,6 +576,152 @@ static void run_combo(const double *Y, double *sink, combo_fn fn, int wpb, int n
 	CHECK(hipEventDestroy(e0)); CHECK(hipEventDestroy(e1));
 }
 
+
+// ------------------------------------------------------------------------------------------- D
+// flag: the combo loop with the workgroup barrier replaced by two counters per panel buffer in LDS --
+// landed[buf] (a wavefront's DMA pieces of the panel are in LDS) and done[buf] (a wavefront has finished
+// reading it).  A wavefront starts panel i as soon as all pieces of i have landed, issues its pieces of
+// i + 1 at the first trip boundary at which every wavefront is done with i - 1, and publishes them two
+// trips later.  Slack: one panel.  imbalance: the wavefronts' trip counts per panel vary like the
+// record counts of real tiles (Poisson(51) per 40 columns x 128 rows); barrier = 1 gives the same loop
+// with s_barrier for comparison.
+__device__ inline uint32_t mix32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+
+template <bool barrier>
+__global__ void __launch_bounds__(16 * 64)
+combo_flag(const double *__restrict__ Y, int64_t ld, int nblocks, int kt, int64_t npanels,
+	   int64_t panels_per_split, double *sink, int imbalance)
+{
+	extern __shared__ double lds[];
+	constexpr int RS = 129, BUF = 64 * RS, NPIECE = 4;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int L = blockIdx.x;
+	const int xcd = L % 8, j = L / 8;
+	const int u = j / nblocks;
+	const int kh = u % kt, sp = (u / kt) * 8 + xcd;
+	const int64_t pa = (int64_t) sp * panels_per_split;
+	int64_t pb = pa + panels_per_split;
+	if (pb > npanels) pb = npanels;
+	if (pa >= pb) return;
+	const int k0 = kh * 64;
+	uint32_t *flags = (uint32_t *) (lds + 2 * BUF);          // landed[0], landed[1], done[0], done[1]
+	for (int i = tid; i < 2 * BUF; i += 16 * 64) lds[i] = 1.0;
+	if (tid < 4) flags[tid] = 0;
+	__syncthreads();
+	auto issue = [&](int64_t p, int buf) {
+#pragma unroll
+		for (int q = 0; q < NPIECE; q++) {
+			const int kk = w * NPIECE + q;
+			const double *src = Y + (int64_t) (k0 + kk) * ld + p * 128 + lane * 2;
+			double *dst = lds + buf * BUF + kk * RS;
+			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) src,
+							 (__attribute__((address_space(3))) void *) dst, 16, 0, 0);
+		}
+	};
+	auto peek = [&](int idx) { return __hip_atomic_load(flags + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+	auto bump = [&](int idx) { if (lane == 0) __hip_atomic_fetch_add(flags + idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+	d16 acc0 = 0.0, acc1 = 0.0;
+	u32x16 ya = 0, yb = 0;
+	u32x8 meta;
+	const int rows[8] = {3, 17, 40, 66, 71, 90, 101, 120};
+	const int cols[8] = {0, 5, 9, 12, 3, 7, 14, 15};
+#pragma unroll
+	for (int q = 0; q < 8; q++) meta[q] = ((uint32_t) (rows[q] * 8) << 16) | (uint32_t) (2 * cols[q]);
+	const double one = 1.0000001;
+	const int64_t np = pb - pa;
+	issue(pa, 0);
+	int carry = 0;                                          // records not yet turned into whole trips of 16
+	for (int64_t i = 0; i < np; i++) {
+		const int buf = (int) (i & 1);
+		// records of this wavefront in this panel: 51.2 on average
+		int recs = 51 + (int) ((i * 16 + w) % 5 == 0);
+		if (imbalance) {
+			const uint32_t h = mix32((uint32_t) (L * 1000003 + i * 16 + w));
+			const int z = (int) (h & 15) + (int) ((h >> 4) & 15) + (int) ((h >> 8) & 15) + (int) ((h >> 12) & 15) - 30;   // ~N(0, 9.2)
+			recs = 51 + (z * 7) / 9 + (int) ((i * 16 + w) % 5 == 0);
+			if (recs < 8) recs = 8;
+		}
+		carry += recs;
+		int n = __builtin_amdgcn_readfirstlane(carry / 16);
+		carry -= n * 16;
+		const uint32_t lanebase = (uint32_t) lane * 1032u + (uint32_t) buf * (BUF * 8u);
+		if constexpr (barrier) {
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			__builtin_amdgcn_s_barrier();
+			if (i + 1 < np) issue(pa + i + 1, buf ^ 1);
+			for (int t = 0; t < n; t++) {
+				uint32_t one_trip = 1;
+				asm volatile(LOOP_HEAD ADDR_A READ_A FMAI_B WAIT ADDR_B READ_B FMAI_A WAIT LOOP_TAIL
+					     : "+{v[44:75]}"(acc0), "+{v[76:107]}"(acc1), [n] "+s"(one_trip), "+{v[12:27]}"(ya),
+					       "+{v[108:123]}"(yb)
+					     : [lb] "v"(lanebase), [one] "s"(one), "{s[28:35]}"(meta) : "memory", "scc", "s36");
+			}
+		} else {
+		// ---- flag protocol
+		// panel i complete in LDS?  (my own pieces were published during panel i - 1, or here for the first)
+		if (i == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); bump(buf); }
+		const uint32_t need = 16u * (uint32_t) ((i >> 1) + 1);
+		while (peek(buf) < need) __builtin_amdgcn_s_sleep(1);
+		bool issued = i + 1 >= np, published = issued;
+		int issued_at = 0;
+		for (int t = 0; t <= n; t++) {
+			if (!issued && (i == 0 || peek(2 + (buf ^ 1)) >= 16u * (uint32_t) (((i - 1) >> 1) + 1))) {
+				issue(pa + i + 1, buf ^ 1);
+				issued = true; issued_at = t;
+			}
+			if (issued && !published && t >= issued_at + 2) {
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				bump(buf ^ 1);
+				published = true;
+			}
+			if (t == n) break;
+			uint32_t one_trip = 1;
+			asm volatile(LOOP_HEAD ADDR_A READ_A FMAI_B WAIT ADDR_B READ_B FMAI_A WAIT LOOP_TAIL
+				     : "+{v[44:75]}"(acc0), "+{v[76:107]}"(acc1), [n] "+s"(one_trip), "+{v[12:27]}"(ya),
+				       "+{v[108:123]}"(yb)
+				     : [lb] "v"(lanebase), [one] "s"(one), "{s[28:35]}"(meta) : "memory", "scc", "s36");
+		}
+		bump(2 + buf);                                      // done with panel i
+		if (!issued) {
+			while (peek(2 + (buf ^ 1)) < 16u * (uint32_t) (((i - 1) >> 1) + 1)) __builtin_amdgcn_s_sleep(1);
+			issue(pa + i + 1, buf ^ 1);
+		}
+		if (!published) {
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			bump(buf ^ 1);
+		}
+		}
+	}
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	if (acc0[0] + acc1[3] + (double) ya[0] + (double) yb[1] == 123.456) sink[0] = acc0[1];
+}
+
+static void run_flag(const double *Y, double *sink, int imbalance, int barrier, const char *what)
+{
+	const int kt = 2, nblocks = 16, nsplit = 8;
+	const int64_t nrow = 999936, ld = 1000000, npanels = nrow / 128;
+	const int64_t pps = (npanels + nsplit - 1) / nsplit;
+	const int nwg = nblocks * kt * nsplit;
+	const size_t ldsb = (size_t) 2 * 64 * 129 * 8 + 64;
+	CHECK(hipFuncSetAttribute((const void *) combo_flag<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsb));
+	CHECK(hipFuncSetAttribute((const void *) combo_flag<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsb));
+	hipEvent_t e0, e1;
+	CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+	float best = 1e30f;
+	for (int rep = 0; rep < 4; rep++) {
+		CHECK(hipEventRecord(e0));
+		if (barrier) hipLaunchKernelGGL(combo_flag<true>, dim3(nwg), dim3(1024), ldsb, 0, Y, ld, nblocks, kt, npanels, pps, sink, imbalance);
+		else hipLaunchKernelGGL(combo_flag<false>, dim3(nwg), dim3(1024), ldsb, 0, Y, ld, nblocks, kt, npanels, pps, sink, imbalance);
+		CHECK(hipEventRecord(e1));
+		CHECK(hipEventSynchronize(e1));
+		float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+		if (rep > 0 && ms < best) best = ms;
+	}
+	printf("flag  %-40s imbalance %d: %.3f ms (%.0f cycles/panel)\n", what, imbalance, best, best * 1e-3 * 2.4e9 / pps);
+	CHECK(hipEventDestroy(e0)); CHECK(hipEventDestroy(e1));
+}
+
 template <int MODE>
 static void run_work(double *sink, int threads, const char *what)
 {
@@ -620,6 +766,17 @@ int main(int argc, char **argv)
 			run_work<7>(sink, threads, "plain add + fma, fixed acc");
 			run_work<8>(sink, threads, "SDWA add + fma, fixed acc");
 		}
+	}
+	if (!strcmp(which, "all") || !strcmp(which, "flag")) {
+		const int64_t maxrow = 1048576 + 1024, K = 128;
+		double *Y;
+		CHECK(hipMalloc(&Y, (size_t) maxrow * K * 8 + 4096));
+		CHECK(hipMemset(Y, 0, (size_t) maxrow * K * 8 + 4096));
+		for (int imb = 0; imb < 2; imb++) {
+			run_flag(Y, sink, imb, 1, "s_barrier per panel (trip by trip)");
+			run_flag(Y, sink, imb, 0, "landed / done counters, slack 1 panel");
+		}
+		CHECK(hipFree(Y));
 	}
 	if (!strcmp(which, "all") || !strcmp(which, "combo")) {
 		const int64_t maxrow = 1048576 + 1024, K = 128;
