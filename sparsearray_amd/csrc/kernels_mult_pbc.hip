@@ -61,6 +61,7 @@ struct svt_dev_pbc {
 	uint4 *rec;            // [nrec] 16-byte records
 	int64_t *tile_ptr;     // [ngroups*npanels + 1]
 	int *col_has_na;       // [ncol]
+	int64_t max_leaf_nnz;  // the longest leaf (a dense column with more non-finite entries than that makes every cell NaN / NA)
 };
 
 #define PCH 256            // panels per build chunk
@@ -354,6 +355,17 @@ pbc_scatter_lds_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__res
 	for (int64_t i = tid; i < nbytes / 16; i += 256) out[i] = ((const uint4 *) img)[i];
 }
 
+__global__ void pbc_max_leaf_kernel(const int64_t *__restrict__ col_ptr, int64_t ncol, unsigned long long *__restrict__ out)
+{
+	const int64_t c = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	unsigned long long n = c < ncol ? (unsigned long long) (col_ptr[c + 1] - col_ptr[c]) : 0ULL;
+	for (int off = 32; off > 0; off >>= 1) {
+		const unsigned long long o = __shfl_xor(n, off, 64);
+		n = o > n ? o : n;
+	}
+	if ((threadIdx.x & 63) == 0 && n > 0) atomicMax(out, n);
+}
+
 // flag = 1 if some column group's record stream does not fit a 32-bit byte cursor
 __global__ void pbc_group_limit_kernel(const int64_t *__restrict__ tile_ptr, int64_t npanels,
 				       int64_t ngroups, int *__restrict__ flag)
@@ -485,6 +497,16 @@ extern "C" svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB
 		}
 		int64_t nrec = 0;
 		if (ok) ok = hipMemcpy(&nrec, h->tile_ptr + ntiles, 8, hipMemcpyDeviceToHost) == hipSuccess;   // (synchronises)
+		if (ok) {                                   // longest leaf (tmp, the scan's scratch, is free again)
+			unsigned long long mx = 0;
+			ok = hipMemset(tmp, 0, 8) == hipSuccess;
+			if (ok) {
+				hipLaunchKernelGGL(pbc_max_leaf_kernel, dim3((unsigned) ((A->ncol + 255) / 256)), dim3(256), 0, 0,
+						   A->col_ptr, A->ncol, (unsigned long long *) tmp);
+				ok = hipMemcpy(&mx, tmp, 8, hipMemcpyDeviceToHost) == hipSuccess;
+			}
+			h->max_leaf_nnz = (int64_t) mx;
+		}
 		h->nrec = nrec;
 		if (ok) {
 			int64_t pad[PBC_TP_PAD];
@@ -1358,12 +1380,15 @@ pbc_transpose_dense_kernel(const double *__restrict__ Yin, int64_t ldY, int64_t 
 // non-finite entries per column and lists their (row, column) positions; a leaf "hits" an entry
 // if the row is among its offsets (binary search, offsets ascend inside a leaf); the fix-up
 // rewrites the cells of the dirty columns by the rule above.  The clean columns are never
-// touched.  More than PBC_DIRTY_CAP entries or PBC_DIRTY_COLS dirty columns: the general kernels
-// redo the whole product as before (a column of NAs is the typical case; correct, just slow).
+// touched.  A column with more non-finite entries than the longest leaf has nonzeros is NaN / NA in every
+// cell without looking at its entries (a column of NAs).  More than PBC_DIRTY_CAP listed entries, more than
+// PBC_DIRTY_COLS listed columns, or a column between PBC_DIRTY_LIGHT and the longest leaf: the general
+// kernels redo the whole product as before.
 // ---------------------------------------------------------------------------
 #define PBC_DIRTY_CAP 8192
 #define PBC_DIRTY_COLS 16
 #define PBC_DIRTY_WORK 16384
+#define PBC_DIRTY_LIGHT 256     // a dense column lists at most this many of its non-finite entries
 struct DirtyWs {
 	int *flags;          // the flag block: [0] product kernel saw a non-finite y, [2] run the general
 	                     // kernels, [3] number of non-finite entries, [5] cells to redo
@@ -1420,8 +1445,10 @@ pbc_dirty_scan_kernel(const double *__restrict__ Y, int64_t rs, int64_t cs, int6
 		const double y = col[r * rs];
 		if (svt_is_finite(y))
 			continue;
-		atomicAdd(d.col_nf + k, 1);
+		const int seen = atomicAdd(d.col_nf + k, 1);
 		if (svt_is_na(y)) d.has_na[k] = 1;
+		if (seen >= PBC_DIRTY_LIGHT)
+			continue;                           // a heavy column: decided without its entries, or by the general kernels
 		const int at = atomicAdd(d.flags + 3, 1);
 		if (at < PBC_DIRTY_CAP) d.list[at] = make_uint2((unsigned) r, (unsigned) k);
 	}
@@ -1431,16 +1458,22 @@ pbc_dirty_scan_kernel(const double *__restrict__ Y, int64_t rs, int64_t cs, int6
 // fix-up and the general kernels: recomputed by every workgroup of the two kernels below from the
 // scan's counters (K <= a few hundred entries) rather than by a launch of its own -- every launch
 // costs ~5 us per product even when the dense operand is clean.  Returns true for "general kernels".
-__device__ inline bool pbc_dirty_plan(int K, const DirtyWs &d, int *slot_lds)
+// Classes of a dirty column k (nf = its non-finite entries): light (nf <= PBC_DIRTY_LIGHT: all listed, gets a
+// slot), saturated (nf > the longest leaf: no leaf can have a nonzero on every non-finite row, every cell is NaN
+// or NA -- a column of NAs, the common case, costs no more than a single Inf), anything in between: general kernels.
+__device__ inline bool pbc_dirty_plan(int K, const DirtyWs &d, int *slot_lds, int64_t max_leaf_nnz)
 {
 	__shared__ int s_general;
 	if (threadIdx.x == 0) {
-		int n = 0;
+		int n = 0, general = d.flags[3] > PBC_DIRTY_CAP;
 		for (int k = 0; k < K; k++) {
-			slot_lds[k] = n;
-			if (d.col_nf[k] > 0) n++;
+			const int nf = d.col_nf[k];
+			slot_lds[k] = -1;
+			if (nf == 0) continue;
+			if (nf <= PBC_DIRTY_LIGHT) slot_lds[k] = n++;
+			else if ((int64_t) nf <= max_leaf_nnz) general = 1;
 		}
-		s_general = (d.flags[3] > PBC_DIRTY_CAP || n > PBC_DIRTY_COLS) ? 1 : 0;
+		s_general = (general || n > PBC_DIRTY_COLS) ? 1 : 0;
 	}
 	__syncthreads();
 	return s_general != 0;
@@ -1448,12 +1481,12 @@ __device__ inline bool pbc_dirty_plan(int K, const DirtyWs &d, int *slot_lds)
 
 __global__ void __launch_bounds__(256)
 pbc_dirty_hits_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__ row_idx,
-		      int64_t ncol, int K, DirtyWs d)
+		      int64_t ncol, int K, DirtyWs d, int64_t max_leaf_nnz)
 {
 	extern __shared__ int slot_lds[];                       // [K]
 	if (d.flags[0] == 0)
 		return;
-	if (pbc_dirty_plan(K, d, slot_lds))
+	if (pbc_dirty_plan(K, d, slot_lds, max_leaf_nnz))
 		return;
 	const int64_t c = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
 	if (c >= ncol)
@@ -1462,6 +1495,8 @@ pbc_dirty_hits_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__rest
 	const int64_t beg = col_ptr[c], end = col_ptr[c + 1];
 	for (int e = blockIdx.y; e < n; e += gridDim.y) {
 		const uint2 rk = d.list[e];
+		if (slot_lds[rk.y] < 0)
+			continue;                           // (the first entries of a saturated column)
 		int64_t lo = beg, hi = end;
 		while (lo < hi) {
 			const int64_t mid = (lo + hi) >> 1;
@@ -1474,12 +1509,12 @@ pbc_dirty_hits_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__rest
 
 __global__ void __launch_bounds__(256)
 pbc_dirty_fix_kernel(const int *__restrict__ col_has_na, int K, int64_t ncol, DirtyWs d,
-		     double *__restrict__ out, int64_t sc, int64_t sk)
+		     double *__restrict__ out, int64_t sc, int64_t sk, int64_t max_leaf_nnz)
 {
 	extern __shared__ int slot_lds[];                       // [K]
 	if (d.flags[0] == 0)
 		return;
-	const bool general = pbc_dirty_plan(K, d, slot_lds);
+	const bool general = pbc_dirty_plan(K, d, slot_lds, max_leaf_nnz);
 	if (general) {
 		if (blockIdx.x == 0 && threadIdx.x == 0) d.flags[2] = 1;    // read by the general kernels' gate
 		return;
@@ -1495,7 +1530,7 @@ pbc_dirty_fix_kernel(const int *__restrict__ col_has_na, int K, int64_t ncol, Di
 		double *cell = out + c * sc + (int64_t) k * sk;
 		if (d.has_na[k] || leaf_na) {
 			*cell = svt_na_real();
-		} else if (d.hit[c * PBC_DIRTY_COLS + slot_lds[k]] < nf) {
+		} else if (slot_lds[k] < 0 || d.hit[c * PBC_DIRTY_COLS + slot_lds[k]] < nf) {
 			*cell = *cell + NAN;
 		} else {
 			// every non-finite entry of the column sits on a nonzero of this leaf: the IEEE sum
@@ -1822,10 +1857,10 @@ static int pbc_phase(const svt_dev_pbc *P, const svt_dev_csc *A,
 		dim3 sg((unsigned) (rb < 128 ? (rb > 0 ? rb : 1) : 128), (unsigned) K);
 		hipLaunchKernelGGL(pbc_dirty_scan_kernel, sg, dim3(256), 0, s, Yd, yrs, ycs, P->nrow, K, P->ncol, dw);
 		dim3 hg((unsigned) ((P->ncol + 255) / 256), 16);
-		hipLaunchKernelGGL(pbc_dirty_hits_kernel, hg, dim3(256), (size_t) K * 4, s, A->col_ptr, A->row_idx, P->ncol, K, dw);
+		hipLaunchKernelGGL(pbc_dirty_hits_kernel, hg, dim3(256), (size_t) K * 4, s, A->col_ptr, A->row_idx, P->ncol, K, dw, P->max_leaf_nnz);
 		dim3 fg((unsigned) ((P->ncol + 255) / 256));
 		hipLaunchKernelGGL(pbc_dirty_fix_kernel, fg, dim3(256), (size_t) K * 4, s, P->col_has_na, K, P->ncol, dw,
-				   out, out_stride_c, out_stride_k);
+				   out, out_stride_c, out_stride_k, P->max_leaf_nnz);
 		hipLaunchKernelGGL(pbc_dirty_redo_kernel, dim3(64), dim3(256), 0, s, A->col_ptr, A->row_idx,
 				   (const double *) A->val, Yd, yrs, ycs, dw, out, out_stride_c, out_stride_k);
 		HIP_TRY(hipGetLastError());

@@ -423,3 +423,39 @@ def test_pbc_auto_layout_picks_by_density(hip, oracle):
         PbcPlan(A, K, 0, 0, 0).run(Yd, nrow, o_auto)
         torch.cuda.synchronize()
         assert_equal(o_auto.cpu().numpy().T, oracle.crossprod(x, y), tol=1e-9, atol=1e-11, what=f"density {dens}")
+
+
+def test_pbc_dirty_column_classes(hip, oracle):
+    """A whole column of NaN / NA in the dense operand (more non-finite entries than the longest leaf has
+    nonzeros: every cell NaN or NA, decided without listing the entries), a column with more entries than
+    the fix-up lists but fewer than the longest leaf (general kernels), and both next to a single Inf."""
+    from sparsearray_amd.device import PbcPlan
+    nrow, ncol, K = 20000, 700, 64
+    cp, ri, v = random_csc(nrow, ncol, 0.01, seed=101)
+    # leaf 9 becomes long: 4000 nonzeros (rows 0 .. 3999)
+    rows9 = np.arange(4000, dtype=np.int32)
+    vals9 = np.random.default_rng(102).uniform(-1, 1, 4000)
+    ri = np.concatenate([ri[:cp[9]], rows9, ri[cp[10]:]])
+    v = np.concatenate([v[:cp[9]], vals9, v[cp[10]:]])
+    shift = 4000 - (cp[10] - cp[9])
+    cp = cp.copy(); cp[10:] += shift
+    x = SVT_SparseArray.from_csc((nrow, ncol), "double", cp, ri, v)
+    A = _dev(cp, ri, v, nrow)
+    plan = PbcPlan(A, K)
+    y0 = np.random.default_rng(103).uniform(-1, 1, (nrow, K))
+    out = torch.zeros((K, ncol), dtype=torch.float64, device="cuda")
+
+    def check(y, what):
+        plan.run(torch.as_tensor(np.ascontiguousarray(y.T), device="cuda"), nrow, out)
+        torch.cuda.synchronize()
+        assert_equal(out.cpu().numpy().T, oracle.crossprod(x, y), tol=1e-9, atol=1e-11, strict_na=True, what=what)
+
+    y = y0.copy(); y[:, 5] = np.nan; y[77, 6] = np.inf
+    check(y, "NaN column (saturated) + one Inf")
+    y = y0.copy(); y[:, 5] = NA_real; y[:, 40] = np.inf; y[3, 41] = -np.inf
+    check(y, "NA column + Inf column (both saturated) + one -Inf")
+    y = y0.copy(); y[:3000, 7] = np.inf                       # 3000 entries: listed 256, longest leaf 4000 -> general kernels
+    check(y, "between the list and the longest leaf")
+    y = y0.copy(); y[:3000, 7] = np.inf; y[:, 8] = np.nan
+    check(y, "in-between column beside a saturated one")
+    check(y0, "clean again")

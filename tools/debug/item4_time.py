@@ -1,5 +1,5 @@
 """BASELINE config 2a: the product with a clean dense operand, with ONE Inf in it (per-column fix-up,
-kernels_mult_pbc.hip), with a whole NaN column (general kernels), and with the dense operand given
+kernels_mult_pbc.hip), with a whole NaN column, and with the dense operand given
 by rows (tcrossprod orientation: device transposition + the same kernel)."""
 import os, sys
 import torch
@@ -35,5 +35,5 @@ t_col = timed(lambda: plan.run(Yn, nrow, out), 3)
 Yrm = Y.t().contiguous()
 t_try = timed(lambda: plan.run(Yrm, K, out, tr_y=True))
 print(f"crossprod(A, Y) config 2a: clean {t_clean:.3f} ms; one Inf in Y {t_inf:.3f} ms ({t_inf / t_clean:.2f}x); "
-      f"a whole NaN column (general kernels) {t_col:.3f} ms; Y given by rows (tcrossprod) {t_try:.3f} ms "
+      f"a whole NaN column {t_col:.3f} ms; Y given by rows (tcrossprod) {t_try:.3f} ms "
       f"({t_try / t_clean:.2f}x)")
