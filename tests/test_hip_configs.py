@@ -157,3 +157,37 @@ def test_two_ranks_same_device_sharded_ops_match_one_rank(hip, tmp_path):
         assert v["colsums_rel_err"] <= 1e-12, (name, v)
         assert v["colvars_identical"], name
         assert v["rowsum_rel_err"] <= 1e-12, (name, v)
+
+
+def _bench_line(args, nproc, port):
+    env = dict(os.environ)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    if nproc == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+               "--gpus", str(nproc), "--backend", "gloo", "--same-device"] + args
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    return json.loads(p.stdout.strip().splitlines()[-1])
+
+
+def test_bench_strong_scaling_rehearsal_same_problem(hip):
+    """bench.py --gpus 2 (strong scaling, two ranks rehearsed on one device over gloo) computes the SAME
+    product as --gpus 1: the global matrix is defined by row blocks that do not depend on the number of
+    ranks, the all-reduced result has the same checksum, and the line names the workload and the scaling."""
+    torch.cuda.empty_cache()
+    common = ["--nrow", "262144", "--ncol", "4000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras"]
+    one = _bench_line(common, 1, 0)
+    two = _bench_line(common, 2, 29700 + os.getpid() % 200)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert two["scaling"] == "strong" and "strong scaling" in two["config"]["workload"]
+    assert one["config"]["nnz_total"] == two["config"]["nnz_total"]
+    a, b = one["config"]["result_checksum"], two["config"]["result_checksum"]
+    assert abs(a["abs_sum"] - b["abs_sum"]) <= 1e-12 * abs(a["abs_sum"])
+    assert abs(a["sum"] - b["sum"]) <= 1e-9 * abs(a["abs_sum"])
+    for line in (one, two):
+        for key in ("metric", "value", "unit", "ms_per_step", "roofline", "dtype", "data", "config"):
+            assert key in line
+        assert line["roofline"]["bound"] == "hbm" and line["roofline"]["frac"] > 0
