@@ -213,6 +213,52 @@ __global__ void aperm_gather_kernel(const unsigned long long *__restrict__ skeys
 	out_val[i] = val[perm[i]];
 }
 
+// ---- leaf-preserving permutations (perm[1] == 1 in R's numbering): the leaves stay what they are and
+// only change places -- the reference shuffles pointers (src/SparseArray_aperm.c:949-957); here: the
+// length of every new leaf from the old col_ptr, a scan, one streaming copy.  No keys, no sort.
+struct LeafMap {
+	int ndim;
+	int64_t new_dim[8];      // extents of the new axes 1 .. ndim-1
+	int64_t old_stride[8];   // leaf stride, in the OLD layout, of the old axis that new axis a takes
+};
+
+__device__ inline int64_t old_leaf_of(const LeafMap &m, int64_t jn)
+{
+	int64_t j = 0;
+	for (int a = 1; a < m.ndim; a++) {
+		const int64_t ia = jn % m.new_dim[a];
+		jn /= m.new_dim[a];
+		j += ia * m.old_stride[a];
+	}
+	return j;
+}
+
+__global__ void aperm_leaf_count_kernel(const int64_t *__restrict__ col_ptr, int64_t nleaves, LeafMap m,
+					int64_t *__restrict__ cnt)
+{
+	const int64_t jn = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if (jn > nleaves) return;
+	if (jn == nleaves) { cnt[jn] = 0; return; }
+	const int64_t j = old_leaf_of(m, jn);
+	cnt[jn] = col_ptr[j + 1] - col_ptr[j];
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+aperm_leaf_copy_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__ row_idx,
+		       const T *__restrict__ val, int64_t nleaves, LeafMap m,
+		       const int64_t *__restrict__ out_ptr, int32_t *__restrict__ out_idx, T *__restrict__ out_val)
+{
+	const int lane = threadIdx.x & 63;
+	const int64_t jn = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);       // one wavefront per new leaf
+	if (jn >= nleaves) return;
+	const int64_t src = col_ptr[old_leaf_of(m, jn)], dst = out_ptr[jn], n = out_ptr[jn + 1] - dst;
+	for (int64_t k = lane; k < n; k += 64) {
+		out_idx[dst + k] = row_idx[src + k];
+		out_val[dst + k] = val[src + k];
+	}
+}
+
 static int aperm_bits(const int64_t *dim, int ndim)
 {
 	double tot = 1.0;
@@ -236,7 +282,13 @@ size_t aperm_ws_bytes(int64_t nnz, const int64_t *dim, int ndim)
 {
 	const size_t n = (size_t) (nnz > 0 ? nnz : 1);
 	const size_t a8 = (n * 8 + 255) / 256 * 256, a4 = (n * 4 + 255) / 256 * 256;
-	return 2 * a8 + 2 * a4 + aperm_sort_tmp(nnz, aperm_bits(dim, ndim)) + 256;
+	// (leaf-preserving permutations: only the scratch of a scan over the leaf counts)
+	double nl = 1.0;
+	for (int a = 1; a < ndim; a++) nl *= (double) (dim[a] > 0 ? dim[a] : 1);
+	size_t scan_b = 0;
+	if (nl < 2147483646.0)
+		(void) hipcub::DeviceScan::ExclusiveSum(NULL, scan_b, (int64_t *) NULL, (int64_t *) NULL, (int) nl + 1);
+	return 2 * a8 + 2 * a4 + aperm_sort_tmp(nnz, aperm_bits(dim, ndim)) + scan_b + 256;
 }
 
 int launch_aperm(const int64_t *col_ptr, const int32_t *row_idx, const void *val, int Rtype,
@@ -273,6 +325,27 @@ int launch_aperm(const int64_t *col_ptr, const int32_t *row_idx, const void *val
 	const unsigned nbl = (unsigned) ((new_nleaves + 1 + 255) / 256);
 	if (nnz == 0) {
 		HIP_TRY(hipMemsetAsync(out_ptr, 0, (size_t) (new_nleaves + 1) * 8, s));
+		return 0;
+	}
+	if (perm[0] == 0 && new_nleaves < ((int64_t) 1 << 31) - 1) {
+		LeafMap lm;
+		lm.ndim = ndim;
+		int64_t os[8], st = 1;
+		for (int a = 1; a < ndim; a++) { os[a] = st; st *= dim[a]; }      // leaf strides of the old axes
+		for (int a = 1; a < ndim; a++) { lm.new_dim[a] = dim[perm[a]]; lm.old_stride[a] = os[perm[a]]; }
+		// counts into out_ptr, exclusive scan in place (the scan's scratch comes from the workspace)
+		hipLaunchKernelGGL(aperm_leaf_count_kernel, dim3(nbl), dim3(256), 0, s, col_ptr, new_nleaves, lm, out_ptr);
+		size_t tb = 0;
+		(void) hipcub::DeviceScan::ExclusiveSum(NULL, tb, out_ptr, out_ptr, (int) (new_nleaves + 1));
+		HIP_TRY(hipcub::DeviceScan::ExclusiveSum(ws, tb, out_ptr, out_ptr, (int) (new_nleaves + 1), s));
+		const unsigned nbc = (unsigned) ((new_nleaves + 3) / 4);
+		if (Rtype == SVT_REALSXP)
+			hipLaunchKernelGGL(aperm_leaf_copy_kernel<double>, dim3(nbc), dim3(256), 0, s, col_ptr, row_idx,
+					   (const double *) val, new_nleaves, lm, out_ptr, out_idx, (double *) out_val);
+		else
+			hipLaunchKernelGGL(aperm_leaf_copy_kernel<int32_t>, dim3(nbc), dim3(256), 0, s, col_ptr, row_idx,
+					   (const int32_t *) val, new_nleaves, lm, out_ptr, out_idx, (int32_t *) out_val);
+		HIP_TRY(hipGetLastError());
 		return 0;
 	}
 	const size_t n = (size_t) nnz;

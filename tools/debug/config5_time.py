@@ -35,7 +35,7 @@ for name, fn, nbytes in (
 # aperm(x, c(3, 1, 2)): dim 3 becomes the leaf dimension; then "row stats along dim 3" are column
 # statistics of the permuted array (R/SparseArray-matrixStats.R:122-190 does exactly that on the host)
 import time
-for perm in ((3, 1, 2), (2, 1, 3)):
+for perm in ((1, 3, 2), (3, 1, 2), (2, 1, 3)):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     P, pdim = A.aperm(D, perm)
     torch.cuda.synchronize(); t1 = time.perf_counter()
