@@ -259,6 +259,62 @@ aperm_leaf_copy_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__res
 	}
 }
 
+// ---- leaf-shattering permutations, 32-bit keys.  A stable sort by the NEW LEAF index alone is enough:
+// two nonzeros of one new leaf differ only in the coordinate that becomes the new row, and the input order
+// (old leaves in order, offsets ascending) already ascends in that coordinate for fixed other ones.  So the
+// key is ceil(log2(new leaves)) bits instead of ceil(log2(prod(dim))): 29 instead of 35 at BASELINE config 5,
+// 32-bit keys, one radix pass less, and the new row travels beside the sort instead of through it.
+__global__ void aperm_key32_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__ row_idx,
+				   const uint32_t *__restrict__ hint, int64_t ncol, int64_t nnz, ApermDims d,
+				   uint32_t *__restrict__ keys, uint32_t *__restrict__ pos, int32_t *__restrict__ newrow)
+{
+	const int64_t k = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= nnz) return;
+	int64_t lo = hint[k >> HINT_SHIFT], hi = hint[(k >> HINT_SHIFT) + 1];      // old leaf of position k
+	if (hi > ncol - 1) hi = ncol - 1;
+	while (lo < hi) {
+		const int64_t mid = (lo + hi + 1) >> 1;
+		if (col_ptr[mid] <= k) lo = mid; else hi = mid - 1;
+	}
+	// d.mul[a] = multiplier of old axis a in the new linear index; new leaf = (linear - new row) / new dim0
+	const int64_t r = row_idx[k];
+	unsigned long long lin = (unsigned long long) r * (unsigned long long) d.mul[0];
+	int64_t nr = d.perm[0] == 0 ? r : 0, rest = lo;
+	for (int a = 1; a < d.ndim; a++) {
+		const int64_t ia = rest % d.dim[a];
+		rest /= d.dim[a];
+		lin += (unsigned long long) ia * (unsigned long long) d.mul[a];
+		if (d.perm[0] == a) nr = ia;
+	}
+	keys[k] = (uint32_t) ((lin - (unsigned long long) nr) / (unsigned long long) d.dim[d.perm[0]]);
+	pos[k] = (uint32_t) k;
+	newrow[k] = (int32_t) nr;
+}
+
+// out_ptr[j] = first sorted position whose leaf is >= j: every sorted element fills the leaves between its
+// predecessor's and its own (most new leaves are empty when leaves shatter: a search per leaf costs more)
+__global__ void aperm_ptr_fill_kernel(const uint32_t *__restrict__ skeys, int64_t nnz, int64_t nleaves,
+				      int64_t *__restrict__ out_ptr)
+{
+	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if (i > nnz) return;
+	const int64_t from = i == 0 ? 0 : (int64_t) skeys[i - 1] + 1;
+	const int64_t to = i == nnz ? nleaves : (int64_t) skeys[i];
+	for (int64_t j = from; j <= to; j++) out_ptr[j] = i;
+}
+
+template <typename T>
+__global__ void aperm_gather32_kernel(const uint32_t *__restrict__ spos, const int32_t *__restrict__ newrow,
+				      const T *__restrict__ val, int64_t nnz, int32_t *__restrict__ out_idx,
+				      T *__restrict__ out_val)
+{
+	const int64_t i = xcd_chunk((nnz + blockDim.x - 1) / blockDim.x) * blockDim.x + threadIdx.x;
+	if (i >= nnz) return;
+	const uint32_t k = spos[i];
+	out_idx[i] = newrow[k];
+	out_val[i] = val[k];
+}
+
 static int aperm_bits(const int64_t *dim, int ndim)
 {
 	double tot = 1.0;
@@ -288,7 +344,12 @@ size_t aperm_ws_bytes(int64_t nnz, const int64_t *dim, int ndim)
 	size_t scan_b = 0;
 	if (nl < 2147483646.0)
 		(void) hipcub::DeviceScan::ExclusiveSum(NULL, scan_b, (int64_t *) NULL, (int64_t *) NULL, (int) nl + 1);
-	return 2 * a8 + 2 * a4 + aperm_sort_tmp(nnz, aperm_bits(dim, ndim)) + scan_b + 256;
+	size_t t32 = 0;
+	(void) hipcub::DeviceRadixSort::SortPairs(NULL, t32, (const uint32_t *) NULL, (uint32_t *) NULL,
+						  (const uint32_t *) NULL, (uint32_t *) NULL, (int) nnz, 0, 32);
+	const size_t need64 = 2 * a8 + 2 * a4 + aperm_sort_tmp(nnz, aperm_bits(dim, ndim));
+	const size_t need32 = 5 * a4 + hint_bytes(nnz) + t32;
+	return (need64 > need32 ? need64 : need32) + scan_b + 256;
 }
 
 int launch_aperm(const int64_t *col_ptr, const int32_t *row_idx, const void *val, int Rtype,
@@ -345,6 +406,36 @@ int launch_aperm(const int64_t *col_ptr, const int32_t *row_idx, const void *val
 		else
 			hipLaunchKernelGGL(aperm_leaf_copy_kernel<int32_t>, dim3(nbc), dim3(256), 0, s, col_ptr, row_idx,
 					   (const int32_t *) val, new_nleaves, lm, out_ptr, out_idx, (int32_t *) out_val);
+		HIP_TRY(hipGetLastError());
+		return 0;
+	}
+	if (new_nleaves < ((int64_t) 1 << 31) - 1) {
+		const size_t a4 = ((size_t) nnz * 4 + 255) / 256 * 256;
+		uint32_t *keys = (uint32_t *) ws, *skeys = (uint32_t *) ((char *) ws + a4);
+		uint32_t *pos = (uint32_t *) ((char *) ws + 2 * a4), *spos = (uint32_t *) ((char *) ws + 3 * a4);
+		int32_t *newrow = (int32_t *) ((char *) ws + 4 * a4);
+		uint32_t *hint = (uint32_t *) ((char *) ws + 5 * a4);
+		void *tmp = (char *) ws + 5 * a4 + hint_bytes(nnz);
+		int bits = 1;
+		while (bits < 32 && ((int64_t) 1 << bits) < new_nleaves) bits++;
+		size_t tb = 0;
+		(void) hipcub::DeviceRadixSort::SortPairs(NULL, tb, (const uint32_t *) NULL, (uint32_t *) NULL,
+							  (const uint32_t *) NULL, (uint32_t *) NULL, (int) nnz, 0, bits);
+		const unsigned nb = (unsigned) ((nnz + 255) / 256);
+		const unsigned nb8 = (unsigned) (((nnz + 255) / 256 + 7) / 8 * 8);
+		const int64_t nblk = (nnz >> HINT_SHIFT) + 1;
+		hipLaunchKernelGGL(col_hint_kernel, dim3((unsigned) ((nblk + 1 + 255) / 256)), dim3(256), 0, s, col_ptr, ncol, nblk, hint);
+		hipLaunchKernelGGL(aperm_key32_kernel, dim3(nb), dim3(256), 0, s, col_ptr, row_idx, hint, ncol, nnz, d,
+				   keys, pos, newrow);
+		HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tb, keys, skeys, pos, spos, (int) nnz, 0, bits, s));
+		hipLaunchKernelGGL(aperm_ptr_fill_kernel, dim3((unsigned) ((nnz + 1 + 255) / 256)), dim3(256), 0, s,
+				   skeys, nnz, new_nleaves, out_ptr);
+		if (Rtype == SVT_REALSXP)
+			hipLaunchKernelGGL(aperm_gather32_kernel<double>, dim3(nb8), dim3(256), 0, s, spos, newrow,
+					   (const double *) val, nnz, out_idx, (double *) out_val);
+		else
+			hipLaunchKernelGGL(aperm_gather32_kernel<int32_t>, dim3(nb8), dim3(256), 0, s, spos, newrow,
+					   (const int32_t *) val, nnz, out_idx, (int32_t *) out_val);
 		HIP_TRY(hipGetLastError());
 		return 0;
 	}
