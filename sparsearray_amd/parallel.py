@@ -143,6 +143,53 @@ def shard_cols_device(A, rank: int, world: int):
     return DeviceCSC(A.nrow, cp.contiguous(), ri, v), blocks
 
 
+def shard_axis_device(A, dim, axis: int, rank: int, world: int):
+    """An N-d array (extents `dim`, dim[0] == A.nrow, leaves in R's order: axis 1 fastest) cut along
+    `axis` >= 1: rank r keeps the leaves whose coordinate on that axis lies in its block.  Returns
+    (shard as a DeviceCSC, its extents, (lo, hi) on the axis).  BASELINE config 5: shard axis 1 (the
+    2e4 columns) of the 2e4 x 2e4 x 64 array, so that every rank owns whole output cells of
+    `rowSums(dims=2)` (a sum over axis 2) and whole leaves for the column statistics: no collective
+    except the gather of the results."""
+    from .device import DeviceCSC
+    dim = [int(d) for d in dim]
+    assert 1 <= axis < len(dim) and dim[0] == A.nrow
+    lo, hi = row_block(dim[axis], rank, world)
+    dev = A.val.device
+    nleaves = A.ncol
+    inner = int(np.prod(dim[1:axis], dtype=np.int64)) if axis > 1 else 1      # leaves per step of `axis`
+    j = torch.arange(nleaves, device=dev)
+    keep = ((j // inner) % dim[axis] >= lo) & ((j // inner) % dim[axis] < hi)
+    counts = (A.col_ptr[1:] - A.col_ptr[:-1])[keep]
+    new_ptr = torch.zeros(int(keep.sum()) + 1, dtype=torch.int64, device=dev)
+    new_ptr[1:] = torch.cumsum(counts, 0)
+    starts = A.col_ptr[:-1][keep]
+    # source position of every kept nonzero: start of its leaf + offset inside the leaf
+    leaf_of = torch.repeat_interleave(torch.arange(counts.numel(), device=dev), counts)
+    src = starts[leaf_of] + (torch.arange(int(new_ptr[-1]), device=dev) - new_ptr[:-1][leaf_of])
+    new_dim = list(dim)
+    new_dim[axis] = hi - lo
+    return DeviceCSC(A.nrow, new_ptr, A.row_idx[src], A.val[src]), tuple(new_dim), (lo, hi)
+
+
+def gather_axis(local: torch.Tensor, out_dim, axis: int, blocks, group=None) -> torch.Tensor:
+    """Inverse of the cut for a result laid out like the array (R order over `out_dim`, rank r holding
+    the slab blocks[r] of `axis`): all-gather of the slabs, then every slab goes to its place."""
+    world = _world(group)
+    if world == 1:
+        return local
+    out_dim = [int(d) for d in out_dim]
+    inner = int(np.prod(out_dim[:axis], dtype=np.int64)) if axis > 0 else 1
+    outer = int(np.prod(out_dim[axis + 1:], dtype=np.int64)) if axis + 1 < len(out_dim) else 1
+    sizes = [inner * (b[1] - b[0]) * outer for b in blocks]
+    flat = gather_columns(local.reshape(-1), sizes, group)
+    out = torch.empty(inner * out_dim[axis] * outer, dtype=local.dtype, device=local.device).view(outer, out_dim[axis], inner)
+    off = 0
+    for (lo, hi), n in zip(blocks, sizes):
+        out[:, lo:hi, :] = flat[off:off + n].view(outer, hi - lo, inner)
+        off += n
+    return out.reshape(-1)
+
+
 class ShardedCrossprod:
     """crossprod(A, Y) with A and Y sharded on rows.  Every rank holds its row block of A (with
     the panel-blocked layout of that block, built once) and of Y; a step computes the rank's

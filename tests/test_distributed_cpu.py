@@ -60,6 +60,12 @@ def _worker(rank, world, port, q):
         part = par.sharded_colsums_rows(None, local=lambda: torch.from_numpy(
             np.asarray(S.colSums(shard), dtype=np.float64).copy()))
         ok5 = np.allclose(part.numpy(), S.colSums(full), rtol=1e-12, atol=1e-12)
+        # slabs of an axis gathered back into place (config 5: results of an array cut along axis 1)
+        full3 = torch.arange(5 * 7 * 3, dtype=torch.float64)
+        blk = [par.row_block(7, r, world) for r in range(world)]
+        lo, hi = blk[rank]
+        mine = full3.view(3, 7, 5)[:, lo:hi, :].reshape(-1)
+        ok5 = ok5 and bool(torch.equal(par.gather_axis(mine, (5, 7, 3), 1, blk), full3))
         q.put((rank, ok1, ok2, ok3, ok4, ok5))
     finally:
         dist.destroy_process_group()

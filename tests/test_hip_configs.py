@@ -137,7 +137,8 @@ def test_config5_aperm_full_size(hip, perm):
 def test_two_ranks_same_device_sharded_ops_match_one_rank(hip, tmp_path):
     """Launches tests/workers/dist_gpu_worker.py as a 2-rank torch.distributed.run job (gloo, both
     ranks on GPU 0) and checks its verdict: row-sharded crossprod + all-reduce, row-sharded
-    colSums + all-reduce, leaf-sharded colVars and rowsum + gather, on slices of configs 2a and 4,
+    colSums + all-reduce, leaf-sharded colVars and rowsum + gather, on slices of configs 2a and 4, and
+    a slice of config 5 cut along axis 1 (per-leaf column sums, rowSums over axis 2, aperm of the shard),
     each against the one-rank result."""
     torch.cuda.empty_cache()
     out = tmp_path / "verdict.json"
@@ -150,7 +151,10 @@ def test_two_ranks_same_device_sharded_ops_match_one_rank(hip, tmp_path):
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     verdict = json.loads(out.read_text())
-    assert set(verdict) == {"config2a_slice", "config4_slice"}
+    assert set(verdict) == {"config2a_slice", "config4_slice", "config5_slice"}
+    v5 = verdict.pop("config5_slice")
+    assert v5["colsums_identical"] and v5["aperm_colsums_identical"], v5
+    assert v5["rowsums_rel_err"] <= 1e-12, v5
     for name, v in verdict.items():
         assert v["same_shard"], name
         assert v["crossprod_rel_err"] <= 1e-12, (name, v)

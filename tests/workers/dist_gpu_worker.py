@@ -74,6 +74,31 @@ def main():
                          "nnz": A.nnz, "rows_rank": r1 - r0, "blocks": blocks}
         del sc, A, Al, As, Ac, Y, Yl, got, ref
         torch.cuda.empty_cache()
+    # ---- BASELINE config 5, a slice: 3-d array cut along axis 1; column statistics per leaf, rowSums over
+    # axis 2 (every output cell owned by one rank), aperm of the shard; results gathered and compared
+    from sparsearray_amd.device import rowsums
+    D = (4000, 600, 16)
+    cp, ri, v = synth.random_device_csc(D[0], D[1] * D[2], 0.005, seed=21, device=dev)
+    A = DeviceCSC(D[0], cp, ri, v)
+    blocks5 = [par.row_block(D[1], r, world) for r in range(world)]
+    As, sdim, (lo, hi) = par.shard_axis_device(A, D, 1, rank, world)
+    cs_loc, _ = colstats(As, "sum")                                   # one sum per leaf of the shard: (hi-lo) x 16
+    cs = par.gather_axis(cs_loc, (D[1], D[2]), 0, blocks5)
+    cs_ref, _ = colstats(A, "sum")
+    rs_loc = rowsums(As, inner=sdim[1])                               # D[0] x (hi-lo): sum over axis 2
+    rs = par.gather_axis(rs_loc, (D[0], D[1]), 1, blocks5)
+    rs_ref = rowsums(A, inner=D[1])
+    Ps, pdim = As.aperm(sdim, (1, 3, 2))                              # leaf-preserving on the shard
+    cs2_loc, _ = colstats(Ps, "sum")                                  # leaves in (axis 2, axis 1) order
+    cs2 = par.gather_axis(cs2_loc, (D[2], D[1]), 1, blocks5)
+    Pf, _ = A.aperm(D, (1, 3, 2))
+    cs2_ref, _ = colstats(Pf, "sum")
+    torch.cuda.synchronize()
+    verdict["config5_slice"] = {
+        "colsums_identical": bool(torch.equal(cs, cs_ref)),
+        "rowsums_rel_err": float((rs - rs_ref).abs().max()) / max(float(rs_ref.abs().max()), 1e-300),
+        "aperm_colsums_identical": bool(torch.equal(cs2, cs2_ref)),
+        "shard_nnz": As.nnz, "axis_block": [lo, hi]}
     dist.barrier()
     if rank == 0:
         with open(out_path, "w") as f:
