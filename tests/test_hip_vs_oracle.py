@@ -509,3 +509,19 @@ def test_crossprod1_large_is_triangular_and_symmetric(hip, oracle):
     assert_equal(got, want, tol=1e-9, atol=1e-11, strict_na=True, what="crossprod(x)")
     g = np.asarray(got)
     assert np.array_equal(g, g.T, equal_nan=True)
+
+
+def test_crossprod_large_very_sparse_takes_gather_kernel(hip, oracle):
+    """Host-level crossprod above the panel-kernel threshold at 0.1 % density: the layout chosen by density is
+    the gather one (rows of Y straight from L2).  Both operand orders, the transposed orientation, an NA leaf
+    and a non-finite entry in the dense operand."""
+    x = _svt(2_000_000, 2000, 0.001, 97)                # 4e6 nonzeros, K = 70: nnz * K = 2.8e8
+    x = _sprinkle(x, 98, [NA_real])
+    rng = np.random.default_rng(99)
+    y = rng.uniform(-1, 1, (2_000_000, 70))
+    assert_equal(hip.crossprod(x, y), oracle.crossprod(x, y), tol=1e-9, atol=1e-11, strict_na=True)
+    assert_equal(hip.crossprod(y, x), oracle.crossprod(y, x), tol=1e-9, atol=1e-11, strict_na=True)
+    yt = np.asfortranarray(y.T)
+    assert_equal(hip.tcrossprod(x.t(), yt), oracle.tcrossprod(x.t(), yt), tol=1e-9, atol=1e-11, strict_na=True)
+    y[1_234_567, 3] = np.inf
+    assert_equal(hip.crossprod(x, y), oracle.crossprod(x, y), tol=1e-9, atol=1e-11, strict_na=True)
