@@ -179,7 +179,7 @@ __global__ void rowstats_minmax_finish_kernel(RowStatsArgs a)
 // --------------------------------------------------------------------------
 // Row-panel variant: no memory-side atomics.
 //
-// The output (inner x nrow cells) is cut into panels of ROWPANEL rows; one
+// The output (inner x nrow cells) is cut into panels of 2048 or 8192 rows; one
 // workgroup owns one (output column i, panel q) pair, keeps its cells in LDS
 // (ds_add_f64 / ds_min_u64 ...), walks the nstrata leaves j = i + s*inner that
 // land on it and stores the finished cells once, coalesced.  The part of leaf j
@@ -187,21 +187,29 @@ __global__ void rowstats_minmax_finish_kernel(RowStatsArgs a)
 // come from a table built by one binary search per (leaf, panel boundary)
 // (rowpanel_table_kernel).  Traffic: A once (12 B/nz) + the table + out once.
 // --------------------------------------------------------------------------
-#define ROWPANEL 2048
+// Panel length: 2048 rows by default (16 bytes of LDS per row serve every operation); the
+// sum-like operations on a zero-background operand with many rows take 8192-row panels -- four
+// times longer leaf segments (81 instead of 20 nonzeros at BASELINE config 2: whole 128-byte
+// lines instead of fragments of them) -- and, when that leaves fewer workgroups than the chip
+// has slots, cut the strata into `gridDim.z` ranges whose partial cells meet in `out` through
+// memory-side atomics (one coalesced add per cell and range).
+#define ROWPANEL_MIN 2048
+#define ROWPANEL_SHIFT 11
+#define ROWPANEL_BIG_SHIFT 13
 #define ROWPANEL_NT 1024
 
 size_t rowstats_panel_ws_bytes(int64_t nrow, int64_t ncol)
 {
-	const int64_t npan = (nrow + ROWPANEL - 1) / ROWPANEL;
+	const int64_t npan = (nrow + ROWPANEL_MIN - 1) / ROWPANEL_MIN;   // the shortest panels
 	return (size_t) (ncol > 0 ? ncol : 1) * (size_t) (npan + 1) * 4 + 64;
 }
 
-// pt[q*ncol + j] = number of offsets of leaf j that are < q*ROWPANEL, q = 0..npan.
+// pt[q*ncol + j] = number of offsets of leaf j that are < q << ps, q = 0..npan.
 // One wavefront per leaf streams its offsets once; the element that is the
 // first of its leaf at or past a panel boundary writes that boundary's entry.
 __global__ void __launch_bounds__(256)
 rowpanel_table_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__ row_idx,
-		      int64_t ncol, int64_t npan, int32_t *__restrict__ pt)
+		      int64_t ncol, int64_t npan, int ps, int32_t *__restrict__ pt)
 {
 	// long leaves: the whole workgroup on one leaf; short ones: a wavefront each
 	const bool wide = gridDim.x == (unsigned) ncol;
@@ -212,16 +220,16 @@ rowpanel_table_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__rest
 		return;
 	const int64_t beg = col_ptr[j], end = col_ptr[j + 1];
 	for (int64_t k = beg + tid; k < end; k += nt) {
-		const int64_t p = row_idx[k] / ROWPANEL;
+		const int64_t p = row_idx[k] >> ps;
 		// previous offset: the lane below holds it, except at the start of a wavefront
 		int prev = __shfl_up((int) p, 1, 64);
 		if ((threadIdx.x & 63) == 0 || k == beg)
-			prev = k == beg ? -1 : row_idx[k - 1] / ROWPANEL;
+			prev = k == beg ? -1 : row_idx[k - 1] >> ps;
 		for (int64_t q = (int64_t) prev + 1; q <= p; q++)
 			pt[q * ncol + j] = (int32_t) (k - beg);
 	}
 	// boundaries past the last offset (all of them for an empty leaf)
-	const int64_t pl = end > beg ? row_idx[end - 1] / ROWPANEL : -1;
+	const int64_t pl = end > beg ? row_idx[end - 1] >> ps : -1;
 	for (int64_t q = pl + 1 + tid; q <= npan; q += nt)
 		pt[q * ncol + j] = (int32_t) (end - beg);
 }
@@ -233,7 +241,7 @@ rowpanel_table_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__rest
 #define PT_LEAVES 16
 __global__ void __launch_bounds__(PT_LEAVES * 64)
 rowpanel_table16_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__ row_idx,
-			int64_t ncol, int64_t npan, int32_t *__restrict__ pt)
+			int64_t ncol, int64_t npan, int ps, int32_t *__restrict__ pt)
 {
 	extern __shared__ int32_t tab[];            // [npan + 1][PT_LEAVES]
 	const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -251,7 +259,7 @@ rowpanel_table16_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__re
 #pragma unroll
 			for (int u = 0; u < 4; u++) {
 				const int64_t k = k0 + u * 64 + lane;
-				const int p = r[u] / ROWPANEL;
+				const int p = r[u] >> ps;
 				int prev = __shfl_up(p, 1, 64);
 				if (lane == 0) prev = carry;
 				carry = __shfl(p, 63, 64);
@@ -260,7 +268,7 @@ rowpanel_table16_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__re
 						tab[(int64_t) q * PT_LEAVES + w] = (int32_t) (k - beg);
 			}
 		}
-		const int64_t pl = end > beg ? row_idx[end - 1] / ROWPANEL : -1;
+		const int64_t pl = end > beg ? row_idx[end - 1] >> ps : -1;
 		for (int64_t q = pl + 1 + lane; q <= npan; q += 64)
 			tab[q * PT_LEAVES + w] = (int32_t) (end - beg);
 	}
@@ -277,22 +285,28 @@ rowpanel_table16_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__re
 // it from the mean segment length so that short segments still fill the wave.
 template <typename T>
 __global__ void __launch_bounds__(ROWPANEL_NT)
-rowstats_panel_kernel(RowStatsArgs a, const int32_t *__restrict__ pt, int64_t npan, int G)
+rowstats_panel_kernel(RowStatsArgs a, const int32_t *__restrict__ pt, int64_t npan, int G, int ps)
 {
-	extern __shared__ unsigned long long lds64[];   // ROWPANEL cells
+	extern __shared__ unsigned long long lds64[];   // 1 << ps cells
 	const int64_t q = blockIdx.x, i = blockIdx.y;
-	const int tid = threadIdx.x;
-	const int64_t r0 = q * ROWPANEL;
-	const int np = (int) (a.nrow - r0 < ROWPANEL ? a.nrow - r0 : ROWPANEL);   // rows in this panel
+	const int tid = threadIdx.x, NT = blockDim.x;
+	const int prow = 1 << ps;
+	const int64_t r0 = q * prow;
+	const int np = (int) (a.nrow - r0 < prow ? a.nrow - r0 : prow);   // rows in this panel
+	// strata range of this workgroup (gridDim.z > 1: sum-like operations only, `out` zeroed)
+	const bool split = gridDim.z > 1;
+	const int64_t s_chunk = (a.nstrata + gridDim.z - 1) / gridDim.z;
+	const int64_t s_lo = (int64_t) blockIdx.z * s_chunk;
+	const int64_t s_hi = s_lo + s_chunk < a.nstrata ? s_lo + s_chunk : a.nstrata;
 	const int64_t cell0 = i * a.nrow + r0;
 	const bool is_dbl = sizeof(T) == 8;
 	const bool narm = a.na_rm != 0;
 	const int oc = a.opcode;
 	const bool is_minmax = oc == SVT_OP_MIN || oc == SVT_OP_MAX;
 	double *accd = (double *) lds64;
-	double *cen = accd + ROWPANEL;                       // centered_X2_sum only
-	int *flg = (int *) (lds64 + ROWPANEL);               // min/max only
-	unsigned int *cov = (unsigned int *) (flg + ROWPANEL);
+	double *cen = accd + prow;                           // centered_X2_sum only
+	int *flg = (int *) (lds64 + prow);                   // min/max only
+	unsigned int *cov = (unsigned int *) (flg + prow);
 	const T *__restrict__ val = (const T *) a.val;
 	const int32_t *__restrict__ row = a.row_idx;
 	const double NAr = svt_na_real();
@@ -302,7 +316,7 @@ rowstats_panel_kernel(RowStatsArgs a, const int32_t *__restrict__ pt, int64_t np
 	//   min / max: the NA background joins instead of the implicit zero (:914-961)
 	const bool nabg = a.na_bg != 0;
 
-	for (int r = tid; r < np; r += ROWPANEL_NT) {
+	for (int r = tid; r < np; r += NT) {
 		if (is_minmax) {
 			lds64[r] = oc == SVT_OP_MIN ? ~0ULL : 0ULL;
 			flg[r] = 0;
@@ -310,7 +324,7 @@ rowstats_panel_kernel(RowStatsArgs a, const int32_t *__restrict__ pt, int64_t np
 		} else if (oc == SVT_OP_CENTERED_X2_SUM) {
 			const double c = a.center ? a.center[cell0 + r] : 0.0;
 			cen[r] = c;
-			accd[r] = a.center ? c * c * (double) a.nstrata : 0.0;
+			accd[r] = a.center && blockIdx.z == 0 ? c * c * (double) a.nstrata : 0.0;
 		} else if (oc == SVT_OP_ANYNA && !nabg) {
 			((int *) lds64)[r] = 0;
 		} else {
@@ -319,64 +333,100 @@ rowstats_panel_kernel(RowStatsArgs a, const int32_t *__restrict__ pt, int64_t np
 		}
 	}
 	__syncthreads();
-	const int sub = tid / G, sl = tid % G, nsub = ROWPANEL_NT / G;
+	const int sub = tid / G, sl = tid % G, nsub = NT / G;
 	const int32_t *__restrict__ pt0 = pt + q * a.ncol, *__restrict__ pt1 = pt0 + a.ncol;
-	int64_t nbeg = 0, nend = 0;
-	if (sub < a.nstrata) {
-		const int64_t j = i + (int64_t) sub * a.inner;
-		const int64_t base = a.col_ptr[j];
-		nbeg = base + pt0[j]; nend = base + pt1[j];
-	}
-	for (int64_t s = sub; s < a.nstrata; s += nsub) {
-		const int64_t beg = nbeg, end = nend;
-		if (s + nsub < a.nstrata) {                  // next segment's bounds, ahead of use
-			const int64_t j = i + (s + nsub) * a.inner;
-			const int64_t base = a.col_ptr[j];
-			nbeg = base + pt0[j]; nend = base + pt1[j];
+	// one nonzero into its cell
+	auto apply = [&](const T v, const int r) {
+		const bool miss = is_dbl ? (v != v) : ((int) v == NA_INT);
+		switch (oc) {
+		case SVT_OP_ANYNA:
+			if (nabg) { if (!miss) atomicAdd(accd + r, 1.0); }
+			else if (miss) ((int *) lds64)[r] = 1;
+			break;
+		case SVT_OP_COUNTNAS:
+			if (nabg ? !miss : miss) atomicAdd(accd + r, 1.0);
+			break;
+		case SVT_OP_SUM:
+			if (nabg && !narm) atomicAdd(cov + r, 1u);
+			if (miss && narm) break;
+			atomicAdd(accd + r, (!is_dbl && miss) ? NAr : (double) v);
+			break;
+		case SVT_OP_CENTERED_X2_SUM: {
+			const double c = cen[r];
+			if (miss && narm) { atomicAdd(accd + r, -(c * c)); break; }
+			const double x = (!is_dbl && miss) ? NAr : (double) v;
+			atomicAdd(accd + r, x * (x - 2 * c));
+			break;
 		}
-		for (int64_t k = beg + sl; k < end; k += G) {
-			const T v = val[k];
-			const int r = (int) (row[k] - r0);
-			const bool miss = is_dbl ? (v != v) : ((int) v == NA_INT);
-			switch (oc) {
-			case SVT_OP_ANYNA:
-				if (nabg) { if (!miss) atomicAdd(accd + r, 1.0); }
-				else if (miss) ((int *) lds64)[r] = 1;
-				break;
-			case SVT_OP_COUNTNAS:
-				if (nabg ? !miss : miss) atomicAdd(accd + r, 1.0);
-				break;
-			case SVT_OP_SUM:
-				if (nabg && !narm) atomicAdd(cov + r, 1u);
-				if (miss && narm) break;
-				atomicAdd(accd + r, (!is_dbl && miss) ? NAr : (double) v);
-				break;
-			case SVT_OP_CENTERED_X2_SUM: {
-				const double c = cen[r];
-				if (miss && narm) { atomicAdd(accd + r, -(c * c)); break; }
-				const double x = (!is_dbl && miss) ? NAr : (double) v;
-				atomicAdd(accd + r, x * (x - 2 * c));
+		default: {
+			atomicAdd(cov + r, 1u);
+			if (miss) {
+				const bool isna = is_dbl ? svt_is_na((double) v) : true;
+				atomicOr(flg + r, isna ? RF_NA : RF_NAN);
 				break;
 			}
-			default: {
-				atomicAdd(cov + r, 1u);
-				if (miss) {
-					const bool isna = is_dbl ? svt_is_na((double) v) : true;
-					atomicOr(flg + r, isna ? RF_NA : RF_NAN);
-					break;
+			atomicOr(flg + r, RF_HAVE);
+			const unsigned long long key = is_dbl ?
+				f64_to_ordered((double) v) :
+				(unsigned long long) ((long long) (int) v + 0x80000000LL);
+			if (oc == SVT_OP_MIN) atomicMin(lds64 + r, key);
+			else atomicMax(lds64 + r, key);
+		}
+		}
+	};
+	// RS_U leaf segments per lane group at a time, their loads in flight together (one segment
+	// after the other leaves a wavefront with a single load pair outstanding: 2.1 TB/s at
+	// BASELINE config 2); the next round's bounds are fetched a round ahead.
+	constexpr int RS_U = 4;
+	int64_t nb[RS_U], ne[RS_U];
+	auto bounds = [&](const int64_t s0) {
+#pragma unroll
+		for (int u = 0; u < RS_U; u++) {
+			const int64_t s = s0 + (int64_t) u * nsub;
+			nb[u] = ne[u] = 0;
+			if (s < s_hi) {
+				const int64_t j = i + s * a.inner;
+				const int64_t base = a.col_ptr[j];
+				nb[u] = base + pt0[j] + sl; ne[u] = base + pt1[j];
+			}
+		}
+	};
+	bounds(s_lo + sub);
+	for (int64_t s = s_lo + sub; s < s_hi; s += (int64_t) nsub * RS_U) {
+		int64_t kb[RS_U], ke[RS_U];
+#pragma unroll
+		for (int u = 0; u < RS_U; u++) { kb[u] = nb[u]; ke[u] = ne[u]; }
+		if (s + (int64_t) nsub * RS_U < s_hi)
+			bounds(s + (int64_t) nsub * RS_U);
+		bool more = true;
+		while (more) {
+			T v[RS_U];
+			int r[RS_U];
+#pragma unroll
+			for (int u = 0; u < RS_U; u++)
+				if (kb[u] < ke[u]) { v[u] = val[kb[u]]; r[u] = (int) (row[kb[u]] - r0); }
+			more = false;
+#pragma unroll
+			for (int u = 0; u < RS_U; u++)
+				if (kb[u] < ke[u]) {
+					apply(v[u], r[u]);
+					kb[u] += G;
+					more |= kb[u] < ke[u];
 				}
-				atomicOr(flg + r, RF_HAVE);
-				const unsigned long long key = is_dbl ?
-					f64_to_ordered((double) v) :
-					(unsigned long long) ((long long) (int) v + 0x80000000LL);
-				if (oc == SVT_OP_MIN) atomicMin(lds64 + r, key);
-				else atomicMax(lds64 + r, key);
-			}
-			}
 		}
 	}
 	__syncthreads();
-	for (int r = tid; r < np; r += ROWPANEL_NT) {
+	if (split) {                                 // partial cells of this strata range
+		for (int r = tid; r < np; r += NT) {
+			if (oc == SVT_OP_ANYNA) {
+				if (((int *) lds64)[r]) ((int *) a.out)[cell0 + r] = 1;
+			} else {
+				atomicAdd((double *) a.out + cell0 + r, accd[r]);
+			}
+		}
+		return;
+	}
+	for (int r = tid; r < np; r += NT) {
 		const int64_t cell = cell0 + r;
 		if (!is_minmax) {
 			if (nabg && (oc == SVT_OP_ANYNA || oc == SVT_OP_COUNTNAS)) {
@@ -431,19 +481,25 @@ int launch_rowstats_panel(const RowStatsArgs &a, void *ws, hipStream_t s)
 {
 	if (a.out_len <= 0)
 		return 0;
-	const int64_t npan = (a.nrow + ROWPANEL - 1) / ROWPANEL;
+	const int oc = a.opcode;
+	const bool sumlike = oc == SVT_OP_SUM || oc == SVT_OP_COUNTNAS || oc == SVT_OP_CENTERED_X2_SUM ||
+		oc == SVT_OP_ANYNA;
+	const bool big = sumlike && !a.na_bg && a.nrow >= (2LL << ROWPANEL_BIG_SHIFT);
+	const int ps = big ? ROWPANEL_BIG_SHIFT : ROWPANEL_SHIFT;
+	const int64_t prow = 1LL << ps;
+	const int64_t npan = (a.nrow + prow - 1) / prow;
 	int32_t *pt = (int32_t *) ws;
 	if (a.inner > 65535)
 		return svt_set_error("row stats: more than 65535 output columns per panel row");
 	if (a.ncol > 0 && (size_t) (npan + 1) * PT_LEAVES * 4 <= 64 * 1024) {
 		hipLaunchKernelGGL(rowpanel_table16_kernel, dim3((unsigned) ((a.ncol + PT_LEAVES - 1) / PT_LEAVES)),
 				   dim3(PT_LEAVES * 64), (size_t) (npan + 1) * PT_LEAVES * 4, s,
-				   a.col_ptr, a.row_idx, a.ncol, npan, pt);
+				   a.col_ptr, a.row_idx, a.ncol, npan, ps, pt);
 	} else if (a.ncol > 0) {                    // very tall arrays: the table rows do not fit LDS
 		// (grid == ncol selects the workgroup-per-leaf form; never equal to (ncol+3)/4 for ncol > 1)
 		const bool wide = a.nnz_hint / a.ncol >= 1024 && a.ncol > 1;
 		hipLaunchKernelGGL(rowpanel_table_kernel, dim3((unsigned) (wide ? a.ncol : (a.ncol + 3) / 4)),
-				   dim3(256), 0, s, a.col_ptr, a.row_idx, a.ncol, npan, pt);
+				   dim3(256), 0, s, a.col_ptr, a.row_idx, a.ncol, npan, ps, pt);
 	}
 	// lanes per leaf segment ~ mean segment length (nnz unknown here: the
 	// caller passes it in a.nnz_hint, 0 = assume long segments)
@@ -452,12 +508,29 @@ int launch_rowstats_panel(const RowStatsArgs &a, void *ws, hipStream_t s)
 		const double seg = (double) a.nnz_hint / ((double) a.ncol * (double) npan);
 		while (G > 8 && seg <= G / 2) G >>= 1;
 	}
-	const size_t lds = (size_t) ROWPANEL * 16;
-	dim3 grid((unsigned) npan, (unsigned) a.inner);
+	// strata ranges: aim at two workgroups per CU when the panels alone are fewer
+	int64_t nsplit = 1;
+	if (big) {
+		nsplit = (2 * 256 + npan * a.inner / 2) / (npan * a.inner);
+		const int64_t cap = a.nstrata / (4 * (ROWPANEL_NT / G));      // >= 4 segments per lane group
+		if (nsplit > cap) nsplit = cap;
+		if (nsplit > 1024) nsplit = 1024;
+		if (nsplit < 1) nsplit = 1;
+	}
+	const int NT = ROWPANEL_NT;
+	const bool centered = oc == SVT_OP_CENTERED_X2_SUM;
+	const size_t lds = sumlike && !a.na_bg ? (size_t) prow * (centered ? 16 : 8) : (size_t) prow * 16;
+	if (nsplit > 1)
+		HIP_TRY(hipMemsetAsync(a.out, 0, (size_t) a.out_len * (oc == SVT_OP_ANYNA ? 4 : 8), s));
+	dim3 grid((unsigned) npan, (unsigned) a.inner, (unsigned) nsplit);
+	if (lds > 64 * 1024)
+		(void) hipFuncSetAttribute(a.Rtype == SVT_REALSXP ? (const void *) rowstats_panel_kernel<double> :
+					   (const void *) rowstats_panel_kernel<int>,
+					   hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
 	if (a.Rtype == SVT_REALSXP)
-		hipLaunchKernelGGL(rowstats_panel_kernel<double>, grid, dim3(ROWPANEL_NT), lds, s, a, pt, npan, G);
+		hipLaunchKernelGGL(rowstats_panel_kernel<double>, grid, dim3(NT), lds, s, a, pt, npan, G, ps);
 	else
-		hipLaunchKernelGGL(rowstats_panel_kernel<int>, grid, dim3(ROWPANEL_NT), lds, s, a, pt, npan, G);
+		hipLaunchKernelGGL(rowstats_panel_kernel<int>, grid, dim3(NT), lds, s, a, pt, npan, G, ps);
 	HIP_TRY(hipGetLastError());
 	return 0;
 }
@@ -701,7 +774,9 @@ int launch_rowsum(const GroupSumArgs &a, hipStream_t s)
 
 // The gather of group[row] is what bounds rowsum (one 64-byte sector from L2 per nonzero): a
 // 16-bit, zero-based copy of the table halves its footprint in L2 (4 MB -> 2 MB at 1e6 rows;
-// 0.657 -> 0.593 ms at BASELINE config 3, copy included).  NA groups take the last slot as in
+// 0.657 -> 0.593 ms at BASELINE config 3, copy included; four nonzeros per thread in flight
+// instead of one change nothing: 1e8 distinct L2 requests over 128 channels are 0.33 ms by
+// themselves).  NA groups take the last slot as in
 // src/rowsum_methods.c:44-64.
 __global__ void group16_kernel(const int *__restrict__ g, int64_t n, int ngroup, uint16_t *__restrict__ g16)
 {

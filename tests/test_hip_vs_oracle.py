@@ -187,6 +187,30 @@ def test_matrixstats_double(hip, oracle, shape, density, na_rm):
 
 
 @pytest.mark.parametrize("na_rm", [False, True])
+@pytest.mark.parametrize("shape,density,dtype", [((40000, 3000), 0.01, "double"), ((40000, 2000), 0.01, "int"),
+                                                 ((20000, 50, 40), 0.02, "double"), ((16384, 700), 0.05, "double"),
+                                                 ((16385, 9), 0.5, "int")])
+def test_row_stats_long_panels_and_strata_ranges(hip, oracle, shape, density, dtype, na_rm):
+    """>= 16384 rows: the sum-like row statistics take 8192-row panels and, with few panels, cut
+    the leaves into ranges whose partial cells are added in `out` (kernels_rowstats.hip);
+    rowMins / rowMaxs keep the short panels.  src/SparseArray_matrixStats.c:599-696."""
+    ncol = int(np.prod(shape[1:]))
+    special = SPECIAL_D[:2] + [3.5, -2.0] if dtype == "double" else [NA_integer, -7, 12]
+    x2 = _sprinkle(_svt(shape[0], ncol, density, 21, dtype), 21, special)
+    x = SVT_SparseArray(shape, x2.type, x2.leaves)
+    for dims in range(1, len(shape)):
+        for op in OPS_ROW:
+            kw = {} if "AnyNAs" in op or "CountNAs" in op else {"na_rm": na_rm}
+            got = getattr(hip, op)(x, dims=dims, **kw)
+            want = getattr(oracle, op)(x, dims=dims, **kw)
+            if got.dtype == np.int32 or (dtype == "int" and op in ("rowSums", "rowCountNAs")):
+                assert_identical(got, want, f"{op} dims={dims}")
+            else:
+                assert_equal(got, want, tol=1e-9, what=f"{op} dims={dims}",
+                             strict_na=op[3:] in ("Mins", "Maxs"), atol=1e-9)
+
+
+@pytest.mark.parametrize("na_rm", [False, True])
 @pytest.mark.parametrize("shape,fill,type_", [((3000, 200), 0.9, "double"), ((500, 40, 6), 0.3, "double"),
                                               ((4000, 64), 0.6, "integer")])
 def test_matrixstats_NaArray_col_ops(hip, oracle, shape, fill, type_, na_rm):
