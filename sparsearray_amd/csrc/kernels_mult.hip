@@ -175,7 +175,7 @@ static ColFlags flags_of(void *ws, int64_t nrow, int64_t Kp)
 	return fl;
 }
 
-static int dense_prepare(const CrossprodArgs &a, const int *run_flag, hipStream_t s);
+static int dense_prepare(const CrossprodArgs &a, const int *run_flag, hipStream_t s, bool clear = true);
 static int crossprod_prepared(const CrossprodArgs &a, const int *run_flag, hipStream_t s);
 
 int launch_dense_prepare(const CrossprodArgs &a, hipStream_t s) { return dense_prepare(a, NULL, s); }
@@ -201,17 +201,26 @@ int launch_dense_prepare_flag(const CrossprodArgs &a, int *any, hipStream_t s)
 }
 int launch_crossprod_prepared(const CrossprodArgs &a, hipStream_t s) { return crossprod_prepared(a, NULL, s); }
 
-// Both phases, skipped on the device when *flag == 0 (see kernels_mult_pbc.hip).
-int launch_crossprod_general_if(const CrossprodArgs &a, const int *flag, hipStream_t s)
+// Both phases, skipped on the device when *flag == 0 (see kernels_mult_pbc.hip).  counters_cleared:
+// whoever sets the flag has zeroed the 2 * Kp per-column counters (crossprod_general_counters) in an
+// earlier launch, so that a product with a clean dense operand does not pay for a memset it never uses.
+int launch_crossprod_general_if(const CrossprodArgs &a, const int *flag, bool counters_cleared, hipStream_t s)
 {
 	if (a.ncol <= 0 || a.K <= 0)
 		return 0;
-	if (dense_prepare(a, flag, s))
+	if (dense_prepare(a, flag, s, !counters_cleared))
 		return -1;
 	return crossprod_prepared(a, flag, s);
 }
 
-static int dense_prepare(const CrossprodArgs &a, const int *run_flag, hipStream_t s)
+int *crossprod_general_counters(void *ws, int64_t nrow, int K, int *n)
+{
+	const int64_t Kp = pad_k(K);
+	*n = (int) (2 * Kp);
+	return flags_of(ws, nrow, Kp).nonfinite;
+}
+
+static int dense_prepare(const CrossprodArgs &a, const int *run_flag, hipStream_t s, bool clear)
 {
 	if (a.K <= 0)
 		return 0;
@@ -220,7 +229,8 @@ static int dense_prepare(const CrossprodArgs &a, const int *run_flag, hipStream_
 		return svt_set_error("crossprod workspace too small");
 	double *Yt = (double *) a.ws;
 	ColFlags fl = flags_of(a.ws, a.nrow, Kp);
-	HIP_TRY(hipMemsetAsync(fl.nonfinite, 0, (size_t) Kp * 8, s));
+	if (clear)
+		HIP_TRY(hipMemsetAsync(fl.nonfinite, 0, (size_t) Kp * 8, s));
 	if (a.nrow > 0) {
 		const int64_t ntile = (a.nrow + 63) / 64;
 		dim3 grid((unsigned) (ntile < 2048 ? ntile : 2048), (unsigned) (Kp / 64));

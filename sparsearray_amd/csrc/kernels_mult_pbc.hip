@@ -571,6 +571,8 @@ struct PbcFlags {
 // [w][0] fetch issue, [1] record loop, [2] barrier after the loop, [3] commit,
 // [4] barrier after commit, [5] panels
 // (kept in the flag block at the head of the workspace, its last 1024 bytes)
+#define PBC_SUBFLAG0 16           // flags[16 .. 63]: "a non-finite entry in block (row split, dense tile) of Y", index modulo 48
+#define PBC_NSUBFLAG 48
 #define PBC_FLAG_BYTES 8192      // [0, 256) flags; [256, ...) per-column counters of the dirty-column fix-up when they fit
 #ifdef SVT_TUNING
 extern "C" int svt_dev_pbc_read_prof(const void *ws, unsigned long long *out)
@@ -1080,7 +1082,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 #define PBC_DMA_CLOBBERS "memory", "scc", "vcc", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99"
 
-template <int NV, bool PROF>
+template <int NV, int PROF>      // PROF (tuning build): 1 = cycles per section of the panel loop (NV <= 2), 2 = prologue / loop / epilogue only
 __global__ void __launch_bounds__(1024)
 crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restrict__ tile_ptr,
 			 int64_t npanels, const double *__restrict__ Y, int64_t ldY, int64_t nrow,
@@ -1221,7 +1223,7 @@ crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restric
 #define PBC_ACC2 "+{v[100:115]}"
 #endif
 #ifdef SVT_TUNING
-	if constexpr (PROF) {
+	if constexpr (PROF == 1) {
 		// tuning build (NV <= 2): cycles per section in v[116:123], see gen_pbc_asm.py
 		u32x16 PV = 0;
 		asm volatile(PBC_DMA_ASM_TEXT_PROF
@@ -1253,8 +1255,11 @@ crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restric
 #undef PBC_ACC1
 #undef PBC_ACC2
 #undef PBC_DMA_STATE
-	if (PB[6] != 0 && (tid & 63) == 0)
+	if (PB[6] != 0 && (tid & 63) == 0) {
 		*fl.y_nonfinite = 1;
+		// which (row split, dense tile) block of Y it was in: the fix-up scans only those
+		fl.y_nonfinite[PBC_SUBFLAG0 + (split * kt + kh) % PBC_NSUBFLAG] = 1;
+	}
 #ifdef SVT_TUNING
 	if (PROF) t_epi = __builtin_readcyclecounter();
 #endif
@@ -1428,36 +1433,113 @@ static DirtyWs dirty_ws_of(void *flag_block, void *tail, int64_t ncol, int64_t K
 	return d;
 }
 
-__global__ void __launch_bounds__(256)
-pbc_dirty_scan_kernel(const double *__restrict__ Y, int64_t rs, int64_t cs, int64_t nrow, int K, int64_t ncol, DirtyWs d)
+// The four steps below run as ONE launch (pbc_dirty_kernel): every launch costs ~5 us per product even when
+// the dense operand is clean -- a tenth of the step of one rank of an 8-GPU run -- and all of them
+// return at once while the product kernel's flag is clear.  With the flag set, the steps are
+// separated by a grid-wide barrier (pbc_grid_barrier); the grid is at most one workgroup per CU, so
+// every workgroup is resident whatever else runs.
+
+// Grid-wide barrier between the steps: what the workgroups stored before it (plain stores and
+// atomics, from any XCD) is read behind it with plain loads.  Producer side: every wavefront waits
+// for its stores, workgroup barrier, one lane releases at agent scope (write-back of the XCD's L2)
+// and adds to the counter; consumer side: the same lane polls, acquires at agent scope
+// (invalidate), workgroup barrier.  `target` = workgroups x barriers passed so far.
+__device__ inline void pbc_grid_barrier(int *ctr, int target, int *give_up)
 {
-	if (d.flags[0] == 0)
-		return;
-	const int k = blockIdx.y;
-	{       // hit counters (read by the hits kernel two launches later)
-		const int64_t nthr = (int64_t) gridDim.x * gridDim.y * blockDim.x;
-		const int64_t me = ((int64_t) blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
-		for (int64_t i = me; i < ncol * PBC_DIRTY_COLS; i += nthr) d.hit[i] = 0;
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		// (bounded: ~1 s of polling, one poll per ~1 us: 256 pollers on the line the adds go to slow them down.  Not expected -- the grid is resident -- but a wavefront must
+		// not spin for ever; giving up hands the product to the general kernels, which redo all of it.)
+		int spins = 0;
+		while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+			__builtin_amdgcn_s_sleep(40);
+			if (++spins > (1 << 20)) { *give_up = 1; break; }
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	}
-	const double *__restrict__ col = Y + (int64_t) k * cs;            // element (r, k) at Y[r * rs + k * cs]
-	for (int64_t r = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; r < nrow;
-	     r += (int64_t) gridDim.x * blockDim.x) {
-		const double y = col[r * rs];
+	__syncthreads();
+}
+
+// step 1: non-finite entries per dense column, their (row, column) list; clears the hit counters
+__device__ inline void pbc_dirty_scan(const double *__restrict__ Y, int64_t rs, int64_t cs, int64_t nrow, int K,
+				      int64_t ncol, const DirtyWs &d, int nsplit, int64_t pps, int kt)
+{
+	const int64_t nthr = (int64_t) gridDim.x * blockDim.x;
+	const int64_t me = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	for (int64_t i = me; i < ncol * PBC_DIRTY_COLS; i += nthr) d.hit[i] = 0;
+	// a workgroup takes a contiguous range of rows through all K dense columns, eight columns in
+	// flight per trip (1 GB to read at BASELINE config 2a, one workgroup per CU); 16-byte loads of
+	// row pairs where the columns are aligned for them
+	auto note = [&](const double y, const int64_t r, const int k) {
 		if (svt_is_finite(y))
-			continue;
+			return;
 		const int seen = atomicAdd(d.col_nf + k, 1);
 		if (svt_is_na(y)) d.has_na[k] = 1;
 		if (seen >= PBC_DIRTY_LIGHT)
-			continue;                           // a heavy column: decided without its entries, or by the general kernels
+			return;                                 // a heavy column: decided without its entries, or by the general kernels
 		const int at = atomicAdd(d.flags + 3, 1);
 		if (at < PBC_DIRTY_CAP) d.list[at] = make_uint2((unsigned) r, (unsigned) k);
+	};
+	// blocks of Y: (row split s, dense tile kh) as the product kernel staged them (pps = panels of 128 rows
+	// per split; 0 = no such record, one block covers everything)
+	const int nblk = pps > 0 ? nsplit * kt : 1;
+	for (int blk = 0; blk < nblk; blk++) {
+		int64_t b_lo = 0, b_hi = nrow;
+		int kb = 0, ke = K;
+		if (pps > 0) {
+			if (d.flags[PBC_SUBFLAG0 + blk % PBC_NSUBFLAG] == 0)
+				continue;
+			const int sp = blk / kt, kh = blk % kt;
+			b_lo = (int64_t) sp * pps * 128;
+			b_hi = b_lo + pps * 128 < nrow ? b_lo + pps * 128 : nrow;
+			kb = kh * 64; ke = kb + 64 < K ? kb + 64 : K;
+		}
+		int64_t chunk = (b_hi - b_lo + gridDim.x - 1) / gridDim.x;
+		chunk = (chunk + 1) & ~(int64_t) 1;             // even: row pairs stay inside a range
+		const int64_t r_lo = b_lo + (int64_t) blockIdx.x * chunk, r_hi = r_lo + chunk < b_hi ? r_lo + chunk : b_hi;
+		if (rs == 1 && (cs & 1) == 0 && (((uintptr_t) Y) & 15) == 0) {
+			for (int64_t r = r_lo + 2 * (int64_t) threadIdx.x; r < r_hi; r += 2 * (int64_t) blockDim.x) {
+				const bool pair = r + 1 < r_hi;
+				for (int k0 = kb; k0 < ke; k0 += 8) {
+					double2 y[8];
+#pragma unroll
+					for (int u = 0; u < 8; u++) {
+						const double *src = Y + r + (int64_t) (k0 + u) * cs;
+						if (k0 + u >= ke) y[u] = make_double2(0.0, 0.0);
+						else if (pair) y[u] = *(const double2 *) src;
+						else y[u] = make_double2(*src, 0.0);
+					}
+#pragma unroll
+					for (int u = 0; u < 8; u++) {
+						note(y[u].x, r, k0 + u);
+						note(y[u].y, r + 1, k0 + u);
+					}
+				}
+			}
+			continue;
+		}
+		for (int64_t r = r_lo + threadIdx.x; r < r_hi; r += blockDim.x) {
+			for (int k0 = kb; k0 < ke; k0 += 8) {
+				double y[8];
+#pragma unroll
+				for (int u = 0; u < 8; u++)
+					y[u] = k0 + u < ke ? Y[r * rs + (int64_t) (k0 + u) * cs] : 0.0;      // element (r, k) at Y[r * rs + k * cs]
+#pragma unroll
+				for (int u = 0; u < 8; u++)
+					note(y[u], r, k0 + u);
+			}
+		}
 	}
 }
 
 // Rank of every dirty column among the dirty ones (slot[k], in LDS) and the decision between the
-// fix-up and the general kernels: recomputed by every workgroup of the two kernels below from the
-// scan's counters (K <= a few hundred entries) rather than by a launch of its own -- every launch
-// costs ~5 us per product even when the dense operand is clean.  Returns true for "general kernels".
+// fix-up and the general kernels, recomputed by every workgroup from the scan's counters (K <= a few
+// hundred entries).  Returns true for "general kernels".
 // Classes of a dirty column k (nf = its non-finite entries): light (nf <= PBC_DIRTY_LIGHT: all listed, gets a
 // slot), saturated (nf > the longest leaf: no leaf can have a nonzero on every non-finite row, every cell is NaN
 // or NA -- a column of NAs, the common case, costs no more than a single Inf), anything in between: general kernels.
@@ -1479,81 +1561,68 @@ __device__ inline bool pbc_dirty_plan(int K, const DirtyWs &d, int *slot_lds, in
 	return s_general != 0;
 }
 
-__global__ void __launch_bounds__(256)
-pbc_dirty_hits_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__ row_idx,
-		      int64_t ncol, int K, DirtyWs d, int64_t max_leaf_nnz)
+// step 2: hit[c][slot] = listed entries of dirty column `slot` that sit on a nonzero of leaf c
+__device__ inline void pbc_dirty_hits(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__ row_idx,
+				      int64_t ncol, const DirtyWs &d, const int *slot_lds)
 {
-	extern __shared__ int slot_lds[];                       // [K]
-	if (d.flags[0] == 0)
-		return;
-	if (pbc_dirty_plan(K, d, slot_lds, max_leaf_nnz))
-		return;
-	const int64_t c = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-	if (c >= ncol)
-		return;
 	const int n = d.flags[3];
-	const int64_t beg = col_ptr[c], end = col_ptr[c + 1];
-	for (int e = blockIdx.y; e < n; e += gridDim.y) {
-		const uint2 rk = d.list[e];
-		if (slot_lds[rk.y] < 0)
-			continue;                           // (the first entries of a saturated column)
-		int64_t lo = beg, hi = end;
-		while (lo < hi) {
-			const int64_t mid = (lo + hi) >> 1;
-			if ((uint32_t) row_idx[mid] < rk.x) lo = mid + 1; else hi = mid;
-		}
-		if (lo < end && (uint32_t) row_idx[lo] == rk.x)
-			atomicAdd(d.hit + c * PBC_DIRTY_COLS + slot_lds[rk.y], 1);
-	}
-}
-
-__global__ void __launch_bounds__(256)
-pbc_dirty_fix_kernel(const int *__restrict__ col_has_na, int K, int64_t ncol, DirtyWs d,
-		     double *__restrict__ out, int64_t sc, int64_t sk, int64_t max_leaf_nnz)
-{
-	extern __shared__ int slot_lds[];                       // [K]
-	if (d.flags[0] == 0)
-		return;
-	const bool general = pbc_dirty_plan(K, d, slot_lds, max_leaf_nnz);
-	if (general) {
-		if (blockIdx.x == 0 && threadIdx.x == 0) d.flags[2] = 1;    // read by the general kernels' gate
-		return;
-	}
-	const int64_t c = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-	if (c >= ncol)
-		return;
-	const bool leaf_na = col_has_na[c] != 0;
-	for (int k = 0; k < K; k++) {
-		const int nf = d.col_nf[k];
-		if (nf == 0)
+	// virtual grid: column blocks of blockDim.x x 16 shares of the list
+	const int64_t cb = (ncol + blockDim.x - 1) / blockDim.x;
+	for (int64_t vb = blockIdx.x; vb < cb * 16; vb += gridDim.x) {
+		const int64_t c = (vb % cb) * blockDim.x + threadIdx.x;
+		if (c >= ncol)
 			continue;
-		double *cell = out + c * sc + (int64_t) k * sk;
-		if (d.has_na[k] || leaf_na) {
-			*cell = svt_na_real();
-		} else if (slot_lds[k] < 0 || d.hit[c * PBC_DIRTY_COLS + slot_lds[k]] < nf) {
-			*cell = *cell + NAN;
-		} else {
-			// every non-finite entry of the column sits on a nonzero of this leaf: the IEEE sum
-			// over the nonzeros.  The product kernel's own value cannot be kept (the zero records
-			// that pad its tiles multiply row 0 of their panel, and 0 * Inf is NaN): the cell
-			// goes on the list of pbc_dirty_redo_kernel.
-			const int at = atomicAdd(d.flags + 5, 1);
-			if (at < PBC_DIRTY_WORK) d.work[at] = make_uint2((unsigned) c, (unsigned) k);
-			else d.flags[2] = 1;            // too many: the general kernels redo the product
+		const int64_t beg = col_ptr[c], end = col_ptr[c + 1];
+		for (int e = (int) (vb / cb); e < n; e += 16) {
+			const uint2 rk = d.list[e];
+			if (slot_lds[rk.y] < 0)
+				continue;                           // (the first entries of a saturated column)
+			int64_t lo = beg, hi = end;
+			while (lo < hi) {
+				const int64_t mid = (lo + hi) >> 1;
+				if ((uint32_t) row_idx[mid] < rk.x) lo = mid + 1; else hi = mid;
+			}
+			if (lo < end && (uint32_t) row_idx[lo] == rk.x)
+				atomicAdd(d.hit + c * PBC_DIRTY_COLS + slot_lds[rk.y], 1);
 		}
 	}
 }
 
-// one wavefront per listed cell: sum of a_i * y_i over the leaf's nonzeros (lane-strided partial
+// step 3: the cells of the dirty columns
+__device__ inline void pbc_dirty_fix(const int *__restrict__ col_has_na, int K, int64_t ncol, const DirtyWs &d,
+				     const int *slot_lds, double *__restrict__ out, int64_t sc, int64_t sk)
+{
+	for (int64_t c = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; c < ncol; c += (int64_t) gridDim.x * blockDim.x) {
+		const bool leaf_na = col_has_na[c] != 0;
+		for (int k = 0; k < K; k++) {
+			const int nf = d.col_nf[k];
+			if (nf == 0)
+				continue;
+			double *cell = out + c * sc + (int64_t) k * sk;
+			if (d.has_na[k] || leaf_na) {
+				*cell = svt_na_real();
+			} else if (slot_lds[k] < 0 || d.hit[c * PBC_DIRTY_COLS + slot_lds[k]] < nf) {
+				*cell = *cell + NAN;
+			} else {
+				// every non-finite entry of the column sits on a nonzero of this leaf: the IEEE sum
+				// over the nonzeros.  The product kernel's own value cannot be kept (the zero records
+				// that pad its tiles multiply row 0 of their panel, and 0 * Inf is NaN): the cell
+				// goes on the list of step 4.
+				const int at = atomicAdd(d.flags + 5, 1);
+				if (at < PBC_DIRTY_WORK) d.work[at] = make_uint2((unsigned) c, (unsigned) k);
+				else d.flags[2] = 1;            // too many: the general kernels redo the product
+			}
+		}
+	}
+}
+
+// step 4: one wavefront per listed cell: sum of a_i * y_i over the leaf's nonzeros (lane-strided partial
 // sums, then a fixed-order butterfly: NaN / Inf class as in the sequential sum, finite parts within
 // rounding)
-__global__ void __launch_bounds__(256)
-pbc_dirty_redo_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__ row_idx,
-		      const double *__restrict__ val, const double *__restrict__ Y, int64_t rs, int64_t cs,
-		      DirtyWs d, double *__restrict__ out, int64_t sc, int64_t sk)
+__device__ inline void pbc_dirty_redo(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__ row_idx,
+				      const double *__restrict__ val, const double *__restrict__ Y, int64_t rs, int64_t cs,
+				      const DirtyWs &d, double *__restrict__ out, int64_t sc, int64_t sk)
 {
-	if (d.flags[0] == 0 || d.flags[2] != 0)       // ([2]: set by the fix kernel, which ran before)
-		return;
 	const int lane = threadIdx.x & 63;
 	const int nw = gridDim.x * (blockDim.x >> 6);
 	int n = d.flags[5];
@@ -1568,6 +1637,55 @@ pbc_dirty_redo_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__rest
 			acc += __shfl_xor(acc, off, 64);
 		if (lane == 0) out[(int64_t) ck.x * sc + (int64_t) ck.y * sk] = acc;
 	}
+}
+
+#define PBC_DIRTY_BARRIER 8     // flags[8]: the barrier counter (cleared with the flags by phase 1)
+__global__ void __launch_bounds__(1024)
+pbc_dirty_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__ row_idx,
+		 const double *__restrict__ val, const int *__restrict__ col_has_na,
+		 const double *__restrict__ Y, int64_t rs, int64_t cs, int64_t nrow, int64_t ncol, int K,
+		 DirtyWs d, double *__restrict__ out, int64_t sc, int64_t sk, int64_t max_leaf_nnz,
+		 int *__restrict__ gen_counters, int n_gen_counters, int nsplit, int64_t pps, int kt)
+{
+	extern __shared__ int slot_lds[];                       // [K]
+	if (d.flags[0] == 0)                                    // (the same answer in every workgroup)
+		return;
+	const int nwg = gridDim.x;
+	// the general kernels' per-column counters: they run (next launches) only if this kernel sets flags[2]
+	if (blockIdx.x == 0)
+		for (int i = threadIdx.x; i < n_gen_counters; i += blockDim.x) gen_counters[i] = 0;
+#ifdef SVT_TUNING
+	unsigned long long tt[8];
+#define PBC_DT(i) tt[i] = __builtin_readcyclecounter();
+#else
+#define PBC_DT(i)
+#endif
+	PBC_DT(0)
+	pbc_dirty_scan(Y, rs, cs, nrow, K, ncol, d, nsplit, pps, kt);
+	PBC_DT(1)
+	pbc_grid_barrier(d.flags + PBC_DIRTY_BARRIER, nwg, d.flags + 2);
+	PBC_DT(2)
+	if (pbc_dirty_plan(K, d, slot_lds, max_leaf_nnz)) {     // (the same answer in every workgroup)
+		if (blockIdx.x == 0 && threadIdx.x == 0) d.flags[2] = 1;    // read by the general kernels' gate
+		return;
+	}
+	pbc_dirty_hits(col_ptr, row_idx, ncol, d, slot_lds);
+	PBC_DT(3)
+	pbc_grid_barrier(d.flags + PBC_DIRTY_BARRIER, 2 * nwg, d.flags + 2);
+	PBC_DT(4)
+	pbc_dirty_fix(col_has_na, K, ncol, d, slot_lds, out, sc, sk);
+	PBC_DT(5)
+	pbc_grid_barrier(d.flags + PBC_DIRTY_BARRIER, 3 * nwg, d.flags + 2);
+	PBC_DT(6)
+	if (d.flags[2] != 0)                                    // (set by step 3: too many cells)
+		return;
+	pbc_dirty_redo(col_ptr, row_idx, val, Y, rs, cs, d, out, sc, sk);
+#ifdef SVT_TUNING
+	PBC_DT(7)
+	if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))
+		printf("dirty wg %d: scan %llu barrier %llu hits %llu barrier %llu fix %llu barrier %llu redo %llu cycles\n",
+		       (int) blockIdx.x, tt[1] - tt[0], tt[2] - tt[1], tt[3] - tt[2], tt[4] - tt[3], tt[5] - tt[4], tt[6] - tt[5], tt[7] - tt[6]);
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -1698,10 +1816,10 @@ static void launch_dma(const svt_dev_pbc *P, const double *Y, int64_t ldY, int K
 	if (rt_ahead + rt_lines * 128 > 4608) rt_ahead = 4608 - rt_lines * 128;
 	if (rt_ahead < 0) rt_ahead = 0;
 #ifdef SVT_TUNING
-	auto kern = (g_pbc_debug == 3 && NV <= 2) ? crossprod_pbc_dma_kernel<(NV <= 2 ? NV : 2), true>
-						  : crossprod_pbc_dma_kernel<NV, false>;
+	auto kern = g_pbc_debug != 3 ? crossprod_pbc_dma_kernel<NV, 0> :
+		    NV <= 2 ? crossprod_pbc_dma_kernel<(NV <= 2 ? NV : 2), 1> : crossprod_pbc_dma_kernel<NV, 2>;
 #else
-	auto kern = crossprod_pbc_dma_kernel<NV, false>;
+	auto kern = crossprod_pbc_dma_kernel<NV, 0>;
 #endif
 	(void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
 	const int nb = (int) P->nblocks - block0;
@@ -1710,7 +1828,8 @@ static void launch_dma(const svt_dev_pbc *P, const double *Y, int64_t ldY, int K
 			   nb, block0, pps, part, Kp, fl, rt_lines, rt_ahead, g_pbc_stagger);
 }
 
-int launch_crossprod_general_if(const CrossprodArgs &a, const int *flag, hipStream_t s);
+int launch_crossprod_general_if(const CrossprodArgs &a, const int *flag, bool counters_cleared, hipStream_t s);
+int *crossprod_general_counters(void *ws, int64_t nrow, int K, int *n);
 int launch_dense_prepare_flag(const CrossprodArgs &a, int *any, hipStream_t s);
 
 // phase 1: the LDS-panel product kernel (partials into ws); phase 2: sum the
@@ -1851,18 +1970,24 @@ static int pbc_phase(const svt_dev_pbc *P, const svt_dev_csc *A,
 	const double *Yd = gath ? (const double *) gen_ws : Yc;
 	const int64_t yrs = gath ? Kp : 1, ycs = gath ? 1 : ldc;
 	if (fast && P->rec != NULL) {
-		// (small grids: while the flag is clear -- every product with a finite operand -- these
-		// launches cost their blocks' start-up and nothing else)
-		const int64_t rb = (P->nrow + 255) / 256;
-		dim3 sg((unsigned) (rb < 128 ? (rb > 0 ? rb : 1) : 128), (unsigned) K);
-		hipLaunchKernelGGL(pbc_dirty_scan_kernel, sg, dim3(256), 0, s, Yd, yrs, ycs, P->nrow, K, P->ncol, dw);
-		dim3 hg((unsigned) ((P->ncol + 255) / 256), 16);
-		hipLaunchKernelGGL(pbc_dirty_hits_kernel, hg, dim3(256), (size_t) K * 4, s, A->col_ptr, A->row_idx, P->ncol, K, dw, P->max_leaf_nnz);
-		dim3 fg((unsigned) ((P->ncol + 255) / 256));
-		hipLaunchKernelGGL(pbc_dirty_fix_kernel, fg, dim3(256), (size_t) K * 4, s, P->col_has_na, K, P->ncol, dw,
-				   out, out_stride_c, out_stride_k, P->max_leaf_nnz);
-		hipLaunchKernelGGL(pbc_dirty_redo_kernel, dim3(64), dim3(256), 0, s, A->col_ptr, A->row_idx,
-				   (const double *) A->val, Yd, yrs, ycs, dw, out, out_stride_c, out_stride_k);
+		// (while the flag is clear -- every product with a finite operand -- this launch costs its
+		// workgroups' start-up and nothing else)
+		int n_gen_counters = 0;
+		int *gen_counters = crossprod_general_counters(gen_ws, A->nrow, K, &n_gen_counters);
+		static int n_cu = 0;
+		if (n_cu == 0) {
+			int dev = 0, v = 0;
+			if (hipGetDevice(&dev) == hipSuccess &&
+			    hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+				n_cu = v;
+			else
+				n_cu = 64;
+		}
+		// one workgroup of 16 wavefronts per CU: all resident, the grid barrier cannot starve
+		hipLaunchKernelGGL(pbc_dirty_kernel, dim3((unsigned) n_cu), dim3(1024), (size_t) K * 4, s,
+				   A->col_ptr, A->row_idx, (const double *) A->val, P->col_has_na, Yd, yrs, ycs,
+				   P->nrow, P->ncol, K, dw, out, out_stride_c, out_stride_k, P->max_leaf_nnz,
+				   gen_counters, n_gen_counters, nsplit, dma ? pps : 0, (int) (Kp / 64));
 		HIP_TRY(hipGetLastError());
 	}
 	// General (slow-path) semantics for everything else that is not finite.
@@ -1872,7 +1997,7 @@ static int pbc_phase(const svt_dev_pbc *P, const svt_dev_csc *A,
 	a.nrow = A->nrow; a.ncol = A->ncol; a.Y = Y; a.ldY = ldY; a.K = K; a.tr_y = tr_y;
 	a.out = out; a.out_stride_c = out_stride_c; a.out_stride_k = out_stride_k;
 	a.ws = gen_ws; a.ws_bytes = gen_bytes;
-	return launch_crossprod_general_if(a, fast && P->rec != NULL ? dw.flags + 2 : fl.y_nonfinite, s);
+	return launch_crossprod_general_if(a, fast && P->rec != NULL ? dw.flags + 2 : fl.y_nonfinite, fast && P->rec != NULL, s);
 }
 
 extern "C" int svt_dev_crossprod_pbc_phase(const svt_dev_pbc *P, const svt_dev_csc *A,
