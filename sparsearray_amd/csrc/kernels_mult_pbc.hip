@@ -1102,12 +1102,13 @@ crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restric
 	// nblocks column blocks are launched, the first of them is block0 of the layout (a symmetric
 	// product only needs the blocks from its dense chunk's first column on); bl counts from 0
 	int bl, kh, split;
-	if ((nsplit & 7) == 0) {
+	const int nfull = nsplit & ~7;                  // row splits dealt to the XCDs whole, eight at a time
+	if (L < nfull * kt * nblocks) {
 		const int xcd = L & 7, j = L >> 3, u = j / nblocks;
 		bl = j % nblocks; kh = u % kt; split = (u / kt) * 8 + xcd;
-	} else {
-		const int u = L / nblocks;
-		bl = L % nblocks; kh = u % kt; split = u / kt;
+	} else {                                        // the other splits: their workgroups go round the XCDs
+		const int Lr = L - nfull * kt * nblocks, u = Lr / nblocks;
+		bl = Lr % nblocks; kh = u % kt; split = nfull + u / kt;
 	}
 	const int b = bl + block0;
 	const int64_t pa = (int64_t) split * panels_per_split;
@@ -1732,17 +1733,29 @@ static int pick_nsplit(const svt_dev_pbc *P, int K, bool dma, int64_t *pps_out)
 	if (units >= 512) {
 		s = 1;                                  // enough column blocks: no row split, no partials
 	} else if (dma && P->npanels >= 8 * 16) {
-		// One workgroup per CU (LDS, VGPRs), 32 CUs per XCD, the column blocks of a
-		// (split, dense tile) pair share an XCD: take the number of splits per XCD
-		// that leaves the last round of each XCD fullest.
-		int64_t best = 1;
-		double best_eff = 0.0;
+		// One workgroup per CU (LDS, VGPRs), 32 CUs per XCD, the column blocks of a (split, dense
+		// tile) pair share an XCD.  Candidates: sx splits per XCD (8 sx in all), plus, where CUs are
+		// left over in the last round, further splits whose workgroups are dealt over all XCDs (28
+		// workgroups per split: 8 x 28 = 224 leave 32 CUs for a ninth split; its panels come through
+		// eight L2s instead of one: 1.757 -> 1.647 ms at 1e6 x 8960, tools/debug/ninth_split.py).
+		// Cost of a candidate: rounds x panels per workgroup x ~1.8 us, plus the partial results (one
+		// ncol x Kp block per split written and read again at ~4 TB/s) -- without that term 64 splits
+		// in 7 full rounds beat 8 splits in one round that leaves an eighth of the CUs idle (2.2 ms).
+		const double t_panel = 1.8e-6, t_split = 2.0 * (double) P->ncol * (double) (kt * 64) * 8.0 / 4e12;
+		double best_t = 1e30;
+		s = 8;
 		for (int64_t sx = 1; sx <= 16 && P->npanels / (8 * sx) >= 16; sx++) {
 			const int64_t u = units * sx, rounds = (u + 31) / 32;
-			const double eff = (double) u / (double) (rounds * 32);
-			if (eff > best_eff + 1e-9) { best_eff = eff; best = sx; }
+			int64_t extra = (rounds * 32 - u) * 8 / units;
+			if (extra > 7) extra = 7;
+			for (int64_t ex = 0; ex <= extra; ex += (extra > 0 ? extra : 1)) {
+				const int64_t cand = 8 * sx + ex;
+				if (P->npanels / cand < 16) continue;
+				const double t = (double) rounds * (double) ((P->npanels + cand - 1) / cand) * t_panel +
+					(double) cand * t_split;
+				if (t < best_t - 1e-9) { best_t = t; s = cand; }
+			}
 		}
-		s = 8 * best;
 	} else {
 		s = (512 + units - 1) / units;          // aim for >= 512 workgroups
 		s = (s + 7) / 8 * 8;                    // whole XCD rounds
