@@ -6,6 +6,11 @@
 // (row index -> position) pairs, which keeps the entries of every output leaf in
 // ascending column order as the SVT format requires (src/leaf_utils.h:12-15),
 // then one gather pass.  Traffic ~ 3 sort passes x 16 B/nz + 28 B/nz.
+// (Round 2 also built a two-pass form -- sort on row >> 4 with 16-bit keys, the low 4 bits riding in
+// the payload, the order inside every 16-row bucket finished by one wavefront inside the gather
+// (ballot ranks + running counters): correct, but 4.4 ms against 4.0: the two passes of 6-byte pairs
+// take as long per pass as 8-byte ones (0.65 ms), and the finishing gather stores to 16 row segments
+// at once instead of one coalesced run: 2.3 ms against 1.5 + 0.12.)
 #include "svt_common.h"
 
 #include <hipcub/hipcub.hpp>

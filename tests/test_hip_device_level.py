@@ -157,7 +157,8 @@ def test_pbc_dma_path_ragged_columns(hip, oracle):
     assert_equal(out.cpu().numpy().T, want, tol=1e-9, atol=1e-11, what="ragged")
 
 
-@pytest.mark.parametrize("shape", [(3000, 700, 0.01), (257, 5, 0.3), (40, 20000, 0.002), (1, 9, 1.0)])
+@pytest.mark.parametrize("shape", [(3000, 700, 0.01), (257, 5, 0.3), (40, 20000, 0.002), (1, 9, 1.0),
+                                   (5003, 3000, 0.05), (17, 4000, 0.5), (2_100_000, 12, 0.0005)])
 @pytest.mark.parametrize("dtype", ["double", "integer"])
 def test_device_transpose(hip, shape, dtype):
     """t(A) on the device == t() of the host mirror (leaf entries in ascending order)."""
@@ -171,6 +172,27 @@ def test_device_transpose(hip, shape, dtype):
     T = A.t()
     torch.cuda.synchronize()
     assert (T.nrow, T.ncol, T.nnz) == (ncol, nrow, len(v))
+    assert np.array_equal(T.col_ptr.cpu().numpy(), tcp)
+    assert np.array_equal(T.row_idx.cpu().numpy(), tri)
+    assert np.array_equal(T.val.cpu().numpy(), tv)
+
+
+def test_device_transpose_skewed_rows(hip):
+    """Rows of very different lengths in one bucket of 16 (the two-pass form of the transposition finishes
+    the order inside such a bucket with one wavefront): a full row, an empty row and sparse rows side by
+    side, plus whole empty buckets."""
+    rng = np.random.default_rng(5)
+    nrow, ncol = 1000, 2500
+    m = np.zeros((nrow, ncol))
+    m[35, :] = rng.normal(size=ncol)                      # full row
+    m[37, ::3] = 1.5
+    m[40:48, :] = np.where(rng.random((8, ncol)) < 0.02, 2.0, 0.0)
+    m[999, 7] = -1.0                                      # rows 48..998 empty
+    x = SVT_SparseArray.from_dense(m, type="double", lacunar=False)
+    cp, ri, v = x.to_csc()
+    tcp, tri, tv = x.t().to_csc()
+    T = _dev(cp, ri, v, nrow).t()
+    torch.cuda.synchronize()
     assert np.array_equal(T.col_ptr.cpu().numpy(), tcp)
     assert np.array_equal(T.row_idx.cpu().numpy(), tri)
     assert np.array_equal(T.val.cpu().numpy(), tv)
