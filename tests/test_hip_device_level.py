@@ -481,3 +481,46 @@ def test_pbc_dirty_column_classes(hip, oracle):
     y = y0.copy(); y[:3000, 7] = np.inf; y[:, 8] = np.nan
     check(y, "in-between column beside a saturated one")
     check(y0, "clean again")
+
+
+def test_pbc_fixup_on_two_streams_at_once(hip):
+    """The non-finite fix-up is one launch whose steps are separated by a grid-wide barrier (one
+    workgroup per CU, kernels_mult_pbc.hip): two products with dirty dense operands in flight on two
+    streams must both finish with the one-stream results, and without the barrier's give-up path
+    (a second of polling) having been taken."""
+    import time
+    from sparsearray_amd.device import DeviceCSC, PbcPlan
+    dev = torch.device("cuda", 0)
+    nrow, ncol, K = 60_000, 1300, 64
+    cp, ri, v = random_csc(nrow, ncol, 0.01, seed=77)
+    A = _dev(cp, ri, v, nrow)
+    rng = np.random.default_rng(78)
+    ys = []
+    for t in range(2):
+        y = rng.uniform(-1, 1, (K, nrow))
+        y[3 + t, int(ri[5 + t])] = np.inf             # on a nonzero of leaf 0: exercises the re-summed cells
+        y[9, 1234 + t] = np.nan
+        ys.append(torch.as_tensor(y, device=dev))
+    plans = [PbcPlan(A, K, 40, 16, 7) for _ in range(2)]
+    want = []
+    for t in range(2):
+        out = torch.zeros((K, ncol), dtype=torch.float64, device=dev)
+        plans[t].run(ys[t], nrow, out)
+        torch.cuda.synchronize()
+        want.append(out.clone())
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    outs = [torch.zeros((K, ncol), dtype=torch.float64, device=dev) for _ in range(2)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for rep in range(20):
+        for t in range(2):
+            with torch.cuda.stream(streams[t]):
+                plans[t].run(ys[t], nrow, outs[t])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    for t in range(2):
+        same_nan = torch.isnan(outs[t]) == torch.isnan(want[t])
+        assert bool(same_nan.all())
+        fin = torch.isfinite(want[t])
+        assert bool((outs[t][fin] == want[t][fin]).all())
+    assert dt < 0.5, f"40 small products took {dt:.2f} s: a grid barrier starved"
