@@ -16,6 +16,8 @@ shapes = [  # (nrow, nleaves, density, inner)
     (100000, 64, 0.05, 1), (100000, 64, 0.05, 4),      # workgroup per column
     (400000, 6, 0.5, 1), (200000, 40, 0.4, 20),        # split long segments
     (1, 5000, 0.5, 1), (257, 1, 0.9, 1), (1000, 10, 0.0, 1),
+    (50000, 5000, 0.004, 1), (33000, 2400, 0.01, 3),    # row sums: 8192-row panels, strata ranges
+    (16384, 900, 0.05, 1), (16383, 900, 0.05, 1),       # on either side of the long-panel threshold
 ]
 worst = 0.0
 for case in range(ncases):
@@ -50,9 +52,12 @@ for case in range(ncases):
     gm, _ = colstats(A, "min", inner=inner)
     if nseg:
         err = max(err, float((gm - mn_ref).abs().max()))
-    if inner == 1 and nrow * 1 <= 400000:
-        rs = rowsums(A)
-        r_ref = torch.zeros(nrow, dtype=torch.float64, device=dev).index_add_(0, torch.as_tensor(ri, device=dev).long(), vt)
+    if nrow * inner <= 400000:
+        # rowSums over the leaves j = i + s * inner of every output column i (dims = 2 when inner > 1)
+        rs = rowsums(A, inner=inner)
+        leaf = torch.repeat_interleave(torch.arange(ncol, device=dev), torch.as_tensor(counts, device=dev))
+        cell = (leaf % inner) * nrow + torch.as_tensor(ri, device=dev).long()
+        r_ref = torch.zeros(nrow * inner, dtype=torch.float64, device=dev).index_add_(0, cell, vt)
         err = max(err, float((rs - r_ref).abs().max() / (1.0 + r_ref.abs().max())))
     torch.cuda.synchronize()
     worst = max(worst, err)
