@@ -9,9 +9,9 @@
 // NA rule (:714-719): na.rm drops NA/NaN from the nonzeros (the padding keeps its
 // size); otherwise any NA/NaN gives NA_real_.  n == 0 gives NA_real_ (:721-722).
 //
-// Device: the nonzero values are copied as f64 keys with every NA/NaN turned into
-// one canonical positive NaN (sorts last), sorted per column by hipcub's segmented
-// radix sort, and one thread per column picks the order statistics by three
+// Device: the nonzero values of the columns that need it are copied as f64 keys with every
+// NA/NaN turned into one canonical positive NaN (sorts last), sorted per column by hipcub's
+// segmented radix sort, and one thread per column picks the order statistics by three
 // binary searches (first key >= 0, first key > 0, first NaN).
 // Most columns of a sparse matrix never get that far: when the middle ranks fall among the
 // zeros (fewer than half of the column's values positive, fewer than half negative) the
@@ -22,20 +22,29 @@
 #include "svt_common.h"
 #include <hipcub/hipcub.hpp>
 
+// Keys of the columns that need a sort (a wavefront per column; the others -- at BASELINE config 2
+// all of them -- return at once: copying every value cost 0.3 ms of a 0.55 ms colMedians there).
 template <typename T>
-__global__ void median_key_kernel(const T *__restrict__ val, int64_t nnz, double *__restrict__ keys)
+__global__ void __launch_bounds__(256)
+median_key_kernel(const int64_t *__restrict__ col_ptr, const T *__restrict__ val, int64_t ncol,
+		  const int64_t *__restrict__ seg_b, const int64_t *__restrict__ seg_e,
+		  double *__restrict__ keys)
 {
-	const int64_t k = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-	if (k >= nnz) return;
-	double d;
-	if (sizeof(T) == 8) {
-		d = (double) val[k];
-	} else {
-		const int v = (int) val[k];
-		d = v == NA_INT ? NAN : (double) v;
+	const int lane = threadIdx.x & 63;
+	const int64_t j = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (j >= ncol || seg_e[j] == seg_b[j]) return;
+	const int64_t beg = col_ptr[j], end = col_ptr[j + 1];
+	for (int64_t k = beg + lane; k < end; k += 64) {
+		double d;
+		if (sizeof(T) == 8) {
+			d = (double) val[k];
+		} else {
+			const int v = (int) val[k];
+			d = v == NA_INT ? NAN : (double) v;
+		}
+		if (d != d) d = __longlong_as_double(0x7FF8000000000000LL);
+		keys[k] = d;
 	}
-	if (d != d) d = __longlong_as_double(0x7FF8000000000000LL);
-	keys[k] = d;
 }
 
 // One wavefront per column: negatives, positives, NA/NaN among the stored values.  Writes the
@@ -141,11 +150,13 @@ int launch_colmedians(const int64_t *col_ptr, const void *val, int Rtype, int64_
 					   (const int *) val, nrow, ncol, na_rm, out, seg_b, seg_e);
 	}
 	if (nnz > 0) {
-		const unsigned nb = (unsigned) ((nnz + 255) / 256);
+		const unsigned nb = (unsigned) ((ncol + 3) / 4);
 		if (Rtype == SVT_REALSXP)
-			hipLaunchKernelGGL(median_key_kernel<double>, dim3(nb), dim3(256), 0, s, (const double *) val, nnz, k_in);
+			hipLaunchKernelGGL(median_key_kernel<double>, dim3(nb), dim3(256), 0, s, col_ptr, (const double *) val,
+					   ncol, seg_b, seg_e, k_in);
 		else
-			hipLaunchKernelGGL(median_key_kernel<int>, dim3(nb), dim3(256), 0, s, (const int *) val, nnz, k_in);
+			hipLaunchKernelGGL(median_key_kernel<int>, dim3(nb), dim3(256), 0, s, col_ptr, (const int *) val,
+					   ncol, seg_b, seg_e, k_in);
 		size_t tmp_bytes = 0;
 		HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(NULL, tmp_bytes, k_in, k_out, (int) nnz, (int) ncol,
 								   seg_b, seg_e));
