@@ -1126,6 +1126,13 @@ crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restric
 	for (int i = 0; i < (NV > 2 ? 2 : NV); i++) acc[i] = 0.0;
 	const bool partial = (nrow & 127) != 0;
 
+	// Which 4 of the panel's 64 pieces (dense columns) this wavefront stages: its own.  (Rotating the
+	// order by the column block -- so that the 16 workgroups of an XCD that pull the same panel do not ask
+	// the L2 for the same lines at the same moment -- makes the staging ALONE 24 % faster, 1.28 -> 0.97 ms,
+	// tools/micro/ceiling_bench.hip stage2; the product kernel does not notice, 1.730-1.745 ms either
+	// way in tools/debug/r2_rot.sh: its workgroups drift apart within a few panels and its panel time is
+	// set by the record work and the barrier, not by the staging.)
+	const int wd = w;
 	// ---- wave-uniform state (SGPR vectors pinned to s[8:11], s[12:27]) ------------
 	u32x4 PA;
 	u32x16 PB;
@@ -1137,7 +1144,7 @@ crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restric
 		PA[3] = (uint32_t) pa;
 		PB[0] = (uint32_t) pb;
 		PB[1] = PBC_DMA_BUF;                            // toggles to 0 for the first panel
-		PB[2] = (uint32_t) (w * 4 * PBC_DMA_ROW + PBC_DMA_BUF);
+		PB[2] = (uint32_t) (wd * 4 * PBC_DMA_ROW + PBC_DMA_BUF);
 		PB[3] = 0;
 		// partial last panel (staged as rows nrow-128 .. nrow-1): its index, the byte shift
 		PB[4] = partial ? (uint32_t) (npanels - 1) : 0xFFFFFFFFu;
@@ -1149,7 +1156,7 @@ crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restric
 		}
 #pragma unroll
 		for (int q = 0; q < 4; q++) {
-			int kk = k0 + w * 4 + q;
+			int kk = k0 + wd * 4 + q;
 			if (kk > K - 1) kk = K - 1;                 // tail of K: a valid column, never stored
 			// (bases one panel back, the offset register starts one panel in: the shift of a
 			// partial last panel must not take the unsigned 32-bit offset below zero)
@@ -1184,12 +1191,12 @@ crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restric
 		const bool clampme = partial && pa == npanels - 1;
 #pragma unroll
 		for (int q = 0; q < 4; q++) {
-			int kk = k0 + w * 4 + q;
+			int kk = k0 + wd * 4 + q;
 			if (kk > K - 1) kk = K - 1;
 			// a partial last panel is staged as rows nrow-128 .. nrow-1
 			const int64_t r0 = clampme ? nrow - 128 : pa * 128;
 			const double *src = Y + (int64_t) kk * ldY + r0 + lane * 2;
-			double *dst = ylds + (w * 4 + q) * 129;
+			double *dst = ylds + (wd * 4 + q) * 129;
 			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) src,
 							 (__attribute__((address_space(3))) void *) dst, 16, 0, 0);
 		}

@@ -116,6 +116,95 @@ static void run_stage(const double *Y, double *sink, int wpb, int layout, int64_
 	CHECK(hipEventDestroy(e0)); CHECK(hipEventDestroy(e1));
 }
 
+// A2. stage2: the same staging with (rot) the piece order rotated by the column block, so that the 16
+// workgroups that share a panel do not ask for the same lines at the same moment, and (mode) the queue
+// kept busy: 0 = as above (wait for the panel, barrier, issue the next), 1 = the next panel is issued
+// before the wait (two panels in flight, counted vmcnt), barrier per panel, 2 = the same without any
+// barrier (every wavefront streams its own pieces).  Nothing reads the buffers: an upper bound on what
+// two buffers can take in.
+template <int WPB>
+__global__ void __launch_bounds__(WPB * 64)
+stage2_kernel(const double *__restrict__ Y, int64_t ld, int nblocks, int kt, int64_t npanels,
+	      int64_t panels_per_split, double *sink, int rot, int mode)
+{
+	extern __shared__ double lds[];
+	constexpr int RS = 129, BUF = 64 * RS, NPIECE = 64 / WPB;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int L = blockIdx.x;
+	const int xcd = L % 8, j = L / 8, u = j / nblocks;
+	const int b = j % nblocks, kh = u % kt, sp = (u / kt) * 8 + xcd;
+	const int64_t pa = (int64_t) sp * panels_per_split;
+	int64_t pb = pa + panels_per_split;
+	if (pb > npanels) pb = npanels;
+	if (pa >= pb) return;
+	const int k0 = kh * 64;
+	const int wr = rot ? (w + b * rot) % WPB : w;
+	double acc = 0.0;
+	auto issue = [&](int64_t p, int buf) {
+#pragma unroll
+		for (int q = 0; q < NPIECE; q++) {
+			const int kk = wr * NPIECE + q;
+			const double *src = Y + (int64_t) (k0 + kk) * ld + p * 128 + lane * 2;
+			double *dst = lds + buf * BUF + kk * RS;
+			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) src,
+							 (__attribute__((address_space(3))) void *) dst, 16, 0, 0);
+		}
+	};
+	const int64_t np = pb - pa;
+	issue(pa, 0);
+	for (int64_t i = 0; i < np; i++) {
+		const int buf = (int) (i & 1);
+		if (mode == 0) {
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			__builtin_amdgcn_s_barrier();
+			if (i + 1 < np) issue(pa + i + 1, buf ^ 1);
+		} else {
+			if (i + 1 < np) {
+				issue(pa + i + 1, buf ^ 1);
+				if (NPIECE == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+				else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+			} else {
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			}
+			if (mode == 1) __builtin_amdgcn_s_barrier();
+		}
+		if ((i & 63) == 63) acc += lds[buf * BUF + lane * RS + (w & 7)];
+	}
+	if (acc == 123.456) sink[0] = acc;
+}
+
+static void run_stage2(const double *Y, double *sink, int wpb, int rot, int mode)
+{
+	const int K = 128, kt = 2, nblocks = 16, nsplit = 8;
+	const int64_t nrow = 999936, ld = 1000000, npanels = nrow / 128;
+	const int64_t pps = (npanels + nsplit - 1) / nsplit;
+	const int nwg = nblocks * kt * nsplit;
+	const size_t ldsb = (size_t) 2 * 64 * 129 * 8;
+	hipEvent_t e0, e1;
+	CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+	float best = 1e30f;
+	for (int rep = 0; rep < 6; rep++) {
+		CHECK(hipEventRecord(e0));
+		if (wpb == 16) {
+			CHECK(hipFuncSetAttribute((const void *) stage2_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsb));
+			hipLaunchKernelGGL((stage2_kernel<16>), dim3(nwg), dim3(16 * 64), ldsb, 0, Y, ld, nblocks, kt, npanels, pps, sink, rot, mode);
+		} else {
+			CHECK(hipFuncSetAttribute((const void *) stage2_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsb));
+			hipLaunchKernelGGL((stage2_kernel<8>), dim3(nwg), dim3(8 * 64), ldsb, 0, Y, ld, nblocks, kt, npanels, pps, sink, rot, mode);
+		}
+		CHECK(hipEventRecord(e1));
+		CHECK(hipEventSynchronize(e1));
+		float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+		if (rep > 0 && ms < best) best = ms;
+	}
+	const double bytes = (double) nblocks * npanels * 128 * K * 8;
+	printf("stage2 wpb %2d rot %d mode %d (%s): %.3f ms, %.1f TB/s, %.1f GB/s per CU, %.0f ns/panel\n", wpb, rot, mode,
+	       mode == 0 ? "drain + barrier" : mode == 1 ? "2 panels in flight + barrier" : "2 panels in flight, no barrier",
+	       best, bytes / best / 1e9, bytes / 256 / best / 1e6, best * 1e6 / pps);
+	CHECK(hipEventDestroy(e0)); CHECK(hipEventDestroy(e1));
+}
+
 // ------------------------------------------------------------------------------------------- B
 typedef double d16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
@@ -793,6 +882,17 @@ int main(int argc, char **argv)
 			run_combo(Y, sink, combo_8, 8, 11, 11, 1167.4, dma, work, "8 x 114 cols, 2 y sets");
 			run_combo(Y, sink, combo_8y1, 8, 11, 11, 1167.4, dma, work, "8 x 114 cols, 1 y set");
 		}
+		CHECK(hipFree(Y));
+	}
+	if (!strcmp(which, "all") || !strcmp(which, "stage2")) {
+		const int64_t maxrow = 1048576 + 1024, K = 128;
+		double *Y;
+		CHECK(hipMalloc(&Y, (size_t) maxrow * K * 8 + 4096));
+		CHECK(hipMemset(Y, 0, (size_t) maxrow * K * 8 + 4096));
+		for (int wpb : {16, 8})
+			for (int mode = 0; mode < 3; mode++)
+				for (int rot : {0, 1, 5})
+					run_stage2(Y, sink, wpb, rot, mode);
 		CHECK(hipFree(Y));
 	}
 	if (!strcmp(which, "all") || !strcmp(which, "stage")) {
