@@ -25,6 +25,10 @@ YSETS = 2: D runs ahead of F into the other y set, so the LDS latency hides unde
 the 16 instructions of F.  YSETS = 1: the read that refills y_j is issued right
 behind the FMA that consumed it (16 VGPRs fewer, LDS latency of the last read
 exposed at the wait).
+DEFER (two y sets): a phase looks at its batch's flags BEFORE the batch; the last batch of a tile keeps its
+FMAs for the far side of the barrier, where they run under the latency of the next tile's first LDS reads --
+the one stretch in which all 16 wavefronts wait for the LDS at once.  Same sums in the same order (identical
+result checksum); 1.735 -> 1.719 ms at config 2a, A/B on one box (tools/debug/r2_rot.sh).
 Measured (tools/debug/exp_pbc.sh): what a phase costs is the round trips behind its
 single wait, not its instructions -- twice the work per phase ran 1.5 % slower --
 hence 8 records per phase (the SGPR file allows no more: 3 x 24).
@@ -78,6 +82,7 @@ else:
     ADDR = 12
     YSET = [20]
     ACC = 36
+DEFER = YSETS == 2 and not EXP and os.environ.get("PBC_DEFER", "1") == "1"
 PROF = False
 out = []
 
@@ -188,17 +193,22 @@ def gen(prof):
     load("B", BATCH)
     e(f"s_add_u32 s10, s10, {2 * BATCH}")
     e("s_waitcnt lgkmcnt(0)")                      # (the boundary code itself never has a load in flight)
-    e(f"s_branch {30 + NPH - 1}f")                 # first panel: enter through the last phase's boundary
+    e(f"s_branch {(50 if DEFER else 30) + NPH - 1}f")   # first panel: enter through the last phase's boundary
 
     # ---- panel boundary after a tile that ended in phase i (one copy per phase: no
     # ---- dispatch chains; the scalar unit is the busiest pipe of this kernel)
-    def boundary(i):
-        e(f"{30 + i}:")
+    def boundary(i, entry=False):
+        # DEFER (two y sets): the FMAs of the tile's last batch run behind the barrier, under the latency
+        # of the first LDS reads of the next tile -- the one stretch in which every wavefront of the
+        # workgroup waits for the LDS at once (the phase that found the end-of-tile flag skipped them).
+        # `entry`: the copy the first panel enters through (nothing to multiply yet).
+        defer = DEFER and not entry
+        e(f"{(50 if entry else 30) + i}:")
         if "nosmem" in EXP:
             e("s_mov_b32 s99, 7")
         stamp(7)                                   # phases
         e("s_cmp_ge_u32 s11, s12")
-        e("s_cbranch_scc1 90f")
+        e(f"s_cbranch_scc1 {(40 + i) if defer else 90}f")
         # bookkeeping and the LDS addresses of the next tile's first batch come before the
         # barrier: wavefronts that arrive early do them while they would wait anyway
         e(f"s_xor_b32 s13, s13, {BUF}")
@@ -211,7 +221,6 @@ def gen(prof):
         # finite check of this workgroup's share of the panel: the first read rides on
         # the LDS wait of the reads below, the rest (few column blocks only) loop at 12
         e("v_add_u32 v6, s13, v3")
-        e("s_mov_b32 m0, s19")
         stamp(4)                                   # boundary bookkeeping
         d8(i, "addr")
         # own pieces of this panel (issued inside the previous tile; the younger touch may fly)
@@ -222,6 +231,9 @@ def gen(prof):
             e("s_barrier")                         # everybody's pieces; everybody done with the previous panel
         stamp(2)                                   # barrier
         d8(i, "read")                              # LDS reads of the batch the next phase multiplies
+        if defer:
+            f8(i, False)
+        e("s_mov_b32 m0, s19")                     # (after the FMAs: the register-index mode writes m0)
         stamp(5)
         if "nofinite" in EXP:
             e("s_waitcnt lgkmcnt(0)")
@@ -269,6 +281,14 @@ def gen(prof):
             e(".p2align 6")                        # (experiment: loop head on a 64-byte boundary)
         e(f"{ph[i]}:")
         load(X2[i % 3], BATCH * i)
+        if i == NPH - 1 and DEFER:
+            e(f"s_add_u32 s10, s10, {TRIP}")
+        if DEFER:
+            # bit 15 of the batch's first meta word: last batch of the tile; bit 14: issue the
+            # LDS-DMA of the next panel after this batch.  One test on the fast path, ahead of the
+            # batch: the end of a tile keeps its FMAs for the far side of the barrier.
+            e(f"s_and_b32 vcc_lo, s{BLK[X0[i % 3]]}, 0xc000")
+            e(f"s_cbranch_scc1 {70 + i}f")
         if YSETS == 2:
             d8(i)
             f8(i, False)
@@ -278,6 +298,8 @@ def gen(prof):
                     sdwa_add(ADDR + j, BLK[X1[i % 3]] + j)
             f8(i, True)
         e("s_waitcnt lgkmcnt(0)")
+        if DEFER:
+            continue
         if i == NPH - 1:
             e(f"s_add_u32 s10, s10, {TRIP}")
         if "nosmem" in EXP:                        # (experiment: 7 batches per tile, issue after the third)
@@ -295,6 +317,20 @@ def gen(prof):
     for i in range(NPH):                           # slow paths: a flagged batch
         r0 = BLK[X0[i % 3]]
         e(f"{70 + i}:")
+        if DEFER:
+            e(f"s_bitcmp1_b32 s{r0}, 15")
+            e(f"s_cbranch_scc1 {80 + i}f")
+            d8(i)                                  # the issue flag alone: the batch as in the phase, then the DMA
+            f8(i, False)
+            e("s_waitcnt lgkmcnt(0)")
+            issue()
+            e(f"s_branch {ph[(i + 1) % NPH]}b")
+            e(f"{80 + i}:")                        # end of the tile (the FMAs wait for the boundary)
+            e(f"s_bitcmp1_b32 s{r0}, 14")
+            e(f"s_cbranch_scc0 {30 + i}f")
+            issue()
+            e(f"s_branch {30 + i}f")
+            continue
         if "nosmem" not in EXP:
             e(f"s_bitcmp1_b32 s{r0}, 14")
             e(f"s_cbranch_scc0 {30 + i}f")         # only the end-of-tile flag
@@ -305,6 +341,12 @@ def gen(prof):
         e(f"s_branch {ph[(i + 1) % NPH]}b")
     for i in range(NPH):
         boundary(i)
+    if DEFER:
+        boundary(NPH - 1, entry=True)
+        for i in range(NPH):                       # no panel left: the last tile's last batch, then out
+            e(f"{40 + i}:")
+            f8(i, False)
+            e("s_branch 90f")
     e("90:")
     e("s_waitcnt vmcnt(0) lgkmcnt(0)")
     return out
