@@ -67,6 +67,35 @@ struct svt_dev_pbc {
 #define PCH 256            // panels per build chunk
 // Tuning builds only (make TUNING=1 -> -DSVT_TUNING; build() does not produce one): knobs of
 // tools/tune_pbc.py.  The product library has constants here and exports none of the setters.
+// After which batch of its tile wavefront w of a workgroup issues its LDS-DMA pieces of the next panel
+// (bit 14 of that batch's first meta word; nb = batches of the tile, the caller clamps).  Pattern 7 --
+// wavefronts 4g..4g+3 after batch g -- is the product's; 12 and 15 time the same, all at once (0) is 3 % slower.
+__device__ inline int64_t pbc_stagger_batch(int stag_mode, int w, int64_t nb)
+{
+	const int g = w >> 2;
+	switch (stag_mode) {
+	case 0: return 0;
+	case 1: return w & 1;
+	case 2: return w & 3;
+	case 3: return g & 1;
+	case 4: return w & 7;
+	case 5: return (w * nb) >> 4;
+	case 6: return (w & 3) * 2;
+	case 7: return g;
+	case 8: return g * 2;
+	case 9: return w >> 1;
+	case 10: return g + 1;
+	case 11: return w >> 3;
+	case 12: return g < 2 ? g : 2;
+	case 13: return g % 3;
+	case 14: return g * 3 / 4;
+	case 15: return g == 0 ? 0 : g == 3 ? 2 : 1;
+	case 16: return g < 1 ? g : 1;
+	case 17: return 1 + (w >> 3);
+	default: return g;
+	}
+}
+
 #ifdef SVT_TUNING
 static int g_pbc_debug = 0;
 static int g_pbc_nsplit = 0;
@@ -75,7 +104,7 @@ static int g_pbc_ahead10 = 20;
 #else
 static constexpr int g_pbc_debug = 0;
 static constexpr int g_pbc_nsplit = 0;
-static constexpr int g_pbc_stagger = 7;   // DMA issue: wavefronts 4g..4g+3 after batch g of their tile (measured best of 12 patterns)
+static constexpr int g_pbc_stagger = 7;   // DMA issue: wavefronts 4g..4g+3 after batch g of their tile (patterns 12 and 15 time the same in the bench, tools/debug/r2_rot.sh)
 static constexpr int g_pbc_ahead10 = 20;  // record touch: look-ahead in tenths of a tile
 #endif
 
@@ -193,14 +222,7 @@ pbc_pass_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__
 				const int64_t start = counts_or_ptr[TILE_OF(p0 + i)];
 				const int w = (int) (wv % 16);
 				const int64_t nb = (stop - start) >> 3;
-				int64_t bi = stag_mode == 0 ? 0 : stag_mode == 1 ? (w & 1) :
-					     stag_mode == 2 ? (w & 3) : stag_mode == 3 ? ((w >> 2) & 1) :
-					     stag_mode == 4 ? (w & 7) : stag_mode == 5 ? ((w * nb) >> 4) :
-					     stag_mode == 6 ? ((w & 3) * 2) : stag_mode == 7 ? (w >> 2) :
-					     stag_mode == 8 ? ((w >> 2) * 2) : stag_mode == 9 ? (w >> 1) :
-					     stag_mode == 10 ? ((w >> 2) + 1) : stag_mode == 11 ? (w >> 3) :
-					     stag_mode == 12 ? ((w >> 2) < 2 ? (w >> 2) : 2) :
-					     stag_mode == 13 ? ((w >> 2) % 3) : ((w >> 2) * 3 / 4);
+				int64_t bi = pbc_stagger_batch(stag_mode, w, nb);
 				if (bi > nb - 1) bi = nb - 1;
 				atomicOr((unsigned int *) ((char *) rec + ((start >> 3) + bi) * 96), 0x4000u);
 			}
@@ -336,14 +358,7 @@ pbc_scatter_lds_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__res
 		*last |= 0x8000u;
 		const int w = (int) (g % 16);
 		const int nb = (stop - start) >> 3;
-		int bi = stag_mode == 0 ? 0 : stag_mode == 1 ? (w & 1) :
-			 stag_mode == 2 ? (w & 3) : stag_mode == 3 ? ((w >> 2) & 1) :
-			 stag_mode == 4 ? (w & 7) : stag_mode == 5 ? ((w * nb) >> 4) :
-			 stag_mode == 6 ? ((w & 3) * 2) : stag_mode == 7 ? (w >> 2) :
-			 stag_mode == 8 ? ((w >> 2) * 2) : stag_mode == 9 ? (w >> 1) :
-			 stag_mode == 10 ? ((w >> 2) + 1) : stag_mode == 11 ? (w >> 3) :
-			 stag_mode == 12 ? ((w >> 2) < 2 ? (w >> 2) : 2) :
-			 stag_mode == 13 ? ((w >> 2) % 3) : ((w >> 2) * 3 / 4);
+		int bi = (int) pbc_stagger_batch(stag_mode, w, nb);
 		if (bi > nb - 1) bi = nb - 1;
 		uint32_t *issue = (uint32_t *) (dst + ((start >> 3) + bi) * 96);
 		*issue |= 0x4000u;
