@@ -31,7 +31,9 @@ the one stretch in which all 16 wavefronts wait for the LDS at once.  Same sums 
 result checksum); 1.735 -> 1.719 ms at config 2a, A/B on one box (tools/debug/r2_rot.sh).
 Measured (tools/debug/exp_pbc.sh): what a phase costs is the round trips behind its
 single wait, not its instructions -- twice the work per phase ran 1.5 % slower --
-hence 8 records per phase (the SGPR file allows no more: 3 x 24).
+hence 8 records per phase (the SGPR file allows no more: 3 x 24).  The order inside a phase -- the 8 address
+adds, the 8 LDS reads, then the 8 FMAs -- beats dealing the reads between the FMAs, one by one or in pairs
+(1.720 / 1.733 / 1.728 ms at config 2a, same box).
 
 DMA issue: all 4 pieces of a wavefront at once, after the batch the layout flags with bit 14
 (batch w & 3 of the tile, or its last one), so that the phases pay one flag test, not two.
