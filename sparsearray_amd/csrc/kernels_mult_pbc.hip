@@ -981,6 +981,7 @@ crossprod_pbc_kernel(const uint4 *__restrict__ rec,
 	[ya0] "=&v"(ya0_), [ya1] "=&v"(ya1_), [ya2] "=&v"(ya2_), [ya3] "=&v"(ya3_),      \
 	[yb0] "=&v"(yb0_), [yb1] "=&v"(yb1_), [yb2] "=&v"(yb2_), [yb3] "=&v"(yb3_)
 #define PBG_CHUNK_PANELS 256     // panels per row split and launch (16: 88 ms, 64: 59, 256: 53, all: 78-87 at config 4)
+#define PBG2_CHUNK_PANELS 160    // the same for the kernel with two dense columns per lane (96: 51.8 ms, 128: 49.7, 160: 49.2, 192: 51.1, 256: 55)
 #define PBG_PANEL_IN [base] "s"(rec_w), [pb] "s"(pbase), [kp] "v"(kp_v), [l8] "v"(lane8)
 
 template <int NV>
@@ -1051,6 +1052,99 @@ crossprod_pbc_gather_kernel(const uint4 *__restrict__ rec, const int64_t *__rest
 		for (int jj = 0; jj < 8; jj++)
 			if (32 + jj < CBW && c0 + 32 + jj < ncol)
 				dst[32 + jj] = accumulate ? dst[32 + jj] + acc8[jj] : acc8[jj];
+	}
+}
+
+// ---------------------------------------------------------------------------
+// Gather kernel, two dense columns per lane (K a multiple of 128): a nonzero fetches the 1 KiB of its
+// row of Yt with ONE 16-byte load per lane and feeds two FMAs -- half the load instructions, half
+// the record loads and half the index switches of the kernel above per (nonzero, dense column), and
+// 16-byte loads move more bytes per L2 request cycle than 8-byte ones.  A lane's two partial sums of
+// column c sit in v[64 + 2c] and v[144 + 2c] (the same register index serves both FMAs); the y
+// registers are pinned to v[224:255] (two sets of four 4-register tuples): 256 VGPRs, 8 wavefronts per
+// CU, each with 8 KiB in flight.
+// ---------------------------------------------------------------------------
+#include "pbg2_asm.inc"       // PBG2_PANEL_TXT, generated by tools/gen_pbg2_asm.py
+#define PBG2_PANEL_OPS                                                                 \
+	[lo] "+s"(lo_), [nb] "+s"(nb_),                                                \
+	[t0] "=&v"(t0_), [t1] "=&v"(t1_), [t2] "=&v"(t2_), [t3] "=&v"(t3_),              \
+	"+{v[224:255]}"(ysets)
+#define PBG2_PANEL_IN [base] "s"(rec_w), [pb] "s"(pbase), [kp] "v"(kp_v), [l16] "v"(lane16)
+typedef uint32_t u32x32_t __attribute__((ext_vector_type(32)));
+
+template <int NV>
+__global__ void __launch_bounds__(256)
+crossprod_pbc_gather2_kernel(const uint4 *__restrict__ rec, const int64_t *__restrict__ tile_ptr,
+			     int64_t npanels, const double *__restrict__ Yt, int64_t Ktp, int K,
+			     int64_t ncol, int64_t panels_per_split, double *__restrict__ part, int64_t Kp,
+			     int CBW, int logR, int64_t p_first, int64_t p_last, int accumulate)
+{
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int split = blockIdx.x, kt = blockIdx.y;
+	const int64_t wv = (int64_t) blockIdx.z * 4 + w;          // column group of this wavefront
+	const int64_t pa = p_first + (int64_t) split * panels_per_split;
+	const int64_t pb = pa + panels_per_split < p_last ? pa + panels_per_split : p_last;
+	if (pa >= pb)
+		return;
+	const int k0 = kt * 128;
+	// lo: dense column k0 + 2 * lane, hi: k0 + 2 * lane + 1; NV == 3 keeps 40 columns (16 + 16 + 8)
+	d16 acc[NV > 2 ? 2 : NV], acch[NV > 2 ? 2 : NV];
+	d8 acc8 = 0.0, acch8 = 0.0;
+#pragma unroll
+	for (int i = 0; i < (NV > 2 ? 2 : NV); i++) { acc[i] = 0.0; acch[i] = 0.0; }
+	u32x32_t ysets = 0;
+	const uint32_t lane16 = (uint32_t) lane * 16u;
+	const uint32_t kp_v = (uint32_t) Ktp;                    // (row offset in bytes = 8 * row * Ktp)
+	const int64_t *__restrict__ tb = tile_ptr + (wv * npanels + pa);
+	const uint4 *__restrict__ rec_w = rec + tb[0];
+	uint32_t off = 0;
+	for (int64_t p = pa; p < pb; p++, tb += 1) {
+		const int64_t tbeg = tb[0], tend = tb[1];
+		uint32_t nb_ = (uint32_t) ((tend - tbeg) / PBC_BATCH);
+		uint32_t lo_ = off;
+		off += nb_ * (PBC_BATCH * 16u);
+		const double *pbase = Yt + (p << logR) * Ktp + k0;
+		uint32_t t0_, t1_, t2_, t3_;
+		if constexpr (NV == 1) {
+			asm volatile(PBG2_PANEL_TXT
+				     : "+{v[64:95]}"(acc[0]), "+{v[144:175]}"(acch[0]), PBG2_PANEL_OPS
+				     : PBG2_PANEL_IN
+				     : PBC_PANEL_CLOBBERS);
+		} else if constexpr (NV == 2) {
+			asm volatile(PBG2_PANEL_TXT
+				     : "+{v[64:95]}"(acc[0]), "+{v[96:127]}"(acc[NV > 1 ? 1 : 0]),
+				       "+{v[144:175]}"(acch[0]), "+{v[176:207]}"(acch[NV > 1 ? 1 : 0]), PBG2_PANEL_OPS
+				     : PBG2_PANEL_IN
+				     : PBC_PANEL_CLOBBERS);
+		} else {
+			asm volatile(PBG2_PANEL_TXT
+				     : "+{v[64:95]}"(acc[0]), "+{v[96:127]}"(acc[NV > 1 ? 1 : 0]), "+{v[128:143]}"(acc8),
+				       "+{v[144:175]}"(acch[0]), "+{v[176:207]}"(acch[NV > 1 ? 1 : 0]), "+{v[208:223]}"(acch8),
+				       PBG2_PANEL_OPS
+				     : PBG2_PANEL_IN
+				     : PBC_PANEL_CLOBBERS);
+		}
+	}
+	// ---- partial results: part[(split*Kp + k) * ncol + c] -----------------
+	const int64_t c0 = wv * CBW;
+	double *__restrict__ dlo = part + ((int64_t) split * Kp + k0 + 2 * lane) * ncol + c0;
+	double *__restrict__ dhi = dlo + ncol;
+#pragma unroll
+	for (int ii = 0; ii < (NV > 2 ? 2 : NV); ii++)
+#pragma unroll
+		for (int jj = 0; jj < 16; jj++)
+			if (ii * 16 + jj < CBW && c0 + ii * 16 + jj < ncol) {
+				dlo[ii * 16 + jj] = accumulate ? dlo[ii * 16 + jj] + acc[ii][jj] : acc[ii][jj];
+				dhi[ii * 16 + jj] = accumulate ? dhi[ii * 16 + jj] + acch[ii][jj] : acch[ii][jj];
+			}
+	if constexpr (NV > 2) {
+#pragma unroll
+		for (int jj = 0; jj < 8; jj++)
+			if (32 + jj < CBW && c0 + 32 + jj < ncol) {
+				dlo[32 + jj] = accumulate ? dlo[32 + jj] + acc8[jj] : acc8[jj];
+				dhi[32 + jj] = accumulate ? dhi[32 + jj] + acch8[jj] : acch8[jj];
+			}
 	}
 }
 
@@ -1735,8 +1829,11 @@ static int64_t pbc_padded_rows(const svt_dev_pbc *P)
 static int pick_nsplit_gather(const svt_dev_pbc *P, int K, int64_t *pps_out)
 {
 	const int64_t kt = ((int64_t) K + 63) / 64;
-	const int64_t waves = P->ngroups * kt;
-	int64_t target = 4096;                               // one round of resident wavefronts (16 per CU)
+	const bool wide = kt % 2 == 0;                       // crossprod_pbc_gather2_kernel: one wavefront per 128 dense columns
+	const int64_t waves = P->ngroups * (wide ? kt / 2 : kt);
+	// wavefronts per launch: ~4096 for both kernels (the 128-column one keeps 8 per CU resident, 8 KiB in
+	// flight each: two rounds; config 4: 4 row splits 49.2 ms, 2 splits 59, 7 and more 83)
+	int64_t target = 4096;
 #ifdef SVT_TUNING
 	if (getenv("SVT_PBG_WAVES")) target = atoll(getenv("SVT_PBG_WAVES"));
 #endif
@@ -1935,15 +2032,19 @@ static int pbc_phase(const svt_dev_pbc *P, const svt_dev_csc *A,
 			pa.tr_y = tr_y; pa.ws = gen_ws; pa.ws_bytes = gen_bytes;
 			if (launch_dense_prepare_flag(pa, fl.y_nonfinite, s))
 				return -1;
-			dim3 grid((unsigned) nsplit, (unsigned) (Kp / 64), (unsigned) P->nblocks);
-			auto kern = nv == 1 ? crossprod_pbc_gather_kernel<1> : nv == 2 ? crossprod_pbc_gather_kernel<2>
-									     : crossprod_pbc_gather_kernel<3>;
+			// whole pairs of 64-wide dense tiles: the kernel with two dense columns per lane
+			const bool wide = Kp % 128 == 0;
+			dim3 grid((unsigned) nsplit, (unsigned) (wide ? Kp / 128 : Kp / 64), (unsigned) P->nblocks);
+			auto kern = wide ? (nv == 1 ? crossprod_pbc_gather2_kernel<1> : nv == 2 ? crossprod_pbc_gather2_kernel<2>
+										     : crossprod_pbc_gather2_kernel<3>)
+					 : (nv == 1 ? crossprod_pbc_gather_kernel<1> : nv == 2 ? crossprod_pbc_gather_kernel<2>
+										     : crossprod_pbc_gather_kernel<3>);
 			// Row chunks as consecutive launches (the partial sums go through memory in between):
 			// inside one launch the wavefronts of all column groups walk the same rows at about the
 			// same pace, so a row of Yt fetched for one group is still in L2 for the others; over a
 			// whole operand they drift apart by more rows than the L2 holds and every record's 512
 			// bytes come from the Infinity Cache or HBM (81.8 ms at BASELINE config 4, i.e. HBM speed).
-			int64_t cpanels = PBG_CHUNK_PANELS;
+			int64_t cpanels = wide ? PBG2_CHUNK_PANELS : PBG_CHUNK_PANELS;
 #ifdef SVT_TUNING
 			if (getenv("SVT_PBG_CHUNK")) cpanels = atoll(getenv("SVT_PBG_CHUNK"));
 #endif
