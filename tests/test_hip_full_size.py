@@ -167,11 +167,14 @@ def test_config5_rowsums_dims2_match_scatter_add(array5):
 # BASELINE config 4 at full size on ONE GPU (1e7 x 5e4 @ 0.1 %, 5e8 nonzeros, 6 GB of CSC):
 # the record stream is > 4 GiB, the kernels' 32-bit cursors are per column group.
 # ---------------------------------------------------------------------------
-def test_config4_full_size_crossprod_and_colsums(hip):
+@pytest.mark.parametrize("Kc", [64, 128], ids=["K64-gather", "K128-gather2"])
+def test_config4_full_size_crossprod_and_colsums(hip, Kc):
+    """Kc = 64: crossprod_pbc_gather_kernel (lane = dense column); Kc = 128 (BASELINE's width): the kernel with
+    two dense columns per lane."""
     from sparsearray_amd import synth
     from sparsearray_amd.device import DeviceCSC, PbcPlan, colstats
     dev = torch.device("cuda", 0)
-    nrow, ncol, Kc = 10_000_000, 50_000, 64
+    nrow, ncol = 10_000_000, 50_000
     cp, ri, v = synth.random_device_csc(nrow, ncol, 0.001, seed=4, device=dev)
     A = DeviceCSC(nrow, cp, ri, v)
     assert A.nnz > 4.9e8
