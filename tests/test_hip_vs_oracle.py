@@ -189,7 +189,10 @@ def test_matrixstats_double(hip, oracle, shape, density, na_rm):
 @pytest.mark.parametrize("na_rm", [False, True])
 @pytest.mark.parametrize("shape,density,dtype", [((40000, 3000), 0.01, "double"), ((40000, 2000), 0.01, "int"),
                                                  ((20000, 50, 40), 0.02, "double"), ((16384, 700), 0.05, "double"),
-                                                 ((16385, 9), 0.5, "int")])
+                                                 ((16385, 9), 0.5, "int"),
+                                                 # many output columns of few short leaves, all rows in LDS
+                                                 # (rowstats_whole_kernel, dims = 2)
+                                                 ((9000, 1100, 6), 0.01, "double"), ((8500, 1030, 3), 0.02, "int")])
 def test_row_stats_long_panels_and_strata_ranges(hip, oracle, shape, density, dtype, na_rm):
     """>= 16384 rows: the sum-like row statistics take 8192-row panels and, with few panels, cut
     the leaves into ranges whose partial cells are added in `out` (kernels_rowstats.hip);
