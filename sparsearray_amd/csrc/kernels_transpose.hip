@@ -248,6 +248,9 @@ __global__ void aperm_leaf_count_kernel(const int64_t *__restrict__ col_ptr, int
 	cnt[jn] = col_ptr[j + 1] - col_ptr[j];
 }
 
+// One wavefront per four new leaves, their bounds and their runs in flight together (a leaf at a time is
+// a chain of three memory latencies per ~100 nonzeros: 1.1 ms for the 3 GB of BASELINE config 5).
+#define APERM_LU 4
 template <typename T>
 __global__ void __launch_bounds__(256)
 aperm_leaf_copy_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__ row_idx,
@@ -255,12 +258,35 @@ aperm_leaf_copy_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__res
 		       const int64_t *__restrict__ out_ptr, int32_t *__restrict__ out_idx, T *__restrict__ out_val)
 {
 	const int lane = threadIdx.x & 63;
-	const int64_t jn = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);       // one wavefront per new leaf
-	if (jn >= nleaves) return;
-	const int64_t src = col_ptr[old_leaf_of(m, jn)], dst = out_ptr[jn], n = out_ptr[jn + 1] - dst;
-	for (int64_t k = lane; k < n; k += 64) {
-		out_idx[dst + k] = row_idx[src + k];
-		out_val[dst + k] = val[src + k];
+	const int64_t j0 = ((int64_t) blockIdx.x * 4 + (threadIdx.x >> 6)) * APERM_LU;
+	if (j0 >= nleaves) return;
+	int64_t src[APERM_LU], dst[APERM_LU], n[APERM_LU];
+#pragma unroll
+	for (int u = 0; u < APERM_LU; u++) {
+		const int64_t jn = j0 + u;
+		src[u] = dst[u] = n[u] = 0;
+		if (jn < nleaves) {
+			src[u] = col_ptr[old_leaf_of(m, jn)];
+			dst[u] = out_ptr[jn];
+			n[u] = out_ptr[jn + 1] - dst[u];
+		}
+	}
+	bool more = true;
+	for (int64_t k = lane; more; k += 64) {
+		int32_t r[APERM_LU];
+		T v[APERM_LU];
+#pragma unroll
+		for (int u = 0; u < APERM_LU; u++)
+			if (k < n[u]) { r[u] = row_idx[src[u] + k]; v[u] = val[src[u] + k]; }
+		more = false;
+#pragma unroll
+		for (int u = 0; u < APERM_LU; u++)
+			if (k < n[u]) {
+				out_idx[dst[u] + k] = r[u];
+				out_val[dst[u] + k] = v[u];
+				more |= k + 64 < n[u];
+			}
+		more = __any(more);
 	}
 }
 
@@ -404,7 +430,7 @@ int launch_aperm(const int64_t *col_ptr, const int32_t *row_idx, const void *val
 		size_t tb = 0;
 		(void) hipcub::DeviceScan::ExclusiveSum(NULL, tb, out_ptr, out_ptr, (int) (new_nleaves + 1));
 		HIP_TRY(hipcub::DeviceScan::ExclusiveSum(ws, tb, out_ptr, out_ptr, (int) (new_nleaves + 1), s));
-		const unsigned nbc = (unsigned) ((new_nleaves + 3) / 4);
+		const unsigned nbc = (unsigned) ((new_nleaves + 4 * APERM_LU - 1) / (4 * APERM_LU));
 		if (Rtype == SVT_REALSXP)
 			hipLaunchKernelGGL(aperm_leaf_copy_kernel<double>, dim3(nbc), dim3(256), 0, s, col_ptr, row_idx,
 					   (const double *) val, new_nleaves, lm, out_ptr, out_idx, (double *) out_val);
