@@ -345,7 +345,10 @@ int svt_dev_transpose(const svt_dev_csc *A, int64_t *out_col_ptr, int32_t *out_r
    R/SparseArray-aperm.R).  `dim` are the array's ndim extents (dim[0] = A->nrow,
    prod(dim[1..]) = A->ncol), `perm` is 1-based as in R.  Output: the CSC layout of
    the permuted array, prod(dim[perm[1..]]) + 1 column pointers and A->nnz entries
-   (caller-allocated); 1 <= ndim <= 8. */
+   (caller-allocated); 1 <= ndim <= 8.  Asynchronous on `stream`, except for permutations whose new
+   leading axis is an old outer axis and whose second axis is the old rows (aperm(x, c(3, 1, 2))): the
+   choice between the per-slab kernel and the key sort reads one counter back and synchronises the
+   stream once. */
 size_t svt_dev_aperm_ws_bytes(int64_t nnz, int ndim, const int64_t *dim);
 int svt_dev_aperm(const svt_dev_csc *A, int ndim, const int64_t *dim, const int *perm,
 		  int64_t *out_col_ptr, int32_t *out_row_idx, void *out_val,

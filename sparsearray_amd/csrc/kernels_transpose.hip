@@ -365,6 +365,123 @@ static size_t aperm_sort_tmp(int64_t nnz, int bits)
 }
 
 // [keys nnz*8][sorted keys nnz*8][pos nnz*4][sorted pos nnz*4][sort temp]
+// ---- slab form: the new leading axis is an old outer axis q of small extent, the old rows become new
+// axis 1 (aperm(x, c(3, 1, 2)) of a 2e4 x 2e4 x 64 array).  For every index of the remaining axes (a slab)
+// the sub-array is a d0 x dq matrix held in dq whole old leaves, to be transposed into d0 new leaves of at
+// most dq entries each, which follow one another in the output.  One workgroup per slab: the slab's
+// nonzeros (a few thousand) are sorted by old row in LDS -- a stable block radix sort on the row alone; the
+// input order, leaf after leaf, already ascends in the index that becomes the new row -- and leave as one
+// coalesced run; the leaf pointers of the slab's d0 new leaves are filled from the sorted rows.  Traffic:
+// the nonzeros once in, once out, and the new leaf pointers (most new leaves are empty: 3.2 GB of
+// pointers for 1.5 GB of nonzeros at BASELINE config 5).  7.8 ms through the global key sort.
+// ---------------------------------------------------------------------------
+#define SLAB_NT 512
+#define SLAB_ITEMS 16
+#define SLAB_CAP (SLAB_NT * SLAB_ITEMS)
+struct SlabMap {
+	int nother;              // axes besides old 0 and old q
+	int64_t new_ext[8];      // their extents, in the order of the new axes 2 .. ndim-1
+	int64_t old_stride[8];   // their leaf strides in the OLD layout
+};
+
+__device__ inline int64_t slab_base_leaf(const SlabMap &m, int64_t g)
+{
+	int64_t j = 0;
+	for (int t = 0; t < m.nother; t++) {
+		const int64_t it = g % m.new_ext[t];
+		g /= m.new_ext[t];
+		j += it * m.old_stride[t];
+	}
+	return j;
+}
+
+// cnt[g] = nonzeros of slab g (cnt[nslab] = 0), *maxcnt = the largest
+__global__ void aperm_slab_count_kernel(const int64_t *__restrict__ col_ptr, SlabMap m, int64_t nslab,
+					int64_t dq, int64_t osq, int64_t *__restrict__ cnt,
+					unsigned long long *__restrict__ maxcnt)
+{
+	const int64_t g = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if (g > nslab) return;
+	if (g == nslab) { cnt[g] = 0; return; }
+	const int64_t j0 = slab_base_leaf(m, g);
+	int64_t n = 0;
+	for (int64_t k = 0; k < dq; k++) {
+		const int64_t j = j0 + k * osq;
+		n += col_ptr[j + 1] - col_ptr[j];
+	}
+	cnt[g] = n;
+	atomicMax(maxcnt, (unsigned long long) n);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(SLAB_NT)
+aperm_slab_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__ row_idx,
+		  const T *__restrict__ val, SlabMap m, int64_t nslab, int64_t d0, int dq, int64_t osq,
+		  int bits, int64_t nnz, const int64_t *__restrict__ slab_base, int64_t *__restrict__ out_ptr,
+		  int32_t *__restrict__ out_idx, T *__restrict__ out_val)
+{
+	typedef hipcub::BlockRadixSort<uint32_t, SLAB_NT, SLAB_ITEMS, uint32_t> Sort;
+	__shared__ typename Sort::TempStorage sort_tmp;
+	__shared__ int32_t off[1025];                   // first slab-local index of every old leaf
+	__shared__ int64_t lbeg[1024];                  // its first position in the old arrays
+	extern __shared__ uint32_t skey[];              // SLAB_CAP sorted rows
+	const int tid = threadIdx.x;
+	const int64_t g = blockIdx.x;
+	const int64_t sb = slab_base[g];
+	const int n = (int) (slab_base[g + 1] - sb);
+	const int64_t j0 = slab_base_leaf(m, g);
+	for (int k = tid; k < dq; k += SLAB_NT) {
+		const int64_t j = j0 + (int64_t) k * osq;
+		lbeg[k] = col_ptr[j];
+		off[k + 1] = (int32_t) (col_ptr[j + 1] - col_ptr[j]);
+	}
+	if (tid == 0) off[0] = 0;
+	__syncthreads();
+	if (tid == 0)                                   // (dq <= 1024 additions; the leaves are few)
+		for (int k = 1; k <= dq; k++) off[k] += off[k - 1];
+	__syncthreads();
+	auto leaf_of = [&](const int e) {               // last k with off[k] <= e
+		int lo = 0, hi = dq - 1;
+		while (lo < hi) {
+			const int mid = (lo + hi + 1) >> 1;
+			if (off[mid] <= e) lo = mid; else hi = mid - 1;
+		}
+		return lo;
+	};
+	uint32_t key[SLAB_ITEMS], pay[SLAB_ITEMS];
+#pragma unroll
+	for (int u = 0; u < SLAB_ITEMS; u++) {
+		const int e = tid * SLAB_ITEMS + u;             // blocked: the input order is the tie-break
+		pay[u] = (uint32_t) e;
+		if (e < n) {
+			const int k = leaf_of(e);
+			key[u] = (uint32_t) row_idx[lbeg[k] + (e - off[k])];
+		} else {
+			key[u] = 1u << bits;                        // past every row
+		}
+	}
+	Sort(sort_tmp).SortBlockedToStriped(key, pay, 0, bits + 1);
+#pragma unroll
+	for (int u = 0; u < SLAB_ITEMS; u++) skey[u * SLAB_NT + tid] = key[u];
+	__syncthreads();
+	const int64_t lp0 = g * d0;                     // first new leaf of the slab
+#pragma unroll
+	for (int u = 0; u < SLAB_ITEMS; u++) {
+		const int sidx = u * SLAB_NT + tid;             // striped: consecutive lanes, consecutive outputs
+		if (sidx >= n) continue;
+		const int e = (int) pay[u];
+		const int k = leaf_of(e);
+		out_idx[sb + sidx] = k;
+		out_val[sb + sidx] = val[lbeg[k] + (e - off[k])];
+		// leaf pointers: every new leaf from the previous entry's row (exclusive) up to this one's starts here
+		const int64_t i = key[u], prev = sidx > 0 ? (int64_t) skey[sidx - 1] : -1;
+		for (int64_t ii = prev + 1; ii <= i; ii++) out_ptr[lp0 + ii] = sb + sidx;
+	}
+	const int64_t last = n > 0 ? (int64_t) skey[n - 1] : -1;
+	for (int64_t ii = last + 1 + tid; ii < d0; ii += SLAB_NT) out_ptr[lp0 + ii] = sb + n;
+	if (g == nslab - 1 && tid == 0) out_ptr[nslab * d0] = nnz;
+}
+
 size_t aperm_ws_bytes(int64_t nnz, const int64_t *dim, int ndim)
 {
 	const size_t n = (size_t) (nnz > 0 ? nnz : 1);
@@ -439,6 +556,54 @@ int launch_aperm(const int64_t *col_ptr, const int32_t *row_idx, const void *val
 					   (const int32_t *) val, new_nleaves, lm, out_ptr, out_idx, (int32_t *) out_val);
 		HIP_TRY(hipGetLastError());
 		return 0;
+	}
+	// slab form (see aperm_slab_kernel): new axis 0 = an old outer axis of <= 1024 entries, new axis 1 = the old
+	// rows, slabs of a few thousand nonzeros.  The largest slab is read back (one synchronisation of the
+	// stream): a slab over the cap sends the array through the key sort below.
+	if (ndim >= 3 && perm[1] == 0 && perm[0] >= 1 && dim[perm[0]] <= 1024 && dim[0] < ((int64_t) 1 << 30)) {
+		const int q = perm[0];
+		int64_t os[8], st = 1;
+		for (int a = 1; a < ndim; a++) { os[a] = st; st *= dim[a]; }
+		SlabMap sm;
+		sm.nother = ndim - 2;
+		int64_t nslab = 1;
+		for (int t = 0; t < ndim - 2; t++) {
+			sm.new_ext[t] = dim[perm[2 + t]];
+			sm.old_stride[t] = os[perm[2 + t]];
+			nslab *= dim[perm[2 + t]];
+		}
+		size_t tb = 0;
+		if (nslab < 2147483646LL)
+			(void) hipcub::DeviceScan::ExclusiveSum(NULL, tb, (int64_t *) NULL, (int64_t *) NULL, (int) (nslab + 1));
+		const size_t a4 = ((size_t) nnz * 4 + 255) / 256 * 256;
+		const size_t cnt_b = ((size_t) (nslab + 2) * 8 + 255) / 256 * 256;
+		if (nslab >= 1 && nslab < 2147483646LL && nnz / nslab <= SLAB_CAP * 9 / 10 && cnt_b + tb + 256 <= 5 * a4) {
+			int64_t *base = (int64_t *) ws;
+			unsigned long long *maxcnt = (unsigned long long *) ((char *) ws + cnt_b);
+			void *scan_tmp = (char *) ws + cnt_b + 256;
+			HIP_TRY(hipMemsetAsync(maxcnt, 0, 8, s));
+			hipLaunchKernelGGL(aperm_slab_count_kernel, dim3((unsigned) ((nslab + 1 + 255) / 256)), dim3(256), 0, s,
+					   col_ptr, sm, nslab, dim[q], os[q], base, maxcnt);
+			unsigned long long mx = 0;
+			HIP_TRY(hipMemcpyAsync(&mx, maxcnt, 8, hipMemcpyDeviceToHost, s));
+			HIP_TRY(hipStreamSynchronize(s));
+			if (mx <= SLAB_CAP) {
+				HIP_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp, tb, base, base, (int) (nslab + 1), s));
+				int bits = 1;
+				while (bits < 31 && ((int64_t) 1 << bits) < dim[0]) bits++;
+				const size_t lds = (size_t) SLAB_CAP * 4;
+				if (Rtype == SVT_REALSXP)
+					hipLaunchKernelGGL(aperm_slab_kernel<double>, dim3((unsigned) nslab), dim3(SLAB_NT), lds, s,
+							   col_ptr, row_idx, (const double *) val, sm, nslab, dim[0], (int) dim[q], os[q],
+							   bits, nnz, base, out_ptr, out_idx, (double *) out_val);
+				else
+					hipLaunchKernelGGL(aperm_slab_kernel<int32_t>, dim3((unsigned) nslab), dim3(SLAB_NT), lds, s,
+							   col_ptr, row_idx, (const int32_t *) val, sm, nslab, dim[0], (int) dim[q], os[q],
+							   bits, nnz, base, out_ptr, out_idx, (int32_t *) out_val);
+				HIP_TRY(hipGetLastError());
+				return 0;
+			}
+		}
 	}
 	if (new_nleaves < ((int64_t) 1 << 31) - 1) {
 		const size_t a4 = ((size_t) nnz * 4 + 255) / 256 * 256;

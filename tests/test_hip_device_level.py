@@ -220,6 +220,40 @@ def test_device_aperm(hip, perm):
     assert np.array_equal(T.val.cpu().numpy(), wv)
 
 
+@pytest.mark.parametrize("dim,nnz,perm,dtype", [
+    ((700, 40, 23), 20000, (3, 1, 2), "integer"),          # slabs of ~500 nonzeros
+    ((5000, 9, 64), 30000, (3, 1, 2), "double"),           # ~3300 per slab, 64 old leaves each
+    ((300, 6, 5, 4), 9000, (3, 1, 2, 4), "double"),        # 4-d: slabs over two remaining axes
+    ((300, 6, 5, 4), 9000, (4, 1, 3, 2), "double"),        #      ... taken in another order
+    ((64, 50, 1), 1500, (3, 1, 2), "double"),              # one entry along the new leading axis
+    ((20000, 3, 64), 800000, (3, 1, 2), "double"),         # slabs over the cap: the key sort takes over
+    ((900, 30, 16), 0, (3, 1, 2), "double"),               # no nonzeros
+])
+def test_device_aperm_slab_form(hip, dim, nnz, perm, dtype):
+    """Permutations whose new leading axis is an old outer axis and whose second axis is the old rows run one
+    workgroup per slab (aperm_slab_kernel, src/SparseArray_aperm.c:892-929 in the reference): against numpy."""
+    rng = np.random.default_rng(45)
+    a = np.zeros(dim, order="F")
+    if nnz:
+        idx = rng.choice(a.size, size=nnz, replace=False)
+        vals = rng.normal(size=nnz) if dtype == "double" else rng.integers(1, 1000, size=nnz)
+        a.reshape(-1, order="F")[idx] = vals
+    if dtype == "integer":
+        a = a.astype(np.int32)
+    x = SVT_SparseArray.from_dense(a, dtype, lacunar=False)
+    cp, ri, v = x.to_csc()
+    A = _dev(cp, ri, v, dim[0])
+    T, new_dim = A.aperm(dim, perm)
+    torch.cuda.synchronize()
+    want = SVT_SparseArray.from_dense(np.asfortranarray(np.transpose(a, [p - 1 for p in perm])), dtype,
+                                      lacunar=False)
+    wcp, wri, wv = want.to_csc()
+    assert new_dim == want.dim
+    assert np.array_equal(T.col_ptr.cpu().numpy(), wcp)
+    assert np.array_equal(T.row_idx.cpu().numpy(), wri)
+    assert np.array_equal(T.val.cpu().numpy(), wv)
+
+
 def test_device_matmul_through_transpose(hip, oracle):
     """x %*% y = crossprod(t(x), y) (R/SparseMatrix-mult.R:195-215) with everything on the
     device: transpose, panel-blocked layout of t(x), product; many column blocks, one row split."""
