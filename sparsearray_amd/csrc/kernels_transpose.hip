@@ -420,7 +420,7 @@ aperm_slab_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict
 		  int bits, int64_t nnz, const int64_t *__restrict__ slab_base, int64_t *__restrict__ out_ptr,
 		  int32_t *__restrict__ out_idx, T *__restrict__ out_val)
 {
-	typedef hipcub::BlockRadixSort<uint32_t, SLAB_NT, SLAB_ITEMS, uint32_t> Sort;
+	typedef hipcub::BlockRadixSort<uint32_t, SLAB_NT, SLAB_ITEMS, uint32_t> Sort;        // (4-bit digits; 5-bit ones, three passes over 15 row bits, need twice the LDS: 3.15 against 2.9 ms)
 	__shared__ typename Sort::TempStorage sort_tmp;
 	__shared__ int32_t off[1025];                   // first slab-local index of every old leaf
 	__shared__ int64_t lbeg[1024];                  // its first position in the old arrays
@@ -449,18 +449,23 @@ aperm_slab_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict
 		return lo;
 	};
 	uint32_t key[SLAB_ITEMS], pay[SLAB_ITEMS];
+	// padding items sort behind every row: the all-ones value of `bits` bits unless that is a row itself
+	const bool spare = d0 < ((int64_t) 1 << bits);
+	const uint32_t pad = spare ? (1u << bits) - 1u : 1u << bits;
+	const int sort_bits = spare ? bits : bits + 1;
 #pragma unroll
 	for (int u = 0; u < SLAB_ITEMS; u++) {
 		const int e = tid * SLAB_ITEMS + u;             // blocked: the input order is the tie-break
 		pay[u] = (uint32_t) e;
 		if (e < n) {
 			const int k = leaf_of(e);
+			pay[u] |= (uint32_t) k << 13;               // (e < 8192, k < 1024: the leaf rides along)
 			key[u] = (uint32_t) row_idx[lbeg[k] + (e - off[k])];
 		} else {
-			key[u] = 1u << bits;                        // past every row
+			key[u] = pad;                               // past every row
 		}
 	}
-	Sort(sort_tmp).SortBlockedToStriped(key, pay, 0, bits + 1);
+	Sort(sort_tmp).SortBlockedToStriped(key, pay, 0, sort_bits);
 #pragma unroll
 	for (int u = 0; u < SLAB_ITEMS; u++) skey[u * SLAB_NT + tid] = key[u];
 	__syncthreads();
@@ -469,8 +474,7 @@ aperm_slab_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict
 	for (int u = 0; u < SLAB_ITEMS; u++) {
 		const int sidx = u * SLAB_NT + tid;             // striped: consecutive lanes, consecutive outputs
 		if (sidx >= n) continue;
-		const int e = (int) pay[u];
-		const int k = leaf_of(e);
+		const int e = (int) (pay[u] & 8191u), k = (int) (pay[u] >> 13);
 		out_idx[sb + sidx] = k;
 		out_val[sb + sidx] = val[lbeg[k] + (e - off[k])];
 		// leaf pointers: every new leaf from the previous entry's row (exclusive) up to this one's starts here
