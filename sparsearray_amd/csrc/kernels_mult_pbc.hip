@@ -1764,7 +1764,7 @@ pbc_dirty_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict_
 		 const double *__restrict__ val, const int *__restrict__ col_has_na,
 		 const double *__restrict__ Y, int64_t rs, int64_t cs, int64_t nrow, int64_t ncol, int K,
 		 DirtyWs d, double *__restrict__ out, int64_t sc, int64_t sk, int64_t max_leaf_nnz,
-		 int *__restrict__ gen_counters, int n_gen_counters, int nsplit, int64_t pps, int kt)
+		 int *__restrict__ gen_counters, int n_gen_counters, int nsplit, int64_t pps, int kt, int starve)
 {
 	extern __shared__ int slot_lds[];                       // [K]
 	if (d.flags[0] == 0)                                    // (the same answer in every workgroup)
@@ -1782,7 +1782,8 @@ pbc_dirty_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict_
 	PBC_DT(0)
 	pbc_dirty_scan(Y, rs, cs, nrow, K, ncol, d, nsplit, pps, kt);
 	PBC_DT(1)
-	pbc_grid_barrier(d.flags + PBC_DIRTY_BARRIER, nwg, d.flags + 2);
+	// (starve: tuning builds only -- a target no barrier reaches, to exercise the give-up path)
+	pbc_grid_barrier(d.flags + PBC_DIRTY_BARRIER, nwg + starve, d.flags + 2);
 	PBC_DT(2)
 	if (pbc_dirty_plan(K, d, slot_lds, max_leaf_nnz)) {     // (the same answer in every workgroup)
 		if (blockIdx.x == 0 && threadIdx.x == 0) d.flags[2] = 1;    // read by the general kernels' gate
@@ -1790,11 +1791,11 @@ pbc_dirty_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict_
 	}
 	pbc_dirty_hits(col_ptr, row_idx, ncol, d, slot_lds);
 	PBC_DT(3)
-	pbc_grid_barrier(d.flags + PBC_DIRTY_BARRIER, 2 * nwg, d.flags + 2);
+	pbc_grid_barrier(d.flags + PBC_DIRTY_BARRIER, 2 * nwg + starve, d.flags + 2);
 	PBC_DT(4)
 	pbc_dirty_fix(col_has_na, K, ncol, d, slot_lds, out, sc, sk);
 	PBC_DT(5)
-	pbc_grid_barrier(d.flags + PBC_DIRTY_BARRIER, 3 * nwg, d.flags + 2);
+	pbc_grid_barrier(d.flags + PBC_DIRTY_BARRIER, 3 * nwg + starve, d.flags + 2);
 	PBC_DT(6)
 	if (d.flags[2] != 0)                                    // (set by step 3: too many cells)
 		return;
@@ -2125,7 +2126,8 @@ static int pbc_phase(const svt_dev_pbc *P, const svt_dev_csc *A,
 		hipLaunchKernelGGL(pbc_dirty_kernel, dim3((unsigned) n_cu), dim3(1024), (size_t) K * 4, s,
 				   A->col_ptr, A->row_idx, (const double *) A->val, P->col_has_na, Yd, yrs, ycs,
 				   P->nrow, P->ncol, K, dw, out, out_stride_c, out_stride_k, P->max_leaf_nnz,
-				   gen_counters, n_gen_counters, nsplit, dma ? pps : 0, (int) (Kp / 64));
+				   gen_counters, n_gen_counters, nsplit, dma ? pps : 0, (int) (Kp / 64),
+				   g_pbc_debug == 7 ? 1000000 : 0);
 		HIP_TRY(hipGetLastError());
 	}
 	// General (slow-path) semantics for everything else that is not finite.
