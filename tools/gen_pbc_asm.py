@@ -33,7 +33,8 @@ Measured (tools/debug/exp_pbc.sh): what a phase costs is the round trips behind 
 single wait, not its instructions -- twice the work per phase ran 1.5 % slower --
 hence 8 records per phase (the SGPR file allows no more: 3 x 24).  The order inside a phase -- the 8 address
 adds, the 8 LDS reads, then the 8 FMAs -- beats dealing the reads between the FMAs, one by one or in pairs
-(1.720 / 1.733 / 1.728 ms at config 2a, same box).
+(1.720 / 1.733 / 1.728 ms at config 2a, same box).  Letting the wavefronts whose lanes lie past the workgroup's
+share of the panel skip the finiteness check costs more in its branch than the check (1.715 -> 1.721 ms).
 
 DMA issue: all 4 pieces of a wavefront at once, after the batch the layout flags with bit 14
 (batch w & 3 of the tile, or its last one), so that the phases pay one flag test, not two.
