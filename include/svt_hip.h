@@ -185,6 +185,22 @@ int svt_colsum_dgCMatrix(int nrow, int ncol, const double *xx, const int *xi,
 			 const int *xp, const int *group, int ngroup,
 			 int na_rm, double *out);
 
+/* C_colMins_dgCMatrix / C_colMaxs_dgCMatrix / C_colRanges_dgCMatrix / C_colVars_dgCMatrix,
+   src/sparseMatrix_utils.c:128-166, 205-223 (registered at src/R_init_SparseArray.c:49-52;
+   R wrappers R/sparseMatrix-utils.R:300-330): column statistics of a dgCMatrix from its
+   Dim, x and p slots (the i slot is not read).  out: ncol doubles; colRanges: ncol x 2
+   column-major (mins, then maxs).  NA / NaN rules of min_double() etc. (:15-103): an NA gives
+   NA_real_ unless na_rm, else a NaN gives NaN; a column with fewer than nrow stored entries
+   starts from 0.  colVars is col_var() (:173-203): IEEE arithmetic throughout. */
+int svt_colMins_dgCMatrix(int nrow, int ncol, const double *xx, const int *xp,
+			  int na_rm, double *out);
+int svt_colMaxs_dgCMatrix(int nrow, int ncol, const double *xx, const int *xp,
+			  int na_rm, double *out);
+int svt_colRanges_dgCMatrix(int nrow, int ncol, const double *xx, const int *xp,
+			    int na_rm, double *out);
+int svt_colVars_dgCMatrix(int nrow, int ncol, const double *xx, const int *xp,
+			  int na_rm, double *out);
+
 /* ---------------------------------------------------------------------- */
 /* 2. Device level                                                         */
 /* ---------------------------------------------------------------------- */
@@ -357,6 +373,14 @@ int svt_dev_aperm(const svt_dev_csc *A, int ndim, const int64_t *dim, const int 
    nnz = sum of x->nzcount). */
 int svt_aperm_SVT(const svt_view *x, const int *perm, int64_t *out_col_ptr,
 		  int32_t *out_row_idx, void *out_val);
+/* C_transpose_2D_SVT, src/SparseArray_aperm.c:395-423 (t() of an SVT_SparseMatrix,
+   R/SparseArray-aperm.R:11-20; every tcrossprod() and the non-native row*() statistics start
+   with it, R/SparseMatrix-mult.R:165-206, R/SparseArray-matrixStats.R:140-147): x is uploaded,
+   transposed on the device (svt_dev_transpose) and t(x) comes back as its CSC layout --
+   x->dim[0] + 1 column pointers and sum(x->nzcount) entries, ascending offsets inside every
+   leaf.  The glue rebuilds the R leaves from it (integration/svt_hip_glue.c). */
+int svt_transpose_2D_SVT(const svt_view *x, int64_t *out_col_ptr,
+			 int32_t *out_row_idx, void *out_val);
 
 #ifdef __cplusplus
 }

@@ -10,6 +10,9 @@
  *   C_colStats_SVT/9        C_rowStats_SVT/9        C_summarize_SVT/7
  *   C_rowsum_SVT/6          C_colsum_SVT/6          C_rowsum_dgCMatrix/4    C_colsum_dgCMatrix/4
  *   C_get_num_procs/0       C_get_max_threads/0     C_set_max_threads/1
+ *   C_transpose_2D_SVT/3    C_aperm_SVT/4           (src/R_init_SparseArray.c:70-72)
+ *   C_colMins_dgCMatrix/2   C_colMaxs_dgCMatrix/2   C_colRanges_dgCMatrix/2  C_colVars_dgCMatrix/2
+ *                                                   (src/R_init_SparseArray.c:49-52)
  *
  * How it is wired in: the reference's bodies keep their code under a new name (suffix _cpu: a one-line
  * rename per function); this file provides the registered names.  Every function follows the same
@@ -45,6 +48,8 @@
 #include "SparseArray_matrixStats.h"
 #include "SparseArray_summarization.h"
 #include "rowsum_methods.h"
+#include "SparseArray_aperm.h"
+#include "sparseMatrix_utils.h"
 #include "thread_control.h"
 
 /* the reference's bodies, renamed */
@@ -59,6 +64,12 @@ SEXP C_rowsum_SVT_cpu(SEXP, SEXP, SEXP, SEXP, SEXP, SEXP);
 SEXP C_colsum_SVT_cpu(SEXP, SEXP, SEXP, SEXP, SEXP, SEXP);
 SEXP C_rowsum_dgCMatrix_cpu(SEXP, SEXP, SEXP, SEXP);
 SEXP C_colsum_dgCMatrix_cpu(SEXP, SEXP, SEXP, SEXP);
+SEXP C_transpose_2D_SVT_cpu(SEXP, SEXP, SEXP);
+SEXP C_aperm_SVT_cpu(SEXP, SEXP, SEXP, SEXP);
+SEXP C_colMins_dgCMatrix_cpu(SEXP, SEXP);
+SEXP C_colMaxs_dgCMatrix_cpu(SEXP, SEXP);
+SEXP C_colRanges_dgCMatrix_cpu(SEXP, SEXP);
+SEXP C_colVars_dgCMatrix_cpu(SEXP, SEXP);
 SEXP C_get_num_procs_cpu(void);
 SEXP C_get_max_threads_cpu(void);
 SEXP C_set_max_threads_cpu(SEXP);
@@ -439,6 +450,152 @@ SEXP C_colsum_dgCMatrix(SEXP x, SEXP group, SEXP ngroup, SEXP na_rm)
 	if (!hip_available())
 		return C_colsum_dgCMatrix_cpu(x, group, ngroup, na_rm);
 	return groupsum_dgCMatrix(x, group, ngroup, na_rm, 1);
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* column statistics of a dgCMatrix -- src/sparseMatrix_utils.c:105-223                             */
+/* ------------------------------------------------------------------------------------------------ */
+typedef int (*dgc_colstat_fn)(int, int, const double *, const int *, int, double *);
+
+static SEXP colstat_dgCMatrix(SEXP x, SEXP na_rm, dgc_colstat_fn fn, int is_range)
+{
+	SEXP x_Dim = GET_SLOT(x, install("Dim"));
+	int x_nrow = INTEGER(x_Dim)[0], x_ncol = INTEGER(x_Dim)[1];
+	SEXP x_slotx = GET_SLOT(x, install("x")), x_slotp = GET_SLOT(x, install("p"));
+	SEXP ans = PROTECT(is_range ? allocMatrix(REALSXP, x_ncol, 2) : NEW_NUMERIC(x_ncol));
+	if (fn(x_nrow, x_ncol, REAL(x_slotx), INTEGER(x_slotp), LOGICAL(na_rm)[0], REAL(ans)) != 0)
+		hip_fail();
+	UNPROTECT(1);
+	return ans;
+}
+
+SEXP C_colMins_dgCMatrix(SEXP x, SEXP na_rm)
+{
+	if (!hip_available())
+		return C_colMins_dgCMatrix_cpu(x, na_rm);
+	return colstat_dgCMatrix(x, na_rm, HIP_FN(svt_colMins_dgCMatrix), 0);
+}
+
+SEXP C_colMaxs_dgCMatrix(SEXP x, SEXP na_rm)
+{
+	if (!hip_available())
+		return C_colMaxs_dgCMatrix_cpu(x, na_rm);
+	return colstat_dgCMatrix(x, na_rm, HIP_FN(svt_colMaxs_dgCMatrix), 0);
+}
+
+SEXP C_colRanges_dgCMatrix(SEXP x, SEXP na_rm)
+{
+	if (!hip_available())
+		return C_colRanges_dgCMatrix_cpu(x, na_rm);
+	return colstat_dgCMatrix(x, na_rm, HIP_FN(svt_colRanges_dgCMatrix), 1);
+}
+
+SEXP C_colVars_dgCMatrix(SEXP x, SEXP na_rm)
+{
+	if (!hip_available())
+		return C_colVars_dgCMatrix_cpu(x, na_rm);
+	return colstat_dgCMatrix(x, na_rm, HIP_FN(svt_colVars_dgCMatrix), 0);
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* t() / aperm() -- src/SparseArray_aperm.c:395-423, 1032-1056                                       */
+/* The library hands back the CSC layout of the permuted array; the R tree is rebuilt from it with   */
+/* the reference's own leaf constructor (_make_leaf_from_two_arrays, src/leaf_utils.c:100-128: a     */
+/* leaf of ones comes out lacunar, an empty range as R_NilValue), NULL subtrees where nothing lands  */
+/* (as REC_aperm_SVT leaves them, :1013-1029).                                                       */
+/* ------------------------------------------------------------------------------------------------ */
+/* leaves [first, first + prod(dim[1..ndim-1])) of the CSC triple -> the subtree over dim[0..ndim-1] */
+static SEXP tree_from_csc(const int *dim, int ndim, SEXPTYPE Rtype, const int64_t *col_ptr,
+			  const int *row_idx, const char *val, size_t esz, R_xlen_t first)
+{
+	if (ndim == 1) {
+		int64_t a = col_ptr[first], n = col_ptr[first + 1] - a;
+		return _make_leaf_from_two_arrays(Rtype, val + (size_t) a * esz, row_idx + a, (int) n);
+	}
+	R_xlen_t stride = 1;
+	for (int k = 1; k < ndim - 1; k++)
+		stride *= dim[k];
+	if (col_ptr[first + stride * dim[ndim - 1]] == col_ptr[first])
+		return R_NilValue;
+	SEXP ans = PROTECT(NEW_LIST(dim[ndim - 1]));
+	for (int i = 0; i < dim[ndim - 1]; i++) {
+		SEXP elt = PROTECT(tree_from_csc(dim, ndim - 1, Rtype, col_ptr, row_idx, val, esz,
+						 first + (R_xlen_t) i * stride));
+		SET_VECTOR_ELT(ans, i, elt);
+		UNPROTECT(1);
+	}
+	UNPROTECT(1);
+	return ans;
+}
+
+static R_xlen_t view_nnz(const svt_view *v)
+{
+	R_xlen_t t = 0;
+	for (int64_t j = 0; j < v->nleaves; j++)
+		t += v->nzcount[j];
+	return t;
+}
+
+SEXP C_transpose_2D_SVT(SEXP x_dim, SEXP x_type, SEXP x_SVT)
+{
+	SEXPTYPE Rtype = _get_and_check_Rtype_from_Rstring(x_type, "C_transpose_2D_SVT", "x_type");
+	if (!hip_available() || !device_type(Rtype))         /* complex, raw, character, list: CPU */
+		return C_transpose_2D_SVT_cpu(x_dim, x_type, x_SVT);
+	if (LENGTH(x_dim) != 2)
+		error("object to transpose must have exactly 2 dimensions");
+	if (x_SVT == R_NilValue)
+		return x_SVT;
+	svt_view xv = make_view(x_dim, Rtype, x_SVT, 0);
+	R_xlen_t nnz = view_nnz(&xv);
+	size_t esz = Rtype == REALSXP ? 8 : 4;
+	int ans_dim[2] = { INTEGER(x_dim)[1], INTEGER(x_dim)[0] };
+	int64_t *cp = (int64_t *) R_alloc((size_t) ans_dim[1] + 1, sizeof(int64_t));
+	int *ri = (int *) R_alloc(nnz > 0 ? (size_t) nnz : 1, sizeof(int));
+	char *vv = (char *) R_alloc(nnz > 0 ? (size_t) nnz : 1, esz);
+	if (HIP_FN(svt_transpose_2D_SVT)(&xv, cp, ri, vv) != 0)
+		hip_fail();
+	return tree_from_csc(ans_dim, 2, Rtype, cp, ri, vv, esz, 0);
+}
+
+SEXP C_aperm_SVT(SEXP x_dim, SEXP x_type, SEXP x_SVT, SEXP perm)
+{
+	SEXPTYPE Rtype = _get_and_check_Rtype_from_Rstring(x_type, "C_aperm_SVT", "x_type");
+	int ndim = LENGTH(x_dim);
+	if (!hip_available() || !device_type(Rtype) || ndim > 8)
+		return C_aperm_SVT_cpu(x_dim, x_type, x_SVT, perm);
+	/* check_perm(), src/SparseArray_aperm.c:455-474 */
+	if (!IS_INTEGER(perm))
+		error("'perm' must be an integer vector");
+	if (LENGTH(perm) != ndim)
+		error("'length(perm)' not equal to number of dimensions of array to permute");
+	int identity = 1, taken[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	for (int a = 0; a < ndim; a++) {
+		int q = INTEGER(perm)[a];
+		if (q == NA_INTEGER || q < 1 || q > ndim)
+			error("invalid 'perm' argument");
+		if (taken[q - 1])
+			error("'perm' cannot contain duplicates");
+		taken[q - 1] = 1;
+		if (q != a + 1)
+			identity = 0;
+	}
+	if (identity || x_SVT == R_NilValue)                  /* :1044-1045 */
+		return x_SVT;
+	int *ans_dim = (int *) R_alloc(ndim, sizeof(int));
+	R_xlen_t new_nl = 1;
+	for (int a = 0; a < ndim; a++)
+		ans_dim[a] = INTEGER(x_dim)[INTEGER(perm)[a] - 1];
+	for (int a = 1; a < ndim; a++)
+		new_nl *= ans_dim[a];
+	svt_view xv = make_view(x_dim, Rtype, x_SVT, 0);
+	R_xlen_t nnz = view_nnz(&xv);
+	size_t esz = Rtype == REALSXP ? 8 : 4;
+	int64_t *cp = (int64_t *) R_alloc((size_t) new_nl + 1, sizeof(int64_t));
+	int *ri = (int *) R_alloc(nnz > 0 ? (size_t) nnz : 1, sizeof(int));
+	char *vv = (char *) R_alloc(nnz > 0 ? (size_t) nnz : 1, esz);
+	if (HIP_FN(svt_aperm_SVT)(&xv, INTEGER(perm), cp, ri, vv) != 0)
+		hip_fail();
+	return tree_from_csc(ans_dim, ndim, Rtype, cp, ri, vv, esz, 0);
 }
 
 /* ------------------------------------------------------------------------------------------------ */

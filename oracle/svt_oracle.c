@@ -1715,6 +1715,228 @@ int orc_colsum_dgCMatrix(int nrow, int ncol, const double *xx, const int *xi,
 }
 
 /* ========================================================================
+ * Column statistics of a dgCMatrix -- sparseMatrix_utils.c:8-223.  Only the
+ * Dim, x and p slots are read (:108-113, :145-150, :207-212).
+ */
+
+/* sparseMatrix_utils.c:15-39 */
+static double dgc_min_double(const double *x, int x_len, int narm, int start_on_zero)
+{
+	double min = start_on_zero ? 0.0 : INFINITY;
+	int min_is_NaN = 0;
+	for (int i = 0; i < x_len; i++) {
+		double xi = x[i];
+		if (is_R_NA(xi)) {
+			if (narm)
+				continue;
+			return NA_REAL;
+		}
+		if (min_is_NaN)
+			continue;
+		if (is_R_NaN(xi)) {
+			if (narm)
+				continue;
+			min = xi;
+			min_is_NaN = 1;
+			continue;
+		}
+		if (xi < min)
+			min = xi;
+	}
+	return min;
+}
+
+/* sparseMatrix_utils.c:41-65 */
+static double dgc_max_double(const double *x, int x_len, int narm, int start_on_zero)
+{
+	double max = start_on_zero ? 0.0 : -INFINITY;
+	int max_is_NaN = 0;
+	for (int i = 0; i < x_len; i++) {
+		double xi = x[i];
+		if (is_R_NA(xi)) {
+			if (narm)
+				continue;
+			return NA_REAL;
+		}
+		if (max_is_NaN)
+			continue;
+		if (is_R_NaN(xi)) {
+			if (narm)
+				continue;
+			max = xi;
+			max_is_NaN = 1;
+			continue;
+		}
+		if (xi > max)
+			max = xi;
+	}
+	return max;
+}
+
+/* sparseMatrix_utils.c:67-103 */
+static void dgc_minmax_double(const double *x, int x_len, int narm, int start_on_zero,
+			      double *min, double *max)
+{
+	double tmp_min, tmp_max;
+	if (start_on_zero) {
+		tmp_min = tmp_max = 0.0;
+	} else {
+		tmp_min = INFINITY;
+		tmp_max = -INFINITY;
+	}
+	int is_NaN = 0;
+	for (int i = 0; i < x_len; i++) {
+		double xi = x[i];
+		if (is_R_NA(xi)) {
+			if (narm)
+				continue;
+			*min = *max = NA_REAL;
+			return;
+		}
+		if (is_NaN)
+			continue;
+		if (is_R_NaN(xi)) {
+			if (narm)
+				continue;
+			tmp_min = tmp_max = xi;
+			is_NaN = 1;
+			continue;
+		}
+		if (xi < tmp_min)
+			tmp_min = xi;
+		if (xi > tmp_max)
+			tmp_max = xi;
+	}
+	*min = tmp_min;
+	*max = tmp_max;
+}
+
+/* C_colExtrema_dgCMatrix + C_colMins_dgCMatrix, sparseMatrix_utils.c:105-132 */
+int orc_colMins_dgCMatrix(int nrow, int ncol, const double *xx, const int *xp,
+			  int na_rm, double *out)
+{
+	for (int j = 0; j < ncol; j++) {
+		int offset = xp[j], nzcount = xp[j + 1] - offset;
+		out[j] = dgc_min_double(xx + offset, nzcount, na_rm, nzcount < nrow);
+	}
+	return 0;
+}
+
+/* C_colMaxs_dgCMatrix, sparseMatrix_utils.c:134-138 */
+int orc_colMaxs_dgCMatrix(int nrow, int ncol, const double *xx, const int *xp,
+			  int na_rm, double *out)
+{
+	for (int j = 0; j < ncol; j++) {
+		int offset = xp[j], nzcount = xp[j + 1] - offset;
+		out[j] = dgc_max_double(xx + offset, nzcount, na_rm, nzcount < nrow);
+	}
+	return 0;
+}
+
+/* C_colRanges_dgCMatrix, sparseMatrix_utils.c:143-166: ans is ncol x 2 */
+int orc_colRanges_dgCMatrix(int nrow, int ncol, const double *xx, const int *xp,
+			    int na_rm, double *out)
+{
+	for (int j = 0; j < ncol; j++) {
+		int offset = xp[j], nzcount = xp[j + 1] - offset;
+		dgc_minmax_double(xx + offset, nzcount, na_rm, nzcount < nrow,
+				  out + j, out + ncol + j);
+	}
+	return 0;
+}
+
+/* col_sum(), sparseMatrix_utils.c:173-188 */
+static double dgc_col_sum(const double *x, int x_len, int nrow, int narm, int *sample_size)
+{
+	*sample_size = nrow;
+	double sum = 0.0;
+	for (int i = 0; i < x_len; i++) {
+		double xi = x[i];
+		if (narm && isnan(xi)) {
+			(*sample_size)--;
+			continue;
+		}
+		sum += xi;
+	}
+	return sum;
+}
+
+/* col_var(), sparseMatrix_utils.c:190-203 */
+static double dgc_col_var(const double *x, int x_len, int nrow, int narm)
+{
+	int sample_size;
+	double sum = dgc_col_sum(x, x_len, nrow, narm, &sample_size);
+	double mean = sum / (double) sample_size;
+	double sigma = mean * mean * (nrow - x_len);
+	for (int i = 0; i < x_len; i++) {
+		double xi = x[i];
+		if (narm && isnan(xi))
+			continue;
+		double delta = xi - mean;
+		sigma += delta * delta;
+	}
+	return sigma / (sample_size - 1.0);
+}
+
+/* C_colVars_dgCMatrix, sparseMatrix_utils.c:205-223 */
+int orc_colVars_dgCMatrix(int nrow, int ncol, const double *xx, const int *xp,
+			  int na_rm, double *out)
+{
+	for (int j = 0; j < ncol; j++) {
+		int offset = xp[j], nzcount = xp[j + 1] - offset;
+		out[j] = dgc_col_var(xx + offset, nzcount, nrow, na_rm);
+	}
+	return 0;
+}
+
+/* ========================================================================
+ * 2-D transposition -- C_transpose_2D_SVT, SparseArray_aperm.c:148-423.
+ * The reference's three passes: count the nonzeros of every input row
+ * (collect_stats_on_input_rows, :148-171), allocate the output leaves
+ * (:366-385), scatter column by column (transpose_*_col, :177-241; visiting
+ * the columns in ascending order is what leaves every output leaf sorted by
+ * offset).  Output here: the CSC layout of t(x) (nrow + 1 pointers); lacunar
+ * input leaves come out as explicit ones.
+ */
+int orc_transpose_2D_SVT(const orc_svt *x, int64_t *out_col_ptr,
+			 int32_t *out_row_idx, void *out_val)
+{
+	if (x->ndim != 2)
+		return fail("object to transpose must have exactly 2 dimensions");
+	int nrow = x->dim[0], ncol = x->dim[1];
+	size_t esz = x->Rtype == ORC_DBL ? 8 : 4;
+	for (int i = 0; i <= nrow; i++)
+		out_col_ptr[i] = 0;
+	/* 1st pass: nzcount per input row */
+	for (int j = 0; j < ncol; j++) {
+		leaf_t lf = get_leaf(x, j);
+		for (int k = 0; k < lf.n; k++)
+			out_col_ptr[lf.off[k] + 1]++;
+	}
+	/* 2nd pass: "allocation" = where every output leaf starts */
+	for (int i = 0; i < nrow; i++)
+		out_col_ptr[i + 1] += out_col_ptr[i];
+	/* 3rd pass: fill */
+	int64_t *fill = (int64_t *) malloc(sizeof(int64_t) * (size_t) (nrow > 0 ? nrow : 1));
+	if (fill == NULL)
+		return fail("out of memory");
+	memcpy(fill, out_col_ptr, sizeof(int64_t) * (size_t) nrow);
+	for (int j = 0; j < ncol; j++) {
+		leaf_t lf = get_leaf(x, j);
+		for (int k = 0; k < lf.n; k++) {
+			int64_t p = fill[lf.off[k]]++;
+			out_row_idx[p] = j;
+			if (esz == 8)
+				((double *) out_val)[p] = lf.val ? ((const double *) lf.val)[k] : 1.0;
+			else
+				((int *) out_val)[p] = lf.val ? ((const int *) lf.val)[k] : 1;
+		}
+	}
+	free(fill);
+	return 0;
+}
+
+/* ========================================================================
  * aperm -- SparseArray_aperm.c.  The reference has a leaf-preserving fast
  * path (perm[1] == 1, :949-957) and a counting-sort path that shatters the
  * leaves (:892-929); both produce the unique SVT of base::aperm(dense): here

@@ -59,6 +59,9 @@ class CAbiDispatcher:
             "rowsum_dgCMatrix": (I, [I, I, P, P, P, P, I, I, P]),
             "colsum_dgCMatrix": (I, [I, I, P, P, P, P, I, I, P]),
         }
+        for name in ("colMins_dgCMatrix", "colMaxs_dgCMatrix", "colRanges_dgCMatrix",
+                     "colVars_dgCMatrix"):
+            protos[name] = (I, [I, I, P, P, I, P])
         if hasattr(self.lib, self.prefix + "colMedians_SVT"):      # HIP library (the oracle's is Python)
             protos["colMedians_SVT"] = (I, [V, I, P])
             protos["rowMedians_SVT"] = (I, [V, I, P])
@@ -301,6 +304,50 @@ class CAbiDispatcher:
         if x.dimnames is not None:
             dn = [x.dimnames[p - 1] for p in perm]
         ans = SVT_SparseArray.from_csc(new_dim, x.type, cp, ri[:nnz], vv[:nnz], dimnames=dn)
+        ans.na_background = x.na_background
+        return ans
+
+    # column statistics of a dgCMatrix (src/sparseMatrix_utils.c:105-223) ---------------
+    def _dgc_colstat(self, fname, x, na_rm, ncols_out):
+        (nrow, ncol), p, _i, xx = x
+        p = np.ascontiguousarray(p, np.int32)
+        xx = np.ascontiguousarray(xx, np.float64)
+        out = np.zeros((ncol, ncols_out) if ncols_out > 1 else ncol, dtype=np.float64, order="F")
+        self._check(self._fn(fname)(int(nrow), int(ncol), _ptr(xx), _ptr(p), int(bool(na_rm)),
+                                    _ptr(out)))
+        return out
+
+    def C_colMins_dgCMatrix(self, x, na_rm):
+        return self._dgc_colstat("colMins_dgCMatrix", x, na_rm, 1)
+
+    def C_colMaxs_dgCMatrix(self, x, na_rm):
+        return self._dgc_colstat("colMaxs_dgCMatrix", x, na_rm, 1)
+
+    def C_colRanges_dgCMatrix(self, x, na_rm):
+        return self._dgc_colstat("colRanges_dgCMatrix", x, na_rm, 2)
+
+    def C_colVars_dgCMatrix(self, x, na_rm):
+        return self._dgc_colstat("colVars_dgCMatrix", x, na_rm, 1)
+
+    # t() (src/SparseArray_aperm.c:395-423) ----------------------------------------------
+    def C_transpose_2D_SVT(self, x: SVT_SparseArray):
+        """Returns t(x) as an SVT_SparseArray (the glue rebuilds the R leaves the same way)."""
+        if x.ndim != 2:
+            raise SparseArrayError("object to transpose must have exactly 2 dimensions")
+        nnz = x.nzcount()
+        cp = np.zeros(x.dim[0] + 1, dtype=np.int64)
+        ri = np.zeros(max(nnz, 1), dtype=np.int32)
+        vv = np.zeros(max(nnz, 1), dtype=x.np_dtype)
+        view = make_view(x)
+        f = self._fn("transpose_2D_SVT")
+        f.restype = ctypes.c_int
+        f.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p]
+        self._check(f(ctypes.addressof(view), cp.ctypes.data, ri.ctypes.data, vv.ctypes.data))
+        dn = None
+        if x.dimnames is not None:
+            dn = [x.dimnames[1], x.dimnames[0]]
+        ans = SVT_SparseArray.from_csc((x.dim[1], x.dim[0]), x.type, cp, ri[:nnz], vv[:nnz],
+                                       dimnames=dn)
         ans.na_background = x.na_background
         return ans
 

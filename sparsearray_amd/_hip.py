@@ -25,12 +25,13 @@ EXPORTS = [
     "svt_summarize_SVT", "svt_colStats_out_Rtype", "svt_colStats_SVT",
     "svt_rowStats_SVT", "svt_rowsum_SVT", "svt_colsum_SVT",
     "svt_rowsum_dgCMatrix", "svt_colsum_dgCMatrix",
+    "svt_colMins_dgCMatrix", "svt_colMaxs_dgCMatrix", "svt_colRanges_dgCMatrix", "svt_colVars_dgCMatrix",
     "svt_upload", "svt_wrap_device_csc", "svt_release",
     "svt_dev_crossprod_ws_bytes", "svt_dev_crossprod_csc_dense",
     "svt_dev_dense_prepare", "svt_dev_crossprod_prepared",
     "svt_dev_pbc_build", "svt_dev_pbc_release",
     "svt_dev_crossprod_pbc_ws_bytes", "svt_dev_crossprod_pbc", "svt_dev_crossprod_pbc_phase", "svt_dev_crossprod_pbc_from",
-    "svt_get_num_procs", "svt_get_max_threads", "svt_set_max_threads", "svt_dev_aperm_ws_bytes", "svt_dev_aperm", "svt_aperm_SVT", "svt_dev_transpose_ws_bytes", "svt_dev_transpose", "svt_dev_colstats", "svt_dev_rowstats_ws_bytes", "svt_dev_rowsums", "svt_dev_rowsum",
+    "svt_get_num_procs", "svt_get_max_threads", "svt_set_max_threads", "svt_dev_aperm_ws_bytes", "svt_dev_aperm", "svt_aperm_SVT", "svt_transpose_2D_SVT", "svt_dev_transpose_ws_bytes", "svt_dev_transpose", "svt_dev_colstats", "svt_dev_rowstats_ws_bytes", "svt_dev_rowsums", "svt_dev_rowsum",
 ]
 
 

@@ -9,6 +9,8 @@ as ``src/R_init_SparseArray.c:94,121-134``:
     C_crossprod1_SVT      C_colStats_SVT        C_rowStats_SVT
     C_summarize_SVT       C_rowsum_SVT          C_colsum_SVT
     C_rowsum_dgCMatrix    C_colsum_dgCMatrix
+    C_colMins_dgCMatrix   C_colMaxs_dgCMatrix   C_colRanges_dgCMatrix  C_colVars_dgCMatrix
+    C_transpose_2D_SVT    C_aperm_SVT
 
 The product binds those names to the HIP library (``sparsearray_amd._hip``);
 there is no CPU implementation in this package.  A ``Session`` can be built
@@ -193,6 +195,13 @@ class Session:
                 raise SparseArrayError(f"unable to find an inherited method for function "
                                        f"'{what}' for signature 'x = \"NaMatrix\"'")
 
+    def t(self, x):
+        """t(x) of an SVT_SparseMatrix: t.SVT_SparseMatrix, R/SparseArray-aperm.R:11-20 =
+        one C_transpose_2D_SVT call (src/SparseArray_aperm.c:395-423)."""
+        if x.ndim != 2:
+            raise SparseArrayError("object to transpose must have exactly 2 dimensions")
+        return self.SparseArray_Call("C_transpose_2D_SVT", x)
+
     def crossprod(self, x, y=None):
         self._no_NaArray("crossprod", x, y)
         xs, ys = isinstance(x, SVT_SparseArray), isinstance(y, SVT_SparseArray)
@@ -210,13 +219,13 @@ class Session:
         self._no_NaArray("tcrossprod", x, y)
         xs, ys = isinstance(x, SVT_SparseArray), isinstance(y, SVT_SparseArray)
         if xs and y is None:
-            return self._crossprod1_SparseMatrix(x.t())
+            return self._crossprod1_SparseMatrix(self.t(x))
         if xs and ys:
-            return self._crossprod2_SparseMatrix_SparseMatrix(x.t(), y.t())
+            return self._crossprod2_SparseMatrix_SparseMatrix(self.t(x), self.t(y))
         if xs:
-            return self._crossprod2_SparseMatrix_matrix(x.t(), y, True)
+            return self._crossprod2_SparseMatrix_matrix(self.t(x), y, True)
         if ys:
-            return self._crossprod2_matrix_SparseMatrix(x, y.t(), True)
+            return self._crossprod2_matrix_SparseMatrix(x, self.t(y), True)
         raise TypeError("tcrossprod() needs at least one SVT_SparseArray")
 
     def matmul(self, x, y):
@@ -230,11 +239,11 @@ class Session:
         if xs and ys:
             if has("C_matmul_SVT_SVT"):
                 return self._matmul_fused(x, y)
-            return self._crossprod2_SparseMatrix_SparseMatrix(x.t(), y)
+            return self._crossprod2_SparseMatrix_SparseMatrix(self.t(x), y)
         if xs:
             if has("C_matmul_SVT_mat"):
                 return self._matmul_fused(x, y)
-            return self._crossprod2_SparseMatrix_matrix(x.t(), y)
+            return self._crossprod2_SparseMatrix_matrix(self.t(x), y)
         if ys:
             return self._crossprod2_matrix_SparseMatrix(x, y, True)
         raise TypeError("%*% needs at least one SVT_SparseArray")
@@ -283,7 +292,7 @@ class Session:
         has = getattr(self._call, "has_entry", lambda name: False)
         if has("C_rowMedians_SVT") and x.dim[1] > 0 and x.dim[0] > 0:
             return self.SparseArray_Call("C_rowMedians_SVT", x, bool(na_rm))   # t(x) on the device
-        return self.colMedians(x.t(), na_rm=na_rm)
+        return self.colMedians(self.t(x), na_rm=na_rm)
 
     def _rowStats(self, op, x, na_rm=False, center=None, dims=1):
         # .rowStats_SparseArray, R/SparseArray-matrixStats.R:197-259
@@ -337,7 +346,7 @@ class Session:
         # .OLD_rowStats_SparseArray (:122-190): "aperm(colStats(aperm(x), dims=ndim-dims))",
         # the semantically plain form of :115-118 (the slice-wise tricks of :150-189
         # only avoid the reference's expensive multidimensional transposition)
-        tx = x.t() if x.ndim == 2 else self.aperm(x)
+        tx = self.t(x) if x.ndim == 2 else self.aperm(x)
         ans = self._colStats(op, tx, na_rm, center, x.ndim - dims)
         if isinstance(ans, np.ndarray) and ans.ndim > 1:
             ans = np.ascontiguousarray(np.transpose(ans))
@@ -497,6 +506,30 @@ class Session:
             ans = self.SparseArray_Call("C_colsum_dgCMatrix", x, g,
                                         len(ugroup), bool(na_rm))
         return ans, ugroup
+
+
+    # ------------------------------------------------------------------
+    # column statistics of dgCMatrix objects  (R/sparseMatrix-utils.R:300-330)
+    # ``x`` = ((nrow, ncol), p, i, x) -- the dgCMatrix slots; colnames are not propagated
+    # ------------------------------------------------------------------
+    def _dgc_colstat(self, name, x, na_rm):
+        if not (isinstance(x, tuple) and len(x) == 4):
+            raise SparseArrayError("is(x, \"dgCMatrix\") is not TRUE")
+        if not isinstance(na_rm, (bool, np.bool_)):
+            raise SparseArrayError("'na.rm' must be TRUE or FALSE")
+        return self.SparseArray_Call(name, x, bool(na_rm))
+
+    def colMins_dgCMatrix(self, x, na_rm=False):
+        return self._dgc_colstat("C_colMins_dgCMatrix", x, na_rm)
+
+    def colMaxs_dgCMatrix(self, x, na_rm=False):
+        return self._dgc_colstat("C_colMaxs_dgCMatrix", x, na_rm)
+
+    def colRanges_dgCMatrix(self, x, na_rm=False):
+        return self._dgc_colstat("C_colRanges_dgCMatrix", x, na_rm)
+
+    def colVars_dgCMatrix(self, x, na_rm=False):
+        return self._dgc_colstat("C_colVars_dgCMatrix", x, na_rm)
 
 
 # ---------------------------------------------------------------------------

@@ -265,7 +265,7 @@ colstats_kernel(StatsArgs a)
 		// mean comes from a first full pass (done above: acc, nacnt).
 		double c = a.center;
 		if (c != c)
-			c = brk_na ? NAr : acc / n_eff;
+			c = (brk_na && !a.dgc) ? NAr : acc / n_eff;
 		double acc2 = 0.0;
 		auto step2 = [&](const T v) {
 			if (VT::is_missing(v) && (narm || !is_dbl))
@@ -282,6 +282,10 @@ colstats_kernel(StatsArgs a)
 				step2(val[k]);
 		}
 		acc2 = red_sum<NT>(acc2, my_sm);
+		if (a.dgc) {      // col_var(), src/sparseMatrix_utils.c:190-203: IEEE all the way
+			rd = (c * c * (double) zeros + acc2) / (n_eff - 1.0);
+			break;
+		}
 		if (brk_na) { rd = NAr; break; }
 		rd = acc2 + c * c * (double) zeros;
 		if (oc == SVT_OP_CENTERED_X2_SUM) break;
@@ -338,7 +342,7 @@ __device__ inline double colstats_center(const StatsArgs &a, const ColState &st,
 {
 	double c = a.center;
 	if (c != c)
-		c = colstats_brk(a, st, nz) ? svt_na_real() : st.acc / colstats_neff(a, st, nz);
+		c = (colstats_brk(a, st, nz) && !a.dgc) ? svt_na_real() : st.acc / colstats_neff(a, st, nz);
 	return c;
 }
 
@@ -384,6 +388,7 @@ __device__ inline void colstats_final(const StatsArgs &a, int64_t g, const ColSt
 		}
 		break;
 	case SVT_OP_CENTERED_X2_SUM: case SVT_OP_VAR1: case SVT_OP_SD1:
+		if (a.dgc) { rd = (c * c * (double) zeros + acc2) / (n_eff - 1.0); break; }
 		if (brk_na) { rd = NAr; break; }
 		rd = acc2 + c * c * (double) zeros;
 		if (oc == SVT_OP_CENTERED_X2_SUM) break;

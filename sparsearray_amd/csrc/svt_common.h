@@ -126,6 +126,7 @@ struct StatsArgs {
 	void *out;
 	int *warn_flag;
 	int na_bg;          // NaArray: implicit values are NAs (Rvector_summarization.c:1078-1106)
+	int dgc;            // dgCMatrix flavour of var1 (src/sparseMatrix_utils.c:173-223): plain IEEE, no NA rule
 };
 int launch_colstats(const StatsArgs &a, int64_t nnz, hipStream_t s);
 size_t colmedians_ws_bytes(int64_t nnz, int64_t ncol);

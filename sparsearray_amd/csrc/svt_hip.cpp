@@ -701,9 +701,8 @@ static int device_op_supported(int opcode)
 	return 0;
 }
 
-extern "C" int svt_dev_colstats(const svt_dev_csc *A, int opcode, int na_rm,
-				double center, int64_t inner, void *out,
-				int *warn_flag, void *stream)
+static int dev_colstats_ex(const svt_dev_csc *A, int opcode, int na_rm, double center,
+			   int64_t inner, void *out, int *warn_flag, void *stream, int dgc)
 {
 	if (check_stat_op(opcode, A->Rtype) || device_op_supported(opcode))
 		return -1;
@@ -714,7 +713,15 @@ extern "C" int svt_dev_colstats(const svt_dev_csc *A, int opcode, int na_rm,
 	a.nseg = A->ncol / inner; a.inner = inner; a.seg_len = inner * A->nrow;
 	a.opcode = opcode; a.na_rm = na_rm; a.center = center;
 	a.out = out; a.warn_flag = warn_flag; a.na_bg = A->na_background;
+	a.dgc = dgc;
 	return launch_colstats(a, A->nnz, (hipStream_t) stream);
+}
+
+extern "C" int svt_dev_colstats(const svt_dev_csc *A, int opcode, int na_rm,
+				double center, int64_t inner, void *out,
+				int *warn_flag, void *stream)
+{
+	return dev_colstats_ex(A, opcode, na_rm, center, inner, out, warn_flag, stream, 0);
 }
 
 extern "C" size_t svt_dev_colmedians_ws_bytes(int64_t nnz, int64_t ncol)
@@ -1224,7 +1231,7 @@ static svt_dev_csc *dev_transposed(const svt_dev_csc *A)
 {
 	svt_dev_csc *T = (svt_dev_csc *) calloc(1, sizeof(*T));
 	if (T == NULL) { svt_set_error("out of memory"); return NULL; }
-	T->Rtype = A->Rtype; T->owned = 1;
+	T->Rtype = A->Rtype; T->owned = 1; T->na_background = A->na_background;
 	T->nrow = A->ncol; T->ncol = A->nrow; T->nnz = A->nnz;
 	const size_t n = A->nnz > 0 ? (size_t) A->nnz : 1;
 	DevBuf ws;
@@ -1275,6 +1282,34 @@ struct OwnedCsc {            // releases a handle only if this call built it
 	int own;
 	~OwnedCsc() { if (own) svt_release(t); }
 };
+
+// C_transpose_2D_SVT, src/SparseArray_aperm.c:395-423
+extern "C" int svt_transpose_2D_SVT(const svt_view *x, int64_t *out_col_ptr,
+				    int32_t *out_row_idx, void *out_val)
+{
+	if (ensure_init() || check_view(x))
+		return -1;
+	if (x->ndim != 2)
+		return svt_set_error("object to transpose must have exactly 2 dimensions");
+	const int64_t nrow = x->dim[0];
+	if (x->svt_is_null || x->dim[1] == 0 || nrow == 0) {     // :405-406: nothing to move
+		for (int64_t i = 0; i <= nrow; i++) out_col_ptr[i] = 0;
+		return 0;
+	}
+	CscGuard A(x);
+	if (A.h == NULL) return -1;
+	int own_T = 1;
+	svt_dev_csc *T = transposed_for(A, &own_T);
+	OwnedCsc TA = { T, own_T };
+	if (T == NULL) return -1;
+	HIP_TRY(hipMemcpy(out_col_ptr, T->col_ptr, (size_t) (nrow + 1) * 8, hipMemcpyDeviceToHost));
+	if (T->nnz > 0) {
+		if (staged_download(out_row_idx, T->row_idx, (size_t) T->nnz * 4) ||
+		    staged_download(out_val, T->val, (size_t) T->nnz * elt_size(T->Rtype)))
+			return -1;
+	}
+	return 0;
+}
 
 // x %*% y, y an ordinary matrix: the R method (R/SparseMatrix-mult.R:195-215) is
 // .crossprod2_SparseMatrix_matrix(t(x), y), i.e. C_transpose_2D_SVT on the host
@@ -1738,4 +1773,80 @@ extern "C" int svt_colsum_dgCMatrix(int nrow, int ncol, const double *xx, const 
 				    int na_rm, double *out)
 {
 	return xsum_dgC(nrow, ncol, xx, xi, xp, group, ngroup, na_rm, true, out);
+}
+
+// ==================================================================================
+// Host level: column statistics of a dgCMatrix (src/sparseMatrix_utils.c:106-223)
+// ==================================================================================
+// The (x, p) slots of a dgCMatrix are the CSC layout itself (the 'i' slot is not read, as in
+// the reference: :115-116, :152-153, :213-214).  which: 0 = colMins, 1 = colMaxs,
+// 2 = colRanges (out: ncol x 2, mins then maxs, :155), 3 = colVars.  The extrema follow the
+// SVT rules for doubles (NA wins, then NaN, one implicit zero when nzcount < nrow:
+// min_double/max_double/minmax_double, :15-103); colVars is col_var() (:173-203): plain IEEE
+// arithmetic, no NA rule and no "NA when fewer than two values" rule.
+static int colstat_dgC(int nrow, int ncol, const double *xx, const int *xp, int na_rm,
+		       int which, double *out)
+{
+	if (ensure_init())
+		return -1;
+	if (nrow < 0 || ncol < 0 || xp == NULL)
+		return svt_set_error("invalid dgCMatrix slots");
+	if (ncol == 0)
+		return 0;
+	std::vector<int64_t> cp((size_t) ncol + 1);
+	for (int j = 0; j <= ncol; j++) {
+		if (xp[j] < 0 || (j > 0 && (xp[j] < xp[j - 1] || xp[j] - xp[j - 1] > nrow)))
+			return svt_set_error("invalid dgCMatrix 'p' slot");
+		cp[(size_t) j] = xp[j];
+	}
+	const int64_t nnz = cp[(size_t) ncol];
+	if (nnz > 0 && xx == NULL)
+		return svt_set_error("invalid dgCMatrix slots");
+	DevBuf P, X, O;
+	if (P.upload(cp.data(), cp.size() * 8) || X.upload(xx, (size_t) nnz * 8) ||
+	    O.alloc((size_t) ncol * 8 * (which == 2 ? 2 : 1)))
+		return -1;
+	svt_dev_csc A;
+	memset(&A, 0, sizeof(A));
+	A.Rtype = SVT_REALSXP; A.nrow = nrow; A.ncol = ncol; A.nnz = nnz;
+	A.col_ptr = P.as<int64_t>(); A.val = X.p;
+	const double NA = svt_na_real();
+	int rc;
+	switch (which) {
+	case 0: rc = dev_colstats_ex(&A, SVT_OP_MIN, na_rm, NA, 1, O.p, NULL, 0, 1); break;
+	case 1: rc = dev_colstats_ex(&A, SVT_OP_MAX, na_rm, NA, 1, O.p, NULL, 0, 1); break;
+	case 2:
+		rc = dev_colstats_ex(&A, SVT_OP_MIN, na_rm, NA, 1, O.p, NULL, 0, 1);
+		if (rc == 0)
+			rc = dev_colstats_ex(&A, SVT_OP_MAX, na_rm, NA, 1, O.as<double>() + ncol, NULL, 0, 1);
+		break;
+	default: rc = dev_colstats_ex(&A, SVT_OP_VAR1, na_rm, NA, 1, O.p, NULL, 0, 1); break;
+	}
+	if (rc) return -1;
+	HIP_TRY(hipDeviceSynchronize());
+	return staged_download(out, O.p, (size_t) ncol * 8 * (which == 2 ? 2 : 1));
+}
+
+// C_colMins_dgCMatrix / C_colMaxs_dgCMatrix, src/sparseMatrix_utils.c:128-138
+extern "C" int svt_colMins_dgCMatrix(int nrow, int ncol, const double *xx, const int *xp,
+				     int na_rm, double *out)
+{
+	return colstat_dgC(nrow, ncol, xx, xp, na_rm, 0, out);
+}
+extern "C" int svt_colMaxs_dgCMatrix(int nrow, int ncol, const double *xx, const int *xp,
+				     int na_rm, double *out)
+{
+	return colstat_dgC(nrow, ncol, xx, xp, na_rm, 1, out);
+}
+// C_colRanges_dgCMatrix, src/sparseMatrix_utils.c:143-166
+extern "C" int svt_colRanges_dgCMatrix(int nrow, int ncol, const double *xx, const int *xp,
+				       int na_rm, double *out)
+{
+	return colstat_dgC(nrow, ncol, xx, xp, na_rm, 2, out);
+}
+// C_colVars_dgCMatrix, src/sparseMatrix_utils.c:205-223
+extern "C" int svt_colVars_dgCMatrix(int nrow, int ncol, const double *xx, const int *xp,
+				     int na_rm, double *out)
+{
+	return colstat_dgC(nrow, ncol, xx, xp, na_rm, 3, out);
 }

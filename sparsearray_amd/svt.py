@@ -167,35 +167,28 @@ class SVT_SparseArray:
                                self.svt_is_null, self.na_background)
 
     def t(self) -> "SVT_SparseArray":
-        """2-D transposition (reference: C_transpose_2D_SVT,
-        src/SparseArray_aperm.c:348-423 -- count / allocate / scatter)."""
+        """2-D transposition on the host, for building test and benchmark inputs only: the
+        product's ``t()`` is ``Session.t`` = one ``C_transpose_2D_SVT`` call on the device
+        (reference: src/SparseArray_aperm.c:348-423 -- count / allocate / scatter; a stable
+        sort by row of the column-ordered nonzeros is that scatter)."""
         if self.ndim != 2:
             raise ValueError("t() needs a 2-D object")
         nrow, ncol = self.dim
-        counts = np.zeros(nrow, dtype=np.int64)
-        for lf in self.leaves:
-            if lf is not None:
-                np.add.at(counts, lf[0], 1)
-        offs_out = [np.empty(c, dtype=np.int32) if c else None for c in counts]
-        vals_out = [np.empty(c, dtype=self.np_dtype) if c else None for c in counts]
-        fill = np.zeros(nrow, dtype=np.int64)
-        for j, lf in enumerate(self.leaves):
-            if lf is None:
-                continue
-            offs, vals = lf
-            for k, i in enumerate(offs):
-                p = fill[i]
-                offs_out[i][p] = j
-                vals_out[i][p] = 1 if vals is None else vals[k]
-                fill[i] = p + 1
+        col_ptr, row_idx, val = self.to_csc()
+        col_of = np.repeat(np.arange(ncol, dtype=np.int32), np.diff(col_ptr))
+        order = np.argsort(row_idx, kind="stable")
+        new_ptr = np.zeros(nrow + 1, dtype=np.int64)
+        np.cumsum(np.bincount(row_idx, minlength=nrow), out=new_ptr[1:])
+        new_idx, new_val = col_of[order], val[order]
         leaves: List[Leaf] = []
         for i in range(nrow):
-            if offs_out[i] is None:
+            s, e = int(new_ptr[i]), int(new_ptr[i + 1])
+            if s == e:
                 leaves.append(None)
-            elif not self.na_background and np.all(vals_out[i] == 1):
-                leaves.append((offs_out[i], None))
+            elif not self.na_background and np.all(new_val[s:e] == 1):
+                leaves.append((new_idx[s:e], None))
             else:
-                leaves.append((offs_out[i], vals_out[i]))
+                leaves.append((new_idx[s:e], new_val[s:e]))
         dn = None
         if self.dimnames is not None:
             dn = [self.dimnames[1], self.dimnames[0]]

@@ -729,6 +729,26 @@ for perm in ([4, 3, 2, 1], [1, 3, 2, 4], [2, 4, 1, 3], [3, 1, 4, 2], [1, 2, 4, 3
          np.asfortranarray(np.transpose(ap4, [p - 1 for p in perm])), kwargs={"perm": perm})
 case(SRC_AP + ":95-140", "aperm", [svt(ap4[:, :, 0:0, :], "double")],
      np.asfortranarray(np.transpose(ap4[:, :, 0:0, :], [3, 2, 1, 0])))
+# H3. t()   tests/testthat/test-SparseArray-aperm.R:1-38 (expected: base::t; expect_identical).
+#     `runif(7, min=-5, max=10)` under set.seed(789) is replaced by seven fixed doubles in that
+#     range (R's RNG is unavailable); raw matrices are out of scope.
+tm0 = rmat(7, 10)
+case(SRC_AP + ":11-13", "t", [svt(tm0, "double")], np.asfortranarray(tm0.T))
+tm1 = set_lin(tm0, [5 * k for k in range(1, 15)],
+              [-4.21, 9.5, 0.37, 3.3, -1.08, 7.77, 2.5] * 2)
+for _c, _v in zip([1, 2, 3, 4, 7, 8, 9], [NA_REAL, NAN, INF, 3e9, 256, -0.999, -1]):
+    tm1[1, _c - 1] = _v
+case(SRC_AP + ":15-19", "t", [svt(tm1, "double")], np.asfortranarray(tm1.T))
+case(SRC_AP + ":21-23", "t", [svt(np.asfortranarray(tm1[0:0, :]), "double")],
+     np.asfortranarray(tm1[0:0, :].T))
+case(SRC_AP + ":24-26", "t", [svt(np.asfortranarray(tm1[:, 0:0]), "double")],
+     np.asfortranarray(tm1[:, 0:0].T))
+with np.errstate(all="ignore"):
+    tm1i = np.where(np.isfinite(tm1) & (np.abs(tm1) < 2 ** 31), np.trunc(np.nan_to_num(tm1, posinf=0, neginf=0)), NA_INT).astype(np.int32)
+tm1i[~np.isfinite(tm1) | (np.abs(tm1) >= 2 ** 31)] = NA_INT      # storage.mode(m) <- "integer": NA with a warning
+case(SRC_AP + ":29-31", "t", [svt(tm1i, "integer")], np.asfortranarray(tm1i.T))
+tm1l = np.where(np.isnan(tm1), NA_INT, (tm1 != 0).astype(np.int32)).astype(np.int32)
+case(SRC_AP + ":32-34", "t", [svt(tm1l, "logical")], np.asfortranarray(tm1l.T))
 # row statistics of >2-D arrays that have no native kernel go through aperm
 # (R/SparseArray-matrixStats.R:115-118)
 for dims in (1, 2):
@@ -823,6 +843,55 @@ for narm in (False, True):
     hi = stat_col(d0, lambda v: r_minmax_i(v, narm, False), dtype=np.int32)
     case(SRC_MAN, "colRanges", [D0], np.stack([lo, hi], axis=-1), kwargs=kw)
     case(SRC_MAN, "colVars", [D0], stat_col(d0, lambda v: r_var(v, narm)), "equal", kwargs=kw)
+
+
+# ---------------------------------------------------------------------------
+# K. tests/testthat/test-sparseMatrix-utils.R:23-88  colStats_dgCMatrix
+#    The test draws `rsparsematrix(22, 10, density=0.25)` under set.seed(123); R's RNG is
+#    not available, so a fixed 22 x 10 matrix of the same density stands in (55 nonzeros at
+#    positions and values written out below); the NA / NaN edits of :57-64 are the test's own.
+#    Expected: apply(m, 2, min) etc. on the dense matrix (:29-55); colMins/colMaxs/colRanges
+#    compared with expect_identical, colVars with expect_equal.
+# ---------------------------------------------------------------------------
+SRC_DGC = "tests/testthat/test-sparseMatrix-utils.R"
+_dg = rmat(22, 10)
+_pos = [(3 * k * k + 7 * k + 1) % 220 for k in range(1, 80)]
+_seen = []
+for _q in _pos:
+    if _q not in _seen:
+        _seen.append(_q)
+    if len(_seen) == 55:
+        break
+for _n, _q in enumerate(_seen):
+    _dg[_q % 22, _q // 22] = round(((_n * 37) % 41 - 20) / 8.0 + (0.13 if _n % 3 == 0 else -0.07), 2)
+_dg[_dg == 0] = 0.0
+_dg[2, 0] = NA_REAL      # m0[3L, 1L] <- NA
+_dg[2, 1] = NAN          # m0[3L, 2L] <- NaN
+_dg[3, 3] = NA_REAL      # m0[4L, 4L] <- NA
+_dg[7, 3] = NAN          # m0[8L, 4L] <- NaN
+_dg[3, 7] = NAN          # m0[4L, 8L] <- NaN
+_dg[21, 7] = NA_REAL     # m0[22L, 8L] <- NA
+_dg[:, 8] = NA_REAL      # m0[ , 9L] <- NA
+_dg[:, 9] = NAN          # m0[ , 10L] <- NaN
+
+
+def dgc_colstat_cases(m, src):
+    g = to_dgc(m)
+    for narm in (False, True):
+        kw = {"na_rm": narm}
+        lo = col_apply(m, lambda v: r_minmax_d(v, narm, True))
+        hi = col_apply(m, lambda v: r_minmax_d(v, narm, False))
+        case(src + ":29-34", "colMins_dgCMatrix", [g], lo, kwargs=kw)
+        case(src + ":36-42", "colMaxs_dgCMatrix", [g], hi, kwargs=kw)
+        case(src + ":44-50", "colRanges_dgCMatrix", [g], np.stack([lo, hi], axis=-1), kwargs=kw)
+        case(src + ":52-58", "colVars_dgCMatrix", [g], col_apply(m, lambda v: r_var(v, narm)),
+             "equal", kwargs=kw)
+
+
+dgc_colstat_cases(_dg, SRC_DGC)
+# the same statistics on the rowsum fixtures of test-rowsum-methods.R:69-73 (Inf, -Inf, NA, NaN
+# in one column; a column with no stored entry)
+dgc_colstat_cases(rs1, "tests/testthat/test-rowsum-methods.R:69-73 + " + SRC_DGC)
 
 
 def main():
