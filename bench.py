@@ -259,7 +259,7 @@ def main():
             if same_load and str(tj.get("kernel", "")).startswith(kernel_name.split("<")[0]):
                 traffic = tj.get("hbm_bytes_per_launch")
                 traffic_source = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this " \
-                                 "command, corrected as profiles/README says; not measured in this run)"
+                                 "command, corrected as profiles/README.md says: (2 x FETCH_SIZE + WRITE_SIZE) x 1024; not measured in this run)"
         except Exception:
             traffic = None
     if world == 1:

@@ -83,5 +83,8 @@ def test_reference_vectors_through_the_panel_kernels(hip, case, layout):
         got = out.cpu().numpy().T                   # ncol x K
         if flip:
             got = got.T
+        # expect_identical cases (test-SparseMatrix-mult.R:231-246 etc.): the NA-vs-NaN class of every
+        # cell must be the reference's, through the panel kernels and their non-finite fix-up too
         assert_equal(got, np.asarray(exp, dtype=np.float64).reshape(got.shape), tol=1e-6,
+                     strict_na=case["cmp"] == "identical",
                      what=f"case {case['id']} {case['fn']} [{case['src']}] layout {layout} by_rows {by_rows}")

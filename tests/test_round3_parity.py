@@ -1,0 +1,211 @@
+"""Round-3 parity hardening ("Next round" item 7).
+
+* BASELINE config 1 at its exact shape (randomSparseArray(c(1e4, 1e3), density=0.01): 1e5
+  nonzeros) as a ``-m gpu`` test: colSums / colVars / the other column statistics against the
+  oracle, integer and logical results bit for bit.
+* HIP vs oracle through the RAW dispatchers -- the two C ABIs called with byte-identical
+  arguments, nothing of sparsearray_amd/api.py (type promotion, rowVars from sums, group
+  matching) in between, so logic shared by both sessions cannot mask a difference.
+* The dgCMatrix column statistics and t() through the C ABI at sizes past the golden cases.
+"""
+import numpy as np
+import pytest
+
+from helpers import assert_equal, assert_identical, random_csc
+from sparsearray_amd import NA_integer, NA_real, SVT_SparseArray
+
+pytestmark = pytest.mark.gpu
+
+
+def _config1(dtype="double"):
+    cp, ri, v = random_csc(10_000, 1_000, 0.01, seed=1, dtype=dtype)
+    assert cp[-1] == 100_000                     # R/randomSparseArray.R:25-26: floor(prod(dim) * density)
+    t = "double" if dtype == "double" else "integer"
+    return SVT_SparseArray.from_csc((10_000, 1_000), t, cp, ri, v)
+
+
+def test_config1_exact_shape_double(hip, oracle):
+    """The device adds a leaf's ~100 values with 16 lanes (a different order from the oracle's
+    sequential loop): the doubles agree to 1e-12, far inside the 1e-6 bar; every statistic whose
+    result does not depend on the order of additions is bit-identical."""
+    x = _config1()
+    for fn in ("colSums", "colMeans", "colVars", "colSds"):
+        assert_equal(getattr(hip, fn)(x), getattr(oracle, fn)(x), tol=1e-12, atol=1e-15, what=fn)
+    for fn in ("colMins", "colMaxs", "colAnyNAs", "colCountNAs"):
+        assert_identical(getattr(hip, fn)(x), getattr(oracle, fn)(x), fn)
+    assert_equal(hip.sum(x), oracle.sum(x), tol=1e-12, what="sum")
+    assert_equal(hip.rowSums(x), oracle.rowSums(x), tol=1e-12, atol=1e-15, what="rowSums")
+
+
+def test_config1_exact_shape_integer_bit_exact(hip, oracle):
+    """Integer input: sums accumulate in double and every partial sum is an exact integer
+    (src/Rvector_summarization.c:518-537), so the results are bit-identical whatever the order."""
+    x = _config1("int")
+    for fn in ("colSums", "colMins", "colMaxs", "colAnys", "colAlls", "colMeans", "rowSums"):
+        assert_identical(getattr(hip, fn)(x), getattr(oracle, fn)(x), fn)
+    assert_equal(hip.colVars(x), oracle.colVars(x), tol=1e-12, what="colVars")
+
+
+# ---------------------------------------------------------------------------------------------
+# raw dispatcher calls: no api.Session in between
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def raw():
+    from oracle.oracle import oracle_dispatcher
+    from sparsearray_amd._hip import hip_dispatcher
+    return hip_dispatcher(), oracle_dispatcher()
+
+
+def _special(nrow, ncol, density, seed, dtype="double"):
+    cp, ri, v = random_csc(nrow, ncol, density, seed, dtype)
+    rng = np.random.default_rng(seed + 100)
+    v = v.copy()
+    pick = rng.choice(len(v), size=max(4, len(v) // 50), replace=False)
+    if dtype == "double":
+        v[pick] = rng.choice([NA_real, np.nan, np.inf, -np.inf], size=len(pick))
+    else:
+        v[pick] = NA_integer
+    t = "double" if dtype == "double" else "integer"
+    return SVT_SparseArray.from_csc((nrow, ncol), t, cp, ri, v)
+
+
+@pytest.mark.parametrize("dtype", ["double", "int"])
+def test_raw_colstats_rowstats_summarize(raw, dtype):
+    h, o = raw
+    x = _special(700, 90, 0.04, 3, dtype)
+    ops = ["anyNA", "countNAs", "min", "max", "sum", "prod", "mean", "var1", "sd1", "centered_X2_sum"]
+    if dtype == "int":
+        ops += ["any", "all"]
+    for op in ops:
+        for na_rm in (False, True):
+            center = NA_real if op != "centered_X2_sum" else 0.25
+            (a, wa), (b, wb) = h("C_colStats_SVT", x, op, na_rm, center, 1), \
+                o("C_colStats_SVT", x, op, na_rm, center, 1)
+            assert wa == wb, (op, na_rm)
+            if np.asarray(b).dtype == np.int32:
+                assert_identical(a, b, f"colStats {op} na_rm={na_rm}")
+            else:
+                assert_equal(a, b, tol=1e-9, atol=1e-12, strict_na=op in ("min", "max", "sum", "mean", "prod"),
+                             what=f"colStats {op} na_rm={na_rm}")
+            (a, wa), (b, wb) = h("C_summarize_SVT", x, op, na_rm, center), o("C_summarize_SVT", x, op, na_rm, center)
+            assert wa == wb, (op, na_rm)
+            if np.asarray(b).dtype == np.int32:
+                assert_identical(a, b, f"summarize {op} na_rm={na_rm}")
+            else:
+                assert_equal(a, b, tol=1e-9, atol=1e-12, what=f"summarize {op} na_rm={na_rm}")
+    for op in ("countNAs", "anyNA", "min", "max", "sum", "centered_X2_sum"):
+        for na_rm in (False, True):
+            center = None if op != "centered_X2_sum" else np.linspace(-1, 1, 700)
+            (a, wa), (b, wb) = h("C_rowStats_SVT", x, op, na_rm, center, 1), \
+                o("C_rowStats_SVT", x, op, na_rm, center, 1)
+            assert wa == wb, (op, na_rm)
+            if np.asarray(b).dtype == np.int32:
+                assert_identical(a, b, f"rowStats {op} na_rm={na_rm}")
+            else:
+                assert_equal(a, b, tol=1e-9, atol=1e-12, strict_na=op in ("min", "max", "sum"),
+                             what=f"rowStats {op} na_rm={na_rm}")
+
+
+def test_raw_crossprod_entry_points(raw):
+    h, o = raw
+    x = _special(600, 37, 0.05, 11)
+    y = np.asfortranarray(np.random.default_rng(12).uniform(-1, 1, (600, 19)))
+    y[5, 2] = np.inf
+    y[77, 4] = NA_real
+    z = _special(600, 23, 0.06, 13)
+    assert_equal(h("C_crossprod2_SVT_mat", x, y, False), o("C_crossprod2_SVT_mat", x, y, False),
+                 tol=1e-12, strict_na=True, what="SVT_mat")
+    yt = np.asfortranarray(y.T)
+    assert_equal(h("C_crossprod2_SVT_mat", x, yt, True), o("C_crossprod2_SVT_mat", x, yt, True),
+                 tol=1e-12, strict_na=True, what="SVT_mat tr_y")
+    assert_equal(h("C_crossprod2_mat_SVT", y, x, False), o("C_crossprod2_mat_SVT", y, x, False),
+                 tol=1e-12, strict_na=True, what="mat_SVT")
+    assert_equal(h("C_crossprod2_mat_SVT", yt, x, True), o("C_crossprod2_mat_SVT", yt, x, True),
+                 tol=1e-12, strict_na=True, what="mat_SVT tr_x")
+    assert_equal(h("C_crossprod2_SVT_SVT", x, z), o("C_crossprod2_SVT_SVT", x, z),
+                 tol=1e-12, strict_na=True, what="SVT_SVT")
+    assert_equal(h("C_crossprod1_SVT", x), o("C_crossprod1_SVT", x), tol=1e-12, strict_na=True, what="crossprod1")
+
+
+@pytest.mark.parametrize("dtype", ["double", "int"])
+def test_raw_rowsum_colsum(raw, dtype):
+    h, o = raw
+    x = _special(500, 60, 0.05, 21, dtype)
+    rng = np.random.default_rng(22)
+    g = rng.integers(1, 8, 500).astype(np.int32)
+    g[rng.integers(0, 500, 5)] = NA_integer                 # NA group -> the last group
+    for na_rm in (False, True):
+        (a, ova), (b, ovb) = h("C_rowsum_SVT", x, g, 8, na_rm), o("C_rowsum_SVT", x, g, 8, na_rm)
+        assert ova == ovb
+        (assert_identical if dtype == "int" else
+         (lambda p, q, w: assert_equal(p, q, tol=1e-12, atol=1e-14, what=w)))(a, b, f"rowsum na_rm={na_rm}")
+        gc = rng.integers(1, 6, 60).astype(np.int32)
+        (a, ova), (b, ovb) = h("C_colsum_SVT", x, gc, 5, na_rm), o("C_colsum_SVT", x, gc, 5, na_rm)
+        assert ova == ovb
+        (assert_identical if dtype == "int" else
+         (lambda p, q, w: assert_equal(p, q, tol=1e-12, atol=1e-14, what=w)))(a, b, f"colsum na_rm={na_rm}")
+
+
+def test_raw_transpose_and_aperm(raw):
+    h, o = raw
+    for dtype in ("double", "int"):
+        x = _special(300, 45, 0.07, 31, dtype)
+        a, b = h("C_transpose_2D_SVT", x), o("C_transpose_2D_SVT", x)
+        assert a.dim == b.dim == (45, 300)
+        assert_identical(a.to_dense(), b.to_dense(), f"t() {dtype}")
+        for la, lb in zip(a.leaves, b.leaves):               # leaf by leaf: same offsets in the same order
+            assert (la is None) == (lb is None)
+            if la is not None:
+                assert np.array_equal(la[0], lb[0])
+        a2, b2 = h("C_aperm_SVT", x, [2, 1]), o("C_aperm_SVT", x, [2, 1])
+        assert_identical(a2.to_dense(), b2.to_dense(), f"aperm(2,1) {dtype}")
+        assert_identical(a2.to_dense(), a.to_dense(), "aperm(2,1) == t()")
+
+
+# ---------------------------------------------------------------------------------------------
+# dgCMatrix column statistics (src/sparseMatrix_utils.c:105-223) past the golden sizes
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(5000, 300, 0.02), (64, 2000, 0.3), (3, 17, 0.9), (1, 9, 1.0)])
+def test_dgCMatrix_column_statistics(hip, oracle, shape):
+    nrow, ncol, dens = shape
+    cp, ri, v = random_csc(nrow, ncol, dens, seed=41)
+    v = v.copy()
+    rng = np.random.default_rng(42)
+    if len(v) > 8:
+        pick = rng.choice(len(v), size=max(3, len(v) // 40), replace=False)
+        v[pick] = rng.choice([NA_real, np.nan, np.inf, -np.inf, 0.0], size=len(pick))   # explicit zeros are legal
+    g = ((nrow, ncol), cp.astype(np.int32), ri, v)
+    for na_rm in (False, True):
+        for fn in ("colMins_dgCMatrix", "colMaxs_dgCMatrix", "colRanges_dgCMatrix"):
+            assert_identical(getattr(hip, fn)(g, na_rm), getattr(oracle, fn)(g, na_rm), f"{fn} na_rm={na_rm}")
+        with np.errstate(all="ignore"):
+            assert_equal(hip.colVars_dgCMatrix(g, na_rm), oracle.colVars_dgCMatrix(g, na_rm), tol=1e-9,
+                         atol=1e-13, what=f"colVars_dgCMatrix na_rm={na_rm}")
+
+
+def test_dgCMatrix_column_statistics_zero_extent(hip, oracle):
+    for dim in ((0, 4), (5, 0), (0, 0)):
+        g = (dim, np.zeros(dim[1] + 1, np.int32), np.zeros(0, np.int32), np.zeros(0))
+        for fn in ("colMins_dgCMatrix", "colMaxs_dgCMatrix", "colRanges_dgCMatrix", "colVars_dgCMatrix"):
+            with np.errstate(all="ignore"):
+                a, b = getattr(hip, fn)(g, False), getattr(oracle, fn)(g, False)
+            assert np.asarray(a).shape == np.asarray(b).shape
+            assert_equal(a, b, tol=1e-12, what=f"{fn} {dim}")
+
+
+def test_session_t_goes_through_the_device(hip, oracle):
+    """tcrossprod / rowMedians / the non-native row statistics of a 2-D object transpose with ONE
+    C_transpose_2D_SVT call (no host-side element loop): results as the oracle's."""
+    x = _special(400, 50, 0.06, 51)
+    y = np.asfortranarray(np.random.default_rng(52).uniform(-1, 1, (7, 50)))
+    assert_equal(hip.tcrossprod(x, y), oracle.tcrossprod(x, y), tol=1e-12, strict_na=True, what="tcrossprod")
+    assert_equal(hip.tcrossprod(x), oracle.tcrossprod(x), tol=1e-12, strict_na=True, what="tcrossprod1")
+    xi = _special(400, 50, 0.06, 53, "int")
+    for fn in ("rowProds", "rowAnys", "rowAlls"):
+        a, b = getattr(hip, fn)(xi), getattr(oracle, fn)(xi)
+        if np.asarray(b).dtype == np.int32:
+            assert_identical(a, b, fn)
+        else:
+            assert_equal(a, b, tol=1e-12, strict_na=True, what=fn)
+    t1, t2 = hip.t(x), oracle.t(x)
+    assert_identical(t1.to_dense(), t2.to_dense(), "t()")
