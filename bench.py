@@ -146,7 +146,12 @@ def main():
     strong = a.scaling == "strong"
     if strong:
         # one global problem, cut into row blocks that do not depend on the number of ranks
-        nblocks = 8 if 8 % world == 0 else world
+        # (the global matrix is DEFINED as 8 independently drawn row blocks, so that N = 1, 2, 4, 8 compute the
+        # same product; any other N would be a different problem -- refuse it rather than redefine the matrix)
+        if 8 % world != 0:
+            raise SystemExit(f"--gpus {world}: strong scaling runs the one {nrow}x{ncol} problem, which is defined "
+                             "as 8 row blocks; N must divide 8 (1, 2, 4 or 8).  Use --scaling weak for other N.")
+        nblocks = 8
         per = nblocks // world
         col_ptr, row_idx, val, (r0, r1) = synth.random_device_csc_blocked(
             nrow, ncol, a.density, seed=1, device=dev, nblocks=nblocks, first=rank * per, last=(rank + 1) * per)
