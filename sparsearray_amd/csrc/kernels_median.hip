@@ -10,7 +10,7 @@
 // size); otherwise any NA/NaN gives NA_real_.  n == 0 gives NA_real_ (:721-722).
 //
 // Device: the nonzero values of the columns that need it are copied as f64 keys with every
-// NA/NaN turned into one canonical positive NaN (sorts last), sorted per column by hipcub's
+// NA/NaN turned into one canonical positive NaN (sorts last), sorted per column by rocprim's
 // segmented radix sort, and one thread per column picks the order statistics by three
 // binary searches (first key >= 0, first key > 0, first NaN).
 // Most columns of a sparse matrix never get that far: when the middle ranks fall among the
@@ -20,7 +20,9 @@
 // Roofline: HBM; algorithmic bytes = 8 per nonzero for the count pass, 8 + 8 for the key
 // copy, and 16 per sort pass for the columns that need one.
 #include "svt_common.h"
-#include <hipcub/hipcub.hpp>
+
+#include <string.h>
+#include <rocprim/rocprim.hpp>
 
 // Keys of the columns that need a sort (a wavefront per column; the others -- at BASELINE config 2
 // all of them -- return at once: copying every value cost 0.3 ms of a 0.55 ms colMedians there).
@@ -122,9 +124,9 @@ size_t colmedians_ws_bytes(int64_t nnz, int64_t ncol)
 {
 	size_t tmp = 0;
 	const int64_t n = nnz > 0 ? nnz : 1;
-	(void) hipcub::DeviceSegmentedRadixSort::SortKeys(NULL, tmp, (const double *) NULL, (double *) NULL,
-							  (int) n, (int) (ncol > 0 ? ncol : 1),
-							  (const int64_t *) NULL, (const int64_t *) NULL);
+	(void) rocprim::segmented_radix_sort_keys(NULL, tmp, (const double *) NULL, (double *) NULL,
+						  (unsigned int) n, (unsigned int) (ncol > 0 ? ncol : 1),
+						  (const int64_t *) NULL, (const int64_t *) NULL);
 	return (size_t) n * 16 + tmp + (size_t) (ncol > 0 ? ncol : 1) * 16 + 1024;
 }
 
@@ -158,10 +160,10 @@ int launch_colmedians(const int64_t *col_ptr, const void *val, int Rtype, int64_
 			hipLaunchKernelGGL(median_key_kernel<int>, dim3(nb), dim3(256), 0, s, col_ptr, (const int *) val,
 					   ncol, seg_b, seg_e, k_in);
 		size_t tmp_bytes = 0;
-		HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(NULL, tmp_bytes, k_in, k_out, (int) nnz, (int) ncol,
-								   seg_b, seg_e));
-		HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(tmp, tmp_bytes, k_in, k_out, (int) nnz, (int) ncol,
-								   seg_b, seg_e, 0, 64, s));
+		HIP_TRY(rocprim::segmented_radix_sort_keys(NULL, tmp_bytes, k_in, k_out, (unsigned int) nnz, (unsigned int) ncol,
+							   seg_b, seg_e));
+		HIP_TRY(rocprim::segmented_radix_sort_keys(tmp, tmp_bytes, k_in, k_out, (unsigned int) nnz, (unsigned int) ncol,
+							   seg_b, seg_e, 0u, 64u, s));
 	}
 	hipLaunchKernelGGL(median_pick_kernel, dim3((unsigned) ((ncol + 255) / 256)), dim3(256), 0, s,
 			   col_ptr, k_out, nrow, ncol, na_rm, out, seg_e);

@@ -45,7 +45,10 @@
 // bound is LDS bandwidth: 8 B of LDS read per (nonzero, dense column) pair.
 #include "svt_common.h"
 
-#include <hipcub/hipcub.hpp>
+#include <string.h>
+
+#include "svt_scan.h"
+
 #include <vector>
 
 typedef double d16 __attribute__((ext_vector_type(16)));
@@ -475,11 +478,9 @@ extern "C" svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB
 					   (const double *) A->val, A->ncol, CBW, logR, h->npanels,
 					   h->tile_ptr, (uint4 *) NULL, h->col_has_na, g_pbc_stagger);
 		// exclusive scan in place over ntiles+1 entries (last entry = total)
-		ok = hipcub::DeviceScan::ExclusiveSum(NULL, tmp_bytes, h->tile_ptr, h->tile_ptr,
-						      (int) (ntiles + 1)) == hipSuccess &&
-		     hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16) == hipSuccess &&
-		     hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, h->tile_ptr, h->tile_ptr,
-						      (int) (ntiles + 1)) == hipSuccess;
+		tmp_bytes = exclusive_scan_ws_bytes(ntiles + 1);
+		ok = hipMalloc(&tmp, tmp_bytes) == hipSuccess &&
+		     launch_exclusive_scan_i64(h->tile_ptr, ntiles + 1, tmp, 0) == 0;
 		if (ok) ok = hipMalloc((void **) &h->rec, (size_t) nrec_max * rbytes + PBC_SLACK * 16) == hipSuccess;
 		if (ok) {
 			if (h->fmt == 1) {
@@ -1254,7 +1255,7 @@ crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restric
 		PB[0] = (uint32_t) pb;
 		PB[1] = PBC_DMA_BUF;                            // toggles to 0 for the first panel
 		PB[2] = (uint32_t) (wd * 4 * PBC_DMA_ROW + PBC_DMA_BUF);
-		PB[3] = 0;
+		PB[3] = (uint32_t) (w >> 2);                    // (s15: the wavefront's rank on its SIMD; read by PBC_SKEW builds only)
 		// partial last panel (staged as rows nrow-128 .. nrow-1): its index, the byte shift
 		PB[4] = partial ? (uint32_t) (npanels - 1) : 0xFFFFFFFFu;
 		PB[5] = partial ? (uint32_t) ((128 - (nrow & 127)) * 8) : 0u;
@@ -1532,8 +1533,6 @@ static DirtyWs dirty_ws_of(void *flag_block, void *tail, int64_t ncol, int64_t K
 __device__ inline void pbc_dirty_scan(const double *__restrict__ Y, int64_t rs, int64_t cs, int64_t nrow, int K,
 				      const DirtyWs &d, int nsplit, int64_t pps, int kt, int64_t wg, int64_t nwg)
 {
-	const int64_t nthr = nwg * blockDim.x;
-	const int64_t me = wg * blockDim.x + threadIdx.x;
 	auto note = [&](const double y, const int64_t r, const int k) {
 		if (svt_is_finite(y))
 			return;
@@ -1545,9 +1544,8 @@ __device__ inline void pbc_dirty_scan(const double *__restrict__ Y, int64_t rs, 
 		if (at < PBC_DIRTY_CAP) d.list[at] = make_uint2((unsigned) r, (unsigned) k);
 	};
 	// blocks of Y: (row split s, dense tile kh) as the product kernel staged them (pps = panels of 128 rows
-	// per split; 0 = no such record, one block covers everything).  Work items of a block: (row pair,
-	// group of 8 dense columns), consecutive threads on consecutive row pairs (16-byte loads where the
-	// columns are aligned for them).
+	// per split; 0 = no such record, one block covers everything).  Consecutive threads take consecutive
+	// row pairs of 8 dense columns (16-byte loads where the columns are aligned for them).
 	const int nblk = pps > 0 ? nsplit * kt : 1;
 	const bool pairs = rs == 1 && (cs & 1) == 0 && (((uintptr_t) Y) & 15) == 0;
 	for (int blk = 0; blk < nblk; blk++) {
@@ -1563,41 +1561,46 @@ __device__ inline void pbc_dirty_scan(const double *__restrict__ Y, int64_t rs, 
 		}
 		if (b_hi <= b_lo || ke <= kb)
 			continue;
+		// The group of 8 dense columns is the same for a whole workgroup (wave-uniform counter addresses:
+		// the compiler turns the 64 adds of a wavefront into one -- a column of NaNs is 1e6 adds on one
+		// counter otherwise, 13 ms instead of 0.3); the workgroups that share a group stride over the rows.
 		const int64_t ncg = (ke - kb + 7) / 8;
-		if (pairs) {
-			const int64_t nrp = (b_hi - b_lo + 1) / 2;
-			for (int64_t it = me; it < nrp * ncg; it += nthr) {
-				const int64_t r = b_lo + 2 * (it % nrp);
-				const int k0 = kb + 8 * (int) (it / nrp);
-				const bool pair = r + 1 < b_hi;
-				double2 y[8];
-#pragma unroll
-				for (int u = 0; u < 8; u++) {
-					const double *src = Y + r + (int64_t) (k0 + u) * cs;
-					if (k0 + u >= ke) y[u] = make_double2(0.0, 0.0);
-					else if (pair) y[u] = *(const double2 *) src;
-					else y[u] = make_double2(*src, 0.0);
-				}
-#pragma unroll
-				for (int u = 0; u < 8; u++) {
-					note(y[u].x, r, k0 + u);
-					note(y[u].y, r + 1, k0 + u);
-				}
-			}
+		const bool dealt = nwg >= ncg;
+		const int64_t nsub = dealt ? nwg / ncg : nwg, sub = dealt ? wg / ncg : wg;
+		if (sub >= nsub)
 			continue;
-		}
-		const int64_t nr = b_hi - b_lo;
-		for (int64_t it = me; it < nr * ncg; it += nthr) {
-			// (consecutive threads on consecutive column groups: contiguous in a row-major operand)
-			const int64_t r = b_lo + it / ncg;
-			const int k0 = kb + 8 * (int) (it % ncg);
-			double y[8];
+		for (int64_t cg = dealt ? wg % ncg : 0; cg < ncg; cg += dealt ? ncg : 1) {
+			const int k0 = kb + 8 * (int) cg;
+			if (pairs) {
+				const int64_t nrp = (b_hi - b_lo + 1) / 2;
+				for (int64_t rp = sub * blockDim.x + threadIdx.x; rp < nrp; rp += nsub * blockDim.x) {
+					const int64_t r = b_lo + 2 * rp;
+					const bool pair = r + 1 < b_hi;
+					double2 y[8];
 #pragma unroll
-			for (int u = 0; u < 8; u++)
-				y[u] = k0 + u < ke ? Y[r * rs + (int64_t) (k0 + u) * cs] : 0.0;      // element (r, k) at Y[r * rs + k * cs]
+					for (int u = 0; u < 8; u++) {
+						const double *src = Y + r + (int64_t) (k0 + u) * cs;
+						if (k0 + u >= ke) y[u] = make_double2(0.0, 0.0);
+						else if (pair) y[u] = *(const double2 *) src;
+						else y[u] = make_double2(*src, 0.0);
+					}
 #pragma unroll
-			for (int u = 0; u < 8; u++)
-				note(y[u], r, k0 + u);
+					for (int u = 0; u < 8; u++) {
+						note(y[u].x, r, k0 + u);
+						note(y[u].y, r + 1, k0 + u);
+					}
+				}
+				continue;
+			}
+			for (int64_t r = b_lo + sub * blockDim.x + threadIdx.x; r < b_hi; r += nsub * blockDim.x) {
+				double y[8];
+#pragma unroll
+				for (int u = 0; u < 8; u++)
+					y[u] = k0 + u < ke ? Y[r * rs + (int64_t) (k0 + u) * cs] : 0.0;      // element (r, k) at Y[r * rs + k * cs]
+#pragma unroll
+				for (int u = 0; u < 8; u++)
+					note(y[u], r, k0 + u);
+			}
 		}
 	}
 }

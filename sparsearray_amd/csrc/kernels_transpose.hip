@@ -13,8 +13,295 @@
 // at once instead of one coalesced run: 2.3 ms against 1.5 + 0.12.)
 #include "svt_common.h"
 
-#include <hipcub/hipcub.hpp>
+#include <string.h>
 
+#include "svt_scan.h"
+
+#include <rocprim/rocprim.hpp>
+
+// ---------------------------------------------------------------------------
+// Exclusive scan of an int64 array (svt_scan.h)
+// ---------------------------------------------------------------------------
+__device__ inline int64_t wave_incl_scan_i64(int64_t v)
+{
+	const int lane = threadIdx.x & 63;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const int64_t t = __shfl_up(v, o, SVT_WAVE);
+		if (lane >= o) v += t;
+	}
+	return v;
+}
+
+// tile of SVT_SCAN_TILE elements per workgroup: exclusive scan in place, tile total to sums[block]
+__global__ void __launch_bounds__(SVT_SCAN_NT)
+scan_tile_kernel(int64_t *__restrict__ data, int64_t n, int64_t *__restrict__ sums)
+{
+	__shared__ int64_t wtot[SVT_SCAN_NT / SVT_WAVE];
+	const int64_t base = (int64_t) blockIdx.x * SVT_SCAN_TILE + (int64_t) threadIdx.x * SVT_SCAN_ITEMS;
+	int64_t v[SVT_SCAN_ITEMS], run = 0;
+#pragma unroll
+	for (int u = 0; u < SVT_SCAN_ITEMS; u++) {
+		v[u] = base + u < n ? data[base + u] : 0;
+		const int64_t t = v[u];
+		v[u] = run;                                     // exclusive within the thread
+		run += t;
+	}
+	const int64_t incl = wave_incl_scan_i64(run);
+	const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	if (lane == 63) wtot[w] = incl;
+	__syncthreads();
+	int64_t off = incl - run;
+	for (int i = 0; i < w; i++) off += wtot[i];
+#pragma unroll
+	for (int u = 0; u < SVT_SCAN_ITEMS; u++)
+		if (base + u < n) data[base + u] = v[u] + off;
+	if (threadIdx.x == SVT_SCAN_NT - 1 && sums != NULL) sums[blockIdx.x] = off + run;
+}
+
+__global__ void __launch_bounds__(SVT_SCAN_NT)
+scan_add_kernel(int64_t *__restrict__ data, int64_t n, const int64_t *__restrict__ sums)
+{
+	const int64_t add = sums[blockIdx.x];
+	const int64_t base = (int64_t) blockIdx.x * SVT_SCAN_TILE + (int64_t) threadIdx.x * SVT_SCAN_ITEMS;
+#pragma unroll
+	for (int u = 0; u < SVT_SCAN_ITEMS; u++)
+		if (base + u < n) data[base + u] += add;
+}
+
+int launch_exclusive_scan_i64(int64_t *data, int64_t n, void *ws, hipStream_t s)
+{
+	if (n <= 0)
+		return 0;
+	const int64_t nb = (n + SVT_SCAN_TILE - 1) / SVT_SCAN_TILE;
+	if (nb > 0x7FFFFFFFLL)
+		return svt_set_error("exclusive scan: too many elements");
+	int64_t *sums = (int64_t *) ws;
+	hipLaunchKernelGGL(scan_tile_kernel, dim3((unsigned) nb), dim3(SVT_SCAN_NT), 0, s, data, n, nb > 1 ? sums : (int64_t *) NULL);
+	if (nb > 1) {
+		if (launch_exclusive_scan_i64(sums, nb, (char *) ws + ((size_t) nb * 8 + 255) / 256 * 256, s))
+			return -1;
+		hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned) nb), dim3(SVT_SCAN_NT), 0, s, data, n, sums);
+	}
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+// ---------------------------------------------------------------------------
+// t(A): bucketed transposition (round 3; replaces the radix sort of (row, position) pairs of rounds 1-2).
+//
+// What the reference does serially -- count per row, allocate, scatter column by column
+// (src/SparseArray_aperm.c:148-393) -- is stable because it visits the columns in order.  The parallel
+// form below keeps that order without a general-purpose sort by using what a CSC operand gives for free:
+// the rows inside a column ascend (src/leaf_utils.h:12-15), so the nonzeros of one column that fall into
+// a given range of rows are one contiguous run, found by two binary searches.
+//
+//   fine bucket   = F consecutive rows (F = 64, 128 or 256: ~10^4 nonzeros), the unit of the last pass
+//   coarse bucket = 16 fine buckets
+//   group         = 512 consecutive columns, one thread per column
+//
+//   pass 1 (count)   workgroup (group g, coarse bucket i): every thread finds its column's run of rows in
+//                    the coarse bucket and counts it by fine bucket; table[fine bucket][g] = the group's
+//                    total (16 numbers per workgroup).
+//   scan             exclusive scan of the table, fine-bucket-major: where the piece (fine bucket, g)
+//                    starts in an intermediate array ordered (fine bucket, group, column, row).
+//   pass 2 (scatter) the same workgroups copy their runs to those pieces: position = piece start + the
+//                    nonzeros of the same fine bucket in the group's earlier columns (a scan over the 512
+//                    threads, per fine bucket) + the index inside the column's run.  Every piece is a few
+//                    KB written by one workgroup within microseconds.
+//   pass 3 (finish)  one workgroup per fine bucket: its ~10^4 nonzeros are contiguous and already in column
+//                    order; a stable counting sort on the F rows (ranks inside a wavefront from ballots of
+//                    the row bits, across wavefronts from a small LDS table) puts them in (row, column) order
+//                    at their final place, and gives the row pointers.
+//
+// Traffic at 1e8 nonzeros (f64): pass 1 reads the offsets (0.4 GB), pass 2 reads 1.2 GB and writes 1.3 GB
+// (column 4 B + row-in-bucket 1 B + value 8 B), pass 3 reads 1.3 GB and writes 1.2 GB: 5.4 GB against
+// 7.6 GB for the sort-and-gather form, and no pass scatters single elements across the whole array.
+// Shapes it does not fit (rows with more than ~500 nonzeros on average, or less than one nonzero per
+// column and coarse bucket) take the key sort of launch_transpose_sorted() below.
+// ---------------------------------------------------------------------------
+#define T2_NT 512                 // columns per group = threads per workgroup of passes 1-2
+#define T2_NFINE 16               // fine buckets per coarse bucket
+
+struct T2Shape {
+	int fbits;                // log2(F)
+	int64_t nfb;              // fine buckets
+	int64_t ncoarse;
+	int64_t ngroups;
+};
+
+// first position in [lo, hi) whose row is >= r
+__device__ inline int64_t t2_lower_bound(const int32_t *__restrict__ row_idx, int64_t lo, int64_t hi, int64_t r)
+{
+	while (lo < hi) {
+		const int64_t mid = (lo + hi) >> 1;
+		if ((int64_t) row_idx[mid] < r) lo = mid + 1; else hi = mid;
+	}
+	return lo;
+}
+
+template <typename T, bool SCATTER>
+__global__ void __launch_bounds__(T2_NT)
+transpose_bucket_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__ row_idx,
+			const T *__restrict__ val, int64_t nrow, int64_t ncol, T2Shape sh,
+			int64_t *__restrict__ table, int32_t *__restrict__ col1, uint8_t *__restrict__ rlow1,
+			T *__restrict__ val1)
+{
+	__shared__ uint32_t cnt[T2_NFINE][T2_NT];       // [fine bucket][thread]: count, then exclusive prefix over the threads
+	__shared__ int64_t piece[T2_NFINE];
+	const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+	const int64_t g = (int64_t) blockIdx.x % sh.ngroups, i = (int64_t) blockIdx.x / sh.ngroups;
+	const int64_t r_lo = (i * T2_NFINE) << sh.fbits;
+	int64_t r_hi = ((i + 1) * T2_NFINE) << sh.fbits;
+	if (r_hi > nrow) r_hi = nrow;
+	const int64_t c = g * T2_NT + t;
+	int64_t a = 0, b = 0;
+	if (c < ncol) {
+		const int64_t beg = col_ptr[c], end = col_ptr[c + 1];
+		a = t2_lower_bound(row_idx, beg, end, r_lo);
+		b = t2_lower_bound(row_idx, a, end, r_hi);
+	}
+#pragma unroll
+	for (int s = 0; s < T2_NFINE; s++) cnt[s][t] = 0;
+	for (int64_t k = a; k < b; k++)                 // (only this thread touches column t of cnt)
+		cnt[((int64_t) row_idx[k] - r_lo) >> sh.fbits][t]++;
+	__syncthreads();
+	// exclusive prefix over the 512 threads, two fine buckets per wavefront
+	for (int s = 2 * w; s < 2 * w + 2; s++) {
+		uint32_t carry = 0;
+		for (int j = 0; j < T2_NT / 64; j++) {
+			const uint32_t v = cnt[s][j * 64 + lane];
+			uint32_t incl = v;
+#pragma unroll
+			for (int o = 1; o < 64; o <<= 1) {
+				const uint32_t u = __shfl_up(incl, o, SVT_WAVE);
+				if (lane >= o) incl += u;
+			}
+			cnt[s][j * 64 + lane] = carry + incl - v;
+			carry += __shfl(incl, 63, SVT_WAVE);
+		}
+		const int64_t fb = i * T2_NFINE + s;
+		if (lane == 0 && fb < sh.nfb) {
+			if (!SCATTER) table[fb * sh.ngroups + g] = carry;
+			else piece[s] = table[fb * sh.ngroups + g];
+		}
+	}
+	if (!SCATTER)
+		return;
+	__syncthreads();
+	for (int64_t k = a; k < b; k++) {
+		const int64_t rr = (int64_t) row_idx[k] - r_lo;
+		const int s = (int) (rr >> sh.fbits);
+		const int64_t dst = piece[s] + cnt[s][t]++;
+		col1[dst] = (int32_t) c;
+		rlow1[dst] = (uint8_t) (rr & (((int64_t) 1 << sh.fbits) - 1));
+		val1[dst] = val[k];
+	}
+}
+
+#define T3_NT 1024
+template <typename T>
+__global__ void __launch_bounds__(T3_NT)
+transpose_finish_kernel(const int64_t *__restrict__ table, T2Shape sh, int64_t nrow, int64_t nnz,
+			const int32_t *__restrict__ col1, const uint8_t *__restrict__ rlow1,
+			const T *__restrict__ val1, int64_t *__restrict__ out_ptr,
+			int32_t *__restrict__ out_idx, T *__restrict__ out_val)
+{
+	__shared__ int32_t start[256], run[2][256];     // per row of the bucket: first output slot, slots used so far
+	__shared__ int32_t wcnt[2][T3_NT / 64][256];    // per wavefront and row: entries of the current chunk
+	// (run and wcnt alternate between two copies from chunk to chunk: two barriers per chunk)
+	const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+	const int F = 1 << sh.fbits;
+	const int64_t fb = blockIdx.x;
+	const int64_t b0 = table[fb * sh.ngroups], b1 = fb + 1 < sh.nfb ? table[(fb + 1) * sh.ngroups] : nnz;
+	const int64_t n = b1 - b0;
+	if (t < F) { start[t] = 0; run[0][t] = 0; }
+	for (int x = t; x < 2 * (T3_NT / 64) * 256; x += T3_NT) (&wcnt[0][0][0])[x] = 0;
+	__syncthreads();
+	for (int64_t e = t; e < n; e += T3_NT) atomicAdd(&start[rlow1[b0 + e]], 1);
+	__syncthreads();
+	if (w == 0) {                                   // exclusive scan of the F (<= 256) counts, 4 per lane
+		int32_t v[4], tot = 0;
+#pragma unroll
+		for (int u = 0; u < 4; u++) { v[u] = lane * 4 + u < F ? start[lane * 4 + u] : 0; tot += v[u]; }
+		int32_t incl = tot;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			const int32_t x = __shfl_up(incl, o, SVT_WAVE);
+			if (lane >= o) incl += x;
+		}
+		int32_t off = incl - tot;
+#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			const int r = lane * 4 + u;
+			if (r < F) {
+				start[r] = off;
+				const int64_t row = (fb << sh.fbits) + r;
+				if (row < nrow) out_ptr[row] = b0 + off;
+			}
+			off += v[u];
+		}
+	}
+	if (fb == sh.nfb - 1 && t == 0) out_ptr[nrow] = nnz;
+	__syncthreads();
+	const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+	int p = 0;
+	for (int64_t c0 = 0; c0 < n; c0 += T3_NT, p ^= 1) {
+		const int64_t e = c0 + t;
+		const bool valid = e < n;
+		const int r = valid ? (int) rlow1[b0 + e] : 0;
+		// lanes of this wavefront that hold the same row (and are valid): one ballot per row bit
+		uint64_t peers = __ballot(valid);
+		for (int bit = 0; bit < sh.fbits; bit++) {
+			const uint64_t m = __ballot((r >> bit) & 1);
+			peers &= ((r >> bit) & 1) ? m : ~m;
+		}
+		const int rank = __popcll(peers & lt);
+		if (valid && rank == 0) wcnt[p][w][r] = __popcll(peers);
+		__syncthreads();
+		if (valid) {
+			int32_t before = 0;
+			for (int ww = 0; ww < w; ww++) before += wcnt[p][ww][r];
+			const int64_t dst = b0 + start[r] + run[p][r] + before + rank;
+			out_idx[dst] = col1[b0 + e];
+			out_val[dst] = val1[b0 + e];
+		}
+		if (t < F) {
+			int32_t tot = 0;
+			for (int ww = 0; ww < T3_NT / 64; ww++) tot += wcnt[p][ww][t];
+			run[p ^ 1][t] = run[p][t] + tot;
+		}
+		// the other copy of wcnt (read in the previous round, before the barrier above) is clear again for the next
+		for (int x = t; x < (T3_NT / 64) * 256; x += T3_NT) (&wcnt[p ^ 1][0][0])[x] = 0;
+		__syncthreads();
+	}
+}
+
+// the bucketed form applies to this operand: fills *sh
+static bool t2_shape(int64_t nrow, int64_t ncol, int64_t nnz, T2Shape *sh)
+{
+	if (nrow <= 0 || ncol <= 0 || nnz <= 0)
+		return false;
+	const double per_row = (double) nnz / (double) nrow, per_col = (double) nnz / (double) ncol;
+	int fbits = -1;
+	for (int fb = 8; fb >= 6; fb--)                 // the largest bucket of <= 32768 nonzeros
+		if (ldexp(per_row, fb) <= 32768.0) { fbits = fb; break; }
+	if (fbits < 0)
+		return false;
+	const double coarse_rows = ldexp((double) T2_NFINE, fbits);
+	if (per_col * coarse_rows / (double) nrow < 1.0)        // less than one nonzero per thread of passes 1-2
+		return false;
+	sh->fbits = fbits;
+	sh->nfb = (nrow + ((int64_t) 1 << fbits) - 1) >> fbits;
+	sh->ncoarse = (sh->nfb + T2_NFINE - 1) / T2_NFINE;
+	sh->ngroups = (ncol + T2_NT - 1) / T2_NT;
+	const double ntab = (double) sh->nfb * (double) sh->ngroups, nwg = (double) sh->ncoarse * (double) sh->ngroups;
+	return ntab < 1.0e8 && nwg < 2.0e9;
+}
+
+static size_t t2_a(size_t n, size_t esz) { return (n * esz + 255) / 256 * 256; }
+
+// ---- fallback: stable LSD radix sort of (row -> position) pairs, then a gather (rounds 1-2; any shape) ----
 __global__ void iota_u32_kernel(uint32_t *__restrict__ p, int64_t n)
 {
 	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
@@ -91,9 +378,9 @@ __global__ void transpose_gather_kernel(const int64_t *__restrict__ col_ptr, int
 static size_t sort_tmp_bytes(int64_t nnz, int end_bit)
 {
 	size_t b = 0;
-	(void) hipcub::DeviceRadixSort::SortPairs(NULL, b, (const int32_t *) NULL, (int32_t *) NULL,
-						  (const uint32_t *) NULL, (uint32_t *) NULL,
-						  (int) nnz, 0, end_bit);
+	(void) rocprim::radix_sort_pairs(NULL, b, (const int32_t *) NULL, (int32_t *) NULL,
+					 (const uint32_t *) NULL, (uint32_t *) NULL,
+					 (size_t) nnz, 0u, (unsigned) end_bit);
 	return b;
 }
 
@@ -110,13 +397,13 @@ static size_t hint_bytes(int64_t nnz)
 }
 
 // [sorted rows nnz*4][positions nnz*4][sorted positions nnz*4][column hints][radix-sort temp]
-size_t transpose_ws_bytes(int64_t nrow, int64_t nnz)
+static size_t transpose_sorted_ws_bytes(int64_t nrow, int64_t nnz)
 {
 	const size_t a = ((size_t) (nnz > 0 ? nnz : 1) * 4 + 255) / 256 * 256;
 	return 3 * a + hint_bytes(nnz) + sort_tmp_bytes(nnz, key_bits(nrow)) + 256;
 }
 
-int launch_transpose(const int64_t *col_ptr, const int32_t *row_idx, const void *val, int Rtype,
+static int launch_transpose_sorted(const int64_t *col_ptr, const int32_t *row_idx, const void *val, int Rtype,
 		     int64_t nrow, int64_t ncol, int64_t nnz, int64_t *out_ptr, int32_t *out_idx,
 		     void *out_val, void *ws, hipStream_t s)
 {
@@ -140,7 +427,7 @@ int launch_transpose(const int64_t *col_ptr, const int32_t *row_idx, const void 
 	hipLaunchKernelGGL(iota_u32_kernel, dim3(nb), dim3(256), 0, s, pos, nnz);
 	const int64_t nblk = (nnz >> HINT_SHIFT) + 1;
 	hipLaunchKernelGGL(col_hint_kernel, dim3((unsigned) ((nblk + 1 + 255) / 256)), dim3(256), 0, s, col_ptr, ncol, nblk, hint);
-	HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tb, row_idx, srows, pos, perm, (int) nnz, 0, bits, s));
+	HIP_TRY(rocprim::radix_sort_pairs(tmp, tb, row_idx, srows, pos, perm, (size_t) nnz, 0u, (unsigned) bits, s));
 	hipLaunchKernelGGL(row_bounds_kernel, dim3(nbr), dim3(256), 0, s, srows, nnz, nrow, out_ptr);
 	if (Rtype == SVT_REALSXP)
 		hipLaunchKernelGGL(transpose_gather_kernel<double>, dim3(nb8), dim3(256), 0, s, col_ptr, ncol,
@@ -148,6 +435,80 @@ int launch_transpose(const int64_t *col_ptr, const int32_t *row_idx, const void 
 	else
 		hipLaunchKernelGGL(transpose_gather_kernel<int32_t>, dim3(nb8), dim3(256), 0, s, col_ptr, ncol,
 				   (const int32_t *) val, perm, hint, nnz, out_idx, (int32_t *) out_val);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+
+// workspace of the bucketed form: [reserve: table (nfb * ngroups + 1) * 8, scan scratch][columns nnz*4][rows in
+// bucket nnz][values nnz*8]
+// Head of the workspace kept for the bucket table and its scan scratch.  The caller sizes the workspace
+// from (nrow, nnz) alone; the shapes the bucketed form accepts have at most ~nnz / 8 + nrow / 64 table
+// entries (at least one nonzero per column and coarse bucket), and never more than 64 MiB are set aside:
+// a larger table sends the operand through the key sort.
+static size_t t2_reserve(int64_t nrow, int64_t nnz)
+{
+	const double per_row = nrow > 0 ? (double) nnz / (double) nrow : 0.0;
+	const double ntab = (double) nnz / 8.0 + (double) nrow / 64.0 + 8.0 * per_row + 16.0;
+	const double b = 2.0 * 8.0 * ntab + 8192.0;
+	const size_t cap = (size_t) 64 << 20;
+	return b >= (double) cap ? cap : ((size_t) b + 255) / 256 * 256;
+}
+
+size_t transpose_ws_bytes(int64_t nrow, int64_t nnz)
+{
+	const size_t n = (size_t) (nnz > 0 ? nnz : 1);
+	const size_t sorted = transpose_sorted_ws_bytes(nrow, nnz);
+	const size_t b2 = t2_reserve(nrow, nnz) + t2_a(n, 4) + t2_a(n, 1) + t2_a(n, 8) + 512;
+	return sorted > b2 ? sorted : b2;
+}
+
+int launch_transpose(const int64_t *col_ptr, const int32_t *row_idx, const void *val, int Rtype,
+		     int64_t nrow, int64_t ncol, int64_t nnz, int64_t *out_ptr, int32_t *out_idx,
+		     void *out_val, void *ws, hipStream_t s)
+{
+	if (nnz >= ((int64_t) 1 << 31))
+		return svt_set_error("svt_dev_transpose: more than 2^31-1 nonzeros");
+	if (nnz == 0) {
+		HIP_TRY(hipMemsetAsync(out_ptr, 0, (size_t) (nrow + 1) * 8, s));
+		return 0;
+	}
+	T2Shape sh;
+	const size_t reserve = t2_reserve(nrow, nnz);
+	if (!t2_shape(nrow, ncol, nnz, &sh) ||
+	    t2_a((size_t) (sh.nfb * sh.ngroups + 1), 8) + exclusive_scan_ws_bytes(sh.nfb * sh.ngroups + 1) > reserve)
+		return launch_transpose_sorted(col_ptr, row_idx, val, Rtype, nrow, ncol, nnz, out_ptr, out_idx, out_val, ws, s);
+	const int64_t ntab = sh.nfb * sh.ngroups + 1;
+	char *p = (char *) ws;
+	int64_t *table = (int64_t *) p;            p += t2_a((size_t) ntab, 8);
+	void *scan_ws = p;                         p += exclusive_scan_ws_bytes(ntab);
+	p = (char *) ws + reserve;
+	int32_t *col1 = (int32_t *) p;             p += t2_a((size_t) nnz, 4);
+	uint8_t *rlow1 = (uint8_t *) p;            p += t2_a((size_t) nnz, 1);
+	void *val1 = p;
+	const unsigned nwg = (unsigned) (sh.ngroups * sh.ncoarse);
+	// (fine buckets past the last row of the last coarse bucket are never counted: clear the table)
+	HIP_TRY(hipMemsetAsync(table, 0, (size_t) ntab * 8, s));
+	if (Rtype == SVT_REALSXP) {
+		hipLaunchKernelGGL((transpose_bucket_kernel<double, false>), dim3(nwg), dim3(T2_NT), 0, s, col_ptr, row_idx,
+				   (const double *) val, nrow, ncol, sh, table, col1, rlow1, (double *) val1);
+	} else {
+		hipLaunchKernelGGL((transpose_bucket_kernel<int32_t, false>), dim3(nwg), dim3(T2_NT), 0, s, col_ptr, row_idx,
+				   (const int32_t *) val, nrow, ncol, sh, table, col1, rlow1, (int32_t *) val1);
+	}
+	if (launch_exclusive_scan_i64(table, ntab, scan_ws, s))
+		return -1;
+	if (Rtype == SVT_REALSXP) {
+		hipLaunchKernelGGL((transpose_bucket_kernel<double, true>), dim3(nwg), dim3(T2_NT), 0, s, col_ptr, row_idx,
+				   (const double *) val, nrow, ncol, sh, table, col1, rlow1, (double *) val1);
+		hipLaunchKernelGGL(transpose_finish_kernel<double>, dim3((unsigned) sh.nfb), dim3(T3_NT), 0, s, table, sh, nrow,
+				   nnz, col1, rlow1, (const double *) val1, out_ptr, out_idx, (double *) out_val);
+	} else {
+		hipLaunchKernelGGL((transpose_bucket_kernel<int32_t, true>), dim3(nwg), dim3(T2_NT), 0, s, col_ptr, row_idx,
+				   (const int32_t *) val, nrow, ncol, sh, table, col1, rlow1, (int32_t *) val1);
+		hipLaunchKernelGGL(transpose_finish_kernel<int32_t>, dim3((unsigned) sh.nfb), dim3(T3_NT), 0, s, table, sh, nrow,
+				   nnz, col1, rlow1, (const int32_t *) val1, out_ptr, out_idx, (int32_t *) out_val);
+	}
 	HIP_TRY(hipGetLastError());
 	return 0;
 }
@@ -358,9 +719,9 @@ static int aperm_bits(const int64_t *dim, int ndim)
 static size_t aperm_sort_tmp(int64_t nnz, int bits)
 {
 	size_t b = 0;
-	(void) hipcub::DeviceRadixSort::SortPairs(NULL, b, (const unsigned long long *) NULL,
-						  (unsigned long long *) NULL, (const uint32_t *) NULL,
-						  (uint32_t *) NULL, (int) nnz, 0, bits);
+	(void) rocprim::radix_sort_pairs(NULL, b, (const unsigned long long *) NULL,
+					 (unsigned long long *) NULL, (const uint32_t *) NULL,
+					 (uint32_t *) NULL, (size_t) nnz, 0u, (unsigned) bits);
 	return b;
 }
 
@@ -420,8 +781,8 @@ aperm_slab_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict
 		  int bits, int64_t nnz, const int64_t *__restrict__ slab_base, int64_t *__restrict__ out_ptr,
 		  int32_t *__restrict__ out_idx, T *__restrict__ out_val)
 {
-	typedef hipcub::BlockRadixSort<uint32_t, SLAB_NT, SLAB_ITEMS, uint32_t> Sort;        // (4-bit digits; 5-bit ones, three passes over 15 row bits, need twice the LDS: 3.15 against 2.9 ms)
-	__shared__ typename Sort::TempStorage sort_tmp;
+	typedef rocprim::block_radix_sort<uint32_t, SLAB_NT, SLAB_ITEMS, uint32_t, 1, 1, 4> Sort;        // (4-bit digits; 5-bit ones, three passes over 15 row bits, need twice the LDS: 3.15 against 2.9 ms)
+	__shared__ typename Sort::storage_type sort_tmp;
 	__shared__ int32_t off[1025];                   // first slab-local index of every old leaf
 	__shared__ int64_t lbeg[1024];                  // its first position in the old arrays
 	extern __shared__ uint32_t skey[];              // SLAB_CAP sorted rows
@@ -465,7 +826,7 @@ aperm_slab_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict
 			key[u] = pad;                               // past every row
 		}
 	}
-	Sort(sort_tmp).SortBlockedToStriped(key, pay, 0, sort_bits);
+	Sort().sort_to_striped(key, pay, sort_tmp, 0u, (unsigned) sort_bits);
 #pragma unroll
 	for (int u = 0; u < SLAB_ITEMS; u++) skey[u * SLAB_NT + tid] = key[u];
 	__syncthreads();
@@ -495,10 +856,10 @@ size_t aperm_ws_bytes(int64_t nnz, const int64_t *dim, int ndim)
 	for (int a = 1; a < ndim; a++) nl *= (double) (dim[a] > 0 ? dim[a] : 1);
 	size_t scan_b = 0;
 	if (nl < 2147483646.0)
-		(void) hipcub::DeviceScan::ExclusiveSum(NULL, scan_b, (int64_t *) NULL, (int64_t *) NULL, (int) nl + 1);
+		scan_b = exclusive_scan_ws_bytes((int64_t) nl + 1);
 	size_t t32 = 0;
-	(void) hipcub::DeviceRadixSort::SortPairs(NULL, t32, (const uint32_t *) NULL, (uint32_t *) NULL,
-						  (const uint32_t *) NULL, (uint32_t *) NULL, (int) nnz, 0, 32);
+	(void) rocprim::radix_sort_pairs(NULL, t32, (const uint32_t *) NULL, (uint32_t *) NULL,
+					 (const uint32_t *) NULL, (uint32_t *) NULL, (size_t) nnz, 0u, 32u);
 	const size_t need64 = 2 * a8 + 2 * a4 + aperm_sort_tmp(nnz, aperm_bits(dim, ndim));
 	const size_t need32 = 5 * a4 + hint_bytes(nnz) + t32;
 	return (need64 > need32 ? need64 : need32) + scan_b + 256;
@@ -548,9 +909,8 @@ int launch_aperm(const int64_t *col_ptr, const int32_t *row_idx, const void *val
 		for (int a = 1; a < ndim; a++) { lm.new_dim[a] = dim[perm[a]]; lm.old_stride[a] = os[perm[a]]; }
 		// counts into out_ptr, exclusive scan in place (the scan's scratch comes from the workspace)
 		hipLaunchKernelGGL(aperm_leaf_count_kernel, dim3(nbl), dim3(256), 0, s, col_ptr, new_nleaves, lm, out_ptr);
-		size_t tb = 0;
-		(void) hipcub::DeviceScan::ExclusiveSum(NULL, tb, out_ptr, out_ptr, (int) (new_nleaves + 1));
-		HIP_TRY(hipcub::DeviceScan::ExclusiveSum(ws, tb, out_ptr, out_ptr, (int) (new_nleaves + 1), s));
+		if (launch_exclusive_scan_i64(out_ptr, new_nleaves + 1, ws, s))
+			return -1;
 		const unsigned nbc = (unsigned) ((new_nleaves + 4 * APERM_LU - 1) / (4 * APERM_LU));
 		if (Rtype == SVT_REALSXP)
 			hipLaunchKernelGGL(aperm_leaf_copy_kernel<double>, dim3(nbc), dim3(256), 0, s, col_ptr, row_idx,
@@ -578,7 +938,7 @@ int launch_aperm(const int64_t *col_ptr, const int32_t *row_idx, const void *val
 		}
 		size_t tb = 0;
 		if (nslab < 2147483646LL)
-			(void) hipcub::DeviceScan::ExclusiveSum(NULL, tb, (int64_t *) NULL, (int64_t *) NULL, (int) (nslab + 1));
+			tb = exclusive_scan_ws_bytes(nslab + 1);
 		const size_t a4 = ((size_t) nnz * 4 + 255) / 256 * 256;
 		const size_t cnt_b = ((size_t) (nslab + 2) * 8 + 255) / 256 * 256;
 		if (nslab >= 1 && nslab < 2147483646LL && nnz / nslab <= SLAB_CAP * 9 / 10 && cnt_b + tb + 256 <= 5 * a4) {
@@ -592,7 +952,8 @@ int launch_aperm(const int64_t *col_ptr, const int32_t *row_idx, const void *val
 			HIP_TRY(hipMemcpyAsync(&mx, maxcnt, 8, hipMemcpyDeviceToHost, s));
 			HIP_TRY(hipStreamSynchronize(s));
 			if (mx <= SLAB_CAP) {
-				HIP_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp, tb, base, base, (int) (nslab + 1), s));
+				if (launch_exclusive_scan_i64(base, nslab + 1, scan_tmp, s))
+					return -1;
 				int bits = 1;
 				while (bits < 31 && ((int64_t) 1 << bits) < dim[0]) bits++;
 				const size_t lds = (size_t) SLAB_CAP * 4;
@@ -619,15 +980,15 @@ int launch_aperm(const int64_t *col_ptr, const int32_t *row_idx, const void *val
 		int bits = 1;
 		while (bits < 32 && ((int64_t) 1 << bits) < new_nleaves) bits++;
 		size_t tb = 0;
-		(void) hipcub::DeviceRadixSort::SortPairs(NULL, tb, (const uint32_t *) NULL, (uint32_t *) NULL,
-							  (const uint32_t *) NULL, (uint32_t *) NULL, (int) nnz, 0, bits);
+		(void) rocprim::radix_sort_pairs(NULL, tb, (const uint32_t *) NULL, (uint32_t *) NULL,
+						 (const uint32_t *) NULL, (uint32_t *) NULL, (size_t) nnz, 0u, (unsigned) bits);
 		const unsigned nb = (unsigned) ((nnz + 255) / 256);
 		const unsigned nb8 = (unsigned) (((nnz + 255) / 256 + 7) / 8 * 8);
 		const int64_t nblk = (nnz >> HINT_SHIFT) + 1;
 		hipLaunchKernelGGL(col_hint_kernel, dim3((unsigned) ((nblk + 1 + 255) / 256)), dim3(256), 0, s, col_ptr, ncol, nblk, hint);
 		hipLaunchKernelGGL(aperm_key32_kernel, dim3(nb), dim3(256), 0, s, col_ptr, row_idx, hint, ncol, nnz, d,
 				   keys, pos, newrow);
-		HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tb, keys, skeys, pos, spos, (int) nnz, 0, bits, s));
+		HIP_TRY(rocprim::radix_sort_pairs(tmp, tb, keys, skeys, pos, spos, (size_t) nnz, 0u, (unsigned) bits, s));
 		hipLaunchKernelGGL(aperm_ptr_fill_kernel, dim3((unsigned) ((nnz + 1 + 255) / 256)), dim3(256), 0, s,
 				   skeys, nnz, new_nleaves, out_ptr);
 		if (Rtype == SVT_REALSXP)
@@ -651,7 +1012,7 @@ int launch_aperm(const int64_t *col_ptr, const int32_t *row_idx, const void *val
 	const unsigned nb = (unsigned) ((nnz + 255) / 256);
 	const unsigned nb8 = (unsigned) (((nnz + 255) / 256 + 7) / 8 * 8);
 	hipLaunchKernelGGL(aperm_key_kernel, dim3(nb), dim3(256), 0, s, col_ptr, row_idx, ncol, nnz, d, keys, pos);
-	HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tb, keys, skeys, pos, spos, (int) nnz, 0, bits, s));
+	HIP_TRY(rocprim::radix_sort_pairs(tmp, tb, keys, skeys, pos, spos, (size_t) nnz, 0u, (unsigned) bits, s));
 	hipLaunchKernelGGL(aperm_bounds_kernel, dim3(nbl), dim3(256), 0, s, skeys, nnz, new_nleaves, new_dim0, out_ptr);
 	if (Rtype == SVT_REALSXP)
 		hipLaunchKernelGGL(aperm_gather_kernel<double>, dim3(nb8), dim3(256), 0, s, skeys, spos,

@@ -207,8 +207,9 @@ def test_session_t_goes_through_the_device(hip, oracle):
     C_transpose_2D_SVT call (no host-side element loop): results as the oracle's."""
     x = _special(400, 50, 0.06, 51, one_per_leaf=True)
     y = np.asfortranarray(np.random.default_rng(52).uniform(-1, 1, (7, 50)))
-    assert_equal(hip.tcrossprod(x, y), oracle.tcrossprod(x, y), tol=1e-12, strict_na=True, what="tcrossprod")
-    assert_equal(hip.tcrossprod(x), oracle.tcrossprod(x), tol=1e-12, strict_na=True, what="tcrossprod1")
+    # (rows of x = leaves of t(x) may hold a NaN and an NA together: IEEE-propagated class, not pinned)
+    assert_equal(hip.tcrossprod(x, y), oracle.tcrossprod(x, y), tol=1e-12, what="tcrossprod")
+    assert_equal(hip.tcrossprod(x), oracle.tcrossprod(x), tol=1e-12, what="tcrossprod1")
     xi = _special(400, 50, 0.06, 53, "int")
     for fn in ("rowProds", "rowAnys", "rowAlls"):
         a, b = getattr(hip, fn)(xi), getattr(oracle, fn)(xi)

@@ -48,7 +48,7 @@ Register map (fixed physical registers; the kernel pins C++ vectors to them):
         s11 next panel index         s12 end panel
         s13 LDS byte offset of the buffer holding the current panel (0 / BUF)
         s14 LDS byte address of this wavefront's first DMA piece in buffer 1
-        s15 phase to resume at       s16, s17, s19 unused
+        s15 w >> 2 (PBC_SKEW experiment)   s16, s17 partial last panel (index, byte shift)  s19 finite-check iterations - 1
         s18 sticky "non-finite seen"
         s[20:27] DMA source bases of the wavefront's 4 dense columns (start of the row split)
         vcc_lo scratch, vcc_hi return selector of the issue routine, m0 scratch
@@ -86,6 +86,7 @@ else:
     YSET = [20]
     ACC = 36
 DEFER = YSETS == 2 and not EXP and os.environ.get("PBC_DEFER", "1") == "1"
+SKEW = int(os.environ.get("PBC_SKEW", "0"))     # experiment: post-barrier skew of the wavefronts that share a SIMD
 PROF = False
 out = []
 
@@ -232,6 +233,19 @@ def gen(prof):
         stamp(1)                                   # own DMA pieces
         if "nobarrier" not in EXP:
             e("s_barrier")                         # everybody's pieces; everybody done with the previous panel
+        if SKEW:
+            # Round-3 experiment (PBC_SKEW=n): the barrier releases the four wavefronts of a SIMD in the same
+            # state, and they stay aligned for the tile -- all reading LDS, then all multiplying (the
+            # 'work' leg takes 1.40 ms behind a barrier against 0.95 ms free-running).
+            # Wavefront w waits (w >> 2) * n * 64 cycles behind the barrier (s15 = w >> 2).
+            e("s_mov_b32 vcc_lo, s15")
+            e("17:")
+            e("s_cmp_eq_u32 vcc_lo, 0")
+            e("s_cbranch_scc1 18f")
+            e(f"s_sleep {SKEW}")
+            e("s_sub_u32 vcc_lo, vcc_lo, 1")
+            e("s_branch 17b")
+            e("18:")
         stamp(2)                                   # barrier
         d8(i, "read")                              # LDS reads of the batch the next phase multiplies
         if defer:
