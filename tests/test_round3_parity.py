@@ -219,3 +219,26 @@ def test_session_t_goes_through_the_device(hip, oracle):
             assert_equal(a, b, tol=1e-12, strict_na=True, what=fn)
     t1, t2 = hip.t(x), oracle.t(x)
     assert_identical(t1.to_dense(), t2.to_dense(), "t()")
+
+
+# ---------------------------------------------------------------------------------------------
+# rowsum(): the row-panel kernel (group ids staged in LDS, NC columns per workgroup) -- it takes over for
+# double operands with >= 65536 rows
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ngroup", [1, 7, 1000, 2300, 6000])
+@pytest.mark.parametrize("shape", [(70_000, 37, 0.02), (200_001, 5, 0.3), (65_536, 130, 0.001)])
+def test_rowsum_row_panel_kernel(hip, oracle, ngroup, shape):
+    nrow, ncol, dens = shape
+    cp, ri, v = random_csc(nrow, ncol, dens, seed=61)
+    v = v.copy()
+    rng = np.random.default_rng(62)
+    if len(v) > 20:
+        v[rng.choice(len(v), 6, replace=False)] = [np.nan, NA_real, np.inf, -np.inf, np.nan, 1e300]
+    x = SVT_SparseArray.from_csc((nrow, ncol), "double", cp, ri, v)
+    g = rng.integers(0, ngroup, nrow)
+    grp = [None if rng.random() < 1e-4 else int(k) for k in g]          # a few NA groups
+    for na_rm in (False, True):
+        a, ua = hip.rowsum(x, grp, na_rm=na_rm)
+        b, ub = oracle.rowsum(x, grp, na_rm=na_rm)
+        assert ua == ub
+        assert_equal(a, b, tol=1e-9, atol=1e-12, what=f"rowsum ngroup={ngroup} na_rm={na_rm}")
