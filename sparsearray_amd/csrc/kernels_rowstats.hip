@@ -923,90 +923,6 @@ rowsum_f64_lds16_kernel(GroupSumArgs a, const uint16_t *__restrict__ g16)
 		out[g] = acc[g];
 }
 
-// Round 3: the group ids go through LDS too.  With one workgroup per column every nonzero fetches its row's
-// group id from L2 -- one 64-byte sector per nonzero, 1e8 L2 requests at BASELINE config 3, which is what the
-// kernel above runs at (0.59 ms for 1.28 GB).  Here a workgroup owns NC <= 16 columns (one wavefront each, their
-// NC x ngroup sums in LDS) and walks the rows panel by panel: the 16-bit group ids of a panel of R rows are
-// staged in LDS once (coalesced, double-buffered: the next panel's ids travel through registers while the
-// current panel is consumed; one barrier per panel) and serve all NC columns, so the table is read
-// ncol / NC times in whole lines (1.25 GB at config 3) instead of once per nonzero in sectors (6.4 GB).
-// A wavefront keeps the 64 nonzeros it has loaded until their panel comes round (offsets ascend inside a
-// leaf, src/leaf_utils.h:12-15), so nothing is read twice.  compute_rowsum_doubles, src/rowsum_methods.c:44-64.
-#define RSP_NT 1024
-__global__ void __launch_bounds__(RSP_NT)
-rowsum_f64_panel_kernel(GroupSumArgs a, const uint16_t *__restrict__ g16, int NC, int logR, int64_t nblocks)
-{
-	extern __shared__ double rsp_lds[];                     // [NC][ngroup] sums, then 2 x [R] group ids
-	const int R = 1 << logR;
-	const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-	double *acc = rsp_lds;
-	uint16_t *gbuf = (uint16_t *) (rsp_lds + (size_t) NC * a.ngroup);
-	const double *__restrict__ val = (const double *) a.val;
-	const int64_t npanel = (a.nrow + R - 1) >> logR;
-	const int per_thread = (R + RSP_NT - 1) / RSP_NT;       // ids per thread per panel (R >= 1024: whole numbers)
-	for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
-		const int64_t j = blk * NC + w;                 // this wavefront's column
-		const bool mine = w < NC && j < a.ncol;
-		for (int g = t; g < NC * a.ngroup; g += RSP_NT) acc[g] = 0.0;
-		// first panel straight into buffer 0
-		for (int u = 0; u < per_thread; u++) {
-			const int64_t r = (int64_t) u * RSP_NT + t;
-			if (r < R) gbuf[r] = r < a.nrow ? g16[r] : (uint16_t) 0;
-		}
-		__syncthreads();
-		int64_t cur = 0, end = 0;
-		if (mine) { cur = col_beg(a, j); end = col_beg(a, j + 1); }
-		// the 64 nonzeros in flight: row (INT_MAX = none / consumed) and value
-		int32_t r_in = 0x7FFFFFFF;
-		double v_in = 0.0;
-		bool need = mine;                               // wave-uniform: load the next 64
-		double *my = acc + (size_t) w * a.ngroup;
-		for (int64_t p = 0; p < npanel; p++) {
-			const uint16_t *gb = gbuf + (size_t) (p & 1) * R;
-			// ids of panel p + 1 on their way (registers; written to the other buffer behind the work)
-			uint16_t nxt[16];
-			const int64_t nbase = (p + 1) << logR;
-#pragma unroll
-			for (int u = 0; u < 16; u++) {
-				const int64_t r = nbase + (int64_t) u * RSP_NT + t;
-				nxt[u] = (u < per_thread && (int64_t) u * RSP_NT + t < R && r < a.nrow) ? g16[r] : (uint16_t) 0;
-			}
-			if (mine) {
-				const int64_t p_end = (p + 1) << logR, p_beg = p << logR;
-				for (;;) {
-					if (need) {
-						const int64_t k = cur + lane;
-						r_in = k < end ? a.row_idx[k] : 0x7FFFFFFF;
-						v_in = k < end ? val[k] : 0.0;
-						cur += 64;
-						need = false;
-					}
-					if ((int64_t) r_in < p_end) {           // (consumed lanes hold INT_MAX)
-						if (!(a.na_rm && v_in != v_in))
-							atomicAdd(&my[gb[r_in - p_beg]], v_in);
-						r_in = 0x7FFFFFFF;
-					}
-					// every lane consumed and more to come: next batch; otherwise this panel is done
-					if (__any(r_in != 0x7FFFFFFF) || cur >= end) break;
-					need = true;
-				}
-			}
-			if (p + 1 < npanel) {
-				uint16_t *gn = gbuf + (size_t) ((p + 1) & 1) * R;
-#pragma unroll
-				for (int u = 0; u < 16; u++)
-					if (u < per_thread && (int64_t) u * RSP_NT + t < R) gn[(int64_t) u * RSP_NT + t] = nxt[u];
-			}
-			__syncthreads();
-		}
-		if (mine) {
-			double *out = (double *) a.out + j * (int64_t) a.ngroup;
-			for (int g = lane; g < a.ngroup; g += 64) out[g] = my[g];
-		}
-		__syncthreads();                                // (the sums are cleared for the next block)
-	}
-}
-
 // Long f64 columns with few groups: LDS accumulators, no memory atomics.
 int launch_rowsum_lds(const GroupSumArgs &a, hipStream_t s)
 {
@@ -1017,24 +933,6 @@ int launch_rowsum_lds(const GroupSumArgs &a, hipStream_t s)
 		HIP_TRY(hipMallocAsync((void **) &g16, (size_t) a.nrow * 2 + 16, s));
 		hipLaunchKernelGGL(group16_kernel, dim3((unsigned) ((a.nrow + 255) / 256)), dim3(256), 0, s,
 				   a.group, a.nrow, a.ngroup, g16);
-		// panel form: NC columns per workgroup (as many as 16 wavefronts and 144 KB of LDS allow beside a
-		// double buffer of R >= 2048 rows' ids), R as tall as fits (<= 16384)
-		const size_t budget = (size_t) 144 << 10;
-		int NC = 16;
-		while (NC > 0 && (size_t) NC * a.ngroup * 8 + 2 * 2048 * 2 > budget) NC--;
-		if (NC >= 4) {
-			int logR = 11;
-			while (logR < 14 && (size_t) NC * a.ngroup * 8 + ((size_t) 4 << (logR + 1)) <= budget) logR++;
-			const size_t lds = (size_t) NC * a.ngroup * 8 + ((size_t) 4 << logR);
-			const int64_t nblocks = (a.ncol + NC - 1) / NC;
-			(void) hipFuncSetAttribute((const void *) rowsum_f64_panel_kernel,
-						   hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-			const unsigned grid = (unsigned) (nblocks < 65536 ? nblocks : 65536);
-			hipLaunchKernelGGL(rowsum_f64_panel_kernel, dim3(grid), dim3(RSP_NT), lds, s, a, g16, NC, logR, nblocks);
-			HIP_TRY(hipGetLastError());
-			HIP_TRY(hipFreeAsync(g16, s));
-			return 0;
-		}
 		hipLaunchKernelGGL(rowsum_f64_lds16_kernel, dim3((unsigned) a.ncol), dim3(256),
 				   (size_t) a.ngroup * 8, s, a, g16);
 		HIP_TRY(hipGetLastError());
