@@ -94,34 +94,44 @@ int launch_exclusive_scan_i64(int64_t *data, int64_t n, void *ws, hipStream_t s)
 // (src/SparseArray_aperm.c:148-393) -- is stable because it visits the columns in order.  The parallel
 // form below keeps that order without a general-purpose sort by using what a CSC operand gives for free:
 // the rows inside a column ascend (src/leaf_utils.h:12-15), so the nonzeros of one column that fall into
-// a given range of rows are one contiguous run, found by two binary searches.
+// a given range of rows are one contiguous run.
 //
-//   fine bucket   = F consecutive rows (F = 64, 128 or 256: ~10^4 nonzeros), the unit of the last pass
+//   fine bucket   = F consecutive rows (a power of two <= 64: ~3000 nonzeros), the unit of the last pass
 //   coarse bucket = 16 fine buckets
-//   group         = 512 consecutive columns, one thread per column
+//   group         = 256 consecutive columns
 //
-//   pass 1 (count)   workgroup (group g, coarse bucket i): every thread finds its column's run of rows in
-//                    the coarse bucket and counts it by fine bucket; table[fine bucket][g] = the group's
-//                    total (16 numbers per workgroup).
-//   scan             exclusive scan of the table, fine-bucket-major: where the piece (fine bucket, g)
-//                    starts in an intermediate array ordered (fine bucket, group, column, row).
-//   pass 2 (scatter) the same workgroups copy their runs to those pieces: position = piece start + the
-//                    nonzeros of the same fine bucket in the group's earlier columns (a scan over the 512
-//                    threads, per fine bucket) + the index inside the column's run.  Every piece is a few
-//                    KB written by one workgroup within microseconds.
-//   pass 3 (finish)  one workgroup per fine bucket: its ~10^4 nonzeros are contiguous and already in column
-//                    order; a stable counting sort on the F rows (ranks inside a wavefront from ballots of
-//                    the row bits, across wavefronts from a small LDS table) puts them in (row, column) order
-//                    at their final place, and gives the row pointers.
+//   pass 1 (count)   a streaming pass over the offsets: a workgroup takes a stretch of one group's nonzeros,
+//                    counts them by fine bucket in LDS and adds its counts to the table
+//                    T[coarse bucket][group][fine bucket in the coarse one].
+//   scan             exclusive scan of T in that order: where the piece (coarse i, group g, fine s) starts
+//                    in an intermediate array ordered (coarse, group, fine, column, row).
+//   pass 2 (scatter) workgroup (g, i), one thread per column: the column's run of rows in the coarse bucket
+//                    (an interpolated guess, then a search over what is left), the position of each of its
+//                    nonzeros among the workgroup's = a scan over the 128 threads per fine bucket; the
+//                    workgroup's nonzeros are assembled in LDS in their final intermediate order and leave
+//                    as ONE contiguous, coalesced copy (the 16 pieces of a workgroup follow one another).
+//   pass 3 (finish)  one workgroup per fine bucket: its pieces (one per group, in group order = column
+//                    order) are read in sequence; a stable counting sort on the F rows (ranks inside a
+//                    wavefront from ballots of the row bits, across wavefronts from a small LDS table) puts
+//                    them in (row, column) order -- in LDS, and from there in one coalesced copy to their
+//                    final place -- and gives the row pointers.
 //
 // Traffic at 1e8 nonzeros (f64): pass 1 reads the offsets (0.4 GB), pass 2 reads 1.2 GB and writes 1.3 GB
-// (column 4 B + row-in-bucket 1 B + value 8 B), pass 3 reads 1.3 GB and writes 1.2 GB: 5.4 GB against
-// 7.6 GB for the sort-and-gather form, and no pass scatters single elements across the whole array.
-// Shapes it does not fit (rows with more than ~500 nonzeros on average, or less than one nonzero per
-// column and coarse bucket) take the key sort of launch_transpose_sorted() below.
+// (column 4 B + row-in-bucket 1 B + value 8 B), pass 3 reads 1.3 GB and writes 1.2 GB: 5.4 GB, every
+// store coalesced.  (The first version of this round wrote pass 2 straight to memory, fine-bucket-major:
+// every lane of a store instruction in another line, 48 open write streams per workgroup -- 7.5 ms for that
+// pass alone; and counted with one thread per column and two binary searches: 2.2 ms.)
+// Shapes it does not fit (less than one nonzero per column and coarse bucket) take the key sort of
+// launch_transpose_sorted() below.
 // ---------------------------------------------------------------------------
-#define T2_NT 512                 // columns per group = threads per workgroup of passes 1-2
+#define T2_NT 256                 // columns per group = threads per workgroup of pass 2
 #define T2_NFINE 16               // fine buckets per coarse bucket
+#define T2_CAP 2048               // nonzeros a pass-2 workgroup assembles in LDS (more: straight to memory)
+#define T1_NT 1024
+#define T1_HIST 32768             // fine buckets counted per sweep of pass 1 (LDS)
+#define T3_NT 512
+#define T3_CAP 4096               // nonzeros a pass-3 workgroup ranks in one round (more: round by round, straight to memory)
+#define T3_STAGE 2048             // of which the LDS image of the output holds this many at a time
 
 struct T2Shape {
 	int fbits;                // log2(F)
@@ -129,6 +139,69 @@ struct T2Shape {
 	int64_t ncoarse;
 	int64_t ngroups;
 };
+
+__device__ inline int64_t t2_slot(const T2Shape &sh, int64_t fb, int64_t g)
+{
+	return ((fb / T2_NFINE) * sh.ngroups + g) * T2_NFINE + (fb % T2_NFINE);
+}
+
+// pass 1: workgroup = 16 columns (16 divides the group size), one per wavefront (coalesced along the column); counts by fine bucket in
+// LDS, and cstart[i * ncol + c] = first position of column c whose row lies in coarse bucket i or later
+// (i = 0 .. ncoarse), which is where pass 2 finds its runs without a search.
+__global__ void __launch_bounds__(T1_NT)
+transpose_count_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__ row_idx,
+		       int64_t ncol, T2Shape sh, unsigned long long *__restrict__ table,
+		       uint32_t *__restrict__ cstart)
+{
+	extern __shared__ uint32_t hist[];              // [T1_HIST]
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const int64_t c = (int64_t) blockIdx.x * (T1_NT / 64) + w;
+	const int64_t g = ((int64_t) blockIdx.x * (T1_NT / 64)) / T2_NT;          // (16 divides 128: one group per workgroup)
+	const int cshift = sh.fbits + 4;                // log2(rows per coarse bucket)
+	int64_t beg = 0, end = 0;
+	if (c < ncol) { beg = col_ptr[c]; end = col_ptr[c + 1]; }
+	for (int64_t w0 = 0; w0 < sh.nfb; w0 += T1_HIST) {          // (one sweep unless there are > 32768 fine buckets)
+		const int64_t w1 = w0 + T1_HIST < sh.nfb ? w0 + T1_HIST : sh.nfb;
+		for (int x = threadIdx.x; x < (int) (w1 - w0); x += T1_NT) hist[x] = 0;
+		__syncthreads();
+		for (int64_t kb = beg; kb < end; kb += 256) {           // four batches of 64 in flight
+			int32_t r4[4];
+#pragma unroll
+			for (int u = 0; u < 4; u++) r4[u] = kb + u * 64 + lane < end ? row_idx[kb + u * 64 + lane] : 0x7FFFFFFF;
+			const int32_t r_before = kb > beg ? row_idx[kb - 1] : -1;
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				const int64_t k0 = kb + u * 64, k = k0 + lane;
+				if (k0 >= end) break;
+				const int32_t r = r4[u];
+				if (k < end) {
+					const int64_t fb = (int64_t) r >> sh.fbits;
+					if (fb >= w0 && fb < w1) atomicAdd(&hist[fb - w0], 1u);
+				}
+				if (w0 == 0 && c < ncol) {
+					// coarse buckets that start at position k: those after the previous entry's, up to this one's
+					int32_t rp = __shfl_up(r, 1, SVT_WAVE);
+					const int32_t last_prev = __shfl(r4[u > 0 ? u - 1 : 0], 63, SVT_WAVE);      // (all lanes take part)
+					if (lane == 0) rp = u == 0 ? r_before : last_prev;
+					const int64_t ip = rp < 0 ? -1 : ((int64_t) rp >> cshift);
+					const int64_t ic = k < end ? ((int64_t) r >> cshift) : (k == end ? sh.ncoarse : ip);
+					for (int64_t i = ip + 1; i <= ic; i++) cstart[i * ncol + c] = (uint32_t) k;
+				}
+			}
+		}
+		if (w0 == 0 && c < ncol && lane == 0) {
+			// (a column whose length is a multiple of 64 -- or zero -- has not closed its last buckets)
+			if (((end - beg) & 63) == 0) {
+				const int64_t ip = end > beg ? ((int64_t) row_idx[end - 1] >> cshift) : -1;
+				for (int64_t i = ip + 1; i <= sh.ncoarse; i++) cstart[i * ncol + c] = (uint32_t) end;
+			}
+		}
+		__syncthreads();
+		for (int x = threadIdx.x; x < (int) (w1 - w0); x += T1_NT)
+			if (hist[x]) atomicAdd(table + t2_slot(sh, w0 + x, g), (unsigned long long) hist[x]);
+		__syncthreads();
+	}
+}
 
 // first position in [lo, hi) whose row is >= r
 __device__ inline int64_t t2_lower_bound(const int32_t *__restrict__ row_idx, int64_t lo, int64_t hi, int64_t r)
@@ -140,15 +213,125 @@ __device__ inline int64_t t2_lower_bound(const int32_t *__restrict__ row_idx, in
 	return lo;
 }
 
-template <typename T, bool SCATTER>
-__global__ void __launch_bounds__(T2_NT)
-transpose_bucket_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__ row_idx,
-			const T *__restrict__ val, int64_t nrow, int64_t ncol, T2Shape sh,
-			int64_t *__restrict__ table, int32_t *__restrict__ col1, uint8_t *__restrict__ rlow1,
-			T *__restrict__ val1)
+// Passes 2 and 3 are the same operation: a workgroup holds a SEQUENCE of nonzeros made of pieces (pass 2:
+// the runs of its 128 columns inside the coarse bucket; pass 3: the pieces of its fine bucket, one per
+// group) and splits it by a small key (pass 2: the fine bucket, 4 bits; pass 3: the row inside the bucket,
+// <= 6 bits) keeping the order inside every key.  Element x of the sequence is read by thread x mod NT
+// (consecutive lanes = consecutive addresses inside a piece: coalesced), kept in registers, ranked --
+// rank inside the wavefront from one ballot per key bit, the wavefronts' counts per key in an LDS table,
+// prefixed in element order -- and written to its place in an LDS image of the output, which leaves in one
+// linear copy.  Sequences longer than the image (NT * ITEMS elements) go round by round, straight to memory.
+template <int NT, int ITEMS, int MAXKEYS>
+struct SplitLds {
+	int32_t binstart[MAXKEYS];              // first output slot of every key (histogram first, then its prefix)
+	int32_t run[MAXKEYS];                   // slots used by earlier rounds
+	int32_t rtot[MAXKEYS];                  // elements of the current round
+	int32_t totu[ITEMS][MAXKEYS];           // per key: elements of the chunks before chunk u (this round)
+	uint16_t wc[ITEMS][NT / 64][MAXKEYS];   // per key: elements of chunk u in the wavefronts before w (<= NT)
+};
+
+// lanes of the wavefront whose element is valid and has the same key: one ballot per key bit
+__device__ inline uint64_t split_peers(bool valid, int key, int kbits)
 {
-	__shared__ uint32_t cnt[T2_NFINE][T2_NT];       // [fine bucket][thread]: count, then exclusive prefix over the threads
-	__shared__ int64_t piece[T2_NFINE];
+	uint64_t peers = __ballot(valid);
+	for (int bit = 0; bit < kbits; bit++) {
+		const uint64_t m = __ballot((key >> bit) & 1);
+		peers &= ((key >> bit) & 1) ? m : ~m;
+	}
+	return peers;
+}
+
+// binstart[0 .. nkeys) holds the histogram: turn it into its exclusive prefix (nkeys <= 256, wavefront 0;
+// the other wavefronts wait at the caller's barrier).  f(k, start) is called for every key by the lane that
+// owns it.
+template <typename F>
+__device__ inline void split_scan_bins(int32_t *binstart, int nkeys, F f)
+{
+	const int lane = threadIdx.x & 63;
+	if ((threadIdx.x >> 6) != 0) return;
+	int32_t v[4], tot = 0;
+#pragma unroll
+	for (int u = 0; u < 4; u++) { v[u] = lane * 4 + u < nkeys ? binstart[lane * 4 + u] : 0; tot += v[u]; }
+	int32_t incl = tot;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const int32_t x = __shfl_up(incl, o, SVT_WAVE);
+		if (lane >= o) incl += x;
+	}
+	int32_t off = incl - tot;
+#pragma unroll
+	for (int u = 0; u < 4; u++) {
+		const int k = lane * 4 + u;
+		if (k < nkeys) { binstart[k] = off; f(k, off); }
+		off += v[u];
+	}
+}
+
+// Output slots of one round: key[u] (valid[u]) belongs to element u * NT + t of the round.  All threads of
+// the workgroup call it; nkeys = 1 << kbits <= MAXKEYS.
+template <int NT, int ITEMS, int MAXKEYS>
+__device__ inline void split_round(SplitLds<NT, ITEMS, MAXKEYS> &L, const bool (&valid)[ITEMS],
+				   const int (&key)[ITEMS], int kbits, int32_t (&at)[ITEMS])
+{
+	const int t = threadIdx.x, lane = t & 63, w = t >> 6, nkeys = 1 << kbits;
+	const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+	for (int k = t; k < nkeys; k += NT) { L.run[k] += L.rtot[k]; L.rtot[k] = 0; }      // the previous round's elements
+	for (int x = t; x < ITEMS * (NT / 64) * MAXKEYS / 2; x += NT) ((uint32_t *) &L.wc[0][0][0])[x] = 0;
+	__syncthreads();
+	int rank[ITEMS];
+#pragma unroll
+	for (int u = 0; u < ITEMS; u++) {
+		const uint64_t peers = split_peers(valid[u], key[u], kbits);
+		rank[u] = __popcll(peers & lt);
+		if (valid[u] && rank[u] == 0) L.wc[u][w][key[u]] = (uint16_t) __popcll(peers);
+	}
+	__syncthreads();
+	// exclusive prefix in element order (chunk u, then wavefront w), per key
+	for (int x = t; x < ITEMS * nkeys; x += NT) {
+		const int u = x / nkeys, k = x % nkeys;
+		int32_t sum = 0;
+		for (int ww = 0; ww < NT / 64; ww++) { const int32_t v = L.wc[u][ww][k]; L.wc[u][ww][k] = (uint16_t) sum; sum += v; }
+		L.totu[u][k] = sum;
+	}
+	__syncthreads();
+	for (int k = t; k < nkeys; k += NT) {
+		int32_t sum = 0;
+		for (int u = 0; u < ITEMS; u++) { const int32_t v = L.totu[u][k]; L.totu[u][k] = sum; sum += v; }
+		L.rtot[k] = sum;
+	}
+	__syncthreads();
+#pragma unroll
+	for (int u = 0; u < ITEMS; u++)
+		at[u] = valid[u] ? L.binstart[key[u]] + L.run[key[u]] + L.totu[u][key[u]] + L.wc[u][w][key[u]] + rank[u] : 0;
+}
+
+// last j in [0, np) with pre[j] <= x  (pre[0] = 0, pre[np] = length of the sequence > x)
+__device__ inline int split_piece_of(const int32_t *pre, int np, int32_t x)
+{
+	int lo = 0, hi = np - 1;
+	while (lo < hi) {
+		const int mid = (lo + hi + 1) >> 1;
+		if (pre[mid] <= x) lo = mid; else hi = mid - 1;
+	}
+	return lo;
+}
+
+// pass 2
+#define T2_ITEMS (T2_CAP / T2_NT)
+template <typename T>
+__global__ void __launch_bounds__(T2_NT)
+transpose_scatter_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__ row_idx,
+			 const T *__restrict__ val, int64_t nrow, int64_t ncol, T2Shape sh,
+			 const int64_t *__restrict__ table, const uint32_t *__restrict__ cstart,
+			 int32_t *__restrict__ col1, uint8_t *__restrict__ rlow1, T *__restrict__ val1)
+{
+	__shared__ SplitLds<T2_NT, T2_ITEMS, T2_NFINE> L;
+	__shared__ int64_t pa[T2_NT];                   // first position of every column's run
+	__shared__ int32_t ppre[T2_NT + 1];             // lengths of the runs, then their prefix
+	__shared__ uint8_t owner[T2_CAP];               // column (0 .. 255) of every element of the sequence
+	__shared__ int32_t s_col[T2_CAP];
+	__shared__ T s_val[T2_CAP];
+	__shared__ uint8_t s_row[T2_CAP];
 	const int t = threadIdx.x, lane = t & 63, w = t >> 6;
 	const int64_t g = (int64_t) blockIdx.x % sh.ngroups, i = (int64_t) blockIdx.x / sh.ngroups;
 	const int64_t r_lo = (i * T2_NFINE) << sh.fbits;
@@ -156,125 +339,245 @@ transpose_bucket_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__re
 	if (r_hi > nrow) r_hi = nrow;
 	const int64_t c = g * T2_NT + t;
 	int64_t a = 0, b = 0;
-	if (c < ncol) {
-		const int64_t beg = col_ptr[c], end = col_ptr[c + 1];
-		a = t2_lower_bound(row_idx, beg, end, r_lo);
-		b = t2_lower_bound(row_idx, a, end, r_hi);
+	if (c < ncol) {                                 // the column's run: recorded by pass 1 (coalesced: consecutive columns)
+		a = cstart[i * ncol + c];
+		b = cstart[(i + 1) * ncol + c];
 	}
-#pragma unroll
-	for (int s = 0; s < T2_NFINE; s++) cnt[s][t] = 0;
-	for (int64_t k = a; k < b; k++)                 // (only this thread touches column t of cnt)
-		cnt[((int64_t) row_idx[k] - r_lo) >> sh.fbits][t]++;
-	__syncthreads();
-	// exclusive prefix over the 512 threads, two fine buckets per wavefront
-	for (int s = 2 * w; s < 2 * w + 2; s++) {
-		uint32_t carry = 0;
-		for (int j = 0; j < T2_NT / 64; j++) {
-			const uint32_t v = cnt[s][j * 64 + lane];
-			uint32_t incl = v;
-#pragma unroll
-			for (int o = 1; o < 64; o <<= 1) {
-				const uint32_t u = __shfl_up(incl, o, SVT_WAVE);
-				if (lane >= o) incl += u;
-			}
-			cnt[s][j * 64 + lane] = carry + incl - v;
-			carry += __shfl(incl, 63, SVT_WAVE);
-		}
-		const int64_t fb = i * T2_NFINE + s;
-		if (lane == 0 && fb < sh.nfb) {
-			if (!SCATTER) table[fb * sh.ngroups + g] = carry;
-			else piece[s] = table[fb * sh.ngroups + g];
-		}
-	}
-	if (!SCATTER)
-		return;
-	__syncthreads();
-	for (int64_t k = a; k < b; k++) {
-		const int64_t rr = (int64_t) row_idx[k] - r_lo;
-		const int s = (int) (rr >> sh.fbits);
-		const int64_t dst = piece[s] + cnt[s][t]++;
-		col1[dst] = (int32_t) c;
-		rlow1[dst] = (uint8_t) (rr & (((int64_t) 1 << sh.fbits) - 1));
-		val1[dst] = val[k];
-	}
-}
-
-#define T3_NT 1024
-template <typename T>
-__global__ void __launch_bounds__(T3_NT)
-transpose_finish_kernel(const int64_t *__restrict__ table, T2Shape sh, int64_t nrow, int64_t nnz,
-			const int32_t *__restrict__ col1, const uint8_t *__restrict__ rlow1,
-			const T *__restrict__ val1, int64_t *__restrict__ out_ptr,
-			int32_t *__restrict__ out_idx, T *__restrict__ out_val)
-{
-	__shared__ int32_t start[256], run[2][256];     // per row of the bucket: first output slot, slots used so far
-	__shared__ int32_t wcnt[2][T3_NT / 64][256];    // per wavefront and row: entries of the current chunk
-	// (run and wcnt alternate between two copies from chunk to chunk: two barriers per chunk)
-	const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-	const int F = 1 << sh.fbits;
-	const int64_t fb = blockIdx.x;
-	const int64_t b0 = table[fb * sh.ngroups], b1 = fb + 1 < sh.nfb ? table[(fb + 1) * sh.ngroups] : nnz;
-	const int64_t n = b1 - b0;
-	if (t < F) { start[t] = 0; run[0][t] = 0; }
-	for (int x = t; x < 2 * (T3_NT / 64) * 256; x += T3_NT) (&wcnt[0][0][0])[x] = 0;
-	__syncthreads();
-	for (int64_t e = t; e < n; e += T3_NT) atomicAdd(&start[rlow1[b0 + e]], 1);
-	__syncthreads();
-	if (w == 0) {                                   // exclusive scan of the F (<= 256) counts, 4 per lane
-		int32_t v[4], tot = 0;
-#pragma unroll
-		for (int u = 0; u < 4; u++) { v[u] = lane * 4 + u < F ? start[lane * 4 + u] : 0; tot += v[u]; }
-		int32_t incl = tot;
+	pa[t] = a;
+	// prefix of the run lengths over the threads
+	{
+		__shared__ int32_t wsum[T2_NT / 64];
+		const int32_t v = (int32_t) (b - a);
+		int32_t incl = v;
 #pragma unroll
 		for (int o = 1; o < 64; o <<= 1) {
 			const int32_t x = __shfl_up(incl, o, SVT_WAVE);
 			if (lane >= o) incl += x;
 		}
-		int32_t off = incl - tot;
+		if (lane == 63) wsum[w] = incl;
+		if (t < T2_NFINE) { L.binstart[t] = 0; L.run[t] = 0; L.rtot[t] = 0; }
+		__syncthreads();
+		int32_t off = 0;
+		for (int ww = 0; ww < w; ww++) off += wsum[ww];
+		ppre[t + 1] = incl + off;
+		if (t == 0) ppre[0] = 0;
+		__syncthreads();
+	}
+	const int32_t n = ppre[T2_NT];
+	const int64_t base = table[(i * sh.ngroups + g) * T2_NFINE];     // start of the workgroup's stretch
+	if (n <= T2_CAP) {
+		for (int32_t x = ppre[t]; x < ppre[t + 1]; x++) owner[x] = (uint8_t) t;
+		__syncthreads();
+	}
+	const int fmask = (1 << sh.fbits) - 1;
+	const bool staged = n <= T2_CAP;
+	if (!staged) {
+		// more than the image holds (rare): the histogram needs a pass of its own
+		for (int32_t x = t; x < n; x += T2_NT) {
+			const int j = split_piece_of(ppre, T2_NT, x);
+			const int q = (int) ((int64_t) row_idx[pa[j] + (x - ppre[j])] - r_lo);
+			atomicAdd(&L.binstart[q >> sh.fbits], 1);
+		}
+		__syncthreads();
+		split_scan_bins(L.binstart, T2_NFINE, [](int, int32_t) {});
+		__syncthreads();
+	}
+	for (int32_t x0 = 0; x0 < n; x0 += T2_CAP) {
+		bool valid[T2_ITEMS];
+		int key[T2_ITEMS], rl[T2_ITEMS], cj[T2_ITEMS];
+		int32_t rw[T2_ITEMS];
+		T vv[T2_ITEMS];
+		int32_t at[T2_ITEMS];
+		int64_t kk[T2_ITEMS];
 #pragma unroll
-		for (int u = 0; u < 4; u++) {
-			const int r = lane * 4 + u;
-			if (r < F) {
-				start[r] = off;
-				const int64_t row = (fb << sh.fbits) + r;
-				if (row < nrow) out_ptr[row] = b0 + off;
-			}
-			off += v[u];
+		for (int u = 0; u < T2_ITEMS; u++) {
+			const int32_t x = x0 + u * T2_NT + t;
+			valid[u] = x < n;
+			cj[u] = !valid[u] ? 0 : (n <= T2_CAP ? (int) owner[x] : split_piece_of(ppre, T2_NT, x));
+			kk[u] = valid[u] ? pa[cj[u]] + (x - ppre[cj[u]]) : 0;
+		}
+		// (all loads of the round in flight together: one memory latency per round, not one per element)
+#pragma unroll
+		for (int u = 0; u < T2_ITEMS; u++) rw[u] = valid[u] ? row_idx[kk[u]] : 0;
+#pragma unroll
+		for (int u = 0; u < T2_ITEMS; u++) vv[u] = valid[u] ? val[kk[u]] : (T) 0;
+#pragma unroll
+		for (int u = 0; u < T2_ITEMS; u++) {
+			const int q = valid[u] ? (int) ((int64_t) rw[u] - r_lo) : 0;
+			key[u] = q >> sh.fbits; rl[u] = q & fmask;
+		}
+		if (staged) {                                   // the only round: histogram from the registers
+#pragma unroll
+			for (int u = 0; u < T2_ITEMS; u++) if (valid[u]) atomicAdd(&L.binstart[key[u]], 1);
+			__syncthreads();
+			split_scan_bins(L.binstart, T2_NFINE, [](int, int32_t) {});
+			__syncthreads();
+		}
+		split_round<T2_NT, T2_ITEMS, T2_NFINE>(L, valid, key, 4, at);
+#pragma unroll
+		for (int u = 0; u < T2_ITEMS; u++) {
+			if (!valid[u]) continue;
+			const int32_t cc = (int32_t) (g * T2_NT + cj[u]);
+			if (staged) { s_col[at[u]] = cc; s_row[at[u]] = (uint8_t) rl[u]; s_val[at[u]] = vv[u]; }
+			else { col1[base + at[u]] = cc; rlow1[base + at[u]] = (uint8_t) rl[u]; val1[base + at[u]] = vv[u]; }
 		}
 	}
-	if (fb == sh.nfb - 1 && t == 0) out_ptr[nrow] = nnz;
+	if (!staged)
+		return;
 	__syncthreads();
-	const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-	int p = 0;
-	for (int64_t c0 = 0; c0 < n; c0 += T3_NT, p ^= 1) {
-		const int64_t e = c0 + t;
-		const bool valid = e < n;
-		const int r = valid ? (int) rlow1[b0 + e] : 0;
-		// lanes of this wavefront that hold the same row (and are valid): one ballot per row bit
-		uint64_t peers = __ballot(valid);
-		for (int bit = 0; bit < sh.fbits; bit++) {
-			const uint64_t m = __ballot((r >> bit) & 1);
-			peers &= ((r >> bit) & 1) ? m : ~m;
-		}
-		const int rank = __popcll(peers & lt);
-		if (valid && rank == 0) wcnt[p][w][r] = __popcll(peers);
-		__syncthreads();
-		if (valid) {
-			int32_t before = 0;
-			for (int ww = 0; ww < w; ww++) before += wcnt[p][ww][r];
-			const int64_t dst = b0 + start[r] + run[p][r] + before + rank;
-			out_idx[dst] = col1[b0 + e];
-			out_val[dst] = val1[b0 + e];
-		}
-		if (t < F) {
-			int32_t tot = 0;
-			for (int ww = 0; ww < T3_NT / 64; ww++) tot += wcnt[p][ww][t];
-			run[p ^ 1][t] = run[p][t] + tot;
-		}
-		// the other copy of wcnt (read in the previous round, before the barrier above) is clear again for the next
-		for (int x = t; x < (T3_NT / 64) * 256; x += T3_NT) (&wcnt[p ^ 1][0][0])[x] = 0;
-		__syncthreads();
+	for (int32_t e = t; e < n; e += T2_NT) {
+		col1[base + e] = s_col[e];
+		rlow1[base + e] = s_row[e];
+		val1[base + e] = s_val[e];
 	}
+}
+
+// pass 3
+#define T3_ITEMS (T3_CAP / T3_NT)
+template <typename T>
+__global__ void __launch_bounds__(T3_NT)
+transpose_finish_kernel(const int64_t *__restrict__ table, T2Shape sh, int64_t nrow, int64_t nnz,
+			const int32_t *__restrict__ col1, const uint8_t *__restrict__ rlow1,
+			const T *__restrict__ val1, const int64_t *__restrict__ fb_base,
+			int64_t *__restrict__ out_ptr, int32_t *__restrict__ out_idx, T *__restrict__ out_val)
+{
+	extern __shared__ unsigned char t3_lds[];
+	// [split tables][piece starts ngroups * 8][piece prefix (ngroups + 1) * 4][sorted columns CAP][sorted values CAP]
+	typedef SplitLds<T3_NT, T3_ITEMS, 64> Tables;
+	Tables &L = *(Tables *) t3_lds;
+	const int ng = (int) sh.ngroups;
+	int64_t *pa = (int64_t *) (t3_lds + ((sizeof(Tables) + 15) & ~(size_t) 15));
+	int32_t *ppre = (int32_t *) (pa + ng);
+	int32_t *s_idx = ppre + ((ng + 1 + 3) & ~3);
+	T *s_val = (T *) (s_idx + T3_STAGE);
+	const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+	const int F = 1 << sh.fbits;
+	const int64_t fb = blockIdx.x, ci = fb / T2_NFINE;
+	const int sf = (int) (fb % T2_NFINE);
+	// the pieces of this fine bucket, one per group: starts, sizes, then the prefix of the sizes
+	for (int g = t; g < ng; g += T3_NT) {
+		const int64_t slot = (ci * ng + g) * T2_NFINE + sf;
+		const int64_t p0 = table[slot];
+		pa[g] = p0;
+		ppre[g + 1] = (int32_t) (table[slot + 1] - p0);
+	}
+	for (int k = t; k < 64; k += T3_NT) { L.binstart[k] = 0; L.run[k] = 0; L.rtot[k] = 0; }
+	__syncthreads();
+	if (w == 0) {                                   // inclusive scan of the piece sizes by one wavefront
+		int32_t carry = 0;
+		for (int g0 = 0; g0 < ng; g0 += 64) {
+			const int g = g0 + lane;
+			const int32_t v = g < ng ? ppre[g + 1] : 0;
+			int32_t incl = v;
+#pragma unroll
+			for (int o = 1; o < 64; o <<= 1) {
+				const int32_t u = __shfl_up(incl, o, SVT_WAVE);
+				if (lane >= o) incl += u;
+			}
+			if (g < ng) ppre[g + 1] = carry + incl;
+			carry += __shfl(incl, 63, SVT_WAVE);
+		}
+		if (lane == 0) ppre[0] = 0;
+	}
+	__syncthreads();
+	const int32_t n = ppre[ng];
+	const int64_t b0 = fb_base[fb];                 // first output position of the bucket's rows
+	const bool staged = n <= T3_CAP;
+	auto bins_done = [&]() {
+		__syncthreads();
+		split_scan_bins(L.binstart, F, [&](int r, int32_t off) {
+			const int64_t row = (fb << sh.fbits) + r;
+			if (row < nrow) out_ptr[row] = b0 + off;
+		});
+		if (fb == sh.nfb - 1 && t == 0) out_ptr[nrow] = nnz;
+		__syncthreads();
+	};
+	if (!staged || n == 0) {
+		// more than the image holds (rare): the histogram needs a pass of its own
+		for (int32_t x = t; x < n; x += T3_NT) {
+			const int j = split_piece_of(ppre, ng, x);
+			atomicAdd(&L.binstart[rlow1[pa[j] + (x - ppre[j])]], 1);
+		}
+		bins_done();
+	}
+	for (int32_t x0 = 0; x0 < n; x0 += T3_CAP) {
+		bool valid[T3_ITEMS];
+		int key[T3_ITEMS];
+		int32_t cc[T3_ITEMS], at[T3_ITEMS];
+		T vv[T3_ITEMS];
+		int64_t kk[T3_ITEMS];
+#pragma unroll
+		for (int u = 0; u < T3_ITEMS; u++) {
+			const int32_t x = x0 + u * T3_NT + t;
+			valid[u] = x < n;
+			const int j = valid[u] ? split_piece_of(ppre, ng, x) : 0;
+			kk[u] = valid[u] ? pa[j] + (x - ppre[j]) : 0;
+		}
+		// (all loads of the round in flight together)
+#pragma unroll
+		for (int u = 0; u < T3_ITEMS; u++) key[u] = valid[u] ? (int) rlow1[kk[u]] : 0;
+#pragma unroll
+		for (int u = 0; u < T3_ITEMS; u++) cc[u] = valid[u] ? col1[kk[u]] : 0;
+#pragma unroll
+		for (int u = 0; u < T3_ITEMS; u++) vv[u] = valid[u] ? val1[kk[u]] : (T) 0;
+		if (staged) {                                   // the only round: histogram from the registers
+#pragma unroll
+			for (int u = 0; u < T3_ITEMS; u++) if (valid[u]) atomicAdd(&L.binstart[key[u]], 1);
+			bins_done();
+		}
+		split_round<T3_NT, T3_ITEMS, 64>(L, valid, key, sh.fbits, at);
+		if (!staged) {
+#pragma unroll
+			for (int u = 0; u < T3_ITEMS; u++)
+				if (valid[u]) { out_idx[b0 + at[u]] = cc[u]; out_val[b0 + at[u]] = vv[u]; }
+			continue;
+		}
+		// the LDS image holds a quarter of the output at a time (the elements stay in registers): 24 KB
+		// instead of 96, three workgroups per CU instead of one
+		for (int32_t q0 = 0; q0 < n; q0 += T3_STAGE) {
+			const int32_t q1 = q0 + T3_STAGE < n ? q0 + T3_STAGE : n;
+			__syncthreads();
+#pragma unroll
+			for (int u = 0; u < T3_ITEMS; u++)
+				if (valid[u] && at[u] >= q0 && at[u] < q1) { s_idx[at[u] - q0] = cc[u]; s_val[at[u] - q0] = vv[u]; }
+			__syncthreads();
+			for (int32_t e = q0 + t; e < q1; e += T3_NT) { out_idx[b0 + e] = s_idx[e - q0]; out_val[b0 + e] = s_val[e - q0]; }
+		}
+	}
+}
+
+// fb_base[fb] = nonzeros in the fine buckets before fb (= first output position of its rows): the sum of
+// the table over (group, fine = fb) ... computed from the scanned table: the pieces of one COARSE bucket are
+// contiguous, so base(coarse i) = T[(i * ngroups) * 16]; inside it the fine buckets are interleaved by group.
+__global__ void transpose_fb_base_kernel(const int64_t *__restrict__ table, T2Shape sh, int64_t nnz,
+					 int64_t *__restrict__ fb_base)
+{
+	// one wavefront per coarse bucket: sizes of its 16 fine buckets summed over the groups, then a prefix
+	const int lane = threadIdx.x & 63;
+	const int64_t ci = (int64_t) blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	if (ci >= sh.ncoarse) return;
+	const int64_t ng = sh.ngroups;
+	int64_t acc[T2_NFINE];
+#pragma unroll
+	for (int s = 0; s < T2_NFINE; s++) acc[s] = 0;
+	const int64_t tot = ng * T2_NFINE;                // slots of this coarse bucket
+	const int64_t s0 = ci * tot;
+	for (int64_t x = lane; x < tot; x += 64) {
+		const int64_t sz = table[s0 + x + 1] - table[s0 + x];
+		const int s = (int) (x % T2_NFINE);
+#pragma unroll
+		for (int q = 0; q < T2_NFINE; q++) if (q == s) acc[q] += sz;
+	}
+	int64_t run = table[s0];
+#pragma unroll
+	for (int s = 0; s < T2_NFINE; s++) {
+		int64_t v = acc[s];
+		for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, SVT_WAVE);
+		const int64_t fb = ci * T2_NFINE + s;
+		if (lane == 0 && fb < sh.nfb) fb_base[fb] = run;
+		run += v;
+	}
+	if (ci == sh.ncoarse - 1 && lane == 0) fb_base[sh.nfb] = nnz;
 }
 
 // the bucketed form applies to this operand: fills *sh
@@ -283,20 +586,23 @@ static bool t2_shape(int64_t nrow, int64_t ncol, int64_t nnz, T2Shape *sh)
 	if (nrow <= 0 || ncol <= 0 || nnz <= 0)
 		return false;
 	const double per_row = (double) nnz / (double) nrow, per_col = (double) nnz / (double) ncol;
-	int fbits = -1;
-	for (int fb = 8; fb >= 6; fb--)                 // the largest bucket of <= 32768 nonzeros
-		if (ldexp(per_row, fb) <= 32768.0) { fbits = fb; break; }
-	if (fbits < 0)
-		return false;
-	const double coarse_rows = ldexp((double) T2_NFINE, fbits);
-	if (per_col * coarse_rows / (double) nrow < 1.0)        // less than one nonzero per thread of passes 1-2
+	// the largest F <= 64 with ~3000 nonzeros per fine bucket (pass 3 ranks 4096 per round) and ~1500 per
+	// pass-2 workgroup (it assembles 2048 in LDS)
+	int fbits = 6;
+	while (fbits > 0 && (ldexp(per_row, fbits) > 3072.0 ||
+			     (double) T2_NT * per_col * ldexp((double) T2_NFINE, fbits) / (double) nrow > 1536.0))
+		fbits--;
+	if (per_col * ldexp((double) T2_NFINE, fbits) / (double) nrow < 1.0)      // less than one nonzero per thread of pass 2
 		return false;
 	sh->fbits = fbits;
 	sh->nfb = (nrow + ((int64_t) 1 << fbits) - 1) >> fbits;
 	sh->ncoarse = (sh->nfb + T2_NFINE - 1) / T2_NFINE;
 	sh->ngroups = (ncol + T2_NT - 1) / T2_NT;
-	const double ntab = (double) sh->nfb * (double) sh->ngroups, nwg = (double) sh->ncoarse * (double) sh->ngroups;
-	return ntab < 1.0e8 && nwg < 2.0e9;
+	const double ntab = (double) sh->ncoarse * (double) sh->ngroups * T2_NFINE;
+	const double nwg = (double) sh->ncoarse * (double) sh->ngroups;
+	if ((double) (sh->ncoarse + 1) * (double) ncol > 2.0 * (double) nnz + 32.0)     // (the table of coarse-bucket starts)
+		return false;
+	return ntab < 1.0e8 && nwg < 2.0e9 && sh->ngroups <= 6000;      // (pass 3 keeps one int per group in LDS)
 }
 
 static size_t t2_a(size_t n, size_t esz) { return (n * esz + 255) / 256 * 256; }
@@ -442,16 +748,16 @@ static int launch_transpose_sorted(const int64_t *col_ptr, const int32_t *row_id
 
 // workspace of the bucketed form: [reserve: table (nfb * ngroups + 1) * 8, scan scratch][columns nnz*4][rows in
 // bucket nnz][values nnz*8]
-// Head of the workspace kept for the bucket table and its scan scratch.  The caller sizes the workspace
-// from (nrow, nnz) alone; the shapes the bucketed form accepts have at most ~nnz / 8 + nrow / 64 table
-// entries (at least one nonzero per column and coarse bucket), and never more than 64 MiB are set aside:
-// a larger table sends the operand through the key sort.
+// Head of the workspace kept for the bucket table, the fine buckets' output positions and the scan scratch.
+// The caller sizes the workspace from (nrow, nnz) alone; the shapes the bucketed form accepts (at least one
+// nonzero per column and coarse bucket) have at most ~nnz / 8 + 512 * nnz / nrow table entries and at most
+// nrow fine buckets, and never more than 96 MiB are set aside: an operand that needs more takes the key sort.
 static size_t t2_reserve(int64_t nrow, int64_t nnz)
 {
 	const double per_row = nrow > 0 ? (double) nnz / (double) nrow : 0.0;
-	const double ntab = (double) nnz / 8.0 + (double) nrow / 64.0 + 8.0 * per_row + 16.0;
-	const double b = 2.0 * 8.0 * ntab + 8192.0;
-	const size_t cap = (size_t) 64 << 20;
+	const double ntab = (double) nnz / 8.0 + 512.0 * per_row + (double) nrow + 4096.0;
+	const double b = 8.25 * ntab + 65536.0;
+	const size_t cap = (size_t) 96 << 20;
 	return b >= (double) cap ? cap : ((size_t) b + 255) / 256 * 256;
 }
 
@@ -459,8 +765,46 @@ size_t transpose_ws_bytes(int64_t nrow, int64_t nnz)
 {
 	const size_t n = (size_t) (nnz > 0 ? nnz : 1);
 	const size_t sorted = transpose_sorted_ws_bytes(nrow, nnz);
-	const size_t b2 = t2_reserve(nrow, nnz) + t2_a(n, 4) + t2_a(n, 1) + t2_a(n, 8) + 512;
+	// (+ the coarse-bucket starts per column: (ncoarse + 1) * ncol <= 2 * nnz entries for the shapes accepted)
+	const size_t b2 = t2_reserve(nrow, nnz) + t2_a(n, 4) + t2_a(n, 1) + t2_a(n, 8) + t2_a(2 * n + 64, 4) + 512;
 	return sorted > b2 ? sorted : b2;
+}
+
+template <typename T>
+static int launch_transpose_bucketed(const int64_t *col_ptr, const int32_t *row_idx, const T *val,
+				     int64_t nrow, int64_t ncol, int64_t nnz, const T2Shape &sh, int64_t *out_ptr,
+				     int32_t *out_idx, T *out_val, void *ws, size_t reserve, hipStream_t s)
+{
+	const int64_t ntab = sh.ncoarse * sh.ngroups * T2_NFINE + 1;
+	char *p = (char *) ws;
+	int64_t *table = (int64_t *) p;            p += t2_a((size_t) ntab, 8);
+	int64_t *fb_base = (int64_t *) p;          p += t2_a((size_t) (sh.nfb + 1), 8);
+	void *scan_ws = p;
+	p = (char *) ws + reserve;
+	int32_t *col1 = (int32_t *) p;             p += t2_a((size_t) nnz, 4);
+	uint8_t *rlow1 = (uint8_t *) p;            p += t2_a((size_t) nnz, 1);
+	T *val1 = (T *) p;                         p += t2_a((size_t) nnz, 8);
+	uint32_t *cstart = (uint32_t *) p;         // [(ncoarse + 1) * ncol]
+	HIP_TRY(hipMemsetAsync(table, 0, (size_t) ntab * 8, s));
+	const size_t hist_b = (size_t) (sh.nfb < T1_HIST ? sh.nfb : T1_HIST) * 4;
+	(void) hipFuncSetAttribute((const void *) transpose_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+				   T1_HIST * 4);
+	hipLaunchKernelGGL(transpose_count_kernel, dim3((unsigned) ((ncol + T1_NT / 64 - 1) / (T1_NT / 64))), dim3(T1_NT),
+			   hist_b, s, col_ptr, row_idx, ncol, sh, (unsigned long long *) table, cstart);
+	if (launch_exclusive_scan_i64(table, ntab, scan_ws, s))
+		return -1;
+	hipLaunchKernelGGL(transpose_fb_base_kernel, dim3((unsigned) ((sh.ncoarse + 3) / 4)), dim3(256), 0, s,
+			   table, sh, nnz, fb_base);
+	hipLaunchKernelGGL(transpose_scatter_kernel<T>, dim3((unsigned) (sh.ngroups * sh.ncoarse)), dim3(T2_NT), 0, s,
+			   col_ptr, row_idx, val, nrow, ncol, sh, table, cstart, col1, rlow1, val1);
+	const size_t lds = ((sizeof(SplitLds<T3_NT, T3_ITEMS, 64>) + 15) & ~(size_t) 15) + (size_t) sh.ngroups * 8 +
+			   (size_t) ((sh.ngroups + 1 + 3) & ~(int64_t) 3) * 4 + (size_t) T3_STAGE * 4 + (size_t) T3_STAGE * sizeof(T);
+	(void) hipFuncSetAttribute((const void *) transpose_finish_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+				   (int) lds);
+	hipLaunchKernelGGL(transpose_finish_kernel<T>, dim3((unsigned) sh.nfb), dim3(T3_NT), lds, s, table, sh, nrow, nnz,
+			   col1, rlow1, val1, fb_base, out_ptr, out_idx, out_val);
+	HIP_TRY(hipGetLastError());
+	return 0;
 }
 
 int launch_transpose(const int64_t *col_ptr, const int32_t *row_idx, const void *val, int Rtype,
@@ -475,42 +819,18 @@ int launch_transpose(const int64_t *col_ptr, const int32_t *row_idx, const void 
 	}
 	T2Shape sh;
 	const size_t reserve = t2_reserve(nrow, nnz);
-	if (!t2_shape(nrow, ncol, nnz, &sh) ||
-	    t2_a((size_t) (sh.nfb * sh.ngroups + 1), 8) + exclusive_scan_ws_bytes(sh.nfb * sh.ngroups + 1) > reserve)
+	bool bucketed = t2_shape(nrow, ncol, nnz, &sh);
+	if (bucketed) {
+		const int64_t ntab = sh.ncoarse * sh.ngroups * T2_NFINE + 1;
+		bucketed = t2_a((size_t) ntab, 8) + t2_a((size_t) (sh.nfb + 1), 8) + exclusive_scan_ws_bytes(ntab) <= reserve;
+	}
+	if (!bucketed)
 		return launch_transpose_sorted(col_ptr, row_idx, val, Rtype, nrow, ncol, nnz, out_ptr, out_idx, out_val, ws, s);
-	const int64_t ntab = sh.nfb * sh.ngroups + 1;
-	char *p = (char *) ws;
-	int64_t *table = (int64_t *) p;            p += t2_a((size_t) ntab, 8);
-	void *scan_ws = p;                         p += exclusive_scan_ws_bytes(ntab);
-	p = (char *) ws + reserve;
-	int32_t *col1 = (int32_t *) p;             p += t2_a((size_t) nnz, 4);
-	uint8_t *rlow1 = (uint8_t *) p;            p += t2_a((size_t) nnz, 1);
-	void *val1 = p;
-	const unsigned nwg = (unsigned) (sh.ngroups * sh.ncoarse);
-	// (fine buckets past the last row of the last coarse bucket are never counted: clear the table)
-	HIP_TRY(hipMemsetAsync(table, 0, (size_t) ntab * 8, s));
-	if (Rtype == SVT_REALSXP) {
-		hipLaunchKernelGGL((transpose_bucket_kernel<double, false>), dim3(nwg), dim3(T2_NT), 0, s, col_ptr, row_idx,
-				   (const double *) val, nrow, ncol, sh, table, col1, rlow1, (double *) val1);
-	} else {
-		hipLaunchKernelGGL((transpose_bucket_kernel<int32_t, false>), dim3(nwg), dim3(T2_NT), 0, s, col_ptr, row_idx,
-				   (const int32_t *) val, nrow, ncol, sh, table, col1, rlow1, (int32_t *) val1);
-	}
-	if (launch_exclusive_scan_i64(table, ntab, scan_ws, s))
-		return -1;
-	if (Rtype == SVT_REALSXP) {
-		hipLaunchKernelGGL((transpose_bucket_kernel<double, true>), dim3(nwg), dim3(T2_NT), 0, s, col_ptr, row_idx,
-				   (const double *) val, nrow, ncol, sh, table, col1, rlow1, (double *) val1);
-		hipLaunchKernelGGL(transpose_finish_kernel<double>, dim3((unsigned) sh.nfb), dim3(T3_NT), 0, s, table, sh, nrow,
-				   nnz, col1, rlow1, (const double *) val1, out_ptr, out_idx, (double *) out_val);
-	} else {
-		hipLaunchKernelGGL((transpose_bucket_kernel<int32_t, true>), dim3(nwg), dim3(T2_NT), 0, s, col_ptr, row_idx,
-				   (const int32_t *) val, nrow, ncol, sh, table, col1, rlow1, (int32_t *) val1);
-		hipLaunchKernelGGL(transpose_finish_kernel<int32_t>, dim3((unsigned) sh.nfb), dim3(T3_NT), 0, s, table, sh, nrow,
-				   nnz, col1, rlow1, (const int32_t *) val1, out_ptr, out_idx, (int32_t *) out_val);
-	}
-	HIP_TRY(hipGetLastError());
-	return 0;
+	if (Rtype == SVT_REALSXP)
+		return launch_transpose_bucketed<double>(col_ptr, row_idx, (const double *) val, nrow, ncol, nnz, sh, out_ptr,
+							 out_idx, (double *) out_val, ws, reserve, s);
+	return launch_transpose_bucketed<int32_t>(col_ptr, row_idx, (const int32_t *) val, nrow, ncol, nnz, sh, out_ptr,
+						  out_idx, (int32_t *) out_val, ws, reserve, s);
 }
 
 // ---------------------------------------------------------------------------
