@@ -14,6 +14,11 @@ colSums/colVars/... (col stats)        leaves (columns) by nnz     all-gather of
 colSums on a ROW-sharded operand       rows                        all-reduce of ncol scalars
 rowsum(A, group)                       leaves (columns) by nnz     all-gather of ngroup x ncol/N
 A %*% Y (tall result)                  rows of A = rows of result  none (each rank owns rows)
+crossprod(A) / crossprod(A, B) sparse  leaves of A (block of result all-gather of the other sparse
+                                       rows per rank)              operand, once (ragged CSC)
+colsum(A, group)                       leaves (columns) by nnz     all-reduce of nrow x ngroup
+rowSums(A), 2-D                        rows (result owned)         all-gather of nrow / N sums
+                                       or leaves                   or all-reduce of nrow sums
 =====================================  ==========================  ===========================
 
 Everything here works on device-resident operands (`DeviceCSC`) and calls the HIP library for
@@ -291,3 +296,64 @@ def sharded_matmul(A_rows_t_plan, Y2: torch.Tensor, out_local: torch.Tensor):
     no collective."""
     A_rows_t_plan.run(Y2, Y2.shape[1], out_local)
     return out_local
+
+
+# --------------------------------------------------------------------------------------------
+# the rows of SURVEY.md section 8e that move a sparse operand or reduce a dense one
+# --------------------------------------------------------------------------------------------
+def allgather_csc(col_ptr, row_idx, val, blocks, group=None):
+    """Leaf blocks (one per rank, `blocks[r]` = its leaf range) -> the whole operand on every rank:
+    ragged all-gather of the leaf lengths, the offsets and the values; col_ptr rebuilt by a prefix sum.
+    This is the one transfer of unary crossprod(A) / crossprod(A, B): every rank needs all leaves of the
+    other operand (6 GB once at BASELINE config 4; src/SparseMatrix_mult.c:827-908, 1037-1101 walk them
+    in place)."""
+    lens = (col_ptr[1:] - col_ptr[:-1]).contiguous()
+    ncols = [b[1] - b[0] for b in blocks]
+    all_lens = gather_columns(lens, ncols, group)
+    nnzs = []
+    off = 0
+    for n in ncols:
+        nnzs.append(int(all_lens[off:off + n].sum()))
+        off += n
+    all_idx = gather_columns(row_idx.contiguous(), nnzs, group)
+    all_val = gather_columns(val.contiguous(), nnzs, group)
+    full_ptr = torch.zeros(all_lens.numel() + 1, dtype=torch.int64, device=all_lens.device)
+    full_ptr[1:] = torch.cumsum(all_lens, 0)
+    return full_ptr, all_idx, all_val
+
+
+def sharded_crossprod_sparse(local_product: Callable, B_block, blocks_B, group=None, gather_result=True,
+                             blocks_A=None):
+    """crossprod(A, B), both sparse (B = A for the unary form): rank r holds leaf block r of A and of B.
+    `B_block` = (col_ptr, row_idx, val) of the rank's block of B; `local_product(B_full)` returns the rank's
+    block of result rows, (ncol_A_local, ncol_B), from its block of A and the gathered B.  With
+    `gather_result` the row blocks are all-gathered into the ncol_A x ncol_B matrix (`blocks_A` = leaf
+    ranges of A per rank)."""
+    B_full = allgather_csc(*B_block, blocks_B, group)
+    part = local_product(B_full)
+    if not gather_result or _world(group) == 1:
+        return part
+    return gather_columns(part.contiguous(), [b[1] - b[0] for b in (blocks_A or blocks_B)], group)
+
+
+def sharded_colsum(local_colsum: Callable, group=None) -> torch.Tensor:
+    """colsum(A, group) with the leaves sharded: a group of columns spans ranks, so every rank adds the
+    leaves it holds into its own nrow x ngroup partial (src/rowsum_methods.c:204-255) and the partials
+    are all-reduced.  (Integer input: int64 partials, NA / overflow flags reduced with MAX by the caller.)"""
+    part = local_colsum()
+    if _world(group) > 1:
+        dist.all_reduce(part, op=dist.ReduceOp.SUM, group=group)
+    return part
+
+
+def sharded_rowsums_2d(local_rowsums: Callable, blocks=None, group=None) -> torch.Tensor:
+    """rowSums(A) of a 2-D operand.  `blocks` = row ranges per rank: the operand is sharded on rows, every
+    rank owns its nrow / N sums and they are all-gathered (no reduction).  `blocks` = None: sharded on
+    leaves, the nrow partial sums are all-reduced (8 MB at BASELINE config 2)."""
+    part = local_rowsums()
+    if _world(group) == 1:
+        return part
+    if blocks is not None:
+        return gather_columns(part.contiguous(), [b[1] - b[0] for b in blocks], group)
+    dist.all_reduce(part, op=dist.ReduceOp.SUM, group=group)
+    return part

@@ -66,7 +66,40 @@ def _worker(rank, world, port, q):
         lo, hi = blk[rank]
         mine = full3.view(3, 7, 5)[:, lo:hi, :].reshape(-1)
         ok5 = ok5 and bool(torch.equal(par.gather_axis(mine, (5, 7, 3), 1, blk), full3))
-        q.put((rank, ok1, ok2, ok3, ok4, ok5))
+        # unary crossprod(A) and crossprod(A, B), both sparse: leaf blocks, all-gather of the other operand
+        bcp, bri, bv = par.col_shard_csc(torch.from_numpy(cp), torch.from_numpy(ri), torch.from_numpy(v), c0, c1)
+
+        def prod_with(full_csc):
+            fcp, fri, fv = (a.numpy() for a in full_csc)
+            other = SVT_SparseArray.from_csc((nrow, len(fcp) - 1), "double", fcp, fri, fv)
+            return torch.from_numpy(np.ascontiguousarray(S.crossprod(sub, other)))
+        got1 = par.sharded_crossprod_sparse(prod_with, (bcp.contiguous(), bri, bv), blocks)
+        ok6 = np.allclose(got1.numpy(), S.crossprod(full), rtol=1e-12, atol=1e-12)
+        cpB, riB, vB = random_csc(nrow, 11, 0.05, seed=8)
+        fullB = SVT_SparseArray.from_csc((nrow, 11), "double", cpB, riB, vB)
+        blocksB = par.col_blocks_by_nnz(cpB, world)
+        b0, b1 = blocksB[rank]
+        Bblk = par.col_shard_csc(torch.from_numpy(cpB), torch.from_numpy(riB), torch.from_numpy(vB), b0, b1)
+        got2 = par.sharded_crossprod_sparse(prod_with, (Bblk[0].contiguous(), Bblk[1], Bblk[2]), blocksB,
+                                            blocks_A=blocks)
+        ok6 = ok6 and np.allclose(got2.numpy(), S.crossprod(full, fullB), rtol=1e-12, atol=1e-12)
+        # colsum: leaves sharded, partials all-reduced (groups of columns span the ranks)
+        cgrp = list(np.random.default_rng(9).integers(1, 5, ncol))
+        ug = sorted(set(cgrp))
+        loc_cs = np.zeros((nrow, len(ug)))
+        sub_cs, sub_ug = S.colsum(sub, cgrp[c0:c1])
+        for k, gname in enumerate(sub_ug):
+            loc_cs[:, ug.index(gname)] = np.asarray(sub_cs)[:, k]
+        got_cs = par.sharded_colsum(lambda: torch.from_numpy(loc_cs))
+        ok7 = np.allclose(got_cs.numpy(), np.asarray(S.colsum(full, cgrp)[0]), rtol=1e-12, atol=1e-12)
+        # 2-D rowSums: owned rows (all-gather) and sharded leaves (all-reduce)
+        rblocks = [par.row_block(nrow, r, world) for r in range(world)]
+        got_rs = par.sharded_rowsums_2d(lambda: torch.from_numpy(np.asarray(S.rowSums(shard), dtype=np.float64).copy()),
+                                        blocks=rblocks)
+        got_rs2 = par.sharded_rowsums_2d(lambda: torch.from_numpy(np.asarray(S.rowSums(sub), dtype=np.float64).copy()))
+        want_rs = np.asarray(S.rowSums(full))
+        ok7 = ok7 and np.array_equal(got_rs.numpy(), want_rs) and np.allclose(got_rs2.numpy(), want_rs, rtol=1e-12, atol=1e-12)
+        q.put((rank, ok1, ok2, ok3, ok4, ok5, ok6, ok7))
     finally:
         dist.destroy_process_group()
 
@@ -83,7 +116,9 @@ def test_row_sharded_crossprod_and_column_sharded_colsums_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, ok1, ok2, ok3, ok4, ok5 in res:
+    for rank, ok1, ok2, ok3, ok4, ok5, ok6, ok7 in res:
+        assert ok6, f"rank {rank}: sharded sparse x sparse / unary crossprod differs"
+        assert ok7, f"rank {rank}: sharded colsum / 2-D rowSums differ"
         assert ok1, f"rank {rank}: sharded crossprod differs"
         assert ok2, f"rank {rank}: sharded colSums differs"
         assert ok3, f"rank {rank}: torch/numpy row filter differ"
