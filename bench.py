@@ -353,6 +353,23 @@ def main():
             return best
         ex["once_per_operand"] = {"layout_build_ms": wall(lambda: PbcPlan(A, K, a.cbw, a.wpb, a.logr)),
                                   "transpose_ms": wall(lambda: A.t())}
+        # what a FIRST product on a resident CSC operand costs (everything the step excludes): crossprod =
+        # layout build + product; A %*% Y = t(A) + layout of t(A) + product
+        def first_crossprod():
+            pl = PbcPlan(A, K, a.cbw, a.wpb, a.logr)
+            o_ = torch.empty((K, ncol), dtype=torch.float64, device=dev)
+            pl.run(Y, lrow, o_)
+            return o_
+
+        def first_matmul():
+            T_ = A.t()
+            pl = PbcPlan(T_, K, a.cbw, a.wpb, a.logr)
+            o_ = torch.empty((K, lrow), dtype=torch.float64, device=dev)
+            pl.run(Y2f, ncol, o_)
+            return o_
+        Y2f = synth.random_dense(ncol, K, seed=202, device=dev)
+        ex["first_call_from_resident_csc"] = {"crossprod_ms": wall(first_crossprod), "matmul_A_Y_ms": wall(first_matmul)}
+        del Y2f
         # config 2b: A %*% Y2 (Y2 = ncol x K) = crossprod(t(A), Y2), t(A) and its layout built on device
         T = A.t()
         plan_t = PbcPlan(T, K, a.cbw, a.wpb, a.logr)

@@ -128,7 +128,8 @@ int launch_exclusive_scan_i64(int64_t *data, int64_t n, void *ws, hipStream_t s)
 #define T2_NFINE 16               // fine buckets per coarse bucket
 #define T2_CAP 2048               // nonzeros a pass-2 workgroup assembles in LDS (more: straight to memory)
 #define T1_NT 1024
-#define T1_HIST 32768             // fine buckets counted per sweep of pass 1 (LDS)
+#define T1_HIST 65536             // fine buckets counted per sweep of pass 1 (LDS: two 16-bit counters per word --
+                                  // a workgroup's 16 columns hold at most 16 * 64 nonzeros of one fine bucket)
 #define T3_NT 512
 #define T3_CAP 4096               // nonzeros a pass-3 workgroup ranks in one round (more: round by round, straight to memory)
 #define T3_STAGE 2048             // of which the LDS image of the output holds this many at a time
@@ -153,7 +154,7 @@ transpose_count_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__res
 		       int64_t ncol, T2Shape sh, unsigned long long *__restrict__ table,
 		       uint32_t *__restrict__ cstart)
 {
-	extern __shared__ uint32_t hist[];              // [T1_HIST]
+	extern __shared__ uint32_t hist[];              // [T1_HIST / 2]
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	const int64_t c = (int64_t) blockIdx.x * (T1_NT / 64) + w;
 	const int64_t g = ((int64_t) blockIdx.x * (T1_NT / 64)) / T2_NT;          // (16 divides 128: one group per workgroup)
@@ -162,7 +163,7 @@ transpose_count_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__res
 	if (c < ncol) { beg = col_ptr[c]; end = col_ptr[c + 1]; }
 	for (int64_t w0 = 0; w0 < sh.nfb; w0 += T1_HIST) {          // (one sweep unless there are > 32768 fine buckets)
 		const int64_t w1 = w0 + T1_HIST < sh.nfb ? w0 + T1_HIST : sh.nfb;
-		for (int x = threadIdx.x; x < (int) (w1 - w0); x += T1_NT) hist[x] = 0;
+		for (int x = threadIdx.x; x < (int) ((w1 - w0 + 1) >> 1); x += T1_NT) hist[x] = 0;
 		__syncthreads();
 		for (int64_t kb = beg; kb < end; kb += 256) {           // four batches of 64 in flight
 			int32_t r4[4];
@@ -176,7 +177,7 @@ transpose_count_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__res
 				const int32_t r = r4[u];
 				if (k < end) {
 					const int64_t fb = (int64_t) r >> sh.fbits;
-					if (fb >= w0 && fb < w1) atomicAdd(&hist[fb - w0], 1u);
+					if (fb >= w0 && fb < w1) atomicAdd(&hist[(fb - w0) >> 1], 1u << (16 * (int) ((fb - w0) & 1)));
 				}
 				if (w0 == 0 && c < ncol) {
 					// coarse buckets that start at position k: those after the previous entry's, up to this one's
@@ -197,8 +198,10 @@ transpose_count_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__res
 			}
 		}
 		__syncthreads();
-		for (int x = threadIdx.x; x < (int) (w1 - w0); x += T1_NT)
-			if (hist[x]) atomicAdd(table + t2_slot(sh, w0 + x, g), (unsigned long long) hist[x]);
+		for (int x = threadIdx.x; x < (int) (w1 - w0); x += T1_NT) {
+			const uint32_t n = (hist[x >> 1] >> (16 * (x & 1))) & 0xFFFFu;
+			if (n) atomicAdd(table + t2_slot(sh, w0 + x, g), (unsigned long long) n);
+		}
 		__syncthreads();
 	}
 }
@@ -786,9 +789,9 @@ static int launch_transpose_bucketed(const int64_t *col_ptr, const int32_t *row_
 	T *val1 = (T *) p;                         p += t2_a((size_t) nnz, 8);
 	uint32_t *cstart = (uint32_t *) p;         // [(ncoarse + 1) * ncol]
 	HIP_TRY(hipMemsetAsync(table, 0, (size_t) ntab * 8, s));
-	const size_t hist_b = (size_t) (sh.nfb < T1_HIST ? sh.nfb : T1_HIST) * 4;
+	const size_t hist_b = (size_t) ((sh.nfb < T1_HIST ? sh.nfb : T1_HIST) + 1) / 2 * 4;
 	(void) hipFuncSetAttribute((const void *) transpose_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-				   T1_HIST * 4);
+				   T1_HIST * 2);
 	hipLaunchKernelGGL(transpose_count_kernel, dim3((unsigned) ((ncol + T1_NT / 64 - 1) / (T1_NT / 64))), dim3(T1_NT),
 			   hist_b, s, col_ptr, row_idx, ncol, sh, (unsigned long long *) table, cstart);
 	if (launch_exclusive_scan_i64(table, ntab, scan_ws, s))
