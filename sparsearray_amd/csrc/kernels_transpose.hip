@@ -127,6 +127,7 @@ int launch_exclusive_scan_i64(int64_t *data, int64_t n, void *ws, hipStream_t s)
 #define T2_NT 256                 // columns per group = threads per workgroup of pass 2
 #define T2_NFINE 16               // fine buckets per coarse bucket
 #define T2_CAP 2048               // nonzeros a pass-2 workgroup assembles in LDS (more: straight to memory)
+#define T2_CPW 8                  // coarse buckets a pass-2 workgroup takes, one after the other
 #define T1_NT 1024
 #define T1_HIST 65536             // fine buckets counted per sweep of pass 1 (LDS: two 16-bit counters per word --
                                   // a workgroup's 16 columns hold at most 16 * 64 nonzeros of one fine bucket)
@@ -147,8 +148,9 @@ __device__ inline int64_t t2_slot(const T2Shape &sh, int64_t fb, int64_t g)
 }
 
 // pass 1: workgroup = 16 columns (16 divides the group size), one per wavefront (coalesced along the column); counts by fine bucket in
-// LDS, and cstart[i * ncol + c] = first position of column c whose row lies in coarse bucket i or later
-// (i = 0 .. ncoarse), which is where pass 2 finds its runs without a search.
+// LDS, and cstart[c * (ncoarse + 1) + i] = first position of column c whose row lies in coarse bucket i or
+// later (i = 0 .. ncoarse), which is where pass 2 finds its runs without a search (a wavefront writes the
+// starts of its column next to one another; a pass-2 workgroup reads nine consecutive ones per column).
 __global__ void __launch_bounds__(T1_NT)
 transpose_count_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__ row_idx,
 		       int64_t ncol, T2Shape sh, unsigned long long *__restrict__ table,
@@ -186,7 +188,7 @@ transpose_count_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__res
 					if (lane == 0) rp = u == 0 ? r_before : last_prev;
 					const int64_t ip = rp < 0 ? -1 : ((int64_t) rp >> cshift);
 					const int64_t ic = k < end ? ((int64_t) r >> cshift) : (k == end ? sh.ncoarse : ip);
-					for (int64_t i = ip + 1; i <= ic; i++) cstart[i * ncol + c] = (uint32_t) k;
+					for (int64_t i = ip + 1; i <= ic; i++) cstart[c * (sh.ncoarse + 1) + i] = (uint32_t) k;
 				}
 			}
 		}
@@ -194,7 +196,7 @@ transpose_count_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__res
 			// (a column whose length is a multiple of 64 -- or zero -- has not closed its last buckets)
 			if (((end - beg) & 63) == 0) {
 				const int64_t ip = end > beg ? ((int64_t) row_idx[end - 1] >> cshift) : -1;
-				for (int64_t i = ip + 1; i <= sh.ncoarse; i++) cstart[i * ncol + c] = (uint32_t) end;
+				for (int64_t i = ip + 1; i <= sh.ncoarse; i++) cstart[c * (sh.ncoarse + 1) + i] = (uint32_t) end;
 			}
 		}
 		__syncthreads();
@@ -336,15 +338,23 @@ transpose_scatter_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__r
 	__shared__ T s_val[T2_CAP];
 	__shared__ uint8_t s_row[T2_CAP];
 	const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-	const int64_t g = (int64_t) blockIdx.x % sh.ngroups, i = (int64_t) blockIdx.x / sh.ngroups;
-	const int64_t r_lo = (i * T2_NFINE) << sh.fbits;
-	int64_t r_hi = ((i + 1) * T2_NFINE) << sh.fbits;
-	if (r_hi > nrow) r_hi = nrow;
+	const int64_t g = (int64_t) blockIdx.x % sh.ngroups, i0 = ((int64_t) blockIdx.x / sh.ngroups) * T2_CPW;
 	const int64_t c = g * T2_NT + t;
+	// where this column's runs of the workgroup's T2_CPW coarse buckets start (recorded by pass 1)
+	uint32_t cs[T2_CPW + 1];
+#pragma unroll
+	for (int q = 0; q <= T2_CPW; q++)
+		cs[q] = (c < ncol && i0 + q <= sh.ncoarse) ? cstart[c * (sh.ncoarse + 1) + i0 + q] : 0u;
+#pragma unroll 1
+	for (int q = 0; q < T2_CPW; q++) {
+	const int64_t i = i0 + q;
+	if (i >= sh.ncoarse) break;                     // (uniform)
+	if (q > 0) __syncthreads();                     // the previous bucket's image has left
+	const int64_t r_lo = (i * T2_NFINE) << sh.fbits;
 	int64_t a = 0, b = 0;
-	if (c < ncol) {                                 // the column's run: recorded by pass 1 (coalesced: consecutive columns)
-		a = cstart[i * ncol + c];
-		b = cstart[(i + 1) * ncol + c];
+	if (c < ncol) {
+#pragma unroll
+		for (int qq = 0; qq < T2_CPW; qq++) if (qq == q) { a = cs[qq]; b = cs[qq + 1]; }
 	}
 	pa[t] = a;
 	// prefix of the run lengths over the threads
@@ -426,12 +436,13 @@ transpose_scatter_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__r
 		}
 	}
 	if (!staged)
-		return;
+		continue;
 	__syncthreads();
 	for (int32_t e = t; e < n; e += T2_NT) {
 		col1[base + e] = s_col[e];
 		rlow1[base + e] = s_row[e];
 		val1[base + e] = s_val[e];
+	}
 	}
 }
 
@@ -798,7 +809,7 @@ static int launch_transpose_bucketed(const int64_t *col_ptr, const int32_t *row_
 		return -1;
 	hipLaunchKernelGGL(transpose_fb_base_kernel, dim3((unsigned) ((sh.ncoarse + 3) / 4)), dim3(256), 0, s,
 			   table, sh, nnz, fb_base);
-	hipLaunchKernelGGL(transpose_scatter_kernel<T>, dim3((unsigned) (sh.ngroups * sh.ncoarse)), dim3(T2_NT), 0, s,
+	hipLaunchKernelGGL(transpose_scatter_kernel<T>, dim3((unsigned) (sh.ngroups * ((sh.ncoarse + T2_CPW - 1) / T2_CPW))), dim3(T2_NT), 0, s,
 			   col_ptr, row_idx, val, nrow, ncol, sh, table, cstart, col1, rlow1, val1);
 	const size_t lds = ((sizeof(SplitLds<T3_NT, T3_ITEMS, 64>) + 15) & ~(size_t) 15) + (size_t) sh.ngroups * 8 +
 			   (size_t) ((sh.ngroups + 1 + 3) & ~(int64_t) 3) * 4 + (size_t) T3_STAGE * 4 + (size_t) T3_STAGE * sizeof(T);
