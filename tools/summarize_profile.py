@@ -12,7 +12,7 @@ import re
 import sys
 
 OURS = ("crossprod", "prep_dense", "colstats", "rowstats", "rowsum", "groupsum",
-        "densify", "pbc_", "reduce_partials", "mirror")
+        "densify", "pbc_", "reduce_partials", "mirror", "transpose_", "scan_tile", "scan_add")
 
 
 def short(name):
