@@ -244,3 +244,40 @@ def test_rowsum_tall_operands(hip, oracle, ngroup, shape):
         b, ub = oracle.rowsum(x, grp, na_rm=na_rm)
         assert ua == ub
         assert_equal(a, b, tol=1e-9, atol=1e-12, what=f"rowsum ngroup={ngroup} na_rm={na_rm}")
+
+
+# ---------------------------------------------------------------------------------------------
+# the bucketed transposition: paths the random shapes of test_hip_device_level.py do not reach
+# ---------------------------------------------------------------------------------------------
+def _check_transpose(m, dtype="double"):
+    import torch
+    from sparsearray_amd.device import DeviceCSC
+    x = SVT_SparseArray.from_dense(m, type=dtype, lacunar=False)
+    cp, ri, v = x.to_csc()
+    tcp, tri, tv = x.t().to_csc()
+    T = DeviceCSC.from_host(m.shape[0], cp, ri, v).t()
+    torch.cuda.synchronize()
+    assert np.array_equal(T.col_ptr.cpu().numpy(), tcp)
+    assert np.array_equal(T.row_idx.cpu().numpy(), tri)
+    assert np.array_equal(T.val.cpu().numpy(), tv)
+
+
+def test_transpose_overfull_buckets(hip):
+    """A band of 64 full rows: one fine bucket holds 32768 nonzeros (more than pass 3 ranks in one round) and
+    one (group, coarse bucket) pair 16384 (more than pass 2 assembles in LDS): the round-by-round paths."""
+    rng = np.random.default_rng(71)
+    m = np.where(rng.random((4096, 512)) < 0.01, rng.normal(size=(4096, 512)), 0.0)
+    m[128:192, :] = rng.normal(size=(64, 512))
+    m[m == 0] = 0.0
+    _check_transpose(m)
+    _check_transpose(np.asfortranarray(m.T))            # wide: 512 rows of ~80 nonzeros, 4096 columns
+
+
+def test_transpose_dense_and_odd_shapes(hip):
+    rng = np.random.default_rng(72)
+    _check_transpose(rng.normal(size=(600, 700)) * (rng.random((600, 700)) < 0.9))      # ~630 nonzeros per row: F = 8
+    _check_transpose(rng.normal(size=(65, 257)) * (rng.random((65, 257)) < 0.3))        # one fine bucket + one row
+    _check_transpose(rng.normal(size=(1, 300)))                                          # a single row
+    _check_transpose(rng.normal(size=(300, 1)))                                          # a single column
+    mi = (rng.integers(-5, 6, (3000, 40)) * (rng.random((3000, 40)) < 0.2)).astype(np.int32)
+    _check_transpose(mi, "integer")
