@@ -52,6 +52,13 @@ def load_library() -> ctypes.CDLL:
                 f"{LIB_PATH} is missing: build it with "
                 "`python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  sparsearray_amd has no CPU path.")
+        # torch ships a HIP runtime of its own; when libsvt_hip.so brings in the system one first, torch's
+        # later initialisation finds "no HIP GPUs".  Device memory and streams come from torch
+        # (sparsearray_amd/device.py), so load it first and let both use one runtime.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.svt_last_error.restype = ctypes.c_char_p
         _lib.svt_device_arch.restype = ctypes.c_char_p

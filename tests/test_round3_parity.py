@@ -10,6 +10,7 @@
 """
 import numpy as np
 import pytest
+import torch  # noqa: F401  (before the HIP library: one HIP runtime per process, see sparsearray_amd/_hip.py)
 
 from helpers import assert_equal, assert_identical, random_csc
 from sparsearray_amd import NA_integer, NA_real, SVT_SparseArray
