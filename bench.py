@@ -63,6 +63,9 @@ def parse():
                    help="nccl (= RCCL, the product path); gloo only to rehearse the N > 1 control flow on a one-GPU box")
     p.add_argument("--same-device", action="store_true",
                    help="rehearsal only: every rank uses GPU 0 (needs --backend gloo)")
+    p.add_argument("--reduce", choices=["rccl", "peer"], default="rccl",
+                   help="N > 1: rccl = all-reduce of the result (default); peer = peer-to-peer copies of the partials + "
+                        "a local sum (sparsearray_amd/parallel.py, PeerReducer; no collective kernel)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extras", action="store_true")
     a = p.parse_args()
@@ -178,7 +181,7 @@ def main():
         del del_me, wcp, wri, wv
         torch.cuda.synchronize()
         t_l = time.perf_counter()
-        sc = par.ShardedCrossprod(A, K, None, a.cbw, a.wpb, a.logr)
+        sc = par.ShardedCrossprod(A, K, None, a.cbw, a.wpb, a.logr, reducer=a.reduce)
         torch.cuda.synchronize()
         layout_ms = (time.perf_counter() - t_l) * 1e3
         auto_gather = (a.cbw, a.wpb, a.logr) == (0, 0, 0) and a.density * 40 * 128 < 12 and lrow >= 4096
@@ -271,8 +274,10 @@ def main():
         para = "1 GPU"
     elif strong:
         para = (f"strong scaling: the one {nrow}x{ncol} problem, rows (contracted dimension) of A and Y sharded over "
-                f"{world} ranks; all-reduce of the ncol x K result inside every step, overlapped with the next "
-                "step's product (sparsearray_amd/parallel.py)")
+                f"{world} ranks; " + ("all-reduce of the ncol x K result inside every step, overlapped with the next "
+                                      "step's product" if a.reduce == "rccl" else
+                                      "partials exchanged by peer-to-peer copies and summed locally (PeerReducer), the sum "
+                                      "of a step taken at the start of the next") + " (sparsearray_amd/parallel.py)")
     else:
         para = (f"weak scaling: every rank owns its own {nrow}x{ncol} block of a {world}x taller matrix; all-reduce "
                 "of the ncol x K result inside every step")

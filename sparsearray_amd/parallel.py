@@ -195,26 +195,163 @@ def gather_axis(local: torch.Tensor, out_dim, axis: int, blocks, group=None) -> 
     return out.reshape(-1)
 
 
+class PeerReducer:
+    """Sum of one (K, ncol) partial per rank on every rank WITHOUT a collective kernel: every rank copies
+    its partial into a staging slot it owns in every peer's memory (peer-to-peer copies: the copy engines
+    on a GPU node, no CU taken from the product kernel, which fills every CU's registers and LDS so that
+    an RCCL kernel cannot run beside it -- DESIGN.md section 5), and every rank adds up its `world` slots
+    with one small local kernel.  10 MB per peer and step at BASELINE config 2a, over all 7 xGMI links at once.
+
+    Opt-in (`ShardedCrossprod(..., reducer="peer")`, `bench.py --reduce peer`): the default stays RCCL's
+    all-reduce.  Only the control flow can be exercised on the boxes this was written on (one GPU:
+    `tests/workers/dist_gpu_worker.py` runs two ranks on one device; `tests/test_distributed_cpu.py` runs it on
+    CPU over shared memory); that the copies take the copy engines and overlap the product is what an 8-GPU
+    node has to show.
+
+    Windows: `staging[b][p]` (this rank's memory, written by rank p) is mapped into every peer through
+    torch's CUDA IPC (shared memory on CPU).  Ordering between processes: per buffer an interprocess event
+    `pushed` (recorded behind this rank's copies) and one `consumed` (behind this rank's sum), plus two
+    counters per buffer in host shared memory that say the record has been ISSUED -- a wait on an
+    interprocess event sees the latest record issued at the time of the wait, so the waiter first spins on
+    the counter (host side, microseconds: all ranks run the same loop), then lets its stream wait for the event.
+    Per step and rank: world copies, one sum, 2 event records, 2 * (world - 1) event waits."""
+
+    def __init__(self, shape, dtype, device, group=None, nbuf: int = 2, timeout_s: float = 60.0):
+        import pickle
+        from multiprocessing.reduction import ForkingPickler
+        import torch.multiprocessing as tmp
+        self.group, self.nbuf, self.timeout_s = group, nbuf, timeout_s
+        self.world, self.me = _world(group), _rank(group)
+        self.cuda = torch.device(device).type == "cuda"
+        self.shape = tuple(shape)
+        # (handles travel as bytes through all_gather_object: host tensors are shared by file name, not by descriptor)
+        tmp.set_sharing_strategy("file_system")
+        self.staging = torch.zeros((nbuf, self.world) + self.shape, dtype=dtype, device=device)
+        self.flags = torch.zeros((2, nbuf), dtype=torch.int64)          # [pushed | consumed][buffer], host memory
+        if not self.cuda:
+            self.staging.share_memory_()
+        self.flags.share_memory_()
+        mine = {"staging": bytes(ForkingPickler.dumps(self.staging)), "flags": bytes(ForkingPickler.dumps(self.flags))}
+        if self.cuda:
+            self.copy_stream = torch.cuda.Stream(device=device)
+            self.pushed_ev = [torch.cuda.Event(enable_timing=False, interprocess=True) for _ in range(nbuf)]
+            self.consumed_ev = [torch.cuda.Event(enable_timing=False, interprocess=True) for _ in range(nbuf)]
+            self.part_ready = [torch.cuda.Event() for _ in range(nbuf)]
+            for ev in self.pushed_ev + self.consumed_ev:
+                ev.record()                                              # (an event must have been recorded to be shared)
+            mine["pushed"] = [ev.ipc_handle() for ev in self.pushed_ev]
+            mine["consumed"] = [ev.ipc_handle() for ev in self.consumed_ev]
+            mine["device"] = torch.device(device).index
+        self.pushes_done = [None] * nbuf
+        handles = [None] * self.world
+        dist.all_gather_object(handles, mine, group=group)
+        self.peer_staging, self.peer_flags, self.peer_pushed, self.peer_consumed = [], [], [], []
+        for p, h in enumerate(handles):
+            if p == self.me:
+                self.peer_staging.append(self.staging); self.peer_flags.append(self.flags)
+                self.peer_pushed.append(getattr(self, "pushed_ev", None)); self.peer_consumed.append(getattr(self, "consumed_ev", None))
+                continue
+            self.peer_staging.append(pickle.loads(h["staging"]))
+            self.peer_flags.append(pickle.loads(h["flags"]))
+            if self.cuda:
+                dev = torch.device("cuda", h["device"])
+                self.peer_pushed.append([torch.cuda.Event.from_ipc_handle(dev, x) for x in h["pushed"]])
+                self.peer_consumed.append([torch.cuda.Event.from_ipc_handle(dev, x) for x in h["consumed"]])
+            else:
+                self.peer_pushed.append(None); self.peer_consumed.append(None)
+        if self.world > 1:
+            dist.barrier(group=group)          # every rank has opened every window before anyone's tensors can go away
+        self.gen = [0] * nbuf          # generation of the last push / sum of every buffer
+        self.pending = [False] * nbuf
+
+    def _spin(self, flags, row, b, want):
+        import time
+        t0 = time.monotonic()
+        while int(flags[row, b]) < want:
+            if time.monotonic() - t0 > self.timeout_s:
+                raise RuntimeError(f"PeerReducer: rank {self.me} waited {self.timeout_s} s for a peer (flag {row}, buffer {b})")
+            time.sleep(0)
+
+    def push(self, b: int, part: torch.Tensor):
+        """Send `part` (this rank's partial of the step that uses buffer b) to every rank's staging slot."""
+        self.gen[b] += 1
+        g = self.gen[b]
+        if self.cuda:
+            self.part_ready[b].record()                                   # behind the product on the current stream
+            with torch.cuda.stream(self.copy_stream):
+                self.copy_stream.wait_event(self.part_ready[b])
+                for p in range(self.world):
+                    if p != self.me:
+                        # the peer has summed what this slot held (generation g - 1) before it is overwritten
+                        self._spin(self.peer_flags[p], 1, b, g - 1)
+                        self.copy_stream.wait_event(self.peer_consumed[p][b])
+                    self.peer_staging[p][b, self.me].copy_(part, non_blocking=True)
+                self.pushed_ev[b].record(self.copy_stream)
+                self.pushes_done[b] = torch.cuda.Event()
+                self.pushes_done[b].record(self.copy_stream)
+        else:
+            for p in range(self.world):
+                if p != self.me:
+                    self._spin(self.peer_flags[p], 1, b, g - 1)
+                self.peer_staging[p][b, self.me].copy_(part)
+        self.flags[0, b] = g                                              # "my record of pushed[b] has been issued"
+        self.pending[b] = True
+
+    def before_overwrite(self, b: int):
+        """Call before the product writes the partial of buffer b again: its copies must have left."""
+        if self.cuda and self.pushes_done[b] is not None:
+            torch.cuda.current_stream().wait_event(self.pushes_done[b])
+
+    def finish(self, b: int, out: torch.Tensor):
+        """Sum of the `world` partials of buffer b into `out` (on the current stream)."""
+        if not self.pending[b]:
+            return
+        g = self.gen[b]
+        for p in range(self.world):
+            if p != self.me:
+                self._spin(self.peer_flags[p], 0, b, g)
+                if self.cuda:
+                    torch.cuda.current_stream().wait_event(self.peer_pushed[p][b])
+        if self.cuda and self.pushes_done[b] is not None:
+            torch.cuda.current_stream().wait_event(self.pushes_done[b])      # my own slot
+        torch.sum(self.staging[b], dim=0, out=out)
+        if self.cuda:
+            self.consumed_ev[b].record()
+        self.flags[1, b] = g                                              # "my record of consumed[b] has been issued"
+        self.pending[b] = False
+
+
 class ShardedCrossprod:
     """crossprod(A, Y) with A and Y sharded on rows.  Every rank holds its row block of A (with
     the panel-blocked layout of that block, built once) and of Y; a step computes the rank's
-    ncol x K partial with the product kernels and all-reduces it.
+    ncol x K partial with the product kernels and sums the partials over the ranks.
 
-    Two result buffers: the all-reduce of step i runs on the collective's stream while the
-    product of step i + 1 runs on the compute stream; step i + 2 waits for it before it reuses
-    the buffer.  `result()` returns the last finished buffer, laid out (K, ncol) C-contiguous =
-    the column-major ncol x K matrix R would get.
+    reducer = "rccl" (default): all-reduce (`torch.distributed`, RCCL on the GPU box).  Two result buffers:
+    the all-reduce of step i runs on the collective's stream while the product of step i + 1 runs on the
+    compute stream; step i + 2 waits for it before it reuses the buffer.
+    reducer = "peer": `PeerReducer` -- peer-to-peer copies of the partials and one local sum, no collective
+    kernel; the sum of step i is taken at the start of step i + 1 (its copies fly during the product in between).
+    `result()` returns the last finished buffer, laid out (K, ncol) C-contiguous = the column-major ncol x K
+    matrix R would get.
     """
 
-    def __init__(self, A_local, K: int, group=None, cbw: int = 0, wpb: int = 0, logr: int = 0):
+    def __init__(self, A_local, K: int, group=None, cbw: int = 0, wpb: int = 0, logr: int = 0,
+                 reducer: str = "rccl"):
         from .device import PbcPlan
         self.A, self.K, self.group = A_local, int(K), group
         self.plan = PbcPlan(A_local, K, cbw, wpb, logr)
         dev = A_local.val.device
-        nbuf = 2 if _world(group) > 1 else 1
+        world = _world(group)
+        nbuf = 2 if world > 1 else 1
         self.outs = [torch.zeros((self.K, A_local.ncol), dtype=torch.float64, device=dev) for _ in range(nbuf)]
         self.pending = [None] * nbuf
         self.stepno = 0
+        self.peer = None
+        if reducer == "peer" and world > 1:
+            self.peer = PeerReducer((self.K, A_local.ncol), torch.float64, dev, group, nbuf)
+            self.parts = [torch.zeros_like(self.outs[0]) for _ in range(nbuf)]
+        elif reducer not in ("rccl", "peer"):
+            raise ValueError("reducer must be 'rccl' or 'peer'")
 
     def _pick(self) -> int:
         i = self.stepno % len(self.outs)
@@ -229,18 +366,30 @@ class ShardedCrossprod:
         torch events recorded around the dominant kernel."""
         i = self._pick()
         ld = Y_local.shape[1]
+        target = self.outs[i]
+        if self.peer is not None:
+            prev = (i - 1) % len(self.outs)
+            self.peer.finish(prev, self.outs[prev])          # the previous step's sum (its copies had a whole product to land)
+            self.peer.before_overwrite(i)
+            target = self.parts[i]
         if events is not None:
             events[0].record()
-        self.plan.run_phase(1, Y_local, ld, self.outs[i])
+        self.plan.run_phase(1, Y_local, ld, target)
         if events is not None:
             events[1].record()
-        self.plan.run_phase(2, Y_local, ld, self.outs[i])
-        if _world(self.group) > 1:
+        self.plan.run_phase(2, Y_local, ld, target)
+        if self.peer is not None:
+            self.peer.push(i, target)
+        elif _world(self.group) > 1:
             self.pending[i] = dist.all_reduce(self.outs[i], op=dist.ReduceOp.SUM, group=self.group,
                                               async_op=True)
         return i
 
     def wait(self):
+        if self.peer is not None:
+            for i in range(len(self.outs)):
+                self.peer.finish(i, self.outs[i])
+            return
         for i, w in enumerate(self.pending):
             if w is not None:
                 w.wait()

@@ -165,6 +165,61 @@ def test_ragged_gather_in_subgroup_gloo():
     assert all(ok for _, ok in res), res
 
 
+def _peer_worker(rank, world, port, q):
+    """PeerReducer on CPU: the windows are shared memory, the protocol (generation counters, who waits for
+    whom, buffer reuse) is the one the GPU path runs."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sparsearray_amd import parallel as par
+        shape = (3, 50)
+        R = par.PeerReducer(shape, torch.float64, "cpu", None, nbuf=2, timeout_s=60)
+        base = torch.arange(150, dtype=torch.float64).reshape(shape)
+        outs = [torch.zeros(shape, dtype=torch.float64) for _ in range(2)]
+        ok = True
+
+        def want(step):
+            return (step + 1) * world * (world + 1) / 2 + world * base
+        nstep = 9
+        for step in range(nstep):
+            b = step % 2
+            if step > 0:
+                R.finish((step - 1) % 2, outs[(step - 1) % 2])
+                ok = ok and bool(torch.equal(outs[(step - 1) % 2], want(step - 1)))
+            R.before_overwrite(b)
+            R.push(b, (rank + 1) * (step + 1) + base)
+            if rank == 1 and step == 4:
+                import time
+                time.sleep(0.3)                    # a rank that falls behind: the others wait for its counters
+        R.finish((nstep - 1) % 2, outs[(nstep - 1) % 2])
+        ok = ok and bool(torch.equal(outs[(nstep - 1) % 2], want(nstep - 1)))
+        # the same sums through the collective
+        t = (rank + 1) * nstep + base
+        dist.all_reduce(t)
+        ok = ok and bool(torch.equal(t, want(nstep - 1)))
+        dist.barrier()
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_peer_reducer_matches_all_reduce_gloo(world):
+    port = 33500 + os.getpid() % 2000 + world
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_peer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res
+
+
 def test_row_blocks_cover():
     sys.path.insert(0, ROOT)
     from sparsearray_amd.parallel import row_block

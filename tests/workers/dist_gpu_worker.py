@@ -54,6 +54,15 @@ def main():
         torch.cuda.synchronize()
         scale = float(ref.abs().max())
         err_cp = float((got - ref).abs().max()) / scale
+        # the same through the peer-copy reducer (IPC windows, interprocess events; here both ranks on one device)
+        sp = par.ShardedCrossprod(Al, K, reducer="peer")
+        for _ in range(5):                                # five steps: both buffers reused twice
+            sp.step(Yl)
+        gotp = sp.result().clone()
+        torch.cuda.synchronize()
+        err_peer = float((gotp - ref).abs().max()) / scale
+        dist.barrier()
+        del sp
         # colSums of the row shards, all-reduced, vs the one-rank colSums
         cs = par.sharded_colsums_rows(Al)
         cs_ref, _ = colstats(A, "sum")
@@ -69,7 +78,8 @@ def main():
         rs_ref = rowsum(A, grp, ng)
         torch.cuda.synchronize()
         err_rs = float((rs - rs_ref).abs().max()) / max(float(rs_ref.abs().max()), 1e-300)
-        verdict[name] = {"same_shard": bool(same_shard), "crossprod_rel_err": err_cp, "colsums_rel_err": err_cs,
+        verdict[name] = {"same_shard": bool(same_shard), "crossprod_rel_err": err_cp, "crossprod_peer_rel_err": err_peer,
+                         "colsums_rel_err": err_cs,
                          "colvars_identical": bool(torch.equal(cv, cv_ref)), "rowsum_rel_err": err_rs,
                          "nnz": A.nnz, "rows_rank": r1 - r0, "blocks": blocks}
         del sc, A, Al, As, Ac, Y, Yl, got, ref
