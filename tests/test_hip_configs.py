@@ -186,7 +186,11 @@ def test_bench_strong_scaling_rehearsal_same_problem(hip):
     common = ["--nrow", "262144", "--ncol", "4000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras"]
     one = _bench_line(common, 1, 0)
     two = _bench_line(common, 2, 29700 + os.getpid() % 200)
-    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    peer = _bench_line(common + ["--reduce", "peer"], 2, 29950 + os.getpid() % 200)     # PeerReducer instead of all-reduce
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and peer["n_gpus"] == 2
+    c = peer["config"]["result_checksum"]
+    assert abs(c["abs_sum"] - one["config"]["result_checksum"]["abs_sum"]) <= 1e-12 * abs(c["abs_sum"])
+    assert "PeerReducer" in peer["config"]["parallelism"]
     assert two["scaling"] == "strong" and "strong scaling" in two["config"]["workload"]
     assert one["config"]["nnz_total"] == two["config"]["nnz_total"]
     a, b = one["config"]["result_checksum"], two["config"]["result_checksum"]
