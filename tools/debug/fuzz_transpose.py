@@ -1,0 +1,60 @@
+"""Differential fuzzing of the device transposition (bucketed count / scan / scatter, and its key-sort
+fallback for the shapes it does not take) against a stable sort by row on the GPU: random shapes from one
+row to 3e5, from one column to 2e5, densities from 1e-4 to 1, skewed rows and columns, both value types.
+    python tools/debug/fuzz_transpose.py [ncases] [seed]"""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from sparsearray_amd.device import DeviceCSC
+
+ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+dev = torch.device("cuda", 0)
+bad = 0
+for case in range(ncases):
+    nrow = int(rng.choice([1, 2, 63, 64, 65, 255, 1000, 1024, 1025, 4097, 20000, 65537, 300000]))
+    ncol = int(rng.choice([1, 2, 255, 256, 257, 1000, 5000, 40000, 200000]))
+    dens = float(rng.choice([0.0001, 0.001, 0.01, 0.05, 0.3, 1.0]))
+    if nrow * ncol * dens > 3e7:
+        dens = 3e7 / (nrow * ncol)
+    kind = int(rng.integers(0, 4))
+    g = torch.Generator(device=dev); g.manual_seed(int(rng.integers(0, 2 ** 31)))
+    # a dense mask would not fit: draw linear positions
+    n_try = int(nrow * ncol * dens)
+    if n_try <= 0:
+        n_try = 1
+    lin = torch.randint(0, nrow * ncol, (n_try,), generator=g, device=dev, dtype=torch.int64)
+    if kind == 1:                                   # a band of heavy rows
+        r0 = int(rng.integers(0, nrow))
+        extra = torch.arange(ncol, device=dev, dtype=torch.int64) * nrow + r0
+        lin = torch.cat([lin, extra])
+    if kind == 2:                                   # a few fully dense columns
+        for c0 in rng.integers(0, ncol, size=min(3, ncol)):
+            lin = torch.cat([lin, int(c0) * nrow + torch.arange(nrow, device=dev, dtype=torch.int64)])
+    if kind == 3:                                   # rows crowded at the low end
+        lin = (lin // nrow) * nrow + (lin % nrow) % max(1, nrow // 7)
+    lin = torch.unique(lin)                         # sorted: column-major order
+    ri = (lin % nrow).to(torch.int32)
+    col = lin // nrow
+    cp = torch.zeros(ncol + 1, dtype=torch.int64, device=dev)
+    cp[1:] = torch.cumsum(torch.bincount(col, minlength=ncol), 0)
+    is_int = bool(rng.integers(0, 2))
+    if is_int:
+        v = torch.randint(-50, 50, (lin.numel(),), generator=g, device=dev, dtype=torch.int32)
+    else:
+        v = torch.randn(lin.numel(), generator=g, device=dev, dtype=torch.float64)
+    A = DeviceCSC(nrow, cp, ri, v)
+    T = A.t()
+    torch.cuda.synchronize()
+    order = torch.sort(ri.to(torch.int64), stable=True).indices
+    want_idx = col[order].to(torch.int32)
+    want_val = v[order]
+    want_cp = torch.zeros(nrow + 1, dtype=torch.int64, device=dev)
+    want_cp[1:] = torch.cumsum(torch.bincount(ri.to(torch.int64), minlength=nrow), 0)
+    ok = torch.equal(T.col_ptr, want_cp) and torch.equal(T.row_idx, want_idx) and torch.equal(T.val, want_val)
+    if not ok:
+        bad += 1
+        print(f"MISMATCH case {case}: nrow {nrow} ncol {ncol} nnz {lin.numel()} kind {kind} int {is_int}", flush=True)
+    del A, T, lin, ri, col, cp, v, order, want_idx, want_val, want_cp
+print(f"{ncases} cases, {bad} mismatches")
+sys.exit(1 if bad else 0)
