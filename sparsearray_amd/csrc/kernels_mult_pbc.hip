@@ -394,12 +394,48 @@ __global__ void pbc_group_limit_kernel(const int64_t *__restrict__ tile_ptr, int
 	if ((n + PBC_SLACK) * 16 >= ((int64_t) 1 << 32)) *flag = 1;
 }
 
+// End of a build, on the device: the pad entries of the tile table and the zeroed slack behind the records
+// (the look-ahead stages of the kernels read up to 3 batches past the end), and what the host wants to know
+// -- meta[0] = records, meta[1] = longest leaf (pbc_max_leaf_kernel), meta[2] = "a column group too large"
+// (pbc_group_limit_kernel) -- so that one read-back ends the build instead of five synchronous calls.
+__global__ void pbc_build_finish_kernel(int64_t *__restrict__ tile_ptr, int64_t ntiles, char *__restrict__ rec,
+					int rbytes, long long *__restrict__ meta)
+{
+	const int64_t nrec = tile_ptr[ntiles];
+	if (threadIdx.x == 0) meta[0] = nrec;
+	if (threadIdx.x < PBC_TP_PAD) tile_ptr[ntiles + 1 + threadIdx.x] = nrec;
+	uint32_t *slack = (uint32_t *) (rec + (size_t) nrec * rbytes);          // (records are 12 or 16 bytes: 4-byte aligned)
+	for (int x = threadIdx.x; x < PBC_SLACK * 4; x += blockDim.x) slack[x] = 0u;
+}
+
+// The layout's buffers come from the device's stream-ordered pool (stream 0), which keeps what is freed:
+// hipMalloc of the 1.4 GB record array of BASELINE config 2 maps pages for ~0.5 ms on every build, and a
+// build used to spend as long in allocation and its five synchronous calls as in its kernels
+// (2.24 ms for 1.1 ms of kernels).
+static hipError_t pbc_alloc(void **p, size_t n)
+{
+	static bool pool_ready = false;
+	if (!pool_ready) {
+		int dev = 0;
+		hipMemPool_t pool;
+		if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
+			uint64_t keep = ~(uint64_t) 0;
+			(void) hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+		}
+		pool_ready = true;
+	}
+	return hipMallocAsync(p, n ? n : 16, 0);
+}
+static void pbc_free(void *p) { if (p) (void) hipFreeAsync(p, 0); }
+
 extern "C" void svt_dev_pbc_release(svt_dev_pbc *h)
 {
 	if (h == NULL) return;
-	if (h->rec) (void) hipFree(h->rec);
-	if (h->tile_ptr) (void) hipFree(h->tile_ptr);
-	if (h->col_has_na) (void) hipFree(h->col_has_na);
+	// (as hipFree() did implicitly: products on other streams may still be reading the layout)
+	(void) hipDeviceSynchronize();
+	pbc_free(h->rec);
+	pbc_free(h->tile_ptr);
+	pbc_free(h->col_has_na);
 	free(h);
 }
 
@@ -457,8 +493,8 @@ extern "C" svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB
 	void *tmp = NULL;
 	int32_t *bounds = NULL;
 	size_t tmp_bytes = 0;
-	bool ok = hipMalloc((void **) &h->tile_ptr, (size_t) (ntiles + 1 + PBC_TP_PAD) * 8) == hipSuccess &&
-		  hipMalloc((void **) &h->col_has_na, (size_t) (A->ncol > 0 ? A->ncol : 1) * 4) == hipSuccess;
+	bool ok = pbc_alloc((void **) &h->tile_ptr, (size_t) (ntiles + 1 + PBC_TP_PAD) * 8) == hipSuccess &&
+		  pbc_alloc((void **) &h->col_has_na, (size_t) (A->ncol > 0 ? A->ncol : 1) * 4) == hipSuccess;
 	if (ok) ok = hipMemsetAsync(h->tile_ptr, 0, (size_t) (ntiles + 1 + PBC_TP_PAD) * 8, 0) == hipSuccess &&
 		     hipMemsetAsync(h->col_has_na, 0, (size_t) (A->ncol > 0 ? A->ncol : 1) * 4, 0) == hipSuccess;
 	if (ok && A->ncol > 0 && A->nnz > 0) {
@@ -479,9 +515,9 @@ extern "C" svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB
 					   h->tile_ptr, (uint4 *) NULL, h->col_has_na, g_pbc_stagger);
 		// exclusive scan in place over ntiles+1 entries (last entry = total)
 		tmp_bytes = exclusive_scan_ws_bytes(ntiles + 1);
-		ok = hipMalloc(&tmp, tmp_bytes) == hipSuccess &&
+		ok = pbc_alloc(&tmp, tmp_bytes) == hipSuccess &&
 		     launch_exclusive_scan_i64(h->tile_ptr, ntiles + 1, tmp, 0) == 0;
-		if (ok) ok = hipMalloc((void **) &h->rec, (size_t) nrec_max * rbytes + PBC_SLACK * 16) == hipSuccess;
+		if (ok) ok = pbc_alloc((void **) &h->rec, (size_t) nrec_max * rbytes + PBC_SLACK * 16) == hipSuccess;
 		if (ok) {
 			if (h->fmt == 1) {
 				// panels per scatter workgroup: the fewest (>= 16) that give a column ~8 nonzeros per
@@ -492,7 +528,7 @@ extern "C" svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB
 					subp *= 2;
 				const int64_t nchunks = (h->npanels + subp - 1) / subp;
 				const int64_t nb_entries = A->ncol * (nchunks + 1);
-				ok = hipMalloc((void **) &bounds, (size_t) nb_entries * 4) == hipSuccess;
+				ok = pbc_alloc((void **) &bounds, (size_t) nb_entries * 4) == hipSuccess;
 				if (ok) {
 					hipLaunchKernelGGL(pbc_bounds_kernel, dim3((unsigned) ((nb_entries + 255) / 256)), dim3(256), 0, 0,
 							   A->col_ptr, A->row_idx, A->ncol, nchunks, (int64_t) subp << logR, bounds);
@@ -511,50 +547,36 @@ extern "C" svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB
 						   h->npanels, h->tile_ptr, h->rec, h->col_has_na, g_pbc_stagger);
 			}
 		}
-		int64_t nrec = 0;
-		if (ok) ok = hipMemcpy(&nrec, h->tile_ptr + ntiles, 8, hipMemcpyDeviceToHost) == hipSuccess;   // (synchronises)
-		if (ok) {                                   // longest leaf (tmp, the scan's scratch, is free again)
-			unsigned long long mx = 0;
-			ok = hipMemset(tmp, 0, 8) == hipSuccess;
+		// One read-back for the whole build: records, longest leaf, "a column group too large for the
+		// kernels' 32-bit byte cursor" (tmp, the scan's scratch, is free again: >= 256 bytes).
+		long long hmeta[3] = {0, 0, 0};
+		bool too_big = false;
+		if (ok) {
+			long long *meta = (long long *) tmp;
+			ok = hipMemsetAsync(meta, 0, 24, 0) == hipSuccess;
 			if (ok) {
 				hipLaunchKernelGGL(pbc_max_leaf_kernel, dim3((unsigned) ((A->ncol + 255) / 256)), dim3(256), 0, 0,
-						   A->col_ptr, A->ncol, (unsigned long long *) tmp);
-				ok = hipMemcpy(&mx, tmp, 8, hipMemcpyDeviceToHost) == hipSuccess;
-			}
-			h->max_leaf_nnz = (int64_t) mx;
-		}
-		h->nrec = nrec;
-		if (ok) {
-			int64_t pad[PBC_TP_PAD];
-			for (int i = 0; i < PBC_TP_PAD; i++) pad[i] = nrec;
-			// the look-ahead stages of the kernels read up to 3 batches past the end
-			ok = hipMemcpy(h->tile_ptr + ntiles + 1, pad, sizeof(pad), hipMemcpyHostToDevice) == hipSuccess &&
-			     hipMemset((char *) h->rec + (size_t) nrec * rbytes, 0, (size_t) PBC_SLACK * 16) == hipSuccess;
-		}
-		// the kernels walk one group's stream with a 32-bit byte cursor
-		bool too_big = false;
-		if (ok && (nrec + PBC_SLACK) * 16 >= ((int64_t) 1 << 32)) {      // (else no group can be)
-			int *flag = (int *) tmp;                 // scan scratch, >= 16 bytes, free again
-			int hflag = 0;
-			ok = hipMemset(flag, 0, 4) == hipSuccess;
-			if (ok) {
+						   A->col_ptr, A->ncol, (unsigned long long *) (meta + 1));
 				hipLaunchKernelGGL(pbc_group_limit_kernel, dim3((unsigned) ((h->ngroups + 255) / 256)),
-						   dim3(256), 0, 0, h->tile_ptr, h->npanels, h->ngroups, flag);
-				ok = hipMemcpy(&hflag, flag, 4, hipMemcpyDeviceToHost) == hipSuccess;
+						   dim3(256), 0, 0, h->tile_ptr, h->npanels, h->ngroups, (int *) (meta + 2));
+				hipLaunchKernelGGL(pbc_build_finish_kernel, dim3(1), dim3(256), 0, 0, h->tile_ptr, ntiles,
+						   (char *) h->rec, (int) rbytes, meta);
+				ok = hipMemcpy(hmeta, meta, 24, hipMemcpyDeviceToHost) == hipSuccess;      // (synchronises)
 			}
-			too_big = hflag != 0;
+			h->nrec = hmeta[0];
+			h->max_leaf_nnz = hmeta[1];
+			too_big = hmeta[2] != 0;
 		}
 		if (ok && too_big) {
 			svt_set_error("svt_dev_pbc_build: a column group too large for 32-bit record offsets");
-			if (tmp) (void) hipFree(tmp);
-			if (bounds) (void) hipFree(bounds);
+			pbc_free(tmp);
+			pbc_free(bounds);
 			svt_dev_pbc_release(h);
 			return NULL;
 		}
-		if (ok) ok = hipDeviceSynchronize() == hipSuccess;
 	}
-	if (tmp) (void) hipFree(tmp);
-	if (bounds) (void) hipFree(bounds);
+	pbc_free(tmp);
+	pbc_free(bounds);
 	if (!ok) {
 		svt_set_error("svt_dev_pbc_build failed: %s", hipGetErrorString(hipGetLastError()));
 		svt_dev_pbc_release(h);
