@@ -66,6 +66,8 @@ def parse():
     p.add_argument("--reduce", choices=["rccl", "peer"], default="rccl",
                    help="N > 1: rccl = all-reduce of the result (default); peer = peer-to-peer copies of the partials + "
                         "a local sum (sparsearray_amd/parallel.py, PeerReducer; no collective kernel)")
+    p.add_argument("--spare-cus", type=int, default=0,
+                   help="CUs the product kernel leaves idle (room for RCCL's kernels beside it); 0 = none")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extras", action="store_true")
     a = p.parse_args()
@@ -181,7 +183,7 @@ def main():
         del del_me, wcp, wri, wv
         torch.cuda.synchronize()
         t_l = time.perf_counter()
-        sc = par.ShardedCrossprod(A, K, None, a.cbw, a.wpb, a.logr, reducer=a.reduce)
+        sc = par.ShardedCrossprod(A, K, None, a.cbw, a.wpb, a.logr, reducer=a.reduce, spare_cus=a.spare_cus)
         torch.cuda.synchronize()
         layout_ms = (time.perf_counter() - t_l) * 1e3
         auto_gather = (a.cbw, a.wpb, a.logr) == (0, 0, 0) and a.density * 40 * 128 < 12 and lrow >= 4096
@@ -308,6 +310,8 @@ def main():
                                    else "PBC cbw=40 wpb=16 logR=7 (LDS-DMA kernel)") if a.cbw == 0 else \
             f"PBC cbw={a.cbw} wpb={a.wpb} logR={a.logr}"
         res["config"]["layout_build_ms_once_per_operand"] = layout_ms
+        if a.spare_cus:
+            res["config"]["spare_cus"] = a.spare_cus
     if world == 1 and not a.no_extras and a.config == 2:
         def timed(fn, reps=5):
             fn(); torch.cuda.synchronize()
@@ -347,6 +351,17 @@ def main():
         del Yrm, outx
         ex["crossprod_whole_call"] = {"ms": t_clean, "one_Inf_in_Y_ms": t_inf, "plus_a_NaN_column_ms": t_col,
                                       "Y_given_by_rows_ms": t_try}
+        if a.spare_cus == 0:
+            # what the multi-GPU option costs on one GPU: 32 CUs (4 per XCD) left to a collective's kernels
+            from sparsearray_amd.device import set_spare_cus
+            outs = torch.zeros((K, ncol), dtype=torch.float64, device=dev)
+            set_spare_cus(32)
+            t_sp = timed(lambda: plan0.run(Y, lrow, outs), 10)
+            set_spare_cus(0)
+            ex["crossprod_whole_call"]["with_32_CUs_left_idle_ms"] = t_sp
+            ex["crossprod_whole_call"]["with_32_CUs_left_idle_same_result"] = bool(
+                torch.allclose(outs, result(), rtol=1e-11, atol=1e-11))
+            del outs
         # once-per-operand costs, steady state (second call: code objects loaded, allocator warm)
         def wall(fn, reps=3):
             best = 1e30

@@ -290,6 +290,15 @@ int svt_dev_crossprod_pbc(const svt_dev_pbc *P, const svt_dev_csc *A,
 			  int64_t out_stride_k, void *ws, size_t ws_bytes,
 			  void *stream);
 
+/* CUs the LDS-DMA product kernel leaves idle (default 0).  Its workgroups take a whole CU each, so a
+   collective's kernels cannot start beside it; with n > 0 (a multiple of 8: n / 8 per XCD) the row splits are
+   chosen so that at most 256 - n workgroups run -- for the multi-GPU driver, whose all-reduce of step i
+   runs beside the product of step i + 1 (the reference has no counterpart: its OpenMP loop,
+   src/SparseMatrix_mult.c:253-258, owns the cores it is given).  Process-wide; takes effect at the next
+   product (a workspace sized by svt_dev_crossprod_pbc_ws_bytes() fits either setting). */
+void svt_dev_pbc_set_spare_cus(int n);
+int svt_dev_pbc_spare_cus(void);
+
 /* The same, restricted to the leaves from `first_col` on (rounded down to the kernel's block of
    16 * CBW columns): cells of earlier leaves are not written.  What the unary crossprod(x) needs:
    of dense column k only the leaves c >= k (compute_sym_dotprods_*, src/SparseMatrix_mult.c:

@@ -587,6 +587,16 @@ extern "C" svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB
 
 // ---------------------------------------------------------------------------
 // main kernel
+// CUs the LDS-DMA product kernel leaves idle (0 = none).  Its workgroups fill a CU each (132 KB of LDS,
+// 16 x 128 VGPRs), so a collective's kernels (RCCL) cannot start beside it; with n > 0 the row splits are
+// chosen so that at most 256 - n workgroups are launched -- 8 n / 256 CUs of every XCD stay free -- and
+// every split's workgroups go round the XCDs (include/svt_hip.h: svt_dev_pbc_set_spare_cus).
+static int g_pbc_spare_cus = 0;
+extern "C" void svt_dev_pbc_set_spare_cus(int n)
+{
+	g_pbc_spare_cus = n < 0 ? 0 : n > 192 ? 192 : (n + 7) / 8 * 8;
+}
+extern "C" int svt_dev_pbc_spare_cus(void) { return g_pbc_spare_cus; }
 // ---------------------------------------------------------------------------
 #ifdef SVT_TUNING
 // 0 = normal; 2 = timing-only build without the record loop (results wrong by construction);
@@ -1218,7 +1228,7 @@ template <int NV, int PROF>      // PROF (tuning build): 1 = cycles per section 
 __global__ void __launch_bounds__(1024)
 crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restrict__ tile_ptr,
 			 int64_t npanels, const double *__restrict__ Y, int64_t ldY, int64_t nrow,
-			 int K, int64_t ncol, int CBW, int nsplit, int nblocks, int block0,
+			 int K, int64_t ncol, int CBW, int nfull, int nblocks, int block0,
 			 int64_t panels_per_split, double *__restrict__ part, int64_t Kp,
 			 PbcFlags fl, int rt_lines, int rt_ahead, int stag_mode)
 {
@@ -1234,8 +1244,15 @@ crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restric
 	// nblocks column blocks are launched, the first of them is block0 of the layout (a symmetric
 	// product only needs the blocks from its dense chunk's first column on); bl counts from 0
 	int bl, kh, split;
-	const int nfull = nsplit & ~7;                  // row splits dealt to the XCDs whole, eight at a time
-	if (L < nfull * kt * nblocks) {
+	// nfull > 0: row splits dealt to the XCDs whole, eight at a time.  nfull < 0: CUs are kept free, -nfull
+	// workgroups per XCD (workgroup L runs on XCD L % 8): the (split, dense tile, column block) triples are
+	// numbered so that an XCD holds consecutive ones -- a (split, dense tile) group, whose workgroups pull
+	// the same panels of Y, sits on one XCD or straddles two (all round the XCDs: 2.93 instead of 2.1 ms
+	// at config 2a with 32 CUs kept free); numbers past the last split find no panels and leave.
+	if (nfull < 0) {
+		const int V = (L & 7) * (-nfull) + (L >> 3), u = V / nblocks;
+		bl = V % nblocks; kh = u % kt; split = u / kt;
+	} else if (L < nfull * kt * nblocks) {
 		const int xcd = L & 7, j = L >> 3, u = j / nblocks;
 		bl = j % nblocks; kh = u % kt; split = (u / kt) * 8 + xcd;
 	} else {                                        // the other splits: their workgroups go round the XCDs
@@ -1810,12 +1827,22 @@ static int pick_nsplit_gather(const svt_dev_pbc *P, int K, int64_t *pps_out)
 	return (int) s;
 }
 
-static int pick_nsplit(const svt_dev_pbc *P, int K, bool dma, int64_t *pps_out)
+// CUs are kept free (svt_dev_pbc_set_spare_cus) when one round of workgroups fits the rest
+static bool pbc_sparing(const svt_dev_pbc *P, int K)
+{
+	const int64_t units = P->nblocks * (((int64_t) K + 63) / 64);
+	return g_pbc_spare_cus > 0 && units <= 256 - g_pbc_spare_cus && P->npanels >= 8 * 16;
+}
+
+static int pick_nsplit(const svt_dev_pbc *P, int K, bool dma, int64_t *pps_out, bool may_spare = true)
 {
 	const int64_t kt = ((int64_t) K + 63) / 64;
 	const int64_t units = P->nblocks * kt;
 	int64_t s;
-	if (units >= 512) {
+	if (dma && may_spare && pbc_sparing(P, K)) {
+		s = (256 - g_pbc_spare_cus) / units;    // one round on the CUs that may be used
+		if (P->npanels / s < 16) s = P->npanels / 16;
+	} else if (units >= 512) {
 		s = 1;                                  // enough column blocks: no row split, no partials
 	} else if (dma && P->npanels >= 8 * 16) {
 		// One workgroup per CU (LDS, VGPRs), 32 CUs per XCD, the column blocks of a (split, dense
@@ -1858,6 +1885,10 @@ extern "C" size_t svt_dev_crossprod_pbc_ws_bytes(const svt_dev_pbc *P, int K)
 {
 	const int64_t Kp = ((int64_t) K + 63) / 64 * 64;
 	int ns = pick_nsplit(P, K, false, NULL);
+	{                                               // (the knob may change between the query and the launch)
+		const int n0 = pick_nsplit(P, K, true, NULL, false);
+		if (pbc_dma_ok(P, 0) && n0 > ns) ns = n0;
+	}
 	if (pbc_dma_ok(P, 0)) {
 		const int nd = pick_nsplit(P, K, true, NULL);
 		if (nd > ns) ns = nd;
@@ -1921,8 +1952,13 @@ static void launch_dma(const svt_dev_pbc *P, const double *Y, int64_t ldY, int K
 #endif
 	(void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
 	const int nb = (int) P->nblocks - block0;
-	hipLaunchKernelGGL(kern, dim3((unsigned) ((int64_t) nsplit * kt * nb)), dim3(1024), lds, s,
-			   P->rec, P->tile_ptr, P->npanels, Y, ldY, P->nrow, K, P->ncol, P->CBW, nsplit,
+	// with CUs kept free: 8 x per_xcd workgroups, packed XCD by XCD (see the kernel's decode)
+	const bool sparing = pbc_sparing(P, K);
+	const int per_xcd = (256 - g_pbc_spare_cus) / 8;
+	const int nfull = sparing ? -per_xcd : nsplit & ~7;
+	const int64_t nwg = sparing ? (int64_t) 8 * per_xcd : (int64_t) nsplit * kt * nb;
+	hipLaunchKernelGGL(kern, dim3((unsigned) nwg), dim3(1024), lds, s,
+			   P->rec, P->tile_ptr, P->npanels, Y, ldY, P->nrow, K, P->ncol, P->CBW, nfull,
 			   nb, block0, pps, part, Kp, fl, rt_lines, rt_ahead, g_pbc_stagger);
 }
 

@@ -41,6 +41,9 @@ def _lib():
         lib.svt_dev_pbc_build.argtypes = [c_void_p, c_int, c_int, c_int]
         lib.svt_dev_pbc_release.argtypes = [c_void_p]
         lib.svt_dev_pbc_release.restype = None
+        lib.svt_dev_pbc_set_spare_cus.argtypes = [c_int]
+        lib.svt_dev_pbc_set_spare_cus.restype = None
+        lib.svt_dev_pbc_spare_cus.restype = c_int
         lib.svt_dev_crossprod_pbc_ws_bytes.restype = c_size_t
         lib.svt_dev_crossprod_pbc_ws_bytes.argtypes = [c_void_p, c_int]
         lib.svt_dev_crossprod_pbc.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int,
@@ -207,6 +210,16 @@ class PbcPlan:
                 self._p = None
         except Exception:
             pass
+
+
+def set_spare_cus(n: int) -> None:
+    """CUs the LDS-DMA product kernel leaves idle from now on (0 = none; include/svt_hip.h:
+    svt_dev_pbc_set_spare_cus) -- room for a collective's kernels beside the product."""
+    _lib().svt_dev_pbc_set_spare_cus(int(n))
+
+
+def spare_cus() -> int:
+    return int(_lib().svt_dev_pbc_spare_cus())
 
 
 def crossprod_csc_dense(A: DeviceCSC, Y: torch.Tensor) -> torch.Tensor:

@@ -333,12 +333,16 @@ class ShardedCrossprod:
     kernel; the sum of step i is taken at the start of step i + 1 (its copies fly during the product in between).
     `result()` returns the last finished buffer, laid out (K, ncol) C-contiguous = the column-major ncol x K
     matrix R would get.
+    spare_cus = n: the product kernel leaves n CUs idle (process-wide setting of the library) so that the
+    collective's kernels can start beside it; None = leave the setting alone.
     """
 
     def __init__(self, A_local, K: int, group=None, cbw: int = 0, wpb: int = 0, logr: int = 0,
-                 reducer: str = "rccl"):
-        from .device import PbcPlan
+                 reducer: str = "rccl", spare_cus=None):
+        from .device import PbcPlan, set_spare_cus
         self.A, self.K, self.group = A_local, int(K), group
+        if spare_cus is not None:
+            set_spare_cus(spare_cus)
         self.plan = PbcPlan(A_local, K, cbw, wpb, logr)
         dev = A_local.val.device
         world = _world(group)

@@ -185,7 +185,8 @@ def test_bench_strong_scaling_rehearsal_same_problem(hip):
     torch.cuda.empty_cache()
     common = ["--nrow", "262144", "--ncol", "4000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras"]
     one = _bench_line(common, 1, 0)
-    two = _bench_line(common, 2, 29700 + os.getpid() % 200)
+    two = _bench_line(common + ["--spare-cus", "32"], 2, 29700 + os.getpid() % 200)   # and CUs left to the collective
+    assert two["config"]["spare_cus"] == 32
     peer = _bench_line(common + ["--reduce", "peer"], 2, 29950 + os.getpid() % 200)     # PeerReducer instead of all-reduce
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and peer["n_gpus"] == 2
     c = peer["config"]["result_checksum"]

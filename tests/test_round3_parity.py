@@ -282,3 +282,43 @@ def test_transpose_dense_and_odd_shapes(hip):
     _check_transpose(rng.normal(size=(300, 1)))                                          # a single column
     mi = (rng.integers(-5, 6, (3000, 40)) * (rng.random((3000, 40)) < 0.2)).astype(np.int32)
     _check_transpose(mi, "integer")
+
+
+@pytest.mark.parametrize("spare", [32, 64, 128])
+def test_product_with_cus_left_idle(hip, oracle, spare):
+    """svt_dev_pbc_set_spare_cus: fewer row splits, every split's workgroups dealt round the XCDs -- the
+    same product (clean and with a non-finite dense operand); the setting may change between the
+    workspace query and the launch."""
+    from test_hip_device_level import _dev
+    from sparsearray_amd.device import PbcPlan, set_spare_cus, spare_cus
+    nrow, ncol, K = 60000, 1300, 128                       # 3 column blocks x 2 dense tiles, 469 panels
+    cp, ri, v = random_csc(nrow, ncol, 0.01, seed=71)
+    x = SVT_SparseArray.from_csc((nrow, ncol), "double", cp, ri, v)
+    rng = np.random.default_rng(72)
+    A = _dev(cp, ri, v, nrow)
+    plan = PbcPlan(A, K, 40, 16, 7)                        # sized with no CUs spared
+    try:
+        for poison in (False, True):
+            y = rng.uniform(-1, 1, (nrow, K))
+            if poison:
+                y[nrow // 3, 5] = np.inf
+            want = oracle.crossprod(x, y)
+            Yd = torch.as_tensor(np.ascontiguousarray(y.T), device="cuda")
+            outs = []
+            for n in (0, spare):
+                set_spare_cus(n)
+                assert spare_cus() == n
+                out = torch.full((K, ncol), 7.0, dtype=torch.float64, device="cuda")
+                plan.run(Yd, nrow, out)
+                torch.cuda.synchronize()
+                assert_equal(out.cpu().numpy().T, want, tol=1e-9, atol=1e-11, what=f"spare={n} poison={poison}")
+                outs.append(out)
+            assert torch.allclose(outs[0], outs[1], rtol=1e-12, atol=1e-13, equal_nan=True)
+        plan2 = PbcPlan(A, K, 40, 16, 7)                   # sized with CUs spared, run without
+        set_spare_cus(0)
+        out = torch.empty((K, ncol), dtype=torch.float64, device="cuda")
+        plan2.run(Yd, nrow, out)
+        torch.cuda.synchronize()
+        assert_equal(out.cpu().numpy().T, want, tol=1e-9, atol=1e-11, what="sized spared, run unspared")
+    finally:
+        set_spare_cus(0)

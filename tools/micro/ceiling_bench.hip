@@ -373,6 +373,73 @@ combo_16(const double *__restrict__ Y, int64_t ld, int nblocks, int kt, int64_t 
 	}
 	if (acc0[0] + acc1[3] + (double) ya[0] + (double) yb[1] + (double) hi[2] + (double) ad[1] == 123.456) sink[0] = acc0[1];
 }
+// combo_16 with the address adds of the next reads AHEAD of the wait for the current ones
+__global__ void __launch_bounds__(16 * 64)
+combo_16r(const double *__restrict__ Y, int64_t ld, int nblocks, int kt, int64_t npanels,
+	     int64_t panels_per_split, double *sink, double trips_per_panel, int dma, int work)
+{
+	extern __shared__ double lds[];
+	constexpr int RS = 129, BUF = 64 * RS, NPIECE = (64 + 16 - 1) / 16;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int L = blockIdx.x;
+	const int xcd = L % 8, j = L / 8;
+	const int u = j / nblocks;
+	const int kh = u % kt, sp = (u / kt) * 8 + xcd;
+	const int64_t pa = (int64_t) sp * panels_per_split;
+	int64_t pb = pa + panels_per_split;
+	if (pb > npanels) pb = npanels;
+	if (pa >= pb) return;
+	const int k0 = kh * 64;
+	for (int i = tid; i < 2 * BUF; i += 16 * 64) lds[i] = 1.0;
+	__syncthreads();
+	auto issue = [&](int64_t p, int buf) {
+#pragma unroll
+		for (int q = 0; q < NPIECE; q++) {
+			const int kk = w * NPIECE + q;
+			if (kk < 64) {
+				const double *src = Y + (int64_t) (k0 + kk) * ld + p * 128 + lane * 2;
+				double *dst = lds + buf * BUF + kk * RS;
+				__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) src,
+								 (__attribute__((address_space(3))) void *) dst, 16, 0, 0);
+			}
+		}
+	};
+	d16 acc0 = 0.0, acc1 = 0.0;
+	u32x16 ya = 0, yb = 0, hi = 0;
+	u32x8 ad = 0;
+	u32x8 meta;
+	const int rows[8] = {3, 17, 40, 66, 71, 90, 101, 120};
+	const int cols[8] = {0, 5, 9, 12, 3, 7, 14, 15};
+#pragma unroll
+	for (int q = 0; q < 8; q++) meta[q] = ((uint32_t) (rows[q] * 8) << 16) | (uint32_t) (2 * cols[q]);
+	const double one = 1.0000001;
+	if (dma) issue(pa, 0);
+	for (int64_t p = pa; p < pb; p++) {
+		const int buf = (int) ((p - pa) & 1);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__builtin_amdgcn_s_barrier();
+		if (dma && p + 1 < pb) issue(p + 1, buf ^ 1);
+		const int64_t i = p - pa;
+		uint32_t n = (uint32_t) ((int64_t) ((i + 1) * trips_per_panel) - (int64_t) (i * trips_per_panel));
+		n = __builtin_amdgcn_readfirstlane(n);
+		const uint32_t lanebase = (uint32_t) lane * 1032u + (uint32_t) buf * (BUF * 8u);
+		if (work && n > 0) {
+			if constexpr (false) {
+				asm volatile(LOOP_HEAD ADDR_1 FMAR_1 WAIT ADDR_1 FMAR_1 WAIT LOOP_TAIL
+					     : "+{v[44:75]}"(acc0), "+{v[76:107]}"(acc1), [n] "+s"(n), "+{v[12:27]}"(ya),
+					       "+{v[2:9]}"(ad), "+{v[112:127]}"(hi)
+					     : [lb] "v"(lanebase), [one] "s"(one), "{s[28:35]}"(meta) : "memory", "scc", "s36");
+			} else {
+				asm volatile("s_mov_b32 s36, m0\n\t" ADDR_A "1:\n\t" READ_A FMAI_B ADDR_B WAIT READ_B FMAI_A ADDR_A WAIT LOOP_TAIL
+					     : "+{v[44:75]}"(acc0), "+{v[76:107]}"(acc1), [n] "+s"(n), "+{v[12:27]}"(ya),
+					       "+{v[108:123]}"(yb), "+{v[112:127]}"(hi)
+					     : [lb] "v"(lanebase), [one] "s"(one), "{s[28:35]}"(meta) : "memory", "scc", "s36");
+			}
+		}
+	}
+	if (acc0[0] + acc1[3] + (double) ya[0] + (double) yb[1] + (double) hi[2] + (double) ad[1] == 123.456) sink[0] = acc0[1];
+}
 __global__ void __launch_bounds__(12 * 64)
 combo_12(const double *__restrict__ Y, int64_t ld, int nblocks, int kt, int64_t npanels,
 	     int64_t panels_per_split, double *sink, double trips_per_panel, int dma, int work)
@@ -640,10 +707,12 @@ combo_16y1(const double *__restrict__ Y, int64_t ld, int nblocks, int kt, int64_
 
 typedef void (*combo_fn)(const double *, int64_t, int, int, int64_t, int64_t, double *, double, int, int);
 static void run_combo(const double *Y, double *sink, combo_fn fn, int wpb, int nblocks, int nsplit, double rec_per_panel,
-		      int dma, int work, const char *what)
+		      int dma, int work, const char *what, int mult = 1)
 {
+	// mult > 1: a barrier every `mult` panels' worth of records (same total work; meaningful with dma = 0 only)
 	const int kt = 2;
-	const int64_t nrow = 999936, ld = 1000000, npanels = nrow / 128;
+	rec_per_panel *= mult;
+	const int64_t nrow = 999936, ld = 1000000, npanels = nrow / 128 / mult;
 	const int64_t pps = (npanels + nsplit - 1) / nsplit;
 	const int nwg = nblocks * kt * nsplit;
 	const size_t ldsb = (size_t) 2 * 64 * 129 * 8;
@@ -811,6 +880,124 @@ static void run_flag(const double *Y, double *sink, int imbalance, int barrier, 
 	CHECK(hipEventDestroy(e0)); CHECK(hipEventDestroy(e1));
 }
 
+
+// ------------------------------------------------------------------------------------------- E
+// trace: the barrier + work loop of combo_16 (no DMA), one trip per asm block, with s_memtime stamps of
+// workgroup 0 for four panels in mid-run: arrival at the barrier, release, end of every trip.  What the
+// ~1200 cycles that one barrier costs (the `period` runs) are made of.
+#define FR4(M, Y, Y1, A, A1_) I1(M) F1(Y, Y1) R1(A, A1_)
+#define FMAI_B_READ_A ION(28) F1(108, 109) R1(12, 13) FR4(29, 110, 111, 14, 15) FR4(30, 112, 113, 16, 17) FR4(31, 114, 115, 18, 19) FR4(32, 116, 117, 20, 21) FR4(33, 118, 119, 22, 23) FR4(34, 120, 121, 24, 25) FR4(35, 122, 123, 26, 27) IOFF
+#define FMAI_A_READ_B ION(28) F1(12, 13) R1(108, 109) FR4(29, 14, 15, 110, 111) FR4(30, 16, 17, 112, 113) FR4(31, 18, 19, 114, 115) FR4(32, 20, 21, 116, 117) FR4(33, 22, 23, 118, 119) FR4(34, 24, 25, 120, 121) FR4(35, 26, 27, 122, 123) IOFF
+template <int VAR>
+__global__ void __launch_bounds__(16 * 64)
+combo_trace(int64_t npanels, double *sink, unsigned long long *trace, int first, int prio)
+{
+	extern __shared__ double lds[];
+	constexpr int RS = 129, BUF = 64 * RS;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+	for (int i = tid; i < 2 * BUF; i += 16 * 64) lds[i] = 1.0;
+	__syncthreads();
+	d16 acc0 = 0.0, acc1 = 0.0;
+	u32x16 ya = 0, yb = 0;
+	u32x8 meta;
+	const int rows[8] = {3, 17, 40, 66, 71, 90, 101, 120};
+	const int cols[8] = {0, 5, 9, 12, 3, 7, 14, 15};
+#pragma unroll
+	for (int q = 0; q < 8; q++) meta[q] = ((uint32_t) (rows[q] * 8) << 16) | (uint32_t) (2 * cols[q]);
+	const double one = 1.0000001;
+	const bool rec = blockIdx.x == 0 && lane == 0;
+	if (prio == 1) { if ((w >> 2) == 0) __builtin_amdgcn_s_setprio(0); else if ((w >> 2) == 1) __builtin_amdgcn_s_setprio(1); else if ((w >> 2) == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3); }
+	for (int64_t i = 0; i < npanels; i++) {
+		const int buf = (int) (i & 1);
+		const bool tr = rec && i >= first && i < first + 4;
+		unsigned long long *t = trace + ((i - first) * 16 + w) * 8;
+		if (tr) t[0] = __builtin_readcyclecounter();
+		__builtin_amdgcn_s_barrier();
+		if (tr) t[1] = __builtin_readcyclecounter();
+		const int n = (int) ((i + 1) * 16 / 5 - i * 16 / 5);       // 3.2 trips of 16 records per panel
+		const uint32_t lanebase = (uint32_t) lane * 1032u + (uint32_t) buf * (BUF * 8u);
+		for (int k = 0; k < n; k++) {
+			uint32_t one_trip = 1;
+#define TRIP_ASM(BODY) asm volatile(LOOP_HEAD BODY LOOP_TAIL \
+				     : "+{v[44:75]}"(acc0), "+{v[76:107]}"(acc1), [n] "+s"(one_trip), "+{v[12:27]}"(ya), \
+				       "+{v[108:123]}"(yb) \
+				     : [lb] "v"(lanebase), [one] "s"(one), "{s[28:35]}"(meta) : "memory", "scc", "s36")
+			if constexpr (VAR == 1) TRIP_ASM(ADDR_A FMAI_B ADDR_B FMAI_A);
+			else if constexpr (VAR == 2) TRIP_ASM(ADDR_A READ_A WAIT ADDR_B READ_B WAIT);
+			else if constexpr (VAR == 4) TRIP_ASM(ADDR_A FMAI_B_READ_A WAIT ADDR_B FMAI_A_READ_B WAIT);
+			else {
+				if constexpr (VAR == 3) {
+					switch ((((w >> 2) + k) & 3)) {
+					case 0: __builtin_amdgcn_s_setprio(0); break;
+					case 1: __builtin_amdgcn_s_setprio(1); break;
+					case 2: __builtin_amdgcn_s_setprio(2); break;
+					default: __builtin_amdgcn_s_setprio(3); break;
+					}
+				}
+				if constexpr (VAR == 6) {          // priority = trips still to do: whoever lags goes first
+					switch (n - k) {
+					case 1: __builtin_amdgcn_s_setprio(0); break;
+					case 2: __builtin_amdgcn_s_setprio(1); break;
+					case 3: __builtin_amdgcn_s_setprio(2); break;
+					default: __builtin_amdgcn_s_setprio(3); break;
+					}
+				}
+				if constexpr (VAR == 7) {          // the same by half trips (batches of 8)
+					uint32_t one_trip = 1;
+					const int rem = 2 * (n - k);
+					if (rem >= 6) __builtin_amdgcn_s_setprio(3); else if (rem >= 4) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
+					TRIP_ASM(ADDR_A READ_A FMAI_B WAIT);
+					if (rem == 2) __builtin_amdgcn_s_setprio(0);
+					one_trip = 1;
+					TRIP_ASM(ADDR_B READ_B FMAI_A WAIT);
+					if (tr) t[2 + k] = __builtin_readcyclecounter();
+					continue;
+				}
+				if constexpr (VAR == 5) if (k == 0) for (int z = 0; z < (w >> 2); z++) __builtin_amdgcn_s_sleep(2);
+				TRIP_ASM(ADDR_A READ_A FMAI_B WAIT ADDR_B READ_B FMAI_A WAIT);
+			}
+			if (tr) t[2 + k] = __builtin_readcyclecounter();
+		}
+	}
+	if (acc0[0] + acc1[3] + (double) ya[0] + (double) yb[1] == 123.456) sink[0] = acc0[1];
+}
+
+template <int VAR>
+static void run_trace(double *sink, int prio, const char *what)
+{
+	const int64_t npanels = 977;
+	const size_t ldsb = (size_t) 2 * 64 * 129 * 8;
+	CHECK(hipFuncSetAttribute((const void *) combo_trace<VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsb));
+	unsigned long long *trace, h[4 * 16 * 8];
+	CHECK(hipMalloc(&trace, sizeof h));
+	CHECK(hipMemset(trace, 0, sizeof h));
+	hipEvent_t e0, e1;
+	CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+	float ms = 0;
+	for (int rep = 0; rep < 3; rep++) {
+		CHECK(hipEventRecord(e0));
+		hipLaunchKernelGGL(combo_trace<VAR>, dim3(256), dim3(1024), ldsb, 0, npanels, sink, trace, 400, prio);
+		CHECK(hipEventRecord(e1));
+		CHECK(hipEventSynchronize(e1));
+		CHECK(hipEventElapsedTime(&ms, e0, e1));
+	}
+	CHECK(hipMemcpy(h, trace, sizeof h, hipMemcpyDeviceToHost));
+	printf("trace %s, prio %d: %.3f ms for %lld panels; stamps of workgroup 0 (counter ticks relative to the first release of the panel)\n", what, prio, ms, (long long) npanels);
+	for (int p = 1; p < 2; p++) {
+		unsigned long long t0 = ~0ull;
+		for (int w = 0; w < 16; w++) if (h[(p * 16 + w) * 8 + 1] < t0) t0 = h[(p * 16 + w) * 8 + 1];
+		printf(" panel %d\n", p);
+		for (int w = 0; w < 16; w++) {
+			const unsigned long long *t = h + (p * 16 + w) * 8;
+			printf("  wave %2d (SIMD %d, rank %d): arrive %6lld release %5lld trips", w, w & 3, w >> 2, (long long) (t[0] - t0), (long long) (t[1] - t0));
+			for (int k = 0; k < 4; k++) if (t[2 + k]) printf(" %6lld", (long long) (t[2 + k] - t0));
+			printf("\n");
+		}
+	}
+	CHECK(hipFree(trace));
+}
+
 template <int MODE>
 static void run_work(double *sink, int threads, const char *what)
 {
@@ -882,6 +1069,27 @@ int main(int argc, char **argv)
 			run_combo(Y, sink, combo_8, 8, 11, 11, 1167.4, dma, work, "8 x 114 cols, 2 y sets");
 			run_combo(Y, sink, combo_8y1, 8, 11, 11, 1167.4, dma, work, "8 x 114 cols, 1 y set");
 		}
+		CHECK(hipFree(Y));
+	}
+	if (!strcmp(which, "trace")) {
+		run_trace<0>(sink, 0, "full");
+		run_trace<0>(sink, 1, "full, priority = rank");
+		run_trace<1>(sink, 0, "no LDS reads");
+		run_trace<2>(sink, 0, "no FMAs");
+		run_trace<3>(sink, 0, "priority rotates per trip");
+		run_trace<4>(sink, 0, "reads interleaved with the FMAs");
+		run_trace<5>(sink, 0, "skew rank x 128 cycles");
+		run_trace<6>(sink, 0, "priority = trips still to do");
+		run_trace<7>(sink, 0, "priority by half trips still to do");
+	}
+	if (!strcmp(which, "period")) {
+		// how the cost of the barrier depends on its period: no DMA, equal record counts
+		double *Y;
+		CHECK(hipMalloc(&Y, 4096));
+		for (int mult : {1, 2, 4, 8, 32})
+			run_combo(Y, sink, combo_16, 16, 16, 8, 819.2, 0, 1, "barrier period (panels' worth)", mult);
+		for (int mult : {1, 2, 4, 8, 32})
+			run_combo(Y, sink, combo_16r, 16, 16, 8, 819.2, 0, 1, "adds before the wait; period", mult);
 		CHECK(hipFree(Y));
 	}
 	if (!strcmp(which, "all") || !strcmp(which, "stage2")) {
