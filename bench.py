@@ -66,8 +66,9 @@ def parse():
     p.add_argument("--reduce", choices=["rccl", "peer"], default="rccl",
                    help="N > 1: rccl = all-reduce of the result (default); peer = peer-to-peer copies of the partials + "
                         "a local sum (sparsearray_amd/parallel.py, PeerReducer; no collective kernel)")
-    p.add_argument("--spare-cus", type=int, default=0,
-                   help="CUs the product kernel leaves idle (room for RCCL's kernels beside it); 0 = none")
+    p.add_argument("--spare-cus", type=int, default=-1,
+                   help="CUs the product kernel leaves idle (room for RCCL's kernels beside it); 0 = none; "
+                        "default: 32 with --gpus > 1 and the RCCL reducer (+5 %% product time, DESIGN.md section 5), else 0")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extras", action="store_true")
     a = p.parse_args()
@@ -75,6 +76,8 @@ def parse():
     for k in ("nrow", "ncol", "density", "K"):
         if getattr(a, k) is None:
             setattr(a, k, c[k])
+    if a.spare_cus < 0:
+        a.spare_cus = 32 if (a.gpus > 1 and a.reduce == "rccl") else 0
     return a
 
 
