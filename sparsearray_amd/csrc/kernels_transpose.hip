@@ -603,7 +603,7 @@ static bool t2_shape(int64_t nrow, int64_t ncol, int64_t nnz, T2Shape *sh)
 	// the largest F <= 64 with ~3000 nonzeros per fine bucket (pass 3 ranks 4096 per round) and ~1500 per
 	// pass-2 workgroup (it assembles 2048 in LDS)
 	int fbits = 6;
-	while (fbits > 0 && (ldexp(per_row, fbits) > 3072.0 ||
+	while (fbits > 0 && (ldexp(per_row, fbits) > 3520.0 ||
 			     (double) T2_NT * per_col * ldexp((double) T2_NFINE, fbits) / (double) nrow > 1536.0))
 		fbits--;
 	if (per_col * ldexp((double) T2_NFINE, fbits) / (double) nrow < 1.0)      // less than one nonzero per thread of pass 2
