@@ -881,6 +881,140 @@ static void run_flag(const double *Y, double *sink, int imbalance, int barrier, 
 }
 
 
+
+// ------------------------------------------------------------------------------------------- F
+// ring: the combo loop on a ring of B panels of H rows per dense column (LDS image [64][B * H + 1]) with the
+// workgroup barrier replaced by two counters per ring slot -- landed[slot] (a wavefront's DMA pieces of the
+// panel are in LDS) and done[slot] (a wavefront has finished reading it).  A wavefront may run up to B - 1
+// panels ahead of the slowest: it starts panel i when all pieces of i have landed, issues its pieces of
+// panel i + B - 1 (into the slot of panel i - 1) at the first trip boundary at which everybody is done with
+// i - 1, and publishes them a panel later (counted vmcnt: the younger pieces keep flying).  Record counts as
+// in `flag` (Poisson-like around 51.2 * H / 128 per wavefront and panel).
+template <int B, int H>
+__global__ void __launch_bounds__(16 * 64)
+combo_ring(const double *__restrict__ Y, int64_t ld, int nblocks, int kt, int64_t npanels,
+	   int64_t panels_per_split, double *sink, int imbalance)
+{
+	extern __shared__ double lds[];
+	constexpr int RS = B * H + 1, NPIECE = 4, D = B - 1;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int L = blockIdx.x;
+	const int xcd = L % 8, j = L / 8;
+	const int u = j / nblocks;
+	const int kh = u % kt, sp = (u / kt) * 8 + xcd;
+	const int64_t pa = (int64_t) sp * panels_per_split;
+	int64_t pb = pa + panels_per_split;
+	if (pb > npanels) pb = npanels;
+	if (pa >= pb) return;
+	const int k0 = kh * 64;
+	uint32_t *flags = (uint32_t *) (lds + 64 * RS);        // landed[B], done[B]
+	for (int i = tid; i < 64 * RS; i += 16 * 64) lds[i] = 1.0;
+	if (tid < 2 * B) flags[tid] = 0;
+	__syncthreads();
+	auto issue = [&](int64_t p, int slot) {
+		if (lane < H / 2) {
+#pragma unroll
+			for (int q = 0; q < NPIECE; q++) {
+				const int kk = w * NPIECE + q;
+				const double *src = Y + (int64_t) (k0 + kk) * ld + p * H + lane * 2;
+				double *dst = lds + kk * RS + slot * H;
+				__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) src,
+								 (__attribute__((address_space(3))) void *) dst, 16, 0, 0);
+			}
+		}
+	};
+	auto peek = [&](int idx) { return __hip_atomic_load(flags + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+	auto bump = [&](int idx) { if (lane == 0) __hip_atomic_fetch_add(flags + idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+	d16 acc0 = 0.0, acc1 = 0.0;
+	u32x16 ya = 0, yb = 0;
+	u32x8 meta;
+	const int cols[8] = {0, 5, 9, 12, 3, 7, 14, 15};
+#pragma unroll
+	for (int q = 0; q < 8; q++) meta[q] = ((uint32_t) ((((q * 2 + 1) * H) / 17) * 8) << 16) | (uint32_t) (2 * cols[q]);   // rows inside the panel
+	const double one = 1.0000001;
+	const int64_t np = pb - pa;
+	// fill: panels 0 .. D - 1
+	for (int i = 0; i < D && i < np; i++) issue(pa + i, i);
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	for (int i = 0; i < D && i < np; i++) bump(i);
+	int carry = 0;
+	const double mean = 51.2 * H / 128.0;
+	int pend_slot = -1;                                     // slot whose pieces this wavefront issued in the previous panel
+	for (int64_t i = 0; i < np; i++) {
+		const int slot = (int) (i % B);
+		int recs = (int) mean + (int) ((i * 16 + w) % 5 == 0);
+		if (imbalance) {
+			const uint32_t h = mix32((uint32_t) (L * 1000003 + i * 16 + w));
+			const int z = (int) (h & 15) + (int) ((h >> 4) & 15) + (int) ((h >> 8) & 15) + (int) ((h >> 12) & 15) - 30;   // ~N(0, 9.2)
+			recs = (int) (mean + z * sqrt(mean) / 9.2) + (int) ((i * 16 + w) % 5 == 0);
+			if (recs < 4) recs = 4;
+		}
+		carry += recs;
+		int n = __builtin_amdgcn_readfirstlane(carry / 16);
+		carry -= n * 16;
+		const uint32_t lanebase = (uint32_t) lane * (RS * 8u) + (uint32_t) slot * (H * 8u);
+		// panel i complete in LDS?
+		const uint32_t need = 16u * (uint32_t) (i / B + 1);
+		while (peek(slot) < need) __builtin_amdgcn_s_sleep(1);
+		bool issued = i + D >= np;
+		const bool had_issue = !issued;
+		const int tslot = (int) ((i + D) % B);
+		const uint32_t need_done = i >= 1 ? 16u * (uint32_t) ((i - 1) / B + 1) : 0u;
+		for (int t = 0; t <= n; t++) {
+			if (!issued && (i == 0 || peek(B + tslot) >= need_done)) {
+				issue(pa + i + D, tslot);
+				issued = true;
+			}
+			if (t == n) break;
+			uint32_t one_trip = 1;
+			asm volatile(LOOP_HEAD ADDR_A READ_A FMAI_B WAIT ADDR_B READ_B FMAI_A WAIT LOOP_TAIL
+				     : "+{v[44:75]}"(acc0), "+{v[76:107]}"(acc1), [n] "+s"(one_trip), "+{v[12:27]}"(ya),
+				       "+{v[108:123]}"(yb)
+				     : [lb] "v"(lanebase), [one] "s"(one), "{s[28:35]}"(meta) : "memory", "scc", "s36");
+		}
+		bump(B + slot);                                     // done with panel i
+		if (!issued) {                                      // (somebody is more than a panel behind)
+			while (peek(B + tslot) < need_done) __builtin_amdgcn_s_sleep(1);
+			issue(pa + i + D, tslot);
+		}
+		// publish the pieces issued during the PREVIOUS panel: they have had a panel to land
+		if (pend_slot >= 0) {
+			if (had_issue) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+			else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			bump(pend_slot);
+		}
+		pend_slot = had_issue ? tslot : -1;
+	}
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	if (acc0[0] + acc1[3] + (double) ya[0] + (double) yb[1] == 123.456) sink[0] = acc0[1];
+}
+
+template <int B, int H>
+static void run_ring(const double *Y, double *sink, int imbalance)
+{
+	const int kt = 2, nblocks = 16, nsplit = 8;
+	const int64_t nrow = 999936, ld = 1000000, npanels = nrow / H;
+	const int64_t pps = (npanels + nsplit - 1) / nsplit;
+	const int nwg = nblocks * kt * nsplit;
+	const size_t ldsb = (size_t) 64 * (B * H + 1) * 8 + 64;
+	CHECK(hipFuncSetAttribute((const void *) combo_ring<B, H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsb));
+	hipEvent_t e0, e1;
+	CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+	float best = 1e30f;
+	for (int rep = 0; rep < 4; rep++) {
+		CHECK(hipEventRecord(e0));
+		hipLaunchKernelGGL((combo_ring<B, H>), dim3(nwg), dim3(1024), ldsb, 0, Y, ld, nblocks, kt, npanels, pps, sink, imbalance);
+		CHECK(hipEventRecord(e1));
+		CHECK(hipEventSynchronize(e1));
+		float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+		if (rep > 0 && ms < best) best = ms;
+	}
+	printf("ring  %d slots x %3d rows (%zu B of LDS), counters, imbalance %d: %.3f ms (%.0f cycles per 128 rows)\n", B, H, ldsb, imbalance, best,
+	       best * 1e-3 * 2.4e9 / pps * 128.0 / H);
+	CHECK(hipEventDestroy(e0)); CHECK(hipEventDestroy(e1));
+}
+
 // ------------------------------------------------------------------------------------------- E
 // trace: the barrier + work loop of combo_16 (no DMA), one trip per asm block, with s_memtime stamps of
 // workgroup 0 for four panels in mid-run: arrival at the barrier, release, end of every trip.  What the
@@ -1068,6 +1202,21 @@ int main(int argc, char **argv)
 			run_combo(Y, sink, combo_8y1, 8, 12, 10, 1085.4, dma, work, "8 x 106 cols, 1 y set");
 			run_combo(Y, sink, combo_8, 8, 11, 11, 1167.4, dma, work, "8 x 114 cols, 2 y sets");
 			run_combo(Y, sink, combo_8y1, 8, 11, 11, 1167.4, dma, work, "8 x 114 cols, 1 y set");
+		}
+		CHECK(hipFree(Y));
+	}
+	if (!strcmp(which, "ring")) {
+		const int64_t maxrow = 1048576 + 1024, K = 128;
+		double *Y;
+		CHECK(hipMalloc(&Y, (size_t) maxrow * K * 8 + 4096));
+		CHECK(hipMemset(Y, 0, (size_t) maxrow * K * 8 + 4096));
+		for (int imb = 0; imb < 2; imb++) {
+			run_flag(Y, sink, imb, 1, "s_barrier per panel (trip by trip)");
+			run_ring<3, 104>(Y, sink, imb);
+			run_ring<4, 72>(Y, sink, imb);
+			run_ring<4, 64>(Y, sink, imb);
+			run_ring<5, 60>(Y, sink, imb);
+			run_ring<6, 48>(Y, sink, imb);
 		}
 		CHECK(hipFree(Y));
 	}
