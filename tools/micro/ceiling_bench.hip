@@ -777,8 +777,17 @@ combo_flag(const double *__restrict__ Y, int64_t ld, int nblocks, int kt, int64_
 							 (__attribute__((address_space(3))) void *) dst, 16, 0, 0);
 		}
 	};
-	auto peek = [&](int idx) { return __hip_atomic_load(flags + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
-	auto bump = [&](int idx) { if (lane == 0) __hip_atomic_fetch_add(flags + idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+	// (inline asm: for a C++ LDS access the compiler puts s_waitcnt vmcnt(0) first -- the LDS-DMA in flight might
+	// alias it -- and every poll would wait for the whole panel to land; round 2's numbers for this protocol had that)
+	const uint32_t flags_lds = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint32_t *) flags;
+	auto peek = [&](int idx) {
+		uint32_t v;
+		asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(flags_lds + 4u * (uint32_t) idx) : "memory");
+		return (uint32_t) __builtin_amdgcn_readfirstlane(v);
+	};
+	auto bump = [&](int idx) {
+		if (lane == 0) asm volatile("ds_add_u32 %0, %1" : : "v"(flags_lds + 4u * (uint32_t) idx), "v"(1u) : "memory");
+	};
 	d16 acc0 = 0.0, acc1 = 0.0;
 	u32x16 ya = 0, yb = 0;
 	u32x8 meta;
@@ -924,8 +933,17 @@ combo_ring(const double *__restrict__ Y, int64_t ld, int nblocks, int kt, int64_
 			}
 		}
 	};
-	auto peek = [&](int idx) { return __hip_atomic_load(flags + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
-	auto bump = [&](int idx) { if (lane == 0) __hip_atomic_fetch_add(flags + idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+	// (inline asm: for a C++ LDS access the compiler puts s_waitcnt vmcnt(0) first -- the LDS-DMA in flight might
+	// alias it -- and every poll would wait for the whole panel to land; round 2's numbers for this protocol had that)
+	const uint32_t flags_lds = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint32_t *) flags;
+	auto peek = [&](int idx) {
+		uint32_t v;
+		asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(flags_lds + 4u * (uint32_t) idx) : "memory");
+		return (uint32_t) __builtin_amdgcn_readfirstlane(v);
+	};
+	auto bump = [&](int idx) {
+		if (lane == 0) asm volatile("ds_add_u32 %0, %1" : : "v"(flags_lds + 4u * (uint32_t) idx), "v"(1u) : "memory");
+	};
 	d16 acc0 = 0.0, acc1 = 0.0;
 	u32x16 ya = 0, yb = 0;
 	u32x8 meta;
@@ -938,29 +956,32 @@ combo_ring(const double *__restrict__ Y, int64_t ld, int nblocks, int kt, int64_
 	for (int i = 0; i < D && i < np; i++) issue(pa + i, i);
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	for (int i = 0; i < D && i < np; i++) bump(i);
+	// (integer bookkeeping only: the loop below runs once per H rows, and whatever it costs beyond the
+	// protocol itself would be charged to the protocol)
 	int carry = 0;
-	const double mean = 51.2 * H / 128.0;
-	int pend_slot = -1;                                     // slot whose pieces this wavefront issued in the previous panel
+	constexpr int MEAN10 = 512 * H / 128;                   // records per wavefront and panel, tenths
+	int pend_slot = -1;
+	int slot = 0, tslot = D % B;
+	uint32_t need = 16u, need_done = 0u;                    // counters' targets for panel i / for panel i - 1 done
+	int acc10 = 0;
 	for (int64_t i = 0; i < np; i++) {
-		const int slot = (int) (i % B);
-		int recs = (int) mean + (int) ((i * 16 + w) % 5 == 0);
+		acc10 += MEAN10;
+		int recs = acc10 / 10; acc10 -= recs * 10;
 		if (imbalance) {
-			const uint32_t h = mix32((uint32_t) (L * 1000003 + i * 16 + w));
+			const uint32_t h = mix32((uint32_t) (L * 1000003 + (int) i * 16 + w));
 			const int z = (int) (h & 15) + (int) ((h >> 4) & 15) + (int) ((h >> 8) & 15) + (int) ((h >> 12) & 15) - 30;   // ~N(0, 9.2)
-			recs = (int) (mean + z * sqrt(mean) / 9.2) + (int) ((i * 16 + w) % 5 == 0);
-			if (recs < 4) recs = 4;
+			// sd of a Poisson count with this mean: sqrt(51.2 H / 128) = 7.155 sqrt(H / 128); z has sd 9.2
+			constexpr int K256 = (int) (256.0 * 7.155 / 9.2 * (H == 128 ? 1.0 : H == 104 ? 0.9014 : H == 72 ? 0.75 : H == 64 ? 0.7071 : H == 60 ? 0.6847 : 0.6124));
+			recs += (z * K256) >> 8;
+			if (recs < 2) recs = 2;
 		}
 		carry += recs;
-		int n = __builtin_amdgcn_readfirstlane(carry / 16);
-		carry -= n * 16;
+		int n = __builtin_amdgcn_readfirstlane(carry >> 4);
+		carry &= 15;
 		const uint32_t lanebase = (uint32_t) lane * (RS * 8u) + (uint32_t) slot * (H * 8u);
-		// panel i complete in LDS?
-		const uint32_t need = 16u * (uint32_t) (i / B + 1);
 		while (peek(slot) < need) __builtin_amdgcn_s_sleep(1);
 		bool issued = i + D >= np;
 		const bool had_issue = !issued;
-		const int tslot = (int) ((i + D) % B);
-		const uint32_t need_done = i >= 1 ? 16u * (uint32_t) ((i - 1) / B + 1) : 0u;
 		for (int t = 0; t <= n; t++) {
 			if (!issued && (i == 0 || peek(B + tslot) >= need_done)) {
 				issue(pa + i + D, tslot);
@@ -985,6 +1006,10 @@ combo_ring(const double *__restrict__ Y, int64_t ld, int nblocks, int kt, int64_
 			bump(pend_slot);
 		}
 		pend_slot = had_issue ? tslot : -1;
+		// next panel: its slot, the slot its look-ahead goes to (= the slot of this panel's predecessor's successor)
+		need_done = need;                                   // panel i done: the count that `need` was for panel i
+		tslot = slot + D + 1; if (tslot >= B) tslot -= B; if (tslot >= B) tslot -= B;
+		slot++; if (slot == B) { slot = 0; need += 16u; }
 	}
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	if (acc0[0] + acc1[3] + (double) ya[0] + (double) yb[1] == 123.456) sink[0] = acc0[1];
@@ -1215,7 +1240,6 @@ int main(int argc, char **argv)
 			run_ring<3, 104>(Y, sink, imb);
 			run_ring<4, 72>(Y, sink, imb);
 			run_ring<4, 64>(Y, sink, imb);
-			run_ring<5, 60>(Y, sink, imb);
 			run_ring<6, 48>(Y, sink, imb);
 		}
 		CHECK(hipFree(Y));
