@@ -229,7 +229,7 @@ def test_session_t_goes_through_the_device(hip, oracle):
 # 0.59 ms at BASELINE config 3: 41 nonzeros per wavefront between two barriers)
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("ngroup", [1, 7, 1000, 2300, 6000])
-@pytest.mark.parametrize("shape", [(70_000, 37, 0.02), (200_001, 5, 0.3), (65_536, 130, 0.001)])
+@pytest.mark.parametrize("shape", [(70_000, 37, 0.02), (200_001, 5, 0.3), (65_536, 130, 0.001), (100_003, 300, 0.05)])
 def test_rowsum_tall_operands(hip, oracle, ngroup, shape):
     nrow, ncol, dens = shape
     cp, ri, v = random_csc(nrow, ncol, dens, seed=61)
