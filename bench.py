@@ -401,7 +401,30 @@ def main():
         ms = timed(lambda: plan_t.run(Y2, ncol, out2))
         ex["matmul_A_Y(2b)"] = {"ms": ms, "GNZ/s": nnz / ms / 1e6,
                                 "GB/s": (nnz * 12 + ncol * K * 8 + lrow * K * 8) / ms / 1e6}
-        del plan_t, T, out2
+        del plan_t, T
+        # config 3: A %*% B, B = 1e4 x K sparse @ 1 %: the row-panel kernel on A itself (no t(A), no layout, no
+        # dense operand; kernels_spmm.hip); bytes as SURVEY.md section 8(d): A once + B + the dense result
+        from sparsearray_amd.device import matmul_csc_csc, _lib as _dl
+        bcp, bri, bv = synth.random_device_csc(ncol, K, 0.01, seed=303, device=dev)
+        Bs = DeviceCSC(ncol, bcp, bri, bv)
+        ws3 = torch.empty(_dl().svt_dev_matmul_csc_csc_ws_bytes(A.handle), dtype=torch.uint8, device=dev)
+        flag3 = [None]
+
+        def spmm():
+            flag3[0] = matmul_csc_csc(A, Bs, out=out2, ws=ws3)[1]
+        ms = timed(spmm)
+        Bd = torch.zeros((K, ncol), dtype=torch.float64, device=dev)           # the same product by the dense route
+        Bd[torch.repeat_interleave(torch.arange(K, device=dev), bcp[1:] - bcp[:-1]), bri.long()] = bv
+        T = A.t()
+        plan_t = PbcPlan(T, K, a.cbw, a.wpb, a.logr)
+        out3 = torch.empty((K, lrow), dtype=torch.float64, device=dev)
+        ms_dense = timed(lambda: plan_t.run(Bd, ncol, out3))
+        ex["svt_x_svt2(3)"] = {"ms": ms, "GNZ/s": nnz / ms / 1e6,
+                               "GB/s": (nnz * 12 + Bs.nnz * 12 + lrow * K * 8) / ms / 1e6,
+                               "nnz_B": int(Bs.nnz), "not_finite_flag": int(flag3[0].item()),
+                               "dense_route_ms": ms_dense,
+                               "max_abs_diff_vs_dense_route": float((out2 - out3).abs().max().item())}
+        del plan_t, T, out2, out3, Bd, Bs, ws3
         res["extras"] = ex
     if world == 1 and not a.no_cpu_baseline:
         ns = max(1, min(ncol, int(1e8 / max(nnz / ncol, 1))))   # <= 1e8 nz x K: 10-30 core-seconds

@@ -366,6 +366,19 @@ size_t svt_dev_transpose_ws_bytes(int64_t nrow, int64_t nnz);
 int svt_dev_transpose(const svt_dev_csc *A, int64_t *out_col_ptr, int32_t *out_row_idx,
 		      void *out_val, void *ws, size_t ws_bytes, void *stream);
 
+/* x %*% y for two sparse operands, y much sparser than a dense matrix (the `svt %*% svt2` of BASELINE config 3):
+   out[r + k * ldo] = sum over the nonzeros (j, b) of column k of B of b * A[r, j] -- for finite operands the sum
+   the reference forms per cell (C_crossprod2_SVT_SVT on t(x), src/SparseMatrix_mult.c:1037-1101: one operand's
+   leaves expanded, the other's walked over them, :728-820), without the order of its additions (the same
+   products, added as the lane groups get to them; exact for integer operands below 2^53).  A non-finite
+   value or an NA in either operand changes what the reference computes (its dirty-leaf loops multiply the
+   implicit zeros too): then `*not_finite` (device int, may be NULL; the first int of `ws` holds the same flag)
+   is set and `out` must be recomputed by the dense route (svt_matmul_SVT_SVT does).  Every cell of the
+   A->nrow x B->ncol result is written; ws: svt_dev_matmul_csc_csc_ws_bytes(A) bytes.  Asynchronous. */
+size_t svt_dev_matmul_csc_csc_ws_bytes(const svt_dev_csc *A);
+int svt_dev_matmul_csc_csc(const svt_dev_csc *A, const svt_dev_csc *B, double *out, int64_t ldo,
+			   void *ws, size_t ws_bytes, int *not_finite, void *stream);
+
 /* aperm(x, perm) for an N-d operand (C_aperm_SVT, src/SparseArray_aperm.c:935-970;
    R/SparseArray-aperm.R).  `dim` are the array's ndim extents (dim[0] = A->nrow,
    prod(dim[1..]) = A->ncol), `perm` is 1-based as in R.  Output: the CSC layout of

@@ -569,6 +569,22 @@ rowstats_whole_kernel(RowStatsArgs a, int G)
 	}
 }
 
+// pt[q * ncol + j] = number of offsets of leaf j below q << ps, q = 0 .. npan ((npan + 1) * ncol entries)
+void launch_rowpanel_table(const int64_t *col_ptr, const int32_t *row_idx, int64_t ncol, int64_t nnz_hint,
+			   int64_t npan, int ps, int32_t *pt, hipStream_t s)
+{
+	if (ncol > 0 && (size_t) (npan + 1) * PT_LEAVES * 4 <= 64 * 1024) {
+		hipLaunchKernelGGL(rowpanel_table16_kernel, dim3((unsigned) ((ncol + PT_LEAVES - 1) / PT_LEAVES)),
+				   dim3(PT_LEAVES * 64), (size_t) (npan + 1) * PT_LEAVES * 4, s,
+				   col_ptr, row_idx, ncol, npan, ps, pt);
+	} else if (ncol > 0) {                      // very tall arrays: the table rows do not fit LDS
+		// (grid == ncol selects the workgroup-per-leaf form; never equal to (ncol+3)/4 for ncol > 1)
+		const bool wide = nnz_hint / ncol >= 1024 && ncol > 1;
+		hipLaunchKernelGGL(rowpanel_table_kernel, dim3((unsigned) (wide ? ncol : (ncol + 3) / 4)),
+				   dim3(256), 0, s, col_ptr, row_idx, ncol, npan, ps, pt);
+	}
+}
+
 // `ws`: rowstats_panel_ws_bytes() bytes.
 int launch_rowstats_panel(const RowStatsArgs &a, void *ws, hipStream_t s)
 {
@@ -606,16 +622,7 @@ int launch_rowstats_panel(const RowStatsArgs &a, void *ws, hipStream_t s)
 	int32_t *pt = (int32_t *) ws;
 	if (a.inner > 65535)
 		return svt_set_error("row stats: more than 65535 output columns per panel row");
-	if (a.ncol > 0 && (size_t) (npan + 1) * PT_LEAVES * 4 <= 64 * 1024) {
-		hipLaunchKernelGGL(rowpanel_table16_kernel, dim3((unsigned) ((a.ncol + PT_LEAVES - 1) / PT_LEAVES)),
-				   dim3(PT_LEAVES * 64), (size_t) (npan + 1) * PT_LEAVES * 4, s,
-				   a.col_ptr, a.row_idx, a.ncol, npan, ps, pt);
-	} else if (a.ncol > 0) {                    // very tall arrays: the table rows do not fit LDS
-		// (grid == ncol selects the workgroup-per-leaf form; never equal to (ncol+3)/4 for ncol > 1)
-		const bool wide = a.nnz_hint / a.ncol >= 1024 && a.ncol > 1;
-		hipLaunchKernelGGL(rowpanel_table_kernel, dim3((unsigned) (wide ? a.ncol : (a.ncol + 3) / 4)),
-				   dim3(256), 0, s, a.col_ptr, a.row_idx, a.ncol, npan, ps, pt);
-	}
+	launch_rowpanel_table(a.col_ptr, a.row_idx, a.ncol, a.nnz_hint, npan, ps, pt, s);
 	// lanes per leaf segment ~ mean segment length (nnz unknown here: the
 	// caller passes it in a.nnz_hint, 0 = assume long segments)
 	int G = 64;

@@ -1,0 +1,191 @@
+// A %*% B for two sparse operands in the CSC device layout, B much sparser than a dense matrix
+// (svt %*% svt2 of BASELINE config 3: A 1e6 x 1e4 @ 1 %, B 1e4 x 128 @ 1 % = 12800 nonzeros).
+//
+// The reference computes x %*% y as .crossprod2_SparseMatrix_SparseMatrix(t(x), y) ->
+// C_crossprod2_SVT_SVT (src/SparseMatrix_mult.c:1037-1101): it expands the leaves of one operand into a
+// dense buffer and walks the leaves of the other over it (crossprod2_Lpp_* / crossprod2_Rpp_*, :728-820):
+// per output cell the sum, in ascending order of the inner index, of the products over the nonzeros of the
+// walked leaf -- products with the buffer's zeros add exact zeros.  With finite operands that is the sum
+// over the inner indices where BOTH operands hold a nonzero, and that is what this kernel adds up, without
+// a dense operand:  out[:, k] = sum over the nonzeros (j, b) of B[:, k] of  b * A[:, j].
+// (The dense route -- densify B, product on the panel-blocked layout of t(A) -- multiplies every nonzero of A
+// with all K columns: 1.28e10 multiply-adds and a 2.2 ms transposition + a 2 ms layout build where 1.3e8
+// multiply-adds and one pass over the offsets do.)
+//
+// Workgroup = a panel of P rows x KW columns of the result, kept in LDS (KW * P * 8 bytes <= 64 KB: 8192 rows of
+// one column for tall operands, two workgroups per CU).  The part of
+// column j of A that falls into the panel is one contiguous run of its (ascending) offsets; the run bounds
+// come from the table of launch_rowpanel_table() (kernels_rowstats.hip), one pass over A's offsets.  A group
+// of G lanes takes one nonzero of B at a time -- the pairs (j, b) of the workgroup's KW columns, dealt round
+// the groups -- and adds b * A[run] into the column's LDS image (ds_add_f64: two pairs can meet in a row);
+// the image leaves as whole, coalesced columns.  Not a sum in the reference's order: the additions of one
+// cell come in the order the lane groups get to them (differences of the last bits between runs; integer
+// operands give the reference's result exactly as long as the sums stay below 2^53, where the order of the
+// additions does not matter).
+// Config 3 (tools/debug/spmm_sweep.sh, whole call): 8192 x 1 with 32 lanes per run 0.86 ms; 8192 x 2 (128 KB) 1.05; 16384 x 1
+// 0.95; 4096 x 2 1.01; 64 lanes per run 0.97; the dense route 2.35-2.45 ms + 2.2 ms t(A) + 2.0 ms layout once per A.
+//
+// A non-finite value or an NA ANYWHERE in either operand changes what the reference computes (its dirty-leaf
+// loops multiply the implicit zeros too, src/SparseVec_dotprod.c:48-65): a scan of all values (0.8 GB at
+// config 3: 0.16 of the call's ~0.8 ms) raises *flag and the caller takes the dense route.
+#include "svt_common.h"
+
+#define SPMM_NT 1024
+#define SPMM_LDS (64 * 1024)          // per workgroup: two workgroups per CU
+#ifndef SPMM_U
+#define SPMM_U 4
+#endif
+
+size_t spmm_ws_bytes(int64_t nrow, int64_t ninner)
+{
+	// the table of run bounds for the shortest panels this file uses (64 rows)
+	int ps = 13;
+	while (ps > 6 && ((int64_t) 1 << ps) >= 2 * (nrow > 0 ? nrow : 1)) ps--;
+	const int64_t npan = (nrow + ((int64_t) 1 << ps) - 1) >> ps;
+	return (size_t) (ninner > 0 ? ninner : 1) * (size_t) (npan + 1) * 4 + 256;
+}
+
+template <typename T> __device__ inline bool spmm_bad(T v);
+template <> __device__ inline bool spmm_bad<double>(double v) { return !(fabs(v) <= 1.7976931348623157e308); }
+template <> __device__ inline bool spmm_bad<int>(int v) { return v == NA_INT; }
+
+// *flag = 1 when a value is NaN / Inf / NA (doubles) or NA_integer_ (ints): ALL values of an operand, not only
+// those the product reads -- an Inf in a leaf of x poisons its dot products with every leaf of y, matched or not
+// (compute_dotprods2_with_left_double_leaf, src/SparseMatrix_mult.c:632-652: a dirty leaf goes to the loops that
+// multiply the implicit zeros; a clean expanded leaf meets the other operand's Inf as 0 * Inf)
+template <typename T>
+__global__ void __launch_bounds__(256)
+spmm_scan_values_kernel(const T *__restrict__ val, int64_t n, int *__restrict__ flag)
+{
+	bool bad = false;
+	for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t) gridDim.x * blockDim.x)
+		bad |= spmm_bad<T>(val[i]);
+	if (__ballot(bad) != 0 && (threadIdx.x & 63) == 0) *flag = 1;
+}
+
+static void spmm_scan_values(const void *val, int Rtype, int64_t n, int *flag, hipStream_t s)
+{
+	if (n <= 0) return;
+	int64_t nb = (n + 256 * 8 - 1) / (256 * 8);
+	if (nb > 256 * 16) nb = 256 * 16;
+	if (Rtype == SVT_REALSXP)
+		hipLaunchKernelGGL(spmm_scan_values_kernel<double>, dim3((unsigned) nb), dim3(256), 0, s, (const double *) val, n, flag);
+	else
+		hipLaunchKernelGGL(spmm_scan_values_kernel<int>, dim3((unsigned) nb), dim3(256), 0, s, (const int *) val, n, flag);
+}
+
+template <typename TA, typename TB>
+__global__ void __launch_bounds__(SPMM_NT)
+spmm_csc_csc_kernel(SpmmArgs a, int KW, int G)
+{
+	extern __shared__ double acc[];                 // [KW][P]
+	const int tid = threadIdx.x;
+	const int P = 1 << a.ps;
+	const int64_t q = blockIdx.x, r0 = q << a.ps;
+	const int64_t k0 = (int64_t) blockIdx.y * KW;
+	const int kw = (int) (a.K - k0 < KW ? a.K - k0 : KW);
+	const int np = (int) (a.nrow - r0 < P ? a.nrow - r0 : P);
+	for (int x = tid; x < kw * P; x += SPMM_NT) acc[x] = 0.0;
+	// the pairs of the workgroup's columns, flattened: pair t belongs to column kk with pre[kk] <= t < pre[kk + 1]
+	__shared__ int64_t bbeg[17];
+	__shared__ int32_t pre[17];
+	if (tid == 0) {
+		int32_t run = 0;
+		for (int kk = 0; kk < kw; kk++) {
+			bbeg[kk] = a.b_ptr[k0 + kk];
+			pre[kk] = run;
+			run += (int32_t) (a.b_ptr[k0 + kk + 1] - a.b_ptr[k0 + kk]);
+		}
+		pre[kw] = run;
+	}
+	__syncthreads();
+	const int npairs = pre[kw];
+	const int grp = tid / G, sl = tid % G, ngrp = SPMM_NT / G;
+	const TA *__restrict__ av = (const TA *) a.a_val;
+	const TB *__restrict__ bv = (const TB *) a.b_val;
+	const int32_t *__restrict__ pt0 = a.pt + q * a.ninner, *__restrict__ pt1 = pt0 + a.ninner;
+	// SPMM_U pairs per group in flight: their bounds are fetched together, then their runs
+	for (int t0 = grp; t0 < npairs; t0 += SPMM_U * ngrp) {
+		int64_t xb[SPMM_U], xe[SPMM_U];
+		double bval[SPMM_U];
+		int kkof[SPMM_U];
+#pragma unroll
+		for (int u = 0; u < SPMM_U; u++) {
+			const int t = t0 + u * ngrp;
+			xb[u] = xe[u] = 0; bval[u] = 0.0; kkof[u] = 0;
+			if (t < npairs) {
+				int kk = 0;
+				while (kk + 1 < kw && pre[kk + 1] <= t) kk++;
+				const int64_t pos = bbeg[kk] + (t - pre[kk]);
+				const int64_t j = a.b_idx[pos];
+				const TB b = bv[pos];
+				const int64_t base = a.a_ptr[j];
+				xb[u] = base + pt0[j] + sl; xe[u] = base + pt1[j];
+				bval[u] = (double) b; kkof[u] = kk;
+			}
+		}
+		bool more = true;
+		while (more) {
+			TA v[SPMM_U];
+			int r[SPMM_U];
+#pragma unroll
+			for (int u = 0; u < SPMM_U; u++)
+				if (xb[u] < xe[u]) { v[u] = av[xb[u]]; r[u] = (int) (a.a_idx[xb[u]] - r0); }
+			more = false;
+#pragma unroll
+			for (int u = 0; u < SPMM_U; u++)
+				if (xb[u] < xe[u]) {
+					atomicAdd(&acc[kkof[u] * P + r[u]], (double) v[u] * bval[u]);
+					xb[u] += G;
+					more |= xb[u] < xe[u];
+				}
+		}
+	}
+	__syncthreads();
+	for (int kk = 0; kk < kw; kk++) {
+		double *__restrict__ dst = a.out + (k0 + kk) * a.ldo + r0;
+		for (int x = tid; x < np; x += SPMM_NT) dst[x] = acc[kk * P + x];
+	}
+}
+
+// ws: spmm_ws_bytes(nrow, ninner) bytes (the table of run bounds).  Every cell of out[0 .. nrow) x [0 .. K) is written.
+int launch_spmm_csc_csc(SpmmArgs a, int64_t a_nnz, int64_t b_nnz, void *ws, hipStream_t s)
+{
+	if (a.nrow <= 0 || a.K <= 0)
+		return 0;
+	spmm_scan_values(a.a_val, a.a_type, a_nnz, a.flag, s);
+	spmm_scan_values(a.b_val, a.b_type, b_nnz, a.flag, s);
+	int ps = 13;                                    // 8192-row panels; shorter operands: one or two panels
+	while (ps > 6 && ((int64_t) 1 << ps) >= 2 * a.nrow) ps--;
+	const int64_t P = (int64_t) 1 << ps, npan = (a.nrow + P - 1) >> ps;
+	int KW = (int) (SPMM_LDS / (P * 8));
+	if (KW > 16) KW = 16;
+	if (KW > a.K) KW = (int) a.K;
+	// with few panels: fewer columns per workgroup, so that the grid fills the chip
+	while (KW > 1 && npan * ((a.K + KW - 1) / KW) < 512) KW = (KW + 1) / 2;
+	int32_t *pt = (int32_t *) ws;
+	launch_rowpanel_table(a.a_ptr, a.a_idx, a.ninner, a_nnz, npan, ps, pt, s);
+	a.pt = pt; a.npan = npan; a.ps = ps;
+	// lanes per run: the largest power of two <= half its mean length (81 nonzeros at config 3: three trips of
+	// 32 lanes = 96 slots, not two of 64 = 128)
+	int G = 64;
+	if (a.ninner > 0) {
+		const double run = (double) a_nnz / ((double) a.ninner * (double) npan);
+		while (G > 8 && run < 2.0 * G) G >>= 1;
+	}
+	const size_t lds = (size_t) KW * P * 8;
+	dim3 grid((unsigned) npan, (unsigned) ((a.K + KW - 1) / KW));
+	if (grid.y > 65535)
+		return svt_set_error("sparse x sparse product: too many columns for one launch");
+#define SPMM_GO(TA, TB) do { \
+		(void) hipFuncSetAttribute((const void *) spmm_csc_csc_kernel<TA, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); \
+		hipLaunchKernelGGL((spmm_csc_csc_kernel<TA, TB>), grid, dim3(SPMM_NT), lds, s, a, KW, G); } while (0)
+	if (a.a_type == SVT_REALSXP && a.b_type == SVT_REALSXP) SPMM_GO(double, double);
+	else if (a.a_type == SVT_INTSXP && a.b_type == SVT_INTSXP) SPMM_GO(int, int);
+	else if (a.a_type == SVT_REALSXP && a.b_type == SVT_INTSXP) SPMM_GO(double, int);
+	else if (a.a_type == SVT_INTSXP && a.b_type == SVT_REALSXP) SPMM_GO(int, double);
+	else return svt_set_error("sparse x sparse product: unsupported operand types");
+#undef SPMM_GO
+	HIP_TRY(hipGetLastError());
+	return 0;
+}

@@ -156,6 +156,19 @@ size_t rowstats_scratch_bytes(int opcode, int out_Rtype, int64_t out_len);
 int launch_rowstats(const RowStatsArgs &a, int64_t nnz, hipStream_t s);      // memory atomics
 size_t rowstats_panel_ws_bytes(int64_t nrow, int64_t ncol);
 int launch_rowstats_panel(const RowStatsArgs &a, void *ws, hipStream_t s);      // LDS row panels
+void launch_rowpanel_table(const int64_t *col_ptr, const int32_t *row_idx, int64_t ncol, int64_t nnz_hint,
+			   int64_t npan, int ps, int32_t *pt, hipStream_t s);
+
+// sparse x sparse product by row panels (kernels_spmm.hip)
+struct SpmmArgs {
+	const int64_t *a_ptr; const int32_t *a_idx; const void *a_val; int a_type; int64_t nrow, ninner;
+	const int64_t *b_ptr; const int32_t *b_idx; const void *b_val; int b_type; int64_t K;
+	double *out; int64_t ldo;           // out[r + k * ldo]
+	const int32_t *pt; int64_t npan; int ps;
+	int *flag;                          // set when a non-finite value / an NA took part: the result is not the reference's
+};
+size_t spmm_ws_bytes(int64_t nrow, int64_t ninner);
+int launch_spmm_csc_csc(SpmmArgs a, int64_t a_nnz, int64_t b_nnz, void *ws, hipStream_t s);
 
 size_t transpose_ws_bytes(int64_t nrow, int64_t nnz);
 int launch_transpose(const int64_t *col_ptr, const int32_t *row_idx, const void *val, int Rtype,

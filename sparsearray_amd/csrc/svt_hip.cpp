@@ -777,6 +777,42 @@ extern "C" int svt_dev_transpose(const svt_dev_csc *A, int64_t *out_col_ptr, int
 				out_col_ptr, out_row_idx, out_val, ws, (hipStream_t) stream);
 }
 
+// A %*% B, both sparse (kernels_spmm.hip): out[r + k * ldo], r < A->nrow, k < B->ncol.
+extern "C" size_t svt_dev_matmul_csc_csc_ws_bytes(const svt_dev_csc *A)
+{
+	return spmm_ws_bytes(A->nrow, A->ncol) + 256;       // [flag][table of run bounds]
+}
+
+static SpmmArgs spmm_args(const svt_dev_csc *A, const svt_dev_csc *B, double *out, int64_t ldo, int *flag)
+{
+	SpmmArgs a;
+	memset(&a, 0, sizeof(a));
+	a.a_ptr = A->col_ptr; a.a_idx = A->row_idx; a.a_val = A->val; a.a_type = A->Rtype;
+	a.nrow = A->nrow; a.ninner = A->ncol;
+	a.b_ptr = B->col_ptr; a.b_idx = B->row_idx; a.b_val = B->val; a.b_type = B->Rtype; a.K = B->ncol;
+	a.out = out; a.ldo = ldo; a.flag = flag;
+	return a;
+}
+
+extern "C" int svt_dev_matmul_csc_csc(const svt_dev_csc *A, const svt_dev_csc *B, double *out, int64_t ldo,
+				      void *ws, size_t ws_bytes, int *not_finite, void *stream)
+{
+	if (A->ncol != B->nrow)
+		return svt_set_error("svt_dev_matmul_csc_csc: non-conformable operands");
+	if (ws_bytes < svt_dev_matmul_csc_csc_ws_bytes(A))
+		return svt_set_error("svt_dev_matmul_csc_csc: workspace too small");
+	if (ldo < A->nrow)
+		return svt_set_error("svt_dev_matmul_csc_csc: leading dimension of the result too small");
+	hipStream_t s = (hipStream_t) stream;
+	int *flag = (int *) ws;
+	HIP_TRY(hipMemsetAsync(flag, 0, 4, s));
+	if (launch_spmm_csc_csc(spmm_args(A, B, out, ldo, flag), A->nnz, B->nnz, (char *) ws + 256, s))
+		return -1;
+	if (not_finite != NULL)
+		HIP_TRY(hipMemcpyAsync(not_finite, flag, 4, hipMemcpyDeviceToDevice, s));
+	return 0;
+}
+
 static int aperm_args(int ndim, const int *perm, int *perm0)
 {
 	if (ndim < 1 || ndim > 8)
@@ -1377,6 +1413,22 @@ extern "C" int svt_matmul_SVT_SVT(const svt_view *x, const svt_view *y, double *
 	const int64_t Rpp_nops = view_nzcount(x) * out_ncol;
 	CscGuard X(x);
 	if (X.h == NULL) return -1;
+	// y much sparser than a dense matrix (<= 5 % filled), finite operands: the row-panel kernel on x itself,
+	// no transposition, no dense operand (kernels_spmm.hip); a non-finite value or an NA anywhere sends the
+	// product down the reference's route below
+	if (view_nzcount(y) * 20 <= (int64_t) y->dim[0] * y->dim[1]) {
+		CscGuard Ys(y);
+		if (Ys.h == NULL) return -1;
+		DevBuf Os, Ws;
+		int bad = 1;
+		if (Os.alloc(out_n * 8) || Ws.alloc(svt_dev_matmul_csc_csc_ws_bytes(X.h)))
+			return -1;
+		if (svt_dev_matmul_csc_csc(X.h, Ys.h, Os.as<double>(), out_nrow, Ws.p, Ws.bytes, NULL, 0))
+			return -1;
+		HIP_TRY(hipMemcpy(&bad, Ws.p, 4, hipMemcpyDeviceToHost));
+		if (!bad)
+			return staged_download(out, Os.p, out_n * 8) ? -1 : 0;
+	}
 	int own_T = 1;
 	svt_dev_csc *T = transposed_for(X, &own_T);
 	OwnedCsc TX = { T, own_T };

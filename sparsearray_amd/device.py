@@ -54,6 +54,10 @@ def _lib():
                                                     c_size_t, c_void_p, c_int]
         lib.svt_dev_colstats.argtypes = [c_void_p, c_int, c_int, c_double, c_int64,
                                          c_void_p, c_void_p, c_void_p]
+        lib.svt_dev_matmul_csc_csc_ws_bytes.restype = c_size_t
+        lib.svt_dev_matmul_csc_csc_ws_bytes.argtypes = [c_void_p]
+        lib.svt_dev_matmul_csc_csc.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_size_t,
+                                               c_void_p, c_void_p]
         lib.svt_dev_colmedians_ws_bytes.restype = c_size_t
         lib.svt_dev_colmedians_ws_bytes.argtypes = [c_int64, c_int64]
         lib.svt_dev_colmedians.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
@@ -255,6 +259,23 @@ def colmedians(A: DeviceCSC, na_rm=False, out=None, ws=None):
     _check(_lib().svt_dev_colmedians(A.handle, int(na_rm), out.data_ptr(), ws.data_ptr(),
                                      ws.numel(), _stream()))
     return out
+
+
+def matmul_csc_csc(A: DeviceCSC, B: DeviceCSC, out=None, ws=None):
+    """A %*% B for two resident sparse operands, B much sparser than a dense matrix (include/svt_hip.h,
+    svt_dev_matmul_csc_csc).  Returns (out, not_finite): out is the (B.ncol, A.nrow) C-contiguous tensor that is
+    the column-major A.nrow x B.ncol matrix; not_finite is a device int32 tensor, nonzero when a non-finite value
+    or an NA took part -- the result then has to come from the dense route."""
+    assert A.ncol == B.nrow
+    dev = A.val.device
+    if out is None:
+        out = torch.empty((B.ncol, A.nrow), dtype=torch.float64, device=dev)
+    if ws is None:
+        ws = torch.empty(_lib().svt_dev_matmul_csc_csc_ws_bytes(A.handle), dtype=torch.uint8, device=dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    _check(_lib().svt_dev_matmul_csc_csc(A.handle, B.handle, out.data_ptr(), A.nrow, ws.data_ptr(), ws.numel(),
+                                         flag.data_ptr(), _stream()))
+    return out, flag
 
 
 def rowsums(A: DeviceCSC, na_rm=False, inner=1, out=None, ws=None):

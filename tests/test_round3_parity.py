@@ -322,3 +322,56 @@ def test_product_with_cus_left_idle(hip, oracle, spare):
         assert_equal(out.cpu().numpy().T, want, tol=1e-9, atol=1e-11, what="sized spared, run unspared")
     finally:
         set_spare_cus(0)
+
+
+# ---------------------------------------------------------------------------------------------
+# sparse x sparse product by row panels (kernels_spmm.hip)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(50_000, 700, 40, 0.01, 0.02), (9_000, 300, 130, 0.05, 0.01), (100, 60, 7, 0.2, 0.05),
+                                   (20_000, 50, 3, 0.3, 0.04), (70_001, 1200, 17, 0.004, 0.03)])
+@pytest.mark.parametrize("dtype", ["double", "integer"])
+def test_sparse_x_sparse_by_row_panels(hip, oracle, shape, dtype):
+    """svt_dev_matmul_csc_csc against the oracle's x %*% y (the reference's C_crossprod2_SVT_SVT on t(x)) and
+    against the dense route of the library."""
+    from test_hip_device_level import _dev
+    from sparsearray_amd.device import matmul_csc_csc
+    nrow, ninner, K, da, db = shape
+    cpa, ria, va = random_csc(nrow, ninner, da, seed=81)
+    cpb, rib, vb = random_csc(ninner, K, db, seed=82)
+    if dtype == "integer":
+        va = np.round(va * 1000).astype(np.int32); vb = np.round(vb * 1000).astype(np.int32)
+        va[va == 0] = 7; vb[vb == 0] = -3
+    x = SVT_SparseArray.from_csc((nrow, ninner), dtype, cpa, ria, va)
+    y = SVT_SparseArray.from_csc((ninner, K), dtype, cpb, rib, vb)
+    want = oracle.matmul(x, y)
+    A = _dev(cpa, ria, va, nrow)
+    B = _dev(cpb, rib, vb, ninner)
+    out, flag = matmul_csc_csc(A, B)
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0
+    got = out.cpu().numpy().T
+    if dtype == "integer":
+        assert_identical(got, want, what="sparse x sparse, integer")
+    else:
+        assert_equal(got, want, tol=1e-12, atol=1e-13, what="sparse x sparse")
+    # the host-level entry point takes the same kernel for such operands
+    assert_equal(hip.matmul(x, y), want, tol=1e-12, atol=1e-13, what="x %*% y")
+
+
+def test_sparse_x_sparse_not_finite_takes_the_dense_route(hip, oracle):
+    """A non-finite value or an NA in either operand: the flag goes up, and the entry point returns the
+    reference's result (its dirty-leaf loops multiply the implicit zeros too)."""
+    from test_hip_device_level import _dev
+    from sparsearray_amd.device import matmul_csc_csc
+    nrow, ninner, K = 3000, 90, 11
+    cpa, ria, va = random_csc(nrow, ninner, 0.05, seed=83)
+    cpb, rib, vb = random_csc(ninner, K, 0.04, seed=84)
+    for which, poison in (("x", np.inf), ("y", np.nan), ("x", NA_real)):
+        va2, vb2 = va.copy(), vb.copy()
+        (va2 if which == "x" else vb2)[5] = poison
+        x = SVT_SparseArray.from_csc((nrow, ninner), "double", cpa, ria, va2)
+        y = SVT_SparseArray.from_csc((ninner, K), "double", cpb, rib, vb2)
+        _, flag = matmul_csc_csc(_dev(cpa, ria, va2, nrow), _dev(cpb, rib, vb2, ninner))
+        torch.cuda.synchronize()
+        assert int(flag.item()) == 1
+        assert_equal(hip.matmul(x, y), oracle.matmul(x, y), tol=1e-12, atol=1e-13, strict_na=True, what=f"{which} {poison}")
