@@ -451,6 +451,16 @@ def sharded_matmul(A_rows_t_plan, Y2: torch.Tensor, out_local: torch.Tensor):
     return out_local
 
 
+def sharded_matmul_sparse(A_rows, B, out_local=None):
+    """A %*% B, both sparse (BASELINE config 3), with A sharded on rows and B (small) replicated: rank g owns
+    rows [r0, r1) of the result and computes them with the row-panel kernel on its block of A
+    (`device.matmul_csc_csc`); no collective.  Returns (out_local, not_finite): a nonzero flag on ANY rank
+    means the product has to be redone by the dense route on every rank (the caller reduces the flags with
+    `dist.all_reduce(flag, op=MAX)` when it needs the decision to be collective)."""
+    from .device import matmul_csc_csc
+    return matmul_csc_csc(A_rows, B, out=out_local)
+
+
 # --------------------------------------------------------------------------------------------
 # the rows of SURVEY.md section 8e that move a sparse operand or reduce a dense one
 # --------------------------------------------------------------------------------------------
