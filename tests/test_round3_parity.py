@@ -375,3 +375,37 @@ def test_sparse_x_sparse_not_finite_takes_the_dense_route(hip, oracle):
         torch.cuda.synchronize()
         assert int(flag.item()) == 1
         assert_equal(hip.matmul(x, y), oracle.matmul(x, y), tol=1e-12, atol=1e-13, strict_na=True, what=f"{which} {poison}")
+
+
+def test_sparse_x_sparse_random_shapes(hip):
+    """Edge shapes of the row-panel kernel (one panel, a ragged last panel, empty columns and rows, K = 1,
+    more columns than a workgroup takes, dense-ish operands) against a dense numpy product."""
+    from test_hip_device_level import _dev
+    from sparsearray_amd.device import matmul_csc_csc
+    rng = np.random.default_rng(91)
+    shapes = [(1, 1, 1), (63, 5, 1), (64, 1, 3), (129, 40, 19), (8191, 9, 2), (8193, 33, 40), (16385, 3, 70),
+              (30000, 200, 5), (5000, 64, 300), (70000, 17, 33)]
+    for nrow, ninner, K in shapes:
+        for da, db in ((0.3, 0.5), (0.02, 0.05), (0.0, 0.1), (0.1, 0.0)):
+            a = (rng.random((nrow, ninner)) < da) * rng.uniform(-2, 2, (nrow, ninner))
+            b = (rng.random((ninner, K)) < db) * rng.uniform(-2, 2, (ninner, K))
+            if ninner > 2:
+                a[:, ninner // 2] = 0.0                      # an empty column of A
+                b[ninner // 3, :] = 0.0                      # an empty row of B
+            def csc(m):
+                cp = np.zeros(m.shape[1] + 1, dtype=np.int64)
+                ri, vv = [], []
+                for j in range(m.shape[1]):
+                    nz = np.nonzero(m[:, j])[0]
+                    ri.append(nz); vv.append(m[nz, j]); cp[j + 1] = cp[j] + len(nz)
+                return cp, (np.concatenate(ri) if ri else np.zeros(0)).astype(np.int32), \
+                    (np.concatenate(vv) if vv else np.zeros(0)).astype(np.float64)
+            A = _dev(*csc(a), nrow)
+            B = _dev(*csc(b), ninner)
+            out, flag = matmul_csc_csc(A, B)
+            torch.cuda.synchronize()
+            assert int(flag.item()) == 0
+            want = a @ b
+            got = out.cpu().numpy().T
+            assert got.shape == want.shape
+            assert np.allclose(got, want, rtol=1e-12, atol=1e-12), (nrow, ninner, K, da, db, np.abs(got - want).max())
