@@ -373,6 +373,74 @@ combo_16(const double *__restrict__ Y, int64_t ld, int nblocks, int kt, int64_t 
 	}
 	if (acc0[0] + acc1[3] + (double) ya[0] + (double) yb[1] + (double) hi[2] + (double) ad[1] == 123.456) sink[0] = acc0[1];
 }
+// combo_16 with the DMA pieces issued by the two oldest wavefronts of every SIMD only (8 pieces each): they wait
+// at the barrier anyway (`trace`), the youngest are the panel's critical path
+__global__ void __launch_bounds__(16 * 64)
+combo_16old(const double *__restrict__ Y, int64_t ld, int nblocks, int kt, int64_t npanels,
+	     int64_t panels_per_split, double *sink, double trips_per_panel, int dma, int work)
+{
+	extern __shared__ double lds[];
+	constexpr int RS = 129, BUF = 64 * RS, NPIECE = (64 + 16 - 1) / 16;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int L = blockIdx.x;
+	const int xcd = L % 8, j = L / 8;
+	const int u = j / nblocks;
+	const int kh = u % kt, sp = (u / kt) * 8 + xcd;
+	const int64_t pa = (int64_t) sp * panels_per_split;
+	int64_t pb = pa + panels_per_split;
+	if (pb > npanels) pb = npanels;
+	if (pa >= pb) return;
+	const int k0 = kh * 64;
+	for (int i = tid; i < 2 * BUF; i += 16 * 64) lds[i] = 1.0;
+	__syncthreads();
+	auto issue = [&](int64_t p, int buf) {
+#pragma unroll
+		for (int q = 0; q < 2 * NPIECE; q++) {          // the two oldest wavefronts of every SIMD stage the whole panel
+			const int kk = w * 2 * NPIECE + q;
+			if (w < 8 && kk < 64) {
+				const double *src = Y + (int64_t) (k0 + kk) * ld + p * 128 + lane * 2;
+				double *dst = lds + buf * BUF + kk * RS;
+				__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) src,
+								 (__attribute__((address_space(3))) void *) dst, 16, 0, 0);
+			}
+		}
+	};
+	d16 acc0 = 0.0, acc1 = 0.0;
+	u32x16 ya = 0, yb = 0, hi = 0;
+	u32x8 ad = 0;
+	u32x8 meta;
+	const int rows[8] = {3, 17, 40, 66, 71, 90, 101, 120};
+	const int cols[8] = {0, 5, 9, 12, 3, 7, 14, 15};
+#pragma unroll
+	for (int q = 0; q < 8; q++) meta[q] = ((uint32_t) (rows[q] * 8) << 16) | (uint32_t) (2 * cols[q]);
+	const double one = 1.0000001;
+	if (dma) issue(pa, 0);
+	for (int64_t p = pa; p < pb; p++) {
+		const int buf = (int) ((p - pa) & 1);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__builtin_amdgcn_s_barrier();
+		if (dma && p + 1 < pb) issue(p + 1, buf ^ 1);
+		const int64_t i = p - pa;
+		uint32_t n = (uint32_t) ((int64_t) ((i + 1) * trips_per_panel) - (int64_t) (i * trips_per_panel));
+		n = __builtin_amdgcn_readfirstlane(n);
+		const uint32_t lanebase = (uint32_t) lane * 1032u + (uint32_t) buf * (BUF * 8u);
+		if (work && n > 0) {
+			if constexpr (false) {
+				asm volatile(LOOP_HEAD ADDR_1 FMAR_1 WAIT ADDR_1 FMAR_1 WAIT LOOP_TAIL
+					     : "+{v[44:75]}"(acc0), "+{v[76:107]}"(acc1), [n] "+s"(n), "+{v[12:27]}"(ya),
+					       "+{v[2:9]}"(ad), "+{v[112:127]}"(hi)
+					     : [lb] "v"(lanebase), [one] "s"(one), "{s[28:35]}"(meta) : "memory", "scc", "s36");
+			} else {
+				asm volatile(LOOP_HEAD ADDR_A READ_A FMAI_B WAIT ADDR_B READ_B FMAI_A WAIT LOOP_TAIL
+					     : "+{v[44:75]}"(acc0), "+{v[76:107]}"(acc1), [n] "+s"(n), "+{v[12:27]}"(ya),
+					       "+{v[108:123]}"(yb), "+{v[112:127]}"(hi)
+					     : [lb] "v"(lanebase), [one] "s"(one), "{s[28:35]}"(meta) : "memory", "scc", "s36");
+			}
+		}
+	}
+	if (acc0[0] + acc1[3] + (double) ya[0] + (double) yb[1] + (double) hi[2] + (double) ad[1] == 123.456) sink[0] = acc0[1];
+}
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define ADDR_A10 ADDR_A A1(28, 36) A1(30, 37)
 #define ADDR_B10 ADDR_B A1(124, 36) A1(126, 37)
@@ -1348,6 +1416,7 @@ int main(int argc, char **argv)
 			run_combo(Y, sink, combo_16, 16, 16, 8, 819.2, 1, 1, "with the DMA: 16 x 40 cols, 2 y sets");
 			run_combo(Y, sink, combo_16r, 16, 16, 8, 819.2, 1, 1, "with the DMA: adds before the wait");
 			run_combo(Y, sink, combo_16x10, 16, 16, 8, 819.2 * 0.8, 1, 1, "with the DMA: 10 records per batch");
+			run_combo(Y, sink, combo_16old, 16, 16, 8, 819.2, 1, 1, "with the DMA issued by the 8 oldest wavefronts");
 		}
 		CHECK(hipFree(Y));
 	}
