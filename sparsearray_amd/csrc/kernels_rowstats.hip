@@ -939,43 +939,46 @@ rowsum_f64_lds16_kernel(GroupSumArgs a, const uint16_t *__restrict__ g16)
 // with windows of 25600-102400 rows and 14 columns (0.52 with 16: the last round of workgroups is emptier;
 // 0.56-0.59 with windows of 12800 rows; no windows 0.72; two chunks loaded ahead 0.55; the window's ids staged
 // in LDS and looked up there 0.57-0.78: two more barriers per window than the lookups save; every wavefront
-// on the same rows -- what a perfect L1 would give -- 0.35).  In the library: 0.58 -> 0.53 ms for the kernel.
+// on the same rows -- what a perfect L1 would give -- 0.35).  In the library: 0.58 -> 0.51 ms for the kernel.
 // C is chosen so that the last round of workgroups is as full as possible (14 at 1e4 columns: 715 workgroups
 // in 3 rounds).
 #define ROWSUM_WIN 49152
+template <bool NARM>
 __global__ void __launch_bounds__(1024)
-rowsum_f64_cols_kernel(GroupSumArgs a, const uint16_t *__restrict__ g16, int C)
+rowsum_f64_cols_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__ row_idx,
+		       const double *__restrict__ val, int64_t ncol, int64_t nrow, int ngroup,
+		       const uint16_t *__restrict__ g16, double *__restrict__ out, int C)
 {
 	extern __shared__ double acc[];                 // [C][ngroup]
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	const int64_t j = (int64_t) blockIdx.x * C + w;
-	for (int g = threadIdx.x; g < C * a.ngroup; g += C * 64) acc[g] = 0.0;
+	for (int g = threadIdx.x; g < C * ngroup; g += C * 64) acc[g] = 0.0;
 	__syncthreads();
-	double *mine = acc + (int64_t) w * a.ngroup;
-	const double *__restrict__ val = (const double *) a.val;
-	const bool have = j < a.ncol;
-	const int64_t beg = have ? col_beg(a, j) : 0, end = have ? col_beg(a, j + 1) : 0;
+	double *mine = acc + w * ngroup;
+	const bool have = j < ncol;
+	const int64_t beg = have ? col_ptr[j] : 0, end = have ? col_ptr[j + 1] : 0;
 	int64_t k = beg;
-	int32_t r = k + lane < end ? a.row_idx[k + lane] : 0x7FFFFFFF;
+	int32_t r = k + lane < end ? row_idx[k + lane] : 0x7FFFFFFF;
 	double v = k + lane < end ? val[k + lane] : 0.0;
 	for (int64_t R = ROWSUM_WIN; ; R += ROWSUM_WIN) {
+		const int32_t Rc = R < 0x7FFFFFFF ? (int32_t) R : 0x7FFFFFFF;
 		for (;;) {
-			const bool in = (int64_t) r < R;
+			const bool in = r < Rc;
 			const int cnt = __popcll(__ballot(in));
 			const int64_t kn = k + cnt;             // (the rows of a column ascend: the lanes inside the window are the first cnt)
-			const int32_t rn = kn + lane < end ? a.row_idx[kn + lane] : 0x7FFFFFFF;
+			const int32_t rn = kn + lane < end ? row_idx[kn + lane] : 0x7FFFFFFF;
 			const double vn = kn + lane < end ? val[kn + lane] : 0.0;
-			if (in && !(a.na_rm && v != v)) atomicAdd(&mine[g16[r]], v);
+			if (in && !(NARM && v != v)) atomicAdd(&mine[g16[r]], v);
 			k = kn; r = rn; v = vn;
 			if (cnt < 64) break;
 		}
-		if (R >= a.nrow) break;
+		if (R >= nrow) break;
 		__syncthreads();
 	}
 	__syncthreads();
-	for (int g = threadIdx.x; g < C * a.ngroup; g += C * 64) {
-		const int64_t jj = (int64_t) blockIdx.x * C + g / a.ngroup;
-		if (jj < a.ncol) ((double *) a.out)[jj * (int64_t) a.ngroup + g % a.ngroup] = acc[g];
+	for (int g = threadIdx.x; g < C * ngroup; g += C * 64) {
+		const int64_t jj = (int64_t) blockIdx.x * C + g / ngroup;
+		if (jj < ncol) out[jj * (int64_t) ngroup + g % ngroup] = acc[g];
 	}
 }
 
@@ -984,7 +987,7 @@ static int rowsum_cols_per_wg(const GroupSumArgs &a)
 {
 	const int64_t cap = (int64_t) (160 * 1024) / ((int64_t) a.ngroup * 8);
 	int cmax = cap > 16 ? 16 : (int) cap;
-	if (cmax < 4 || a.ncol < 64)
+	if (cmax < 4 || a.ncol < 64 || a.col_ptr64 == NULL)
 		return 0;
 	int best = 0;
 	int64_t best_cost = 0;
@@ -1009,8 +1012,16 @@ int launch_rowsum_lds(const GroupSumArgs &a, hipStream_t s)
 		const int C = rowsum_cols_per_wg(a);
 		if (C > 0) {
 			const size_t lds = (size_t) C * a.ngroup * 8;
-			(void) hipFuncSetAttribute((const void *) rowsum_f64_cols_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-			hipLaunchKernelGGL(rowsum_f64_cols_kernel, dim3((unsigned) ((a.ncol + C - 1) / C)), dim3(C * 64), lds, s, a, g16, C);
+			const dim3 grid((unsigned) ((a.ncol + C - 1) / C));
+			if (a.na_rm) {
+				(void) hipFuncSetAttribute((const void *) rowsum_f64_cols_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+				hipLaunchKernelGGL(rowsum_f64_cols_kernel<true>, grid, dim3(C * 64), lds, s, a.col_ptr64, a.row_idx,
+						   (const double *) a.val, a.ncol, a.nrow, a.ngroup, g16, (double *) a.out, C);
+			} else {
+				(void) hipFuncSetAttribute((const void *) rowsum_f64_cols_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+				hipLaunchKernelGGL(rowsum_f64_cols_kernel<false>, grid, dim3(C * 64), lds, s, a.col_ptr64, a.row_idx,
+						   (const double *) a.val, a.ncol, a.nrow, a.ngroup, g16, (double *) a.out, C);
+			}
 		} else
 		hipLaunchKernelGGL(rowsum_f64_lds16_kernel, dim3((unsigned) a.ncol), dim3(256),
 				   (size_t) a.ngroup * 8, s, a, g16);
