@@ -413,6 +413,13 @@ def main():
         def spmm():
             flag3[0] = matmul_csc_csc(A, Bs, out=out2, ws=ws3)[1]
         ms = timed(spmm)
+        from sparsearray_amd.device import SpmmPlan
+        t_prep = wall(lambda: SpmmPlan(A))
+        sp = SpmmPlan(A)
+        out2b = torch.empty((K, lrow), dtype=torch.float64, device=dev)
+        ms_plan = timed(lambda: sp.run(Bs, out=out2b))
+        same_plan = bool(torch.equal(out2, out2b)) or float((out2 - out2b).abs().max().item()) < 1e-12
+        del sp, out2b
         Bd = torch.zeros((K, ncol), dtype=torch.float64, device=dev)           # the same product by the dense route
         Bd[torch.repeat_interleave(torch.arange(K, device=dev), bcp[1:] - bcp[:-1]), bri.long()] = bv
         T = A.t()
@@ -421,6 +428,8 @@ def main():
         ms_dense = timed(lambda: plan_t.run(Bd, ncol, out3))
         ex["svt_x_svt2(3)"] = {"ms": ms, "GNZ/s": nnz / ms / 1e6,
                                "GB/s": (nnz * 12 + Bs.nnz * 12 + lrow * K * 8) / ms / 1e6,
+                               "with_A_prepared_once_ms": ms_plan, "prepare_A_ms_once_per_operand": t_prep,
+                               "prepared_same_result": same_plan,
                                "nnz_B": int(Bs.nnz), "not_finite_flag": int(flag3[0].item()),
                                "dense_route_ms": ms_dense,
                                "max_abs_diff_vs_dense_route": float((out2 - out3).abs().max().item())}

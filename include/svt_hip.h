@@ -372,12 +372,19 @@ int svt_dev_transpose(const svt_dev_csc *A, int64_t *out_col_ptr, int32_t *out_r
    leaves expanded, the other's walked over them, :728-820), without the order of its additions (the same
    products, added as the lane groups get to them; exact for integer operands below 2^53).  A non-finite
    value or an NA in either operand changes what the reference computes (its dirty-leaf loops multiply the
-   implicit zeros too): then `*not_finite` (device int, may be NULL; the first int of `ws` holds the same flag)
+   implicit zeros too): then `*not_finite` (device int, may be NULL; the second int of `ws` holds the same flag)
    is set and `out` must be recomputed by the dense route (svt_matmul_SVT_SVT does).  Every cell of the
-   A->nrow x B->ncol result is written; ws: svt_dev_matmul_csc_csc_ws_bytes(A) bytes.  Asynchronous. */
+   A->nrow x B->ncol result is written; ws: svt_dev_matmul_csc_csc_ws_bytes(A) bytes.  Asynchronous.
+   What depends on A alone -- the table of run bounds (one pass over its offsets) and the scan of its values --
+   can be done once per operand: svt_dev_matmul_csc_csc_prepare(A, ws) fills `ws`, which
+   svt_dev_matmul_csc_csc_prepared() then only reads (plus its second int, the flag of the last product), as the
+   panel-blocked layout serves crossprod(A, Y); svt_dev_matmul_csc_csc() is the two in a row. */
 size_t svt_dev_matmul_csc_csc_ws_bytes(const svt_dev_csc *A);
 int svt_dev_matmul_csc_csc(const svt_dev_csc *A, const svt_dev_csc *B, double *out, int64_t ldo,
 			   void *ws, size_t ws_bytes, int *not_finite, void *stream);
+int svt_dev_matmul_csc_csc_prepare(const svt_dev_csc *A, void *ws, size_t ws_bytes, void *stream);
+int svt_dev_matmul_csc_csc_prepared(const svt_dev_csc *A, const svt_dev_csc *B, double *out, int64_t ldo,
+				    void *ws, size_t ws_bytes, int *not_finite, void *stream);
 
 /* aperm(x, perm) for an N-d operand (C_aperm_SVT, src/SparseArray_aperm.c:935-970;
    R/SparseArray-aperm.R).  `dim` are the array's ndim extents (dim[0] = A->nrow,

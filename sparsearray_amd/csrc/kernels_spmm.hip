@@ -148,24 +148,45 @@ spmm_csc_csc_kernel(SpmmArgs a, int KW, int G)
 	}
 }
 
-// ws: spmm_ws_bytes(nrow, ninner) bytes (the table of run bounds).  Every cell of out[0 .. nrow) x [0 .. K) is written.
-int launch_spmm_csc_csc(SpmmArgs a, int64_t a_nnz, int64_t b_nnz, void *ws, hipStream_t s)
+// Shape of the launch for an operand with nrow rows (shared by the preparation and the product)
+static void spmm_shape(int64_t nrow, int64_t K, int *ps_out, int64_t *npan_out, int *KW_out)
+{
+	int ps = 13;                                    // 8192-row panels; shorter operands: one or two panels
+	while (ps > 6 && ((int64_t) 1 << ps) >= 2 * nrow) ps--;
+	const int64_t P = (int64_t) 1 << ps, npan = (nrow + P - 1) >> ps;
+	int KW = (int) (SPMM_LDS / (P * 8));
+	if (KW > 16) KW = 16;
+	if (KW > K) KW = (int) K;
+	if (KW < 1) KW = 1;
+	// with few panels: fewer columns per workgroup, so that the grid fills the chip
+	while (KW > 1 && npan * ((K + KW - 1) / KW) < 512) KW = (KW + 1) / 2;
+	*ps_out = ps; *npan_out = npan; *KW_out = KW;
+}
+
+// What depends on A alone: the table of run bounds (into ws) and the scan of its values (raises *flag).
+int launch_spmm_prepare(const SpmmArgs &a, int64_t a_nnz, void *ws, hipStream_t s)
+{
+	if (a.nrow <= 0)
+		return 0;
+	int ps, KW; int64_t npan;
+	spmm_shape(a.nrow, 1, &ps, &npan, &KW);
+	spmm_scan_values(a.a_val, a.a_type, a_nnz, a.flag, s);
+	launch_rowpanel_table(a.a_ptr, a.a_idx, a.ninner, a_nnz, npan, ps, (int32_t *) ws, s);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+// The product on a prepared A (ws as left by launch_spmm_prepare); B's values are scanned here (raises *flag).
+// Every cell of out[0 .. nrow) x [0 .. K) is written.
+int launch_spmm_product(SpmmArgs a, int64_t a_nnz, int64_t b_nnz, const void *ws, hipStream_t s)
 {
 	if (a.nrow <= 0 || a.K <= 0)
 		return 0;
-	spmm_scan_values(a.a_val, a.a_type, a_nnz, a.flag, s);
+	int ps, KW; int64_t npan;
+	spmm_shape(a.nrow, a.K, &ps, &npan, &KW);
 	spmm_scan_values(a.b_val, a.b_type, b_nnz, a.flag, s);
-	int ps = 13;                                    // 8192-row panels; shorter operands: one or two panels
-	while (ps > 6 && ((int64_t) 1 << ps) >= 2 * a.nrow) ps--;
-	const int64_t P = (int64_t) 1 << ps, npan = (a.nrow + P - 1) >> ps;
-	int KW = (int) (SPMM_LDS / (P * 8));
-	if (KW > 16) KW = 16;
-	if (KW > a.K) KW = (int) a.K;
-	// with few panels: fewer columns per workgroup, so that the grid fills the chip
-	while (KW > 1 && npan * ((a.K + KW - 1) / KW) < 512) KW = (KW + 1) / 2;
-	int32_t *pt = (int32_t *) ws;
-	launch_rowpanel_table(a.a_ptr, a.a_idx, a.ninner, a_nnz, npan, ps, pt, s);
-	a.pt = pt; a.npan = npan; a.ps = ps;
+	const int64_t P = (int64_t) 1 << ps;
+	a.pt = (const int32_t *) ws; a.npan = npan; a.ps = ps;
 	// lanes per run: the largest power of two <= half its mean length (81 nonzeros at config 3: three trips of
 	// 32 lanes = 96 slots, not two of 64 = 128)
 	int G = 64;

@@ -168,7 +168,8 @@ struct SpmmArgs {
 	int *flag;                          // set when a non-finite value / an NA took part: the result is not the reference's
 };
 size_t spmm_ws_bytes(int64_t nrow, int64_t ninner);
-int launch_spmm_csc_csc(SpmmArgs a, int64_t a_nnz, int64_t b_nnz, void *ws, hipStream_t s);
+int launch_spmm_prepare(const SpmmArgs &a, int64_t a_nnz, void *ws, hipStream_t s);
+int launch_spmm_product(SpmmArgs a, int64_t a_nnz, int64_t b_nnz, const void *ws, hipStream_t s);
 
 size_t transpose_ws_bytes(int64_t nrow, int64_t nnz);
 int launch_transpose(const int64_t *col_ptr, const int32_t *row_idx, const void *val, int Rtype,

@@ -794,8 +794,20 @@ static SpmmArgs spmm_args(const svt_dev_csc *A, const svt_dev_csc *B, double *ou
 	return a;
 }
 
-extern "C" int svt_dev_matmul_csc_csc(const svt_dev_csc *A, const svt_dev_csc *B, double *out, int64_t ldo,
-				      void *ws, size_t ws_bytes, int *not_finite, void *stream)
+// ws: [int: A holds a non-finite value / an NA][int: the same for the last product, B included][...][table at 256]
+extern "C" int svt_dev_matmul_csc_csc_prepare(const svt_dev_csc *A, void *ws, size_t ws_bytes, void *stream)
+{
+	if (ws_bytes < svt_dev_matmul_csc_csc_ws_bytes(A))
+		return svt_set_error("svt_dev_matmul_csc_csc: workspace too small");
+	hipStream_t s = (hipStream_t) stream;
+	HIP_TRY(hipMemsetAsync(ws, 0, 8, s));
+	svt_dev_csc none;
+	memset(&none, 0, sizeof(none));
+	return launch_spmm_prepare(spmm_args(A, &none, NULL, 0, (int *) ws), A->nnz, (char *) ws + 256, s);
+}
+
+extern "C" int svt_dev_matmul_csc_csc_prepared(const svt_dev_csc *A, const svt_dev_csc *B, double *out, int64_t ldo,
+					       void *ws, size_t ws_bytes, int *not_finite, void *stream)
 {
 	if (A->ncol != B->nrow)
 		return svt_set_error("svt_dev_matmul_csc_csc: non-conformable operands");
@@ -804,13 +816,23 @@ extern "C" int svt_dev_matmul_csc_csc(const svt_dev_csc *A, const svt_dev_csc *B
 	if (ldo < A->nrow)
 		return svt_set_error("svt_dev_matmul_csc_csc: leading dimension of the result too small");
 	hipStream_t s = (hipStream_t) stream;
-	int *flag = (int *) ws;
-	HIP_TRY(hipMemsetAsync(flag, 0, 4, s));
-	if (launch_spmm_csc_csc(spmm_args(A, B, out, ldo, flag), A->nnz, B->nnz, (char *) ws + 256, s))
+	int *flag = (int *) ws + 1;
+	HIP_TRY(hipMemcpyAsync(flag, ws, 4, hipMemcpyDeviceToDevice, s));
+	if (launch_spmm_product(spmm_args(A, B, out, ldo, flag), A->nnz, B->nnz, (char *) ws + 256, s))
 		return -1;
 	if (not_finite != NULL)
 		HIP_TRY(hipMemcpyAsync(not_finite, flag, 4, hipMemcpyDeviceToDevice, s));
 	return 0;
+}
+
+extern "C" int svt_dev_matmul_csc_csc(const svt_dev_csc *A, const svt_dev_csc *B, double *out, int64_t ldo,
+				      void *ws, size_t ws_bytes, int *not_finite, void *stream)
+{
+	if (A->ncol != B->nrow)
+		return svt_set_error("svt_dev_matmul_csc_csc: non-conformable operands");
+	if (svt_dev_matmul_csc_csc_prepare(A, ws, ws_bytes, stream))
+		return -1;
+	return svt_dev_matmul_csc_csc_prepared(A, B, out, ldo, ws, ws_bytes, not_finite, stream);
 }
 
 static int aperm_args(int ndim, const int *perm, int *perm0)
@@ -1425,7 +1447,7 @@ extern "C" int svt_matmul_SVT_SVT(const svt_view *x, const svt_view *y, double *
 			return -1;
 		if (svt_dev_matmul_csc_csc(X.h, Ys.h, Os.as<double>(), out_nrow, Ws.p, Ws.bytes, NULL, 0))
 			return -1;
-		HIP_TRY(hipMemcpy(&bad, Ws.p, 4, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(&bad, (char *) Ws.p + 4, 4, hipMemcpyDeviceToHost));
 		if (!bad)
 			return staged_download(out, Os.p, out_n * 8) ? -1 : 0;
 	}

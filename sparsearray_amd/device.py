@@ -58,6 +58,9 @@ def _lib():
         lib.svt_dev_matmul_csc_csc_ws_bytes.argtypes = [c_void_p]
         lib.svt_dev_matmul_csc_csc.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_size_t,
                                                c_void_p, c_void_p]
+        lib.svt_dev_matmul_csc_csc_prepare.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p]
+        lib.svt_dev_matmul_csc_csc_prepared.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_size_t,
+                                                        c_void_p, c_void_p]
         lib.svt_dev_colmedians_ws_bytes.restype = c_size_t
         lib.svt_dev_colmedians_ws_bytes.argtypes = [c_int64, c_int64]
         lib.svt_dev_colmedians.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
@@ -276,6 +279,27 @@ def matmul_csc_csc(A: DeviceCSC, B: DeviceCSC, out=None, ws=None):
     _check(_lib().svt_dev_matmul_csc_csc(A.handle, B.handle, out.data_ptr(), A.nrow, ws.data_ptr(), ws.numel(),
                                          flag.data_ptr(), _stream()))
     return out, flag
+
+
+class SpmmPlan:
+    """What `A %*% B` (both sparse) needs from A alone -- the table of run bounds per row panel and the scan of
+    its values -- done once (svt_dev_matmul_csc_csc_prepare), as `PbcPlan` does for crossprod(A, Y)."""
+
+    def __init__(self, A: DeviceCSC):
+        self.A = A
+        self.ws = torch.empty(_lib().svt_dev_matmul_csc_csc_ws_bytes(A.handle), dtype=torch.uint8, device=A.val.device)
+        _check(_lib().svt_dev_matmul_csc_csc_prepare(A.handle, self.ws.data_ptr(), self.ws.numel(), _stream()))
+        self.flag = torch.zeros(1, dtype=torch.int32, device=A.val.device)
+
+    def run(self, B: DeviceCSC, out=None):
+        """Returns (out, not_finite) like matmul_csc_csc()."""
+        A = self.A
+        assert A.ncol == B.nrow
+        if out is None:
+            out = torch.empty((B.ncol, A.nrow), dtype=torch.float64, device=A.val.device)
+        _check(_lib().svt_dev_matmul_csc_csc_prepared(A.handle, B.handle, out.data_ptr(), A.nrow, self.ws.data_ptr(),
+                                                      self.ws.numel(), self.flag.data_ptr(), _stream()))
+        return out, self.flag
 
 
 def rowsums(A: DeviceCSC, na_rm=False, inner=1, out=None, ws=None):

@@ -409,3 +409,37 @@ def test_sparse_x_sparse_random_shapes(hip):
             got = out.cpu().numpy().T
             assert got.shape == want.shape
             assert np.allclose(got, want, rtol=1e-12, atol=1e-12), (nrow, ninner, K, da, db, np.abs(got - want).max())
+
+
+def test_sparse_x_sparse_prepared_operand(hip, oracle):
+    """SpmmPlan: the table and the value scan of A once, several B's afterwards -- same results as the one-call
+    form; a non-finite value in A is remembered by the plan, one in B is seen per product."""
+    from test_hip_device_level import _dev
+    from sparsearray_amd.device import SpmmPlan, matmul_csc_csc
+    nrow, ninner = 40_000, 500
+    cpa, ria, va = random_csc(nrow, ninner, 0.02, seed=85)
+    A = _dev(cpa, ria, va, nrow)
+    plan = SpmmPlan(A)
+    for K, seed in ((9, 86), (40, 87)):
+        cpb, rib, vb = random_csc(ninner, K, 0.03, seed=seed)
+        B = _dev(cpb, rib, vb, ninner)
+        out, flag = plan.run(B)
+        ref, _ = matmul_csc_csc(A, B)
+        torch.cuda.synchronize()
+        assert int(flag.item()) == 0
+        assert torch.allclose(out, ref, rtol=1e-13, atol=1e-13)
+        x = SVT_SparseArray.from_csc((nrow, ninner), "double", cpa, ria, va)
+        y = SVT_SparseArray.from_csc((ninner, K), "double", cpb, rib, vb)
+        assert_equal(out.cpu().numpy().T, oracle.matmul(x, y), tol=1e-12, atol=1e-13, what="prepared")
+        vb2 = vb.copy(); vb2[0] = np.inf
+        _, flag = plan.run(_dev(cpb, rib, vb2, ninner))
+        torch.cuda.synchronize()
+        assert int(flag.item()) == 1                      # B's Inf
+        _, flag = plan.run(B)
+        torch.cuda.synchronize()
+        assert int(flag.item()) == 0                      # ... does not stick
+    va2 = va.copy(); va2[len(va2) // 2] = np.nan
+    plan2 = SpmmPlan(_dev(cpa, ria, va2, nrow))
+    _, flag = plan2.run(B)
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 1
