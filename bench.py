@@ -340,6 +340,13 @@ def main():
         ):
             ms = timed(fn)
             ex[name] = {"ms": ms, "GNZ/s": nnz / ms / 1e6, "GB/s": nbytes / ms / 1e6}
+        from sparsearray_amd.device import RowSumsPlan
+        rsp = RowSumsPlan(A)
+        rs_out2 = torch.empty(lrow, dtype=torch.float64, device=dev)
+        ms = timed(lambda: rsp.run(out=rs_out2))
+        ex["rowSums"]["with_the_run_table_built_once_ms"] = ms
+        ex["rowSums"]["same_result"] = bool(torch.allclose(rs_out, rs_out2, rtol=1e-12, atol=1e-13))
+        del rsp, rs_out2
         # the same product when the dense operand is not clean / not column-major
         plan0 = sc.plan
         outx = torch.zeros((K, ncol), dtype=torch.float64, device=dev)

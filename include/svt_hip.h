@@ -339,6 +339,12 @@ int svt_dev_colmedians(const svt_dev_csc *A, int na_rm, double *out, void *ws, s
 size_t svt_dev_rowstats_ws_bytes(int64_t nrow, int64_t ncol);
 int svt_dev_rowsums(const svt_dev_csc *A, int na_rm, int64_t inner,
 		    double *out, void *ws, size_t ws_bytes, void *stream);
+/* The table of run bounds per row panel that svt_dev_rowsums() derives from the operand's offsets (a quarter
+   of its time at BASELINE config 2) depends on the operand and `inner` only: svt_dev_rowsums_prepare() leaves
+   it in `ws` once, svt_dev_rowsums_prepared() -- same operand, same `inner`, same `ws` -- uses it as it is. */
+int svt_dev_rowsums_prepare(const svt_dev_csc *A, int64_t inner, void *ws, size_t ws_bytes, void *stream);
+int svt_dev_rowsums_prepared(const svt_dev_csc *A, int na_rm, int64_t inner,
+			     double *out, void *ws, size_t ws_bytes, void *stream);
 
 /* rowsum(): out (ngroup x ncol, zeroed by the callee); group is a device
    array of nrow 1-based group ids (NA -> last group).  f64 input only at

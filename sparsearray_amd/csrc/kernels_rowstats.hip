@@ -599,6 +599,8 @@ int launch_rowstats_panel(const RowStatsArgs &a, void *ws, hipStream_t s)
 		const double leaf_len = a.ncol > 0 ? (double) a.nnz_hint / (double) a.ncol : 0.0;
 		if (sumlike && !a.na_bg && a.nnz_hint > 0 && a.inner >= 1024 && a.nrow > (1 << ROWPANEL_BIG_SHIFT) &&
 		    lds_whole <= 160 * 1024 && leaf_len <= 512.0 && a.nstrata * leaf_len <= 65536.0) {
+			if (a.table_mode == 1)
+				return 0;                       // (this form needs no table)
 			int G = 64;
 			while (G > 8 && leaf_len <= G / 2) G >>= 1;
 			if (G == 64 && ((int64_t) (leaf_len + 31.0) / 32) * 32 < ((int64_t) (leaf_len + 63.0) / 64) * 64) G = 32;
@@ -622,7 +624,12 @@ int launch_rowstats_panel(const RowStatsArgs &a, void *ws, hipStream_t s)
 	int32_t *pt = (int32_t *) ws;
 	if (a.inner > 65535)
 		return svt_set_error("row stats: more than 65535 output columns per panel row");
-	launch_rowpanel_table(a.col_ptr, a.row_idx, a.ncol, a.nnz_hint, npan, ps, pt, s);
+	if (a.table_mode != 2)
+		launch_rowpanel_table(a.col_ptr, a.row_idx, a.ncol, a.nnz_hint, npan, ps, pt, s);
+	if (a.table_mode == 1) {
+		HIP_TRY(hipGetLastError());
+		return 0;
+	}
 	// lanes per leaf segment ~ mean segment length (nnz unknown here: the
 	// caller passes it in a.nnz_hint, 0 = assume long segments)
 	int G = 64;

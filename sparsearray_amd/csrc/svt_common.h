@@ -151,6 +151,8 @@ struct RowStatsArgs {
 	int *warn_flag;
 	int64_t nnz_hint;       // nonzeros of the operand (launch tuning only), 0 = unknown
 	int na_bg;              // NaArray: implicit entries are NAs (SparseArray_matrixStats.c:756-1019)
+	int table_mode;         // launch_rowstats_panel: 0 = build the table of run bounds and use it, 1 = build it only,
+	                        // 2 = it is in `ws` already (same operand, same operation class)
 };
 size_t rowstats_scratch_bytes(int opcode, int out_Rtype, int64_t out_len);
 int launch_rowstats(const RowStatsArgs &a, int64_t nnz, hipStream_t s);      // memory atomics

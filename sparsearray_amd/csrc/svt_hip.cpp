@@ -745,8 +745,8 @@ extern "C" size_t svt_dev_rowstats_ws_bytes(int64_t nrow, int64_t ncol)
 	return rowstats_panel_ws_bytes(nrow, ncol);
 }
 
-extern "C" int svt_dev_rowsums(const svt_dev_csc *A, int na_rm, int64_t inner,
-			       double *out, void *ws, size_t ws_bytes, void *stream)
+static int dev_rowsums(const svt_dev_csc *A, int na_rm, int64_t inner, double *out, void *ws, size_t ws_bytes,
+		       void *stream, int table_mode)
 {
 	if (inner <= 0 || A->ncol % inner != 0)
 		return svt_set_error("'inner' must divide the number of leaves");
@@ -760,7 +760,28 @@ extern "C" int svt_dev_rowsums(const svt_dev_csc *A, int na_rm, int64_t inner,
 	a.out_len = inner * A->nrow;
 	a.opcode = SVT_OP_SUM; a.na_rm = na_rm; a.out = out; a.nnz_hint = A->nnz;
 	a.na_bg = A->na_background;
+	a.table_mode = table_mode;
 	return launch_rowstats_panel(a, ws, (hipStream_t) stream);
+}
+
+extern "C" int svt_dev_rowsums(const svt_dev_csc *A, int na_rm, int64_t inner,
+			       double *out, void *ws, size_t ws_bytes, void *stream)
+{
+	return dev_rowsums(A, na_rm, inner, out, ws, ws_bytes, stream, 0);
+}
+
+// The table of run bounds per row panel depends on the operand alone (one pass over its offsets, a quarter of
+// a rowSums at BASELINE config 2): built once into `ws`, then any number of svt_dev_rowsums_prepared() calls on
+// the same operand with the same `inner` read it.
+extern "C" int svt_dev_rowsums_prepare(const svt_dev_csc *A, int64_t inner, void *ws, size_t ws_bytes, void *stream)
+{
+	return dev_rowsums(A, 0, inner, NULL, ws, ws_bytes, stream, 1);
+}
+
+extern "C" int svt_dev_rowsums_prepared(const svt_dev_csc *A, int na_rm, int64_t inner,
+					double *out, void *ws, size_t ws_bytes, void *stream)
+{
+	return dev_rowsums(A, na_rm, inner, out, ws, ws_bytes, stream, 2);
 }
 
 extern "C" size_t svt_dev_transpose_ws_bytes(int64_t nrow, int64_t nnz)

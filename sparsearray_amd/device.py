@@ -67,6 +67,8 @@ def _lib():
         lib.svt_dev_rowstats_ws_bytes.restype = c_size_t
         lib.svt_dev_rowstats_ws_bytes.argtypes = [c_int64, c_int64]
         lib.svt_dev_rowsums.argtypes = [c_void_p, c_int, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]
+        lib.svt_dev_rowsums_prepare.argtypes = [c_void_p, c_int64, c_void_p, c_size_t, c_void_p]
+        lib.svt_dev_rowsums_prepared.argtypes = [c_void_p, c_int, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]
         lib.svt_dev_rowsum.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]
         lib.svt_colStats_out_Rtype.argtypes = [c_int, c_int]
         lib.svt_dev_transpose_ws_bytes.restype = c_size_t
@@ -311,6 +313,23 @@ def rowsums(A: DeviceCSC, na_rm=False, inner=1, out=None, ws=None):
     _check(_lib().svt_dev_rowsums(A.handle, int(na_rm), inner, out.data_ptr(), ws.data_ptr(),
                                   ws.numel(), _stream()))
     return out
+
+
+class RowSumsPlan:
+    """rowSums() of a resident operand with the table of run bounds built once (svt_dev_rowsums_prepare)."""
+
+    def __init__(self, A: DeviceCSC, inner=1):
+        self.A, self.inner = A, int(inner)
+        self.ws = torch.empty(_lib().svt_dev_rowstats_ws_bytes(A.nrow, A.ncol), dtype=torch.uint8, device=A.val.device)
+        _check(_lib().svt_dev_rowsums_prepare(A.handle, self.inner, self.ws.data_ptr(), self.ws.numel(), _stream()))
+
+    def run(self, na_rm=False, out=None):
+        A = self.A
+        if out is None:
+            out = torch.empty(self.inner * A.nrow, dtype=torch.float64, device=A.val.device)
+        _check(_lib().svt_dev_rowsums_prepared(A.handle, int(na_rm), self.inner, out.data_ptr(), self.ws.data_ptr(),
+                                               self.ws.numel(), _stream()))
+        return out
 
 
 def rowsum(A: DeviceCSC, group: torch.Tensor, ngroup: int, na_rm=False, out=None):

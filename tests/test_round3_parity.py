@@ -443,3 +443,21 @@ def test_sparse_x_sparse_prepared_operand(hip, oracle):
     _, flag = plan2.run(B)
     torch.cuda.synchronize()
     assert int(flag.item()) == 1
+
+
+@pytest.mark.parametrize("shape", [(70_000, 300, 0.01, 1), (20_000, 64, 0.05, 1), (3_000, 40, 0.1, 1), (40_000, 120, 0.02, 4)])
+def test_rowsums_with_prepared_table(hip, shape):
+    """RowSumsPlan (svt_dev_rowsums_prepare / _prepared): the one-call rowSums, na.rm both ways (the LDS additions of
+    a row come in the order the lane groups get to them: equal up to the last bits)."""
+    from test_hip_device_level import _dev
+    from sparsearray_amd.device import RowSumsPlan, rowsums
+    nrow, ncol, dens, inner = shape
+    cp, ri, v = random_csc(nrow, ncol, dens, seed=95)
+    v = v.copy(); v[3] = np.nan
+    A = _dev(cp, ri, v, nrow)
+    plan = RowSumsPlan(A, inner)
+    for na_rm in (False, True):
+        a = plan.run(na_rm=na_rm)
+        b = rowsums(A, na_rm=na_rm, inner=inner)
+        torch.cuda.synchronize()
+        assert torch.allclose(a, b, rtol=1e-12, atol=1e-13, equal_nan=True)
