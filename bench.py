@@ -68,7 +68,8 @@ def parse():
                         "a local sum (sparsearray_amd/parallel.py, PeerReducer; no collective kernel)")
     p.add_argument("--spare-cus", type=int, default=-1,
                    help="CUs the product kernel leaves idle (room for RCCL's kernels beside it); 0 = none; "
-                        "default: 32 with --gpus > 1 and the RCCL reducer (+5 %% product time, DESIGN.md section 5), else 0")
+                        "default: 32 with --gpus >= 8 and the RCCL reducer (+8 %% product time at an eighth of the rows, "
+                        "DESIGN.md section 5), else 0")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extras", action="store_true")
     a = p.parse_args()
@@ -77,7 +78,9 @@ def parse():
         if getattr(a, k) is None:
             setattr(a, k, c[k])
     if a.spare_cus < 0:
-        a.spare_cus = 32 if (a.gpus > 1 and a.reduce == "rccl") else 0
+        # (what it costs on one GPU at the rank's share of the rows: +11 % at 1/2, +10 % at 1/4, +8 % at 1/8 -- against an
+        # all-reduce of ~0.05-0.08 ms that otherwise waits for the product's CUs: 5 % / 12 % / 30 % of the step)
+        a.spare_cus = 32 if (a.gpus >= 8 and a.reduce == "rccl") else 0
     return a
 
 
