@@ -260,6 +260,66 @@ __device__ inline void pbc1_put(char *img, int64_t ridx, uint32_t meta, double x
 	((double *) (b + 32))[ridx & 7] = x;
 }
 
+// Count pass of the format-1 build as ONE stream over the offsets (round 3; pbc_pass_kernel<0, 1> walks every column
+// once per chunk of 256 panels with two binary searches and two barriers per 64 offsets: 0.46 ms at BASELINE
+// config 2 for 0.4 GB).  Workgroup = one column group (CBW columns, a wavefront per column at a time, four
+// loads per lane in flight): the group's records per panel are counted in LDS (npanels counters), rounded up to
+// whole batches (at least one) and written as the group's row of the tile table; the same pass writes the
+// table of stretch bounds that pbc_bounds_kernel builds with a binary search per entry (0.15 ms): the offset at
+// which a column enters each chunk of `subp` panels is where two neighbouring elements differ in row >> cshift.
+#define PBC_COUNT_MAXPANELS 36000
+__global__ void __launch_bounds__(1024)
+pbc_count_stream_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__ row_idx, int64_t ncol,
+			int CBW, int logR, int64_t npanels, int64_t *__restrict__ counts,
+			int32_t *__restrict__ bounds, int64_t nchunks, int cshift)
+{
+	extern __shared__ uint32_t pbc_hist[];          // [npanels]
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const int64_t g = blockIdx.x;
+	for (int64_t p = threadIdx.x; p < npanels; p += 1024) pbc_hist[p] = 0;
+	__syncthreads();
+	const int64_t c0 = g * CBW, c1 = c0 + CBW < ncol ? c0 + CBW : ncol;
+	for (int64_t c = c0 + w; c < c1; c += 16) {
+		const int64_t beg = col_ptr[c], end = col_ptr[c + 1];
+		int32_t *__restrict__ bc = bounds + c * (nchunks + 1);
+		int64_t carry = -1;                             // chunk of the element before this trip
+		for (int64_t k0 = beg; k0 < end; k0 += 256) {
+			int32_t r4[4];
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				const int64_t k = k0 + u * 64 + lane;
+				r4[u] = k < end ? row_idx[k] : 0x7FFFFFFF;
+			}
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				const int64_t kb = k0 + u * 64, k = kb + lane;
+				if (kb >= end) break;
+				const bool active = k < end;
+				if (active) atomicAdd(&pbc_hist[r4[u] >> logR], 1u);
+				// chunks that start at this position: those after the previous element's, up to this one's
+				// (the first lane past the end closes the column's remaining chunks)
+				const int64_t q = active ? (int64_t) (r4[u] >> cshift) : nchunks;
+				int64_t pq = __shfl_up(q, 1, 64);
+				if (lane == 0) pq = carry;
+				carry = __shfl(q, 63, 64);
+				if (k <= end)
+					for (int64_t i = pq + 1; i <= q; i++) bc[i] = (int32_t) (k - beg);
+			}
+		}
+		// a column whose length is a multiple of 64 (or zero) has not closed its last chunks
+		if (lane == 0 && ((end - beg) & 63) == 0) {
+			const int64_t ql = end > beg ? (int64_t) (row_idx[end - 1] >> cshift) : -1;
+			for (int64_t i = ql + 1; i <= nchunks; i++) bc[i] = (int32_t) (end - beg);
+		}
+	}
+	__syncthreads();
+	for (int64_t p = threadIdx.x; p < npanels; p += 1024) {
+		int64_t n = ((int64_t) pbc_hist[p] + 7) / 8 * 8;
+		if (n == 0) n = 8;                              // no tile without a batch
+		counts[g * npanels + p] = n;
+	}
+}
+
 // bounds[c * (nchunks + 1) + q] = number of nonzeros of column c above row q * subp * R: where the
 // stretches of `subp` panels start inside every column.  One independent binary search per entry
 // (millions in flight), so that the scatter workgroups below start from two table reads instead of
@@ -497,6 +557,15 @@ extern "C" svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB
 		  pbc_alloc((void **) &h->col_has_na, (size_t) (A->ncol > 0 ? A->ncol : 1) * 4) == hipSuccess;
 	if (ok) ok = hipMemsetAsync(h->tile_ptr, 0, (size_t) (ntiles + 1 + PBC_TP_PAD) * 8, 0) == hipSuccess &&
 		     hipMemsetAsync(h->col_has_na, 0, (size_t) (A->ncol > 0 ? A->ncol : 1) * 4, 0) == hipSuccess;
+	// format 1: the scatter workgroups take `subp` panels at a time -- the fewest (>= 16) that give a column ~8
+	// nonzeros per stretch on average (very sparse operands: fewer, larger stretches; the table of stretch bounds
+	// then stays smaller than the operand)
+	int subp = 16;
+	while (subp < 128 && (double) A->nnz * subp < 8.0 * (double) A->ncol * (double) h->npanels)
+		subp *= 2;
+	const int64_t nchunks = (h->npanels + subp - 1) / subp;
+	const int64_t nb_entries = A->ncol * (nchunks + 1);
+	bool bounds_done = false;
 	if (ok && A->ncol > 0 && A->nnz > 0) {
 		const int BATCH = h->fmt == 1 ? 8 : PBC_BATCH;
 		const size_t rbytes = h->fmt == 1 ? 12 : 16;
@@ -505,7 +574,21 @@ extern "C" svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB
 		// the host between its count and scatter passes; the exact count is read back at the end.
 		const int64_t nrec_max = A->nnz + ntiles * (int64_t) (h->fmt == 1 ? BATCH : BATCH - 1);
 		dim3 grid((unsigned) h->ngroups, (unsigned) ((h->npanels + PCH - 1) / PCH));
-		if (h->fmt == 1)
+		if (h->fmt == 1 && h->npanels <= PBC_COUNT_MAXPANELS) {
+			// one stream over the offsets: tile counts and the table of stretch bounds together
+			ok = pbc_alloc((void **) &bounds, (size_t) nb_entries * 4) == hipSuccess;
+			if (ok) {
+				int sl = 0;
+				while ((1 << sl) < subp) sl++;
+				const size_t lds = (size_t) h->npanels * 4;
+				(void) hipFuncSetAttribute((const void *) pbc_count_stream_kernel,
+							   hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+				hipLaunchKernelGGL(pbc_count_stream_kernel, dim3((unsigned) h->ngroups), dim3(1024), lds, 0,
+						   A->col_ptr, A->row_idx, A->ncol, CBW, logR, h->npanels, h->tile_ptr,
+						   bounds, nchunks, logR + sl);
+				bounds_done = true;
+			}
+		} else if (h->fmt == 1)
 			hipLaunchKernelGGL((pbc_pass_kernel<0, 1>), grid, dim3(64), 0, 0, A->col_ptr, A->row_idx,
 					   (const double *) A->val, A->ncol, CBW, logR, h->npanels,
 					   h->tile_ptr, (uint4 *) NULL, h->col_has_na, g_pbc_stagger);
@@ -520,18 +603,11 @@ extern "C" svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB
 		if (ok) ok = pbc_alloc((void **) &h->rec, (size_t) nrec_max * rbytes + PBC_SLACK * 16) == hipSuccess;
 		if (ok) {
 			if (h->fmt == 1) {
-				// panels per scatter workgroup: the fewest (>= 16) that give a column ~8 nonzeros per
-				// stretch on average (very sparse operands: fewer, larger stretches; the table of
-				// stretch bounds then stays smaller than the operand)
-				int subp = 16;
-				while (subp < 128 && (double) A->nnz * subp < 8.0 * (double) A->ncol * (double) h->npanels)
-					subp *= 2;
-				const int64_t nchunks = (h->npanels + subp - 1) / subp;
-				const int64_t nb_entries = A->ncol * (nchunks + 1);
-				ok = pbc_alloc((void **) &bounds, (size_t) nb_entries * 4) == hipSuccess;
+				if (!bounds_done) ok = pbc_alloc((void **) &bounds, (size_t) nb_entries * 4) == hipSuccess;
 				if (ok) {
-					hipLaunchKernelGGL(pbc_bounds_kernel, dim3((unsigned) ((nb_entries + 255) / 256)), dim3(256), 0, 0,
-							   A->col_ptr, A->row_idx, A->ncol, nchunks, (int64_t) subp << logR, bounds);
+					if (!bounds_done)
+						hipLaunchKernelGGL(pbc_bounds_kernel, dim3((unsigned) ((nb_entries + 255) / 256)), dim3(256), 0, 0,
+								   A->col_ptr, A->row_idx, A->ncol, nchunks, (int64_t) subp << logR, bounds);
 					const size_t lds = PBC_IMG_BYTES + (size_t) 2 * subp * CBW * 4;
 					(void) hipFuncSetAttribute((const void *) pbc_scatter_lds_kernel,
 								   hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
