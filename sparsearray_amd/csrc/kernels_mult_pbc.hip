@@ -252,6 +252,7 @@ pbc_pass_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__
 // A stretch larger than the LDS image (a very dense column group) falls back to global stores.
 // ---------------------------------------------------------------------------
 #define PBC_IMG_BYTES 24576
+#define PBC_SC_KEEP 4
 
 __device__ inline void pbc1_put(char *img, int64_t ridx, uint32_t meta, double x)
 {
@@ -380,9 +381,32 @@ pbc_scatter_lds_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__res
 	}
 	__syncthreads();
 	const int total = s_cum[nc];
-	// ---- 2
-	for (int i = tid; i < total; i += 256) {
-		int a = 0, b = nc;                                  // column j with cum[j] <= i < cum[j + 1]
+	// ---- 2  (a thread's first PBC_SC_KEEP elements stay in its registers for step 4: column, row, value --
+	// the second walk then repeats neither the search nor the loads; ~820 elements per workgroup at config 2)
+	int ka[PBC_SC_KEEP], kr[PBC_SC_KEEP];
+	double kx[PBC_SC_KEEP];
+#pragma unroll
+	for (int it = 0; it < PBC_SC_KEEP; it++) {
+		const int i = tid + it * 256;
+		ka[it] = 0; kr[it] = 0; kx[it] = 0.0;
+		if (i < total) {
+			int a = 0, b = nc;                              // column j with cum[j] <= i < cum[j + 1]
+			while (b - a > 1) { const int m = (a + b) >> 1; if (s_cum[m] <= i) a = m; else b = m; }
+			const int64_t k = s_lo[a] + (i - s_cum[a]);
+			ka[it] = a; kr[it] = row_idx[k]; kx[it] = val[k];
+		}
+	}
+#pragma unroll
+	for (int it = 0; it < PBC_SC_KEEP; it++) {
+		const int i = tid + it * 256;
+		if (i < total) {
+			const int p = (int) (((int64_t) kr[it] >> logR) - ps);
+			atomicAdd(&s_cnt[p * nc + ka[it]], 1);
+			atomicMin(&s_first[p * nc + ka[it]], i);
+		}
+	}
+	for (int i = tid + PBC_SC_KEEP * 256; i < total; i += 256) {
+		int a = 0, b = nc;
 		while (b - a > 1) { const int m = (a + b) >> 1; if (s_cum[m] <= i) a = m; else b = m; }
 		const int r = row_idx[s_lo[a] + (i - s_cum[a])];
 		const int p = (int) (((int64_t) r >> logR) - ps);
@@ -400,7 +424,20 @@ pbc_scatter_lds_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__res
 	}
 	__syncthreads();
 	// ---- 4
-	for (int i = tid; i < total; i += 256) {
+#pragma unroll
+	for (int it = 0; it < PBC_SC_KEEP; it++) {
+		const int i = tid + it * 256;
+		if (i < total) {
+			const int a = ka[it], r = kr[it];
+			const double x = kx[it];
+			const int p = (int) (((int64_t) r >> logR) - ps);
+			const int pos = s_cnt[p * nc + a] + (i - s_first[p * nc + a]);
+			const uint32_t ro = (uint32_t) (r - (int32_t) ((p + ps) << logR)) * 8u;
+			pbc1_put(dst, pos, (ro << 16) | (uint32_t) a * 2u, x);
+			if (svt_is_na(x)) col_has_na[c0 + a] = 1;
+		}
+	}
+	for (int i = tid + PBC_SC_KEEP * 256; i < total; i += 256) {
 		int a = 0, b = nc;
 		while (b - a > 1) { const int m = (a + b) >> 1; if (s_cum[m] <= i) a = m; else b = m; }
 		const int64_t k = s_lo[a] + (i - s_cum[a]);
