@@ -461,3 +461,25 @@ def test_rowsums_with_prepared_table(hip, shape):
         b = rowsums(A, na_rm=na_rm, inner=inner)
         torch.cuda.synchronize()
         assert torch.allclose(a, b, rtol=1e-12, atol=1e-13, equal_nan=True)
+
+
+@pytest.mark.parametrize("nrow", [4_700_000, 4_600_000])
+def test_layout_build_count_pass_both_forms(hip, oracle, nrow):
+    """The LDS-DMA layout's count pass: one stream over the offsets with the panels' counters in LDS (up to
+    36000 panels of 128 rows), the chunked walk beyond -- the same product either way."""
+    from test_hip_device_level import _dev
+    from sparsearray_amd.device import PbcPlan
+    ncol, K = 90, 8
+    cp, ri, v = random_csc(nrow, ncol, 0.0008, seed=97)
+    x = SVT_SparseArray.from_csc((nrow, ncol), "double", cp, ri, v)
+    x.svt_is_null = False
+    rng = np.random.default_rng(98)
+    y = rng.uniform(-1, 1, (nrow, K))
+    want = oracle.crossprod(x, y)
+    A = _dev(cp, ri, v, nrow)
+    plan = PbcPlan(A, K, 40, 16, 7)
+    Yd = torch.as_tensor(np.ascontiguousarray(y.T), device="cuda")
+    out = torch.full((K, ncol), 7.0, dtype=torch.float64, device="cuda")
+    plan.run(Yd, nrow, out)
+    torch.cuda.synchronize()
+    assert_equal(out.cpu().numpy().T, want, tol=1e-9, atol=1e-11, what=f"nrow={nrow}")
