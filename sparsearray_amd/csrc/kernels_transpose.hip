@@ -127,7 +127,7 @@ int launch_exclusive_scan_i64(int64_t *data, int64_t n, void *ws, hipStream_t s)
 #define T2_NT 256                 // columns per group = threads per workgroup of pass 2
 #define T2_NFINE 16               // fine buckets per coarse bucket
 #define T2_CAP 2048               // nonzeros a pass-2 workgroup assembles in LDS (more: straight to memory)
-#define T2_CPW 8                  // coarse buckets a pass-2 workgroup takes, one after the other
+#define T2_CPW 2                  // coarse buckets a pass-2 workgroup takes, one after the other (t(A) at config 2: 1 -> 2.06 ms, 2 -> 2.05, 4 -> 2.12, 8 -> 2.20, 16 -> 2.30)
 #define T1_NT 1024
 #define T1_HIST 65536             // fine buckets counted per sweep of pass 1 (LDS: two 16-bit counters per word --
                                   // a workgroup's 16 columns hold at most 16 * 64 nonzeros of one fine bucket)
