@@ -272,7 +272,7 @@ int svt_dev_crossprod_csc_dense(const svt_dev_csc *A, const void *Y,
  * row panels of Y in LDS and per-column partial sums in registers.
  *   CBW   columns per wavefront (<= 64), WPB wavefronts per workgroup, logR = log2(rows per
  *         panel).  (0, 0, 0) = chosen by the operand's density: (40, 16, 7), the LDS-DMA kernel,
- *         or, below ~0.25 % density, (40, 4, 10), the gather kernel (rows of Y straight from L2).
+ *         or, below ~0.25 % density, (40, 4, 9), the gather kernels (rows of Y straight from L2).
  * svt_dev_pbc_build() allocates and synchronises (not for the launch path).
  * svt_dev_crossprod_pbc() has the semantics and the out-indexing of
  * svt_dev_crossprod_csc_dense() (A is needed for the general path that
@@ -298,6 +298,15 @@ int svt_dev_crossprod_pbc(const svt_dev_pbc *P, const svt_dev_csc *A,
    product (a workspace sized by svt_dev_crossprod_pbc_ws_bytes() fits either setting). */
 void svt_dev_pbc_set_spare_cus(int n);
 int svt_dev_pbc_spare_cus(void);
+
+/* Pacing of the gather product (very sparse operands, K a multiple of 128, >= 64 row panels): its grid is
+   persistent, every XCD owns a range of rows, and a wavefront runs at most `dsync` row panels ahead of the
+   slowest wavefront of its XCD that has started, so that the rows of the dense operand the XCD gathers stay
+   in its L2; `pd` = panels of look-ahead of the L2 prefetch; `spin` = polls after which a wavefront that
+   waits in vain stops pacing itself (results never depend on the pacing).  Defaults (3, 2, 256).  dsync < 0:
+   the unpaced kernels (one launch per chunk of rows) run instead.  Process-wide; no reference counterpart
+   (src/SparseMatrix_mult.c:131-152 walks leaf by leaf on the host). */
+void svt_dev_pbc_set_gather_pacing(int dsync, int pd, int spin);
 
 /* The same, restricted to the leaves from `first_col` on (rounded down to the kernel's block of
    16 * CBW columns): cells of earlier leaves are not written.  What the unary crossprod(x) needs:

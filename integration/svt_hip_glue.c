@@ -2,8 +2,9 @@
  * svt_hip_glue.c -- the host shim an R maintainer adds to SparseArray's src/ so that the package's
  * .Call entry points run on an MI355X through libsvt_hip.so (include/svt_hip.h of this repository).
  *
- * NOT compiled in this repository: it needs R's headers (Rdefines.h, R_ext/...) and the package's own
- * internal headers, none of which exist in the build image.  It is the complete text of the binding,
+ * Not BUILT in this repository (no R in the image), but syntax- and type-checked against the reference's
+ * own headers by tests/test_glue_compiles.py (gcc -fsyntax-only with a declarations-only stand-in for
+ * Rdefines.h under tests/r_api_standin/).  It is the complete text of the binding,
  * one function per entry point registered in src/R_init_SparseArray.c:41-43,94,121-134:
  *
  *   C_crossprod2_SVT_mat/7  C_crossprod2_mat_SVT/7  C_crossprod2_SVT_SVT/8  C_crossprod1_SVT/5
@@ -30,8 +31,9 @@
  *   _get_summarize_opcode, _make_SummarizeOp, _init_SummarizeResult,
  *   _make_SEXP_from_summarize_result                                   src/Rvector_summarization.c
  *   unzip_leaf                                                         src/leaf_utils.h:80-140
- *   alloc_ans / compute_rowStats_ans_dim / check_dims / check_rowStats_center /
- *   propagate_colStats_dimnames (static in src/SparseArray_matrixStats.c: made extern)
+ *   alloc_ans / compute_colStats_ans_dim / compute_rowStats_ans_dim / check_dims / check_rowStats_center /
+ *   propagate_colStats_dimnames / propagate_rowStats_dimnames (static in src/SparseArray_matrixStats.c:
+ *   made extern, prototypes below)
  *   check_group (static in src/rowsum_methods.c: made extern)
  */
 #include <Rdefines.h>
@@ -51,6 +53,17 @@
 #include "SparseArray_aperm.h"
 #include "sparseMatrix_utils.h"
 #include "thread_control.h"
+
+/* Helpers that are `static` in the reference and that its maintainer makes extern for this file
+   (src/SparseArray_matrixStats.c:33, 44, 54, 108, 127, 151, 1079; src/rowsum_methods.c:15). */
+int check_dims(SEXP dims, int min, int max);
+SEXP compute_colStats_ans_dim(SEXP x_dim, int dims);
+SEXP compute_rowStats_ans_dim(SEXP x_dim, int ans_ndim);
+SEXP alloc_ans(SEXPTYPE Rtype, SEXP ans_dim, R_xlen_t *out_incs);
+void propagate_colStats_dimnames(SEXP ans, SEXP x_dimnames, int dims);
+void propagate_rowStats_dimnames(SEXP ans, SEXP x_dimnames, int dims);
+const double *check_rowStats_center(SEXP center, SEXP x_dim, int ans_ndim);
+void check_group(SEXP group, int x_nrow, int ngroup);
 
 /* the reference's bodies, renamed */
 SEXP C_crossprod2_SVT_mat_cpu(SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP);
@@ -266,6 +279,28 @@ SEXP C_crossprod1_SVT(SEXP x_dim, SEXP x_type, SEXP x_SVT, SEXP ans_type, SEXP a
 static SEXPTYPE sexptype_of(int svt_Rtype)
 {
 	return svt_Rtype == SVT_REALSXP ? REALSXP : svt_Rtype == SVT_INTSXP ? INTSXP : LGLSXP;
+}
+
+/* Result objects exactly as the reference's entry points make them (src/SparseArray_matrixStats.c:
+   255-266 and 1143-1150): alloc_ans() + the dimnames helper, with the reference's own functions. */
+static SEXP alloc_colStats_ans(SEXPTYPE Rtype, SEXP x_dim, SEXP x_dimnames, int d)
+{
+	SEXP ans_dim = PROTECT(compute_colStats_ans_dim(x_dim, d));
+	int ans_ndim = LENGTH(ans_dim);
+	R_xlen_t *incs = ans_ndim != 0 ? (R_xlen_t *) R_alloc(ans_ndim, sizeof(R_xlen_t)) : NULL;
+	SEXP ans = PROTECT(alloc_ans(Rtype, ans_dim, incs));
+	propagate_colStats_dimnames(ans, x_dimnames, d);
+	UNPROTECT(2);
+	return ans;
+}
+
+static SEXP alloc_rowStats_ans(SEXPTYPE Rtype, SEXP ans_dim, SEXP x_dimnames, int ans_ndim)
+{
+	R_xlen_t *incs = (R_xlen_t *) R_alloc(ans_ndim, sizeof(R_xlen_t));       /* ans_ndim >= 1 */
+	SEXP ans = PROTECT(alloc_ans(Rtype, ans_dim, incs));
+	propagate_rowStats_dimnames(ans, x_dimnames, ans_ndim);
+	UNPROTECT(1);
+	return ans;
 }
 
 SEXP C_colStats_SVT(SEXP x_dim, SEXP x_dimnames, SEXP x_type, SEXP x_SVT, SEXP x_na_background,

@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(64)
 pbc_pass_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__ row_idx,
 		const double *__restrict__ val, int64_t ncol, int CBW, int logR,
 		int64_t npanels, int64_t *__restrict__ counts_or_ptr,
-		uint4 *__restrict__ rec, int *__restrict__ col_has_na, int stag_mode)
+		uint4 *__restrict__ rec, int *__restrict__ col_has_na, int stag_mode, int tile_flags)
 {
 	constexpr int BATCH = FMT == 1 ? 8 : PBC_BATCH;
 	__shared__ int64_t fill[PCH];
@@ -208,7 +208,7 @@ pbc_pass_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__
 		if (p0 + i >= npanels) continue;
 		if (MODE == 0) {
 			int64_t n = (fill[i] + BATCH - 1) / BATCH * BATCH;
-			if (FMT == 1 && n == 0) n = BATCH;          // no tile without a batch
+			if ((FMT == 1 || tile_flags) && n == 0) n = BATCH;  // no tile without a batch
 			counts_or_ptr[TILE_OF(p0 + i)] = n;
 		} else {
 			// fill[i] = one past the last real record; pad up to the next tile
@@ -217,6 +217,10 @@ pbc_pass_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__
 				if (FMT == 1) pbc1_store(rec, q, 0u, 0.0);
 				else rec[q] = make_uint4(0, 0, 0, 0);
 			}
+			// gather layouts: bit 15 of the first column word marks the start of a tile (the kernel that runs a
+			// whole pass as one pipeline changes panels there; the register index is the word's low byte)
+			if (FMT == 0 && tile_flags)
+				atomicOr(&((unsigned int *) rec)[counts_or_ptr[TILE_OF(p0 + i)] * 4 + 1], 0x8000u);
 			if (FMT == 1) {                             // flag the tile's last batch ...
 				atomicOr((unsigned int *) ((char *) rec + ((stop - 8) >> 3) * 96), 0x8000u);
 				// ... and the batch after which the wavefront issues the LDS-DMA of the
@@ -552,7 +556,7 @@ void pbc_auto_layout(int64_t nrow, int64_t ncol, int64_t nnz, int *CBW, int *WPB
 	*CBW = 40;
 	const double per_tile = (double) nnz * 40.0 * 128.0 /
 				((double) (nrow > 0 ? nrow : 1) * (double) (ncol > 0 ? ncol : 1));
-	if (per_tile < 12.0 && nrow >= 4096) { *WPB = 4; *logR = 10; }
+	if (per_tile < 12.0 && nrow >= 4096) { *WPB = 4; *logR = 9; }
 	else { *WPB = 16; *logR = 7; }
 }
 
@@ -609,7 +613,7 @@ extern "C" svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB
 		// Every tile is padded to whole batches (format 1: at least one): at most BATCH - 1 (BATCH)
 		// records of padding per tile.  Allocating for that bound spares the build a round trip to
 		// the host between its count and scatter passes; the exact count is read back at the end.
-		const int64_t nrec_max = A->nnz + ntiles * (int64_t) (h->fmt == 1 ? BATCH : BATCH - 1);
+		const int64_t nrec_max = A->nnz + ntiles * (int64_t) (h->fmt == 1 || h->gather ? BATCH : BATCH - 1);
 		dim3 grid((unsigned) h->ngroups, (unsigned) ((h->npanels + PCH - 1) / PCH));
 		if (h->fmt == 1 && h->npanels <= PBC_COUNT_MAXPANELS) {
 			// one stream over the offsets: tile counts and the table of stretch bounds together
@@ -628,11 +632,11 @@ extern "C" svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB
 		} else if (h->fmt == 1)
 			hipLaunchKernelGGL((pbc_pass_kernel<0, 1>), grid, dim3(64), 0, 0, A->col_ptr, A->row_idx,
 					   (const double *) A->val, A->ncol, CBW, logR, h->npanels,
-					   h->tile_ptr, (uint4 *) NULL, h->col_has_na, g_pbc_stagger);
+					   h->tile_ptr, (uint4 *) NULL, h->col_has_na, g_pbc_stagger, 0);
 		else
 			hipLaunchKernelGGL((pbc_pass_kernel<0, 0>), grid, dim3(64), 0, 0, A->col_ptr, A->row_idx,
 					   (const double *) A->val, A->ncol, CBW, logR, h->npanels,
-					   h->tile_ptr, (uint4 *) NULL, h->col_has_na, g_pbc_stagger);
+					   h->tile_ptr, (uint4 *) NULL, h->col_has_na, g_pbc_stagger, h->gather);
 		// exclusive scan in place over ntiles+1 entries (last entry = total)
 		tmp_bytes = exclusive_scan_ws_bytes(ntiles + 1);
 		ok = pbc_alloc(&tmp, tmp_bytes) == hipSuccess &&
@@ -657,7 +661,7 @@ extern "C" svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB
 			} else {
 				hipLaunchKernelGGL((pbc_pass_kernel<1, 0>), grid, dim3(64), 0, 0, A->col_ptr,
 						   A->row_idx, (const double *) A->val, A->ncol, CBW, logR,
-						   h->npanels, h->tile_ptr, h->rec, h->col_has_na, g_pbc_stagger);
+						   h->npanels, h->tile_ptr, h->rec, h->col_has_na, g_pbc_stagger, h->gather);
 			}
 		}
 		// One read-back for the whole build: records, longest leaf, "a column group too large for the
@@ -734,7 +738,9 @@ struct PbcFlags {
 // (kept in the flag block at the head of the workspace, its last 1024 bytes)
 #define PBC_SUBFLAG0 16           // flags[16 .. 63]: "a non-finite entry in block (row split, dense tile) of Y", index modulo 48
 #define PBC_NSUBFLAG 48
-#define PBC_FLAG_BYTES 8192      // [0, 256) flags; [256, ...) per-column counters of the dirty-column fix-up when they fit
+#define PBC_FLAG_BYTES 16384     // [0, 256) flags; [256, 8192) per-column counters of the dirty-column fix-up when they fit;
+                                 // [8192, 16384) progress words of the XCD-paced gather kernel (8 XCDs x 256)
+#define PBC_PROG_OFFSET 8192
 #ifdef SVT_TUNING
 extern "C" int svt_dev_pbc_read_prof(const void *ws, unsigned long long *out)
 {
@@ -1292,6 +1298,129 @@ crossprod_pbc_gather2_kernel(const uint4 *__restrict__ rec, const int64_t *__res
 				dhi[32 + jj] = accumulate ? dhi[32 + jj] + acch8[jj] : acch8[jj];
 			}
 	}
+}
+
+// ---------------------------------------------------------------------------
+// Gather kernel, XCD-paced (round 4; K a multiple of 128, >= 8 panels per XCD).  The two kernels above leave
+// 64 GB of gathered rows at BASELINE config 4's per-rank share to the Infinity Cache (10.5 TB/s): their
+// wavefronts start a tile with an empty pipeline (two scalar round trips, then the first rows: ~1.5 us of
+// a ~5 us tile) and drift apart by more rows of Yt than an XCD's 4 MiB L2 holds.  Here
+//   * the grid is persistent -- 2 workgroups per CU, workgroup L on XCD L % 8 (the dispatcher deals
+//     workgroups round-robin over the XCDs) -- and XCD x owns the rows of panels [x * npx, (x + 1) * npx):
+//     one partial result per XCD, summed in fixed order by pbc_reduce_kernel;
+//   * a workgroup takes the column blocks slot, slot + nslots, ... (a "pass" each) and a wavefront runs the
+//     whole record stream of a pass -- npx tiles, contiguous in the layout -- as ONE pipeline
+//     (pbgx_asm.inc, tools/gen_pbgx_asm.py): the tile-start flag of the layout switches the panel base;
+//   * at every tile start a wavefront publishes its tile count, prefetches its share of the panel `pd`
+//     tiles ahead into L2 and looks at a snapshot of the counts of the XCD's other wavefronts: it does not
+//     run more than `dsync` tiles ahead of the slowest one that has started.  All the XCD's wavefronts then
+//     gather from a window of (dsync + 1 + pd) panels that stays in its L2.  The protocol only paces: a
+//     wavefront that waits in vain (a spin budget) stops looking, and no result depends on it.
+// ---------------------------------------------------------------------------
+#include "pbgx_asm.inc"       // PBGX_PASS_TXT, generated by tools/gen_pbgx_asm.py
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#define PBGX_CLOBBERS "scc", "vcc", "memory", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s85", "s86", "s87", "s88", "s89", "s94", "s95"
+#define PBGX_OPS                                                                       \
+	[lo] "+s"(lo_), [nb] "+s"(nb_), [step] "+s"(step), [rem] "+s"(rem_), [dsync] "+s"(dsync), \
+	[t0] "=&v"(t0_), [t1] "=&v"(t1_), [t2] "=&v"(t2_), [t3] "=&v"(t3_),              \
+	[vt] "=&v"(vt_), [vd] "=&v"(vd_), "+{v[56:59]}"(snap), "+{v[224:255]}"(ysets)
+#define PBGX_IN [base] "s"(rec_w), [pbl] "s"(pbl), [pbh] "s"(pbh), [pfl] "s"(pfl), [pfh] "s"(pfh),    \
+	[pst] "s"(pst), [pd] "s"(pd_u), [spin] "s"(spin_u), [pgm] "s"(pg_mine), [pga] "s"(pg_all), [pfm] "s"(pf_mask), \
+	[kp] "v"(kp_v), [l16] "v"(lane16), [l128] "v"(lane128), [vz] "v"(vzero)
+#define PBGX_PROG_ENTRIES 256     // progress words per XCD: one per wavefront (64 workgroup slots x 4)
+#define PBGX_DONE 0x7fffffffu
+
+template <int NV>
+__global__ void __launch_bounds__(256)
+crossprod_pbc_gatherx_kernel(const uint4 *__restrict__ rec, const int64_t *__restrict__ tile_ptr,
+			     int64_t npanels, int64_t ngroups, const double *__restrict__ Yt, int64_t Ktp,
+			     int64_t ncol, double *__restrict__ part, int64_t Kp, int CBW, int logR,
+			     int64_t npx, int nkt, int64_t nunits, unsigned int *__restrict__ prog,
+			     int dsync_in, int pd_in, int spin_in, int lpw)
+{
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+	const int64_t pa = (int64_t) xcd * npx;
+	const int64_t pb = pa + npx < npanels ? pa + npx : npanels;
+	if (pa >= pb)
+		return;
+	unsigned int *pg_all = prog + xcd * PBGX_PROG_ENTRIES;
+	unsigned int *pg_mine = pg_all + slot * 4 + w;
+	uint32_t step = 0, dsync = (uint32_t) dsync_in;
+	const uint32_t pd_u = (uint32_t) pd_in, spin_u = (uint32_t) spin_in;
+	const uint32_t pst = (uint32_t) (((int64_t) 8 << logR) * Ktp);          // bytes of Yt per panel
+	const uint64_t pf_mask = lpw >= 64 ? ~0ULL : ((1ULL << lpw) - 1ULL);
+	const uint32_t lane16 = (uint32_t) lane * 16u, lane128 = (uint32_t) lane * 128u, vzero = 0u;
+	const uint32_t kp_v = (uint32_t) Ktp;                    // (row offset in bytes = 8 * row * Ktp)
+	u32x4 snap = 0;
+	u32x32_t ysets = 0;
+	// units (column block, pair of dense tiles) whose column group exists for this wavefront (the last block may be short)
+	int ulim = (int) ((ngroups - w + 3) >> 2) * nkt;
+	if (ulim > (int) nunits) ulim = (int) nunits;
+	for (int u = slot; u < ulim; u += nslots) {
+		// (the division runs on the vector unit: back to scalar registers for the asm operands)
+		const int kt = __builtin_amdgcn_readfirstlane(u % nkt);
+		const int64_t wv = (int64_t) __builtin_amdgcn_readfirstlane(u / nkt) * 4 + w;   // column group of this wavefront
+		const int k0 = kt * 128;
+		// lo: dense column k0 + 2 * lane, hi: k0 + 2 * lane + 1; NV == 3 keeps 40 columns (16 + 16 + 8)
+		d16 acc[NV > 2 ? 2 : NV], acch[NV > 2 ? 2 : NV];
+		d8 acc8 = 0.0, acch8 = 0.0;
+#pragma unroll
+		for (int i = 0; i < (NV > 2 ? 2 : NV); i++) { acc[i] = 0.0; acch[i] = 0.0; }
+		const int64_t tbeg = tile_ptr[wv * npanels + pa], tend = tile_ptr[wv * npanels + pb];
+		const uint4 *__restrict__ rec_w = rec + tbeg;
+		uint32_t nb_ = (uint32_t) ((tend - tbeg) / PBC_BATCH), lo_ = 0, rem_ = (uint32_t) (pb - pa);
+		// the first tile's flag steps the base onto panel pa
+		const uint64_t pbase = (uint64_t) (uintptr_t) Yt + (uint64_t) (((pa - 1) << logR) * Ktp + k0) * 8u;
+		const uint64_t pfb = (uint64_t) (uintptr_t) Yt + (uint64_t) (((pa + pd_in) << logR) * Ktp) * 8u +
+				     (uint64_t) (slot * 4 + w) * (uint64_t) lpw * 128u;
+		const uint32_t pbl = (uint32_t) pbase, pbh = (uint32_t) (pbase >> 32);
+		const uint32_t pfl = (uint32_t) pfb, pfh = (uint32_t) (pfb >> 32);
+		uint32_t t0_, t1_, t2_, t3_, vt_, vd_;
+		if constexpr (NV == 1) {
+			asm volatile(PBGX_PASS_TXT
+				     : "+{v[64:95]}"(acc[0]), "+{v[144:175]}"(acch[0]), PBGX_OPS
+				     : PBGX_IN
+				     : PBGX_CLOBBERS);
+		} else if constexpr (NV == 2) {
+			asm volatile(PBGX_PASS_TXT
+				     : "+{v[64:95]}"(acc[0]), "+{v[96:127]}"(acc[NV > 1 ? 1 : 0]),
+				       "+{v[144:175]}"(acch[0]), "+{v[176:207]}"(acch[NV > 1 ? 1 : 0]), PBGX_OPS
+				     : PBGX_IN
+				     : PBGX_CLOBBERS);
+		} else {
+			asm volatile(PBGX_PASS_TXT
+				     : "+{v[64:95]}"(acc[0]), "+{v[96:127]}"(acc[NV > 1 ? 1 : 0]), "+{v[128:143]}"(acc8),
+				       "+{v[144:175]}"(acch[0]), "+{v[176:207]}"(acch[NV > 1 ? 1 : 0]), "+{v[208:223]}"(acch8),
+				       PBGX_OPS
+				     : PBGX_IN
+				     : PBGX_CLOBBERS);
+		}
+		// ---- partial results of this XCD: part[(xcd*Kp + k) * ncol + c] -------
+		const int64_t c0 = wv * CBW;
+		double *__restrict__ dlo = part + ((int64_t) xcd * Kp + k0 + 2 * lane) * ncol + c0;
+		double *__restrict__ dhi = dlo + ncol;
+#pragma unroll
+		for (int ii = 0; ii < (NV > 2 ? 2 : NV); ii++)
+#pragma unroll
+			for (int jj = 0; jj < 16; jj++)
+				if (ii * 16 + jj < CBW && c0 + ii * 16 + jj < ncol) {
+					dlo[ii * 16 + jj] = acc[ii][jj];
+					dhi[ii * 16 + jj] = acch[ii][jj];
+				}
+		if constexpr (NV > 2) {
+#pragma unroll
+			for (int jj = 0; jj < 8; jj++)
+				if (32 + jj < CBW && c0 + 32 + jj < ncol) {
+					dlo[32 + jj] = acc8[jj];
+					dhi[32 + jj] = acch8[jj];
+				}
+		}
+	}
+	// out of the race: nobody waits for this wavefront any more
+	if (lane == 0)
+		__hip_atomic_store(pg_mine, PBGX_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---------------------------------------------------------------------------
@@ -1916,12 +2045,51 @@ static bool pbc_dma_ok(const svt_dev_pbc *P, int tr_y)
 // records of the next tile, whose row offsets are relative to a panel that may be the last, partial one
 static int64_t pbc_padded_rows(const svt_dev_pbc *P)
 {
-	return P->gather ? (P->npanels << P->logR) : P->nrow;
+	// (one panel more: the XCD-paced kernel's look-ahead batch past its last tile may carry a tile-start flag)
+	return P->gather ? ((P->npanels + 1) << P->logR) : P->nrow;
+}
+
+// Pacing of crossprod_pbc_gatherx_kernel: a wavefront runs at most `dsync` tiles ahead of the slowest started
+// wavefront of its XCD, prefetches `pd` panels ahead, gives up after `spin` polls.  dsync < 0: the kernels
+// with one launch per row chunk (crossprod_pbc_gather2_kernel) run instead.
+static int g_pbgx_dsync = 3, g_pbgx_pd = 2, g_pbgx_spin = 256;
+extern "C" void svt_dev_pbc_set_gather_pacing(int dsync, int pd, int spin)
+{
+	g_pbgx_dsync = dsync;
+	g_pbgx_pd = pd < 0 ? 0 : pd;
+	g_pbgx_spin = spin < 1 ? 1 : spin;
+}
+
+static int pbgx_cus(void)
+{
+	static int cus = 0;
+	if (cus == 0) {
+		int dev = 0, n = 0;
+		if (hipGetDevice(&dev) == hipSuccess &&
+		    hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n >= 8)
+			cus = n;
+		else
+			cus = 256;
+	}
+	return cus;
+}
+
+// the XCD-paced kernel takes whole pairs of 64-wide dense tiles and wants a few panels per XCD
+static bool pbgx_ok(const svt_dev_pbc *P, int K)
+{
+	const int64_t Kp = ((int64_t) K + 63) / 64 * 64;
+	return P->gather && g_pbgx_dsync >= 0 && Kp % 128 == 0 && P->npanels >= 64 && P->WPB == 4 &&
+	       ((int64_t) 8 << P->logR) * Kp < ((int64_t) 1 << 31);
 }
 
 // gather kernel: no staging to share, so splits only have to fill the chip (~8192 wavefronts)
 static int pick_nsplit_gather(const svt_dev_pbc *P, int K, int64_t *pps_out)
 {
+	if (pbgx_ok(P, K)) {                                 // one partial result per XCD with rows
+		const int64_t npx = (P->npanels + 7) / 8;
+		if (pps_out) *pps_out = npx;
+		return (int) ((P->npanels + npx - 1) / npx);
+	}
 	const int64_t kt = ((int64_t) K + 63) / 64;
 	const bool wide = kt % 2 == 0;                       // crossprod_pbc_gather2_kernel: one wavefront per 128 dense columns
 	const int64_t waves = P->ngroups * (wide ? kt / 2 : kt);
@@ -2009,6 +2177,7 @@ extern "C" size_t svt_dev_crossprod_pbc_ws_bytes(const svt_dev_pbc *P, int K)
 	if (P->gather) {
 		const int ng = pick_nsplit_gather(P, K, NULL);
 		if (ng > ns) ns = ng;
+		if (ns < 8) ns = 8;                         // (the pacing knob may change between the query and the launch)
 	}
 	// [flags][partials][general-path workspace; a row-major Y is transposed into it first]
 	// [dirty-column scratch]
@@ -2145,6 +2314,26 @@ static int pbc_phase(const svt_dev_pbc *P, const svt_dev_csc *A,
 			pa.tr_y = tr_y; pa.ws = gen_ws; pa.ws_bytes = gen_bytes;
 			if (launch_dense_prepare_flag(pa, fl.y_nonfinite, s))
 				return -1;
+			if (pbgx_ok(P, K)) {
+				// persistent grid, one row range per XCD, paced (see crossprod_pbc_gatherx_kernel)
+				unsigned int *prog = (unsigned int *) ((char *) ws + PBC_PROG_OFFSET);
+				HIP_TRY(hipMemsetAsync(prog, 0, 8 * PBGX_PROG_ENTRIES * 4, s));
+				int nslots = (pbgx_cus() - g_pbc_spare_cus) / 8 * 2;
+				if (nslots > PBGX_PROG_ENTRIES / 4) nslots = PBGX_PROG_ENTRIES / 4;
+				if (nslots < 2) nslots = 2;
+				const int nkt = (int) (Kp / 128);
+				const int64_t nunits = P->nblocks * nkt;
+				const int64_t lines = (Kp << P->logR) / 16;          // 128-byte lines of Yt per panel
+				int64_t lpw = (lines + nslots * 4 - 1) / (nslots * 4);
+				if (lpw > 64) lpw = 64;
+				auto kx = nv == 1 ? crossprod_pbc_gatherx_kernel<1> : nv == 2 ? crossprod_pbc_gatherx_kernel<2>
+										   : crossprod_pbc_gatherx_kernel<3>;
+				hipLaunchKernelGGL(kx, dim3((unsigned) (8 * nslots)), dim3(256), 0, s, P->rec, P->tile_ptr,
+						   P->npanels, P->ngroups, (const double *) gen_ws, Kp, P->ncol, part, Kp, P->CBW,
+						   P->logR, pps, nkt, nunits, prog, g_pbgx_dsync, g_pbgx_pd, g_pbgx_spin, (int) lpw);
+				HIP_TRY(hipGetLastError());
+				return 0;
+			}
 			// whole pairs of 64-wide dense tiles: the kernel with two dense columns per lane
 			const bool wide = Kp % 128 == 0;
 			dim3 grid((unsigned) nsplit, (unsigned) (wide ? Kp / 128 : Kp / 64), (unsigned) P->nblocks);
@@ -2161,6 +2350,7 @@ static int pbc_phase(const svt_dev_pbc *P, const svt_dev_csc *A,
 #ifdef SVT_TUNING
 			if (getenv("SVT_PBG_CHUNK")) cpanels = atoll(getenv("SVT_PBG_CHUNK"));
 #endif
+			if (P->logR < 10) cpanels <<= 10 - P->logR;          // (the chunk sizes were measured with 1024-row panels)
 			const int64_t chunk = (int64_t) nsplit * cpanels;
 			for (int64_t p0 = 0; p0 < P->npanels; p0 += chunk) {
 				const int64_t p1 = p0 + chunk < P->npanels ? p0 + chunk : P->npanels;

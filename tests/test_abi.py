@@ -74,3 +74,19 @@ def test_generated_asm_is_in_sync(tmp_path):
                    stdout=subprocess.DEVNULL)
     committed = open(os.path.join(root, "sparsearray_amd", "csrc", "pbc_dma_asm.inc")).read()
     assert out.read_text() == committed
+
+
+def test_generated_gatherx_asm_is_in_sync(tmp_path):
+    """sparsearray_amd/csrc/pbgx_asm.inc (the pass loop of the XCD-paced gather kernel) is what
+    tools/gen_pbgx_asm.py writes."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "pbgx_asm.inc"
+    env = dict(os.environ)
+    env["PBGX_ASM_OUT"] = str(out)
+    subprocess.run([sys.executable, os.path.join(root, "tools", "gen_pbgx_asm.py")], check=True, env=env,
+                   stdout=subprocess.DEVNULL)
+    committed = open(os.path.join(root, "sparsearray_amd", "csrc", "pbgx_asm.inc")).read()
+    assert out.read_text() == committed
