@@ -302,11 +302,11 @@ int svt_dev_pbc_spare_cus(void);
 /* Pacing of the gather product (very sparse operands, K a multiple of 128, >= 64 row panels): its grid is
    persistent, every XCD owns a range of rows, and a wavefront runs at most `dsync` row panels ahead of the
    slowest wavefront of its XCD that has started, so that the rows of the dense operand the XCD gathers stay
-   in its L2; `pd` = panels of look-ahead of the L2 prefetch; `spin` = polls after which a wavefront that
-   waits in vain stops pacing itself (results never depend on the pacing).  Defaults (3, 2, 256).  dsync < 0:
+   in its L2; `spin` = polls after which a wavefront that waits in vain stops pacing itself (results never
+   depend on the pacing).  Defaults (2, 256).  dsync < 0:
    the unpaced kernels (one launch per chunk of rows) run instead.  Process-wide; no reference counterpart
    (src/SparseMatrix_mult.c:131-152 walks leaf by leaf on the host). */
-void svt_dev_pbc_set_gather_pacing(int dsync, int pd, int spin);
+void svt_dev_pbc_set_gather_pacing(int dsync, int spin);
 
 /* The same, restricted to the leaves from `first_col` on (rounded down to the kernel's block of
    16 * CBW columns): cells of earlier leaves are not written.  What the unary crossprod(x) needs:

@@ -556,8 +556,12 @@ void pbc_auto_layout(int64_t nrow, int64_t ncol, int64_t nnz, int *CBW, int *WPB
 	*CBW = 40;
 	const double per_tile = (double) nnz * 40.0 * 128.0 /
 				((double) (nrow > 0 ? nrow : 1) * (double) (ncol > 0 ? ncol : 1));
-	if (per_tile < 12.0 && nrow >= 4096) { *WPB = 4; *logR = 9; }
-	else { *WPB = 16; *logR = 7; }
+	if (per_tile < 12.0 && nrow >= 4096) {
+		// the tallest panels that leave the XCD-paced gather kernel its 64 panels (fewer tile starts, less
+		// padding of tiles to whole batches; config 4's rank share: 2048 rows 4.73 ms, 1024: 4.82, 512: 5.2)
+		*WPB = 4;
+		*logR = (nrow >> 11) >= 64 ? 11 : (nrow >> 10) >= 64 ? 10 : 9;
+	} else { *WPB = 16; *logR = 7; }
 }
 
 // Not on the launch path: allocates, synchronises.
@@ -1311,22 +1315,21 @@ crossprod_pbc_gather2_kernel(const uint4 *__restrict__ rec, const int64_t *__res
 //   * a workgroup takes the column blocks slot, slot + nslots, ... (a "pass" each) and a wavefront runs the
 //     whole record stream of a pass -- npx tiles, contiguous in the layout -- as ONE pipeline
 //     (pbgx_asm.inc, tools/gen_pbgx_asm.py): the tile-start flag of the layout switches the panel base;
-//   * at every tile start a wavefront publishes its tile count, prefetches its share of the panel `pd`
-//     tiles ahead into L2 and looks at a snapshot of the counts of the XCD's other wavefronts: it does not
-//     run more than `dsync` tiles ahead of the slowest one that has started.  All the XCD's wavefronts then
-//     gather from a window of (dsync + 1 + pd) panels that stays in its L2.  The protocol only paces: a
+//   * at every tile start a wavefront publishes its tile count and looks at a snapshot of the counts of
+//     the XCD's other wavefronts: it does not run more than `dsync` tiles ahead of the slowest one that has
+//     started.  All the XCD's wavefronts then gather from a window of (dsync + 1) panels that stays in its
+//     L2 (the first gather of a line brings it in for the other 255).  The protocol only paces: a
 //     wavefront that waits in vain (a spin budget) stops looking, and no result depends on it.
 // ---------------------------------------------------------------------------
 #include "pbgx_asm.inc"       // PBGX_PASS_TXT, generated by tools/gen_pbgx_asm.py
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define PBGX_CLOBBERS "scc", "vcc", "memory", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s85", "s86", "s87", "s88", "s89", "s94", "s95"
 #define PBGX_OPS                                                                       \
-	[lo] "+s"(lo_), [nb] "+s"(nb_), [step] "+s"(step), [rem] "+s"(rem_), [dsync] "+s"(dsync), \
+	[lo] "+s"(lo_), [nb] "+s"(nb_), [step] "+s"(step), [dsync] "+s"(dsync),          \
 	[t0] "=&v"(t0_), [t1] "=&v"(t1_), [t2] "=&v"(t2_), [t3] "=&v"(t3_),              \
-	[vt] "=&v"(vt_), [vd] "=&v"(vd_), "+{v[56:59]}"(snap), "+{v[224:255]}"(ysets)
-#define PBGX_IN [base] "s"(rec_w), [pbl] "s"(pbl), [pbh] "s"(pbh), [pfl] "s"(pfl), [pfh] "s"(pfh),    \
-	[pst] "s"(pst), [pd] "s"(pd_u), [spin] "s"(spin_u), [pgm] "s"(pg_mine), [pga] "s"(pg_all), [pfm] "s"(pf_mask), \
-	[kp] "v"(kp_v), [l16] "v"(lane16), [l128] "v"(lane128), [vz] "v"(vzero)
+	[vt] "=&v"(vt_), "+{v[56:59]}"(snap), "+{v[224:255]}"(ysets)
+#define PBGX_IN [base] "s"(rec_w), [pbl] "s"(pbl), [pbh] "s"(pbh), [pst] "s"(pst), [spin] "s"(spin_u), \
+	[pgm] "s"(pg_mine), [pga] "s"(pg_all), [kp] "v"(kp_v), [l16] "v"(lane16), [vz] "v"(vzero)
 #define PBGX_PROG_ENTRIES 256     // progress words per XCD: one per wavefront (64 workgroup slots x 4)
 #define PBGX_DONE 0x7fffffffu
 
@@ -1336,7 +1339,7 @@ crossprod_pbc_gatherx_kernel(const uint4 *__restrict__ rec, const int64_t *__res
 			     int64_t npanels, int64_t ngroups, const double *__restrict__ Yt, int64_t Ktp,
 			     int64_t ncol, double *__restrict__ part, int64_t Kp, int CBW, int logR,
 			     int64_t npx, int nkt, int64_t nunits, unsigned int *__restrict__ prog,
-			     int dsync_in, int pd_in, int spin_in, int lpw)
+			     int dsync_in, int spin_in)
 {
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1348,10 +1351,9 @@ crossprod_pbc_gatherx_kernel(const uint4 *__restrict__ rec, const int64_t *__res
 	unsigned int *pg_all = prog + xcd * PBGX_PROG_ENTRIES;
 	unsigned int *pg_mine = pg_all + slot * 4 + w;
 	uint32_t step = 0, dsync = (uint32_t) dsync_in;
-	const uint32_t pd_u = (uint32_t) pd_in, spin_u = (uint32_t) spin_in;
+	const uint32_t spin_u = (uint32_t) spin_in;
 	const uint32_t pst = (uint32_t) (((int64_t) 8 << logR) * Ktp);          // bytes of Yt per panel
-	const uint64_t pf_mask = lpw >= 64 ? ~0ULL : ((1ULL << lpw) - 1ULL);
-	const uint32_t lane16 = (uint32_t) lane * 16u, lane128 = (uint32_t) lane * 128u, vzero = 0u;
+	const uint32_t lane16 = (uint32_t) lane * 16u, vzero = 0u;
 	const uint32_t kp_v = (uint32_t) Ktp;                    // (row offset in bytes = 8 * row * Ktp)
 	u32x4 snap = 0;
 	u32x32_t ysets = 0;
@@ -1370,14 +1372,11 @@ crossprod_pbc_gatherx_kernel(const uint4 *__restrict__ rec, const int64_t *__res
 		for (int i = 0; i < (NV > 2 ? 2 : NV); i++) { acc[i] = 0.0; acch[i] = 0.0; }
 		const int64_t tbeg = tile_ptr[wv * npanels + pa], tend = tile_ptr[wv * npanels + pb];
 		const uint4 *__restrict__ rec_w = rec + tbeg;
-		uint32_t nb_ = (uint32_t) ((tend - tbeg) / PBC_BATCH), lo_ = 0, rem_ = (uint32_t) (pb - pa);
+		uint32_t nb_ = (uint32_t) ((tend - tbeg) / PBC_BATCH), lo_ = 0;
 		// the first tile's flag steps the base onto panel pa
 		const uint64_t pbase = (uint64_t) (uintptr_t) Yt + (uint64_t) (((pa - 1) << logR) * Ktp + k0) * 8u;
-		const uint64_t pfb = (uint64_t) (uintptr_t) Yt + (uint64_t) (((pa + pd_in) << logR) * Ktp) * 8u +
-				     (uint64_t) (slot * 4 + w) * (uint64_t) lpw * 128u;
 		const uint32_t pbl = (uint32_t) pbase, pbh = (uint32_t) (pbase >> 32);
-		const uint32_t pfl = (uint32_t) pfb, pfh = (uint32_t) (pfb >> 32);
-		uint32_t t0_, t1_, t2_, t3_, vt_, vd_;
+		uint32_t t0_, t1_, t2_, t3_, vt_;
 		if constexpr (NV == 1) {
 			asm volatile(PBGX_PASS_TXT
 				     : "+{v[64:95]}"(acc[0]), "+{v[144:175]}"(acch[0]), PBGX_OPS
@@ -2050,13 +2049,13 @@ static int64_t pbc_padded_rows(const svt_dev_pbc *P)
 }
 
 // Pacing of crossprod_pbc_gatherx_kernel: a wavefront runs at most `dsync` tiles ahead of the slowest started
-// wavefront of its XCD, prefetches `pd` panels ahead, gives up after `spin` polls.  dsync < 0: the kernels
-// with one launch per row chunk (crossprod_pbc_gather2_kernel) run instead.
-static int g_pbgx_dsync = 3, g_pbgx_pd = 2, g_pbgx_spin = 256;
-extern "C" void svt_dev_pbc_set_gather_pacing(int dsync, int pd, int spin)
+// wavefront of its XCD and gives up after `spin` polls.  dsync < 0: the kernels with one launch per row
+// chunk (crossprod_pbc_gather2_kernel) run instead.  (One rank's share of BASELINE config 4, 2048-row
+// panels: dsync 0: 5.69 ms, 1: 4.77, 2: 4.73, 3: 4.80, no pacing at all: 7.9.)
+static int g_pbgx_dsync = 2, g_pbgx_spin = 256;
+extern "C" void svt_dev_pbc_set_gather_pacing(int dsync, int spin)
 {
 	g_pbgx_dsync = dsync;
-	g_pbgx_pd = pd < 0 ? 0 : pd;
 	g_pbgx_spin = spin < 1 ? 1 : spin;
 }
 
@@ -2323,14 +2322,11 @@ static int pbc_phase(const svt_dev_pbc *P, const svt_dev_csc *A,
 				if (nslots < 2) nslots = 2;
 				const int nkt = (int) (Kp / 128);
 				const int64_t nunits = P->nblocks * nkt;
-				const int64_t lines = (Kp << P->logR) / 16;          // 128-byte lines of Yt per panel
-				int64_t lpw = (lines + nslots * 4 - 1) / (nslots * 4);
-				if (lpw > 64) lpw = 64;
 				auto kx = nv == 1 ? crossprod_pbc_gatherx_kernel<1> : nv == 2 ? crossprod_pbc_gatherx_kernel<2>
 										   : crossprod_pbc_gatherx_kernel<3>;
 				hipLaunchKernelGGL(kx, dim3((unsigned) (8 * nslots)), dim3(256), 0, s, P->rec, P->tile_ptr,
 						   P->npanels, P->ngroups, (const double *) gen_ws, Kp, P->ncol, part, Kp, P->CBW,
-						   P->logR, pps, nkt, nunits, prog, g_pbgx_dsync, g_pbgx_pd, g_pbgx_spin, (int) lpw);
+						   P->logR, pps, nkt, nunits, prog, g_pbgx_dsync, g_pbgx_spin);
 				HIP_TRY(hipGetLastError());
 				return 0;
 			}

@@ -44,7 +44,7 @@ def _lib():
         lib.svt_dev_pbc_set_spare_cus.argtypes = [c_int]
         lib.svt_dev_pbc_set_spare_cus.restype = None
         lib.svt_dev_pbc_spare_cus.restype = c_int
-        lib.svt_dev_pbc_set_gather_pacing.argtypes = [c_int, c_int, c_int]
+        lib.svt_dev_pbc_set_gather_pacing.argtypes = [c_int, c_int]
         lib.svt_dev_pbc_set_gather_pacing.restype = None
         lib.svt_dev_crossprod_pbc_ws_bytes.restype = c_size_t
         lib.svt_dev_crossprod_pbc_ws_bytes.argtypes = [c_void_p, c_int]
@@ -233,10 +233,10 @@ def spare_cus() -> int:
     return int(_lib().svt_dev_pbc_spare_cus())
 
 
-def set_gather_pacing(dsync: int = 3, pd: int = 2, spin: int = 256) -> None:
+def set_gather_pacing(dsync: int = 2, spin: int = 256) -> None:
     """Pacing of the gather product of very sparse operands (include/svt_hip.h:
     svt_dev_pbc_set_gather_pacing); dsync < 0 selects the unpaced kernels."""
-    _lib().svt_dev_pbc_set_gather_pacing(int(dsync), int(pd), int(spin))
+    _lib().svt_dev_pbc_set_gather_pacing(int(dsync), int(spin))
 
 
 def crossprod_csc_dense(A: DeviceCSC, Y: torch.Tensor) -> torch.Tensor:

@@ -69,6 +69,99 @@ def test_config3_matmul_sparse_sparse_full_size(config3):
     assert float((out - rs[None, :]).abs().max()) <= 1e-12 * max(1.0, float(rs.abs().max()))
 
 
+def _sampled_rows_err(out, A, Bd, rows):
+    """max over the sampled result rows of |out[:, r] - sum_j A[r, j] * B[j, :]| / sum |terms|, the sum
+    recomputed from A itself with torch gathers."""
+    leaf_of = torch.repeat_interleave(torch.arange(A.ncol, device=Bd.device), A.col_ptr[1:] - A.col_ptr[:-1])
+    worst = 0.0
+    for r in rows:
+        hit = (A.row_idx == r).nonzero().flatten()
+        prod = Bd[:, leaf_of[hit]] * A.val[hit].double()       # (K, nz in the row)
+        scale = prod.abs().sum(dim=1).clamp_min(1e-300)
+        worst = max(worst, float(((out[:, r] - prod.sum(dim=1)).abs() / scale).max()))
+    return worst
+
+
+def test_config3_matmul_row_panel_kernel_full_size(hip, config3):
+    """BASELINE config 3 through the kernel `svt %*% svt2` actually takes (spmm_csc_csc_kernel: row panels of A
+    itself, no t(A), no dense operand), per call (svt_dev_matmul_csc_csc) and with the operand-only work done
+    once (SpmmPlan): 26 result rows recomputed with torch from A and B; the whole result against the dense
+    route (t(A) + panel-blocked layout + densified B); columns of B that partition the inner dimension with
+    ones -> the result's columns add up to rowSums(A); an integer pair bit for bit; one Inf in B raises the
+    flag and the entry point (svt_matmul_SVT_SVT) returns what the dense route does.
+    Reference: src/SparseMatrix_mult.c:728-820, 1037-1101."""
+    from sparsearray_amd import SVT_SparseArray
+    from sparsearray_amd.device import DeviceCSC, PbcPlan, SpmmPlan, matmul_csc_csc, rowsums
+    from helpers import assert_equal
+    A, B = config3
+    dev = A.val.device
+    rows = torch.randint(0, NROW, (24,), generator=torch.Generator().manual_seed(13)).tolist() + [0, NROW - 1]
+    Bd = _dense_of(B)
+    out1, flag1 = matmul_csc_csc(A, B)
+    plan = SpmmPlan(A)
+    out2, flag2 = plan.run(B)
+    torch.cuda.synchronize()
+    assert int(flag1.item()) == 0 and int(flag2.item()) == 0
+    assert _sampled_rows_err(out1, A, Bd, rows) <= 1e-12
+    assert _sampled_rows_err(out2, A, Bd, rows) <= 1e-12
+    # the dense route on the same operands
+    At = A.t()
+    dense_plan = PbcPlan(At, K)
+    ref = torch.empty((K, NROW), dtype=torch.float64, device=dev)
+    dense_plan.run(Bd, NCOL, ref)
+    torch.cuda.synchronize()
+    top = float(ref.abs().max())
+    assert float((out1 - ref).abs().max()) <= 1e-12 * top
+    assert float((out2 - ref).abs().max()) <= 1e-12 * top
+    del out2
+    # ones at rows j with j % K == k in column k: the K result columns add up to rowSums(A)
+    j = torch.arange(NCOL, device=dev)
+    order = torch.argsort(j % K, stable=True)
+    cp1 = torch.zeros(K + 1, dtype=torch.int64, device=dev)
+    cp1[1:] = torch.cumsum(torch.bincount(j % K, minlength=K), 0)
+    B1 = DeviceCSC(NCOL, cp1, order.to(torch.int32), torch.ones(NCOL, dtype=torch.float64, device=dev))
+    out3, flag3 = plan.run(B1)
+    rs = rowsums(A)
+    torch.cuda.synchronize()
+    assert int(flag3.item()) == 0
+    assert float((out3.sum(dim=0) - rs).abs().max()) <= 1e-12 * max(1.0, float(rs.abs().max()))
+    del out3, B1
+    # integer operands: every product and partial sum is an integer far below 2^53 -> any order of
+    # additions gives the same bits as the dense route on the same values held as doubles
+    vi = (A.val * 100).round().to(torch.int32); vi[vi == 0] = 7
+    bi = (B.val * 100).round().to(torch.int32); bi[bi == 0] = -3
+    Ai, Bi = DeviceCSC(NROW, A.col_ptr, A.row_idx, vi), DeviceCSC(NCOL, B.col_ptr, B.row_idx, bi)
+    outi, flagi = matmul_csc_csc(Ai, Bi)
+    Ati = DeviceCSC(NCOL, At.col_ptr, At.row_idx, (At.val * 100).round())
+    Ati.val[Ati.val == 0] = 7.0
+    Bid = _dense_of(DeviceCSC(NCOL, B.col_ptr, B.row_idx, bi.double()))
+    PbcPlan(Ati, K).run(Bid, NCOL, ref)
+    torch.cuda.synchronize()
+    assert int(flagi.item()) == 0
+    assert torch.equal(outi, ref)
+    assert _sampled_rows_err(outi, Ai, Bid, rows[:6]) == 0.0
+    del outi, Ai, Bi, Ati, Bid, vi, bi
+    # one Inf in B: the flag goes up (the result is void) ...
+    bv = B.val.clone(); bv[5] = float("inf")
+    Binf = DeviceCSC(NCOL, B.col_ptr, B.row_idx, bv)
+    _, flag4 = matmul_csc_csc(A, Binf)
+    _, flag5 = plan.run(Binf)
+    torch.cuda.synchronize()
+    assert int(flag4.item()) != 0 and int(flag5.item()) != 0
+    # ... and the entry point returns the dense route's result (the reference's dirty-leaf loops multiply the
+    # implicit zeros of A too: a whole result column of NaN, src/SparseVec_dotprod.c:48-65)
+    dense_plan.run(_dense_of(Binf), NCOL, ref)
+    torch.cuda.synchronize()
+    x = SVT_SparseArray.from_csc((NROW, NCOL), "double", A.col_ptr.cpu().numpy(), A.row_idx.cpu().numpy(),
+                                 A.val.cpu().numpy())
+    y = SVT_SparseArray.from_csc((NCOL, K), "double", B.col_ptr.cpu().numpy(), B.row_idx.cpu().numpy(),
+                                 bv.cpu().numpy())
+    got = np.asarray(hip.matmul(x, y))
+    assert got.shape == (NROW, K)
+    assert_equal(got, ref.cpu().numpy().T, tol=1e-12, atol=1e-13 * top, what="x %*% y with one Inf in y")
+    assert np.isnan(got).any()
+
+
 def test_config3_rowsum_1e3_groups_full_size(config3):
     """rowsum(A, group) with 1e3 groups on 1e6 x 1e4 against torch.index_add_ on the flattened
     ngroup x ncol result (src/rowsum_methods.c:44-64, 281-325)."""

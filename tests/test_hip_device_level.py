@@ -464,6 +464,43 @@ def test_pbc_gather_kernel_matches_oracle(hip, oracle, shape):
         assert_equal(out.cpu().numpy().T, want, tol=1e-9, atol=1e-11, strict_na=True, what=f"by rows, poison {poison}")
 
 
+@pytest.mark.parametrize("cfg", [(40, 11), (32, 10), (16, 9)], ids=["40x2048", "32x1024", "16x512"])
+def test_pbc_gather_xcd_paced_kernel_matches_oracle(hip, oracle, cfg):
+    """crossprod_pbc_gatherx_kernel (persistent grid, one row range per XCD, wavefronts paced through
+    progress words; K = 128, >= 64 panels): against the oracle for the three accumulator widths, a ragged
+    last panel, an empty leaf block at the end of an XCD's range, CUs left idle, and bit for bit against
+    itself with the pacing switched off (no result depends on the protocol) -- the reference's loop is
+    src/SparseMatrix_mult.c:131-152 over src/SparseVec_dotprod.c:28-43."""
+    from sparsearray_amd.device import PbcPlan, set_gather_pacing, set_spare_cus
+    cbw, logr = cfg
+    nrow, ncol, K = (64 << logr) + 777, 1500 + cbw + 3, 128
+    cp, ri, v = random_csc(nrow, ncol, 0.0015, seed=191)
+    keep = ri < nrow - (3 << logr)                      # the last XCD's last panels hold no nonzero at all
+    kept = np.concatenate([[0], np.cumsum(keep)]).astype(np.int64)
+    ri, v, cp = ri[keep], v[keep], kept[cp]
+    x = SVT_SparseArray.from_csc((nrow, ncol), "double", cp, ri, v)
+    A = _dev(cp, ri, v, nrow)
+    plan = PbcPlan(A, K, cbw, 4, logr)
+    y = np.random.default_rng(192).uniform(-1, 1, (nrow, K))
+    Yd = torch.as_tensor(np.ascontiguousarray(y.T), device="cuda")
+    want = oracle.crossprod(x, y)
+    outs = []
+    try:
+        for dsync, spare in ((2, 0), (0, 0), (1_000_000, 0), (2, 96), (-1, 0)):
+            set_gather_pacing(dsync, 64)
+            set_spare_cus(spare)
+            out = torch.full((K, ncol), 3.0, dtype=torch.float64, device="cuda")
+            plan.run(Yd, nrow, out)
+            torch.cuda.synchronize()
+            assert_equal(out.cpu().numpy().T, want, tol=1e-9, atol=1e-11, what=f"dsync {dsync} spare {spare}")
+            outs.append(out)
+    finally:
+        set_gather_pacing()
+        set_spare_cus(0)
+    # same kernel, same order of additions per cell, whatever the pacing
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 def test_pbc_auto_layout_picks_by_density(hip, oracle):
     """svt_dev_pbc_build(A, 0, 0, 0): the gather layout below ~0.25 % density, the LDS-DMA layout
     above; same results either way."""

@@ -1,7 +1,7 @@
 """One rank's share of BASELINE config 4 (1.25e6 x 5e4 @ 0.1 %, Y 1.25e6 x 128) on one GPU: the gather
 product with the unpaced kernels (one launch per row chunk) and with the XCD-paced persistent kernel
 (crossprod_pbc_gatherx_kernel) over a sweep of its pacing knobs and panel heights.
-usage: config4_pacing.py [nrow] [logR,...] ["dsync:pd,..."]"""
+usage: config4_pacing.py [nrow] [logR,...] ["dsync:spin,..."]"""
 import os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,7 +11,7 @@ from sparsearray_amd.device import DeviceCSC, PbcPlan, set_gather_pacing
 
 nrow = int(sys.argv[1]) if len(sys.argv) > 1 else 1_250_000
 logrs = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [9, 10]
-sweep = sys.argv[3] if len(sys.argv) > 3 else "-1:0,3:2,2:1,5:2,8:2,1000000:0,1000000:2"
+sweep = sys.argv[3] if len(sys.argv) > 3 else "-1:256,1:256,2:256,3:256,2:16,2:4096,1000000:1"
 ncol, K = 50_000, 128
 dev = torch.device("cuda", 0)
 cp, ri, v = synth.random_device_csc(nrow, ncol, 0.001, seed=4, device=dev)
@@ -46,12 +46,12 @@ for logr in logrs:
     torch.cuda.synchronize(); tb = (time.perf_counter() - t0) * 1e3
     print(f"layout (40, 4, {logr}): {tb:.1f} ms", flush=True)
     for item in sweep.split(","):
-        d, pd = (int(x) for x in item.split(":"))
-        set_gather_pacing(d, pd, 256)
+        d, sp = (int(x) for x in item.split(":"))
+        set_gather_pacing(d, sp)
         out.zero_()
         ms = timed(lambda: plan.run(Y, nrow, out))
         worst = max(float((out[:, c] - want[c]).abs().max() / want[c].abs().max()) for c in cols)
-        print(f"  logR {logr} dsync {d:8d} pd {pd}: {ms:7.3f} ms  {A.nnz / ms / 1e6:6.1f} GNZ/s  "
+        print(f"  logR {logr} dsync {d:8d} spin {sp}: {ms:7.3f} ms  {A.nnz / ms / 1e6:6.1f} GNZ/s  "
               f"frac {alg / ms / 1e6 / 8000:.4f}  max rel err {worst:.2e}", flush=True)
     del plan
-set_gather_pacing(3, 2, 256)
+set_gather_pacing()

@@ -11,7 +11,6 @@ batch of every tile has bit 15 of its first column word set (every tile has at l
 batch reaches the D stage the boundary code runs -- nothing in it waits for the loads in flight:
     pb (s[86:87], base of the current panel of Yt)  += panel stride
     publish: progress[own entry] = ++step             (one lane, plain store)
-    prefetch: this wavefront's share of the lines of the panel `pd` steps ahead (one load, %[pfm] lanes)
     check the snapshot of all progress entries of the XCD taken at the PREVIOUS boundary (it has landed: at
     least one `s_waitcnt vmcnt(4)` lies in between): somebody started and more than `dsync` tiles behind ->
     spin (fresh snapshots, bounded: after %[spin] polls the wavefront stops synchronising for good)
@@ -19,7 +18,12 @@ batch reaches the D stage the boundary code runs -- nothing in it waits for the 
 The protocol is a pacing hint only: results never depend on it.
 
 Register map: accumulators v[64:143] (lo) and v[144:223] (hi), y sets v[224:239] / v[240:255], snapshot
-v[56:59]; s[36:83] record blocks, s85 M0 save, s[86:87] pb, s[88:89] prefetch pointer, s94 / s95 scratch.
+v[56:59]; s[36:83] record blocks, s85 M0 save, s[86:87] pb, s94 / s95 scratch.
+
+Measured at one rank's share of BASELINE config 4 (round 4, tools/debug/config4_pacing.py): an L2 touch of the
+panel ahead by the wavefronts themselves (one dword per 128-byte line, spread over the XCD's wavefronts) bought
+nothing (4.85 ms with it, 4.72 without: the load sits in the wavefront's in-order vmcnt queue and its HBM miss
+stalls the pipeline once per tile) -- the first gather of a line pulls it into L2 for the other 255 wavefronts.
 """
 import os
 
@@ -60,15 +64,7 @@ def boundary(blk):
     e("v_mov_b32 %[vt], %[step]")
     e("s_mov_b64 exec, 1")
     e("global_store_dword %[vz], %[vt], %[pgm]")
-    e("s_cmp_gt_u32 %[rem], %[pd]")
-    e(f"s_cbranch_scc0 3{n}f")
-    e("s_mov_b64 exec, %[pfm]")
-    e("global_load_dword %[vd], %[l128], s[88:89]")
-    e(f"3{n}:")
     e("s_mov_b64 exec, -1")
-    e("s_add_u32 s88, s88, %[pst]")
-    e("s_addc_u32 s89, s89, 0")
-    e("s_sub_u32 %[rem], %[rem], 1")
     # s94 = max(step - dsync, 1) - 1: the smallest (entry - 1) a started wavefront may show
     e("s_sub_u32 s94, %[step], %[dsync]")
     e("s_cselect_b32 s94, 0, s94")
@@ -129,8 +125,6 @@ def phase(lb, db, dys, fb, fys):
 e("s_mov_b32 s85, m0")
 e("s_mov_b32 s86, %[pbl]")
 e("s_mov_b32 s87, %[pbh]")
-e("s_mov_b32 s88, %[pfl]")
-e("s_mov_b32 s89, %[pfh]")
 e("s_cmp_eq_u32 %[nb], 0")
 e("s_cbranch_scc1 9f")
 load("A")
