@@ -193,8 +193,15 @@ def main():
         torch.cuda.synchronize()
         layout_ms = (time.perf_counter() - t_l) * 1e3
         auto_gather = (a.cbw, a.wpb, a.logr) == (0, 0, 0) and a.density * 40 * 128 < 12 and lrow >= 4096
-        kernel_name = "crossprod_pbc_gather_kernel" if auto_gather or (a.wpb == 4 and a.logr >= 9) \
-            else "crossprod_pbc_dma_kernel"
+        if auto_gather or (a.wpb == 4 and a.logr >= 9):
+            # (pbc_auto_layout / pbgx_ok, kernels_mult_pbc.hip: the XCD-paced kernel wants K in whole pairs of 64-wide
+            # tiles and 64 row panels)
+            g_logr = a.logr if a.logr else (11 if lrow >> 11 >= 64 else 10 if lrow >> 10 >= 64 else 9)
+            paced = ((K + 63) // 64) % 2 == 0 and ((lrow + (1 << g_logr) - 1) >> g_logr) >= 64
+            kernel_name = "crossprod_pbc_gatherx_kernel" if paced else "crossprod_pbc_gather_kernel"
+        else:
+            g_logr = 7
+            kernel_name = "crossprod_pbc_dma_kernel"
 
         def step(ev=None):
             sc.step(Y, ev)
@@ -312,7 +319,7 @@ def main():
                      "kernel_ms": kern_ms},
     }
     if layout_ms is not None:
-        res["config"]["layout"] = ("PBC cbw=40 wpb=4 logR=10 (gather kernel)" if kernel_name.startswith("crossprod_pbc_gather")
+        res["config"]["layout"] = (f"PBC cbw=40 wpb=4 logR={g_logr} (gather kernel)" if kernel_name.startswith("crossprod_pbc_gather")
                                    else "PBC cbw=40 wpb=16 logR=7 (LDS-DMA kernel)") if a.cbw == 0 else \
             f"PBC cbw={a.cbw} wpb={a.wpb} logR={a.logr}"
         res["config"]["layout_build_ms_once_per_operand"] = layout_ms

@@ -303,7 +303,7 @@ int svt_dev_pbc_spare_cus(void);
    persistent, every XCD owns a range of rows, and a wavefront runs at most `dsync` row panels ahead of the
    slowest wavefront of its XCD that has started, so that the rows of the dense operand the XCD gathers stay
    in its L2; `spin` = polls after which a wavefront that waits in vain stops pacing itself (results never
-   depend on the pacing).  Defaults (2, 256).  dsync < 0:
+   depend on the pacing).  Defaults (1, 256).  dsync < 0:
    the unpaced kernels (one launch per chunk of rows) run instead.  Process-wide; no reference counterpart
    (src/SparseMatrix_mult.c:131-152 walks leaf by leaf on the host). */
 void svt_dev_pbc_set_gather_pacing(int dsync, int spin);

@@ -1327,9 +1327,10 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define PBGX_OPS                                                                       \
 	[lo] "+s"(lo_), [nb] "+s"(nb_), [step] "+s"(step), [dsync] "+s"(dsync),          \
 	[t0] "=&v"(t0_), [t1] "=&v"(t1_), [t2] "=&v"(t2_), [t3] "=&v"(t3_),              \
-	[vt] "=&v"(vt_), "+{v[56:59]}"(snap), "+{v[224:255]}"(ysets)
+	[vt] "=&v"(vt_), [vd] "=&v"(vd_), "+{v[56:59]}"(snap), "+{v[224:255]}"(ysets)
 #define PBGX_IN [base] "s"(rec_w), [pbl] "s"(pbl), [pbh] "s"(pbh), [pst] "s"(pst), [spin] "s"(spin_u), \
-	[pgm] "s"(pg_mine), [pga] "s"(pg_all), [kp] "v"(kp_v), [l16] "v"(lane16), [vz] "v"(vzero)
+	[pgm] "s"(pg_mine), [pga] "s"(pg_all), [rbl] "s"(rbl), [rbh] "s"(rbh),            \
+	[kp] "v"(kp_v), [l16] "v"(lane16), [l128] "v"(lane128), [vz] "v"(vzero)
 #define PBGX_PROG_ENTRIES 256     // progress words per XCD: one per wavefront (64 workgroup slots x 4)
 #define PBGX_DONE 0x7fffffffu
 
@@ -1353,7 +1354,7 @@ crossprod_pbc_gatherx_kernel(const uint4 *__restrict__ rec, const int64_t *__res
 	uint32_t step = 0, dsync = (uint32_t) dsync_in;
 	const uint32_t spin_u = (uint32_t) spin_in;
 	const uint32_t pst = (uint32_t) (((int64_t) 8 << logR) * Ktp);          // bytes of Yt per panel
-	const uint32_t lane16 = (uint32_t) lane * 16u, vzero = 0u;
+	const uint32_t lane16 = (uint32_t) lane * 16u, lane128 = (uint32_t) lane * 128u, vzero = 0u;
 	const uint32_t kp_v = (uint32_t) Ktp;                    // (row offset in bytes = 8 * row * Ktp)
 	u32x4 snap = 0;
 	u32x32_t ysets = 0;
@@ -1376,7 +1377,8 @@ crossprod_pbc_gatherx_kernel(const uint4 *__restrict__ rec, const int64_t *__res
 		// the first tile's flag steps the base onto panel pa
 		const uint64_t pbase = (uint64_t) (uintptr_t) Yt + (uint64_t) (((pa - 1) << logR) * Ktp + k0) * 8u;
 		const uint32_t pbl = (uint32_t) pbase, pbh = (uint32_t) (pbase >> 32);
-		uint32_t t0_, t1_, t2_, t3_, vt_;
+		const uint32_t rbl = (uint32_t) (uintptr_t) rec_w, rbh = (uint32_t) ((uint64_t) (uintptr_t) rec_w >> 32);
+		uint32_t t0_, t1_, t2_, t3_, vt_, vd_;
 		if constexpr (NV == 1) {
 			asm volatile(PBGX_PASS_TXT
 				     : "+{v[64:95]}"(acc[0]), "+{v[144:175]}"(acch[0]), PBGX_OPS
@@ -2051,8 +2053,9 @@ static int64_t pbc_padded_rows(const svt_dev_pbc *P)
 // Pacing of crossprod_pbc_gatherx_kernel: a wavefront runs at most `dsync` tiles ahead of the slowest started
 // wavefront of its XCD and gives up after `spin` polls.  dsync < 0: the kernels with one launch per row
 // chunk (crossprod_pbc_gather2_kernel) run instead.  (One rank's share of BASELINE config 4, 2048-row
-// panels: dsync 0: 5.69 ms, 1: 4.77, 2: 4.73, 3: 4.80, no pacing at all: 7.9.)
-static int g_pbgx_dsync = 2, g_pbgx_spin = 256;
+// panels: dsync 0: 5.69 ms, 1: 4.77, 2: 4.73, 3: 4.80, no pacing at all: 7.9; with the L2 touch of the
+// record stream 1: 4.31, 2: 4.43; spin 16: 6.7 -- a wavefront that gives up never paces itself again.)
+static int g_pbgx_dsync = 1, g_pbgx_spin = 256;
 extern "C" void svt_dev_pbc_set_gather_pacing(int dsync, int spin)
 {
 	g_pbgx_dsync = dsync;
@@ -2082,9 +2085,9 @@ static bool pbgx_ok(const svt_dev_pbc *P, int K)
 }
 
 // gather kernel: no staging to share, so splits only have to fill the chip (~8192 wavefronts)
-static int pick_nsplit_gather(const svt_dev_pbc *P, int K, int64_t *pps_out)
+static int pick_nsplit_gather(const svt_dev_pbc *P, int K, int64_t *pps_out, bool unpaced = false)
 {
-	if (pbgx_ok(P, K)) {                                 // one partial result per XCD with rows
+	if (!unpaced && pbgx_ok(P, K)) {                                 // one partial result per XCD with rows
 		const int64_t npx = (P->npanels + 7) / 8;
 		if (pps_out) *pps_out = npx;
 		return (int) ((P->npanels + npx - 1) / npx);
@@ -2174,7 +2177,7 @@ extern "C" size_t svt_dev_crossprod_pbc_ws_bytes(const svt_dev_pbc *P, int K)
 		if (nd > ns) ns = nd;
 	}
 	if (P->gather) {
-		const int ng = pick_nsplit_gather(P, K, NULL);
+		const int ng = pick_nsplit_gather(P, K, NULL, true);
 		if (ng > ns) ns = ng;
 		if (ns < 8) ns = 8;                         // (the pacing knob may change between the query and the launch)
 	}

@@ -233,7 +233,7 @@ def spare_cus() -> int:
     return int(_lib().svt_dev_pbc_spare_cus())
 
 
-def set_gather_pacing(dsync: int = 2, spin: int = 256) -> None:
+def set_gather_pacing(dsync: int = 1, spin: int = 256) -> None:
     """Pacing of the gather product of very sparse operands (include/svt_hip.h:
     svt_dev_pbc_set_gather_pacing); dsync < 0 selects the unpaced kernels."""
     _lib().svt_dev_pbc_set_gather_pacing(int(dsync), int(spin))

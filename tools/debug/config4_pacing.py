@@ -12,9 +12,10 @@ from sparsearray_amd.device import DeviceCSC, PbcPlan, set_gather_pacing
 nrow = int(sys.argv[1]) if len(sys.argv) > 1 else 1_250_000
 logrs = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [9, 10]
 sweep = sys.argv[3] if len(sys.argv) > 3 else "-1:256,1:256,2:256,3:256,2:16,2:4096,1000000:1"
-ncol, K = 50_000, 128
+ncol, K = int(os.environ.get("C4_NCOL", 50_000)), 128
+dens = float(os.environ.get("C4_DENSITY", 0.001))
 dev = torch.device("cuda", 0)
-cp, ri, v = synth.random_device_csc(nrow, ncol, 0.001, seed=4, device=dev)
+cp, ri, v = synth.random_device_csc(nrow, ncol, dens, seed=4, device=dev)
 A = DeviceCSC(nrow, cp, ri, v)
 Y = synth.random_dense(nrow, K, seed=104, device=dev)
 out = torch.zeros((K, ncol), dtype=torch.float64, device=dev)
@@ -51,7 +52,7 @@ for logr in logrs:
         out.zero_()
         ms = timed(lambda: plan.run(Y, nrow, out))
         worst = max(float((out[:, c] - want[c]).abs().max() / want[c].abs().max()) for c in cols)
-        print(f"  logR {logr} dsync {d:8d} spin {sp}: {ms:7.3f} ms  {A.nnz / ms / 1e6:6.1f} GNZ/s  "
+        print(f"  logR {logr} dsync {d:8d} spin {sp}: {ms:7.3f} ms  {A.nnz / ms / 1e6:6.1f} GNZ/s  gathered {A.nnz * K * 8 / ms / 1e9:5.1f} TB/s  "
               f"frac {alg / ms / 1e6 / 8000:.4f}  max rel err {worst:.2e}", flush=True)
     del plan
 set_gather_pacing()

@@ -11,6 +11,10 @@ batch of every tile has bit 15 of its first column word set (every tile has at l
 batch reaches the D stage the boundary code runs -- nothing in it waits for the loads in flight:
     pb (s[86:87], base of the current panel of Yt)  += panel stride
     publish: progress[own entry] = ++step             (one lane, plain store)
+    L2 touch of the wavefront's own record stream 2 KiB ahead of its load cursor (20 lanes, one dword per
+    128-byte line: more than the longest tile it will meet before the next boundary repeats the touch) --
+    records are read once, by scalar loads issued two batches ahead: without the touch every other one
+    waits for HBM (4.50 -> 4.31 ms at one rank's share of BASELINE config 4)
     check the snapshot of all progress entries of the XCD taken at the PREVIOUS boundary (it has landed: at
     least one `s_waitcnt vmcnt(4)` lies in between): somebody started and more than `dsync` tiles behind ->
     spin (fresh snapshots, bounded: after %[spin] polls the wavefront stops synchronising for good)
@@ -18,7 +22,7 @@ batch reaches the D stage the boundary code runs -- nothing in it waits for the 
 The protocol is a pacing hint only: results never depend on it.
 
 Register map: accumulators v[64:143] (lo) and v[144:223] (hi), y sets v[224:239] / v[240:255], snapshot
-v[56:59]; s[36:83] record blocks, s85 M0 save, s[86:87] pb, s94 / s95 scratch.
+v[56:59]; s[36:83] record blocks, s85 M0 save, s[86:87] pb, s[88:89] touch pointer, s94 / s95 scratch.
 
 Measured at one rank's share of BASELINE config 4 (round 4, tools/debug/config4_pacing.py): an L2 touch of the
 panel ahead by the wavefronts themselves (one dword per 128-byte line, spread over the XCD's wavefronts) bought
@@ -28,6 +32,7 @@ stalls the pipeline once per tile) -- the first gather of a line pulls it into L
 import os
 
 BLK = {"A": 36, "B": 52, "C": 68}
+RECTOUCH = int(os.environ.get("PBGX_RECTOUCH", "2048"))   # 0: no L2 touch of the record stream
 YSET = {"a": 224, "b": 240}
 out = []
 nlab = [0]
@@ -64,6 +69,14 @@ def boundary(blk):
     e("v_mov_b32 %[vt], %[step]")
     e("s_mov_b64 exec, 1")
     e("global_store_dword %[vz], %[vt], %[pgm]")
+    if RECTOUCH:
+        # L2 touch of this wavefront's record stream RECTOUCH bytes ahead: 20 lines (one dword each)
+        e("s_add_u32 s88, %[rbl], %[lo]")
+        e("s_addc_u32 s89, %[rbh], 0")
+        e(f"s_add_u32 s88, s88, {RECTOUCH}")
+        e("s_addc_u32 s89, s89, 0")
+        e("s_mov_b64 exec, 0xfffff")
+        e("global_load_dword %[vd], %[l128], s[88:89]")
     e("s_mov_b64 exec, -1")
     # s94 = max(step - dsync, 1) - 1: the smallest (entry - 1) a started wavefront may show
     e("s_sub_u32 s94, %[step], %[dsync]")
