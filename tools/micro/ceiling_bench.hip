@@ -1320,9 +1320,12 @@ static void run_work(double *sink, int threads, const char *what)
 		float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
 		if (rep > 0 && ms < best) best = ms;
 	}
-	// wave-records per CU: waves * iters * 16 (MODE 4: a record covers 2 dense columns per lane = 2 wave-records)
+	// (record x 64 dense columns) units per CU: waves * iters * 16 -- modes 0-3, 5-8: 16 records of 64 dense columns per
+	// trip of the loop; MODE 4: 8 records of 128 dense columns (two units each) per trip, 16 units as well.
+	// (Round 2 counted 32 for MODE 4 and so reported half its time: "0.39-0.41 ms" was 0.78-0.82 ms -- 8 ds_read_b128 of
+	// 1 KiB per trip in ~39 cycles = 210 B/clk/CU of the LDS's 256.)
 	const double waves = threads / 64.0;
-	const double wrec = waves * iters * 16.0 * (MODE == 4 ? 2.0 : 1.0);
+	const double wrec = waves * iters * 16.0;
 	const double cyc = best * 1e-3 * 2.4e9;
 	printf("work  %-44s %2d waves/CU: %.3f ms, %.2f cycles per (record x 64 dense columns) per CU at 2.4 GHz -> config 2a (2e8 of them over 256 CUs) %.3f ms\n",
 	       what, (int) waves, best, cyc / wrec, cyc / wrec * 2e8 / 256 / 2.4e9 * 1e3);
