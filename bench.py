@@ -66,10 +66,13 @@ def parse():
     p.add_argument("--reduce", choices=["rccl", "peer"], default="rccl",
                    help="N > 1: rccl = all-reduce of the result (default); peer = peer-to-peer copies of the partials + "
                         "a local sum (sparsearray_amd/parallel.py, PeerReducer; no collective kernel)")
-    p.add_argument("--spare-cus", type=int, default=-1,
-                   help="CUs the product kernel leaves idle (room for RCCL's kernels beside it); 0 = none; "
-                        "default: 32 with --gpus >= 8 and the RCCL reducer (+8 %% product time at an eighth of the rows, "
-                        "DESIGN.md section 5), else 0")
+    p.add_argument("--spare-cus", type=int, default=0,
+                   help="CUs the product kernel leaves idle (room for RCCL's kernels beside it); default 0 -- at N > 1 the "
+                        "line's `multi_gpu` object times the same steps with 32 CUs left idle as well, so that one run "
+                        "says whether the option pays on real RCCL (it costs +8 %% product time at an eighth of the rows)")
+    p.add_argument("--compare-reducers", action="store_true",
+                   help="N > 1: after the timed steps, time the same steps with the peer-to-peer reducer as well "
+                        "(`multi_gpu.variants`); the RCCL variants (0 and 32 spare CUs) are always there")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extras", action="store_true")
     a = p.parse_args()
@@ -77,11 +80,81 @@ def parse():
     for k in ("nrow", "ncol", "density", "K"):
         if getattr(a, k) is None:
             setattr(a, k, c[k])
-    if a.spare_cus < 0:
-        # (what it costs on one GPU at the rank's share of the rows: +11 % at 1/2, +10 % at 1/4, +8 % at 1/8 -- against an
-        # all-reduce of ~0.05-0.08 ms that otherwise waits for the product's CUs: 5 % / 12 % / 30 % of the step)
-        a.spare_cus = 32 if (a.gpus >= 8 and a.reduce == "rccl") else 0
     return a
+
+
+def multi_gpu_diagnostics(a, dist, par, dev, sc, A, Y, step, finish, kern_ms, ms_per_step, with_colsums):
+    """Why the N > 1 line scales the way it does (every rank runs this; collective calls inside): per-rank kernel time,
+    the result's all-reduce alone, the product alone, the fraction of the collective hidden behind the next product,
+    and the same steps with the other reduction options."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    d = {"backend": dist.get_backend(), "world_size": world, "reducer": a.reduce, "spare_cus": a.spare_cus}
+
+    def gathered(x):
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        out = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        return [float(o.item()) for o in out]
+
+    def region(fn, reps):
+        """ms per call of fn over reps calls: barrier + synchronize on both sides, MAX over the ranks."""
+        fn(); finish(); torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        finish(); torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t = torch.tensor([(time.perf_counter() - t0) / reps * 1e3], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    d["kernel_ms_per_rank"] = gathered(kern_ms)
+    buf = torch.zeros_like(sc.outs[0])
+    d["allreduce_alone_ms"] = region(lambda: dist.all_reduce(buf), 5)
+    d["allreduce_bytes"] = buf.numel() * 8
+    lrow = Y.shape[1]
+    tmp = torch.zeros_like(sc.outs[0])
+
+    def product_only():
+        sc.plan.run(Y, lrow, tmp)
+        if with_colsums:
+            from sparsearray_amd.device import colstats
+            colstats(A, "sum")
+    d["product_alone_ms"] = region(product_only, a.steps)
+    hidden = d["product_alone_ms"] + d["allreduce_alone_ms"] - ms_per_step
+    d["overlap_fraction"] = max(0.0, min(1.0, hidden / d["allreduce_alone_ms"])) if d["allreduce_alone_ms"] > 0 else None
+    variants = {}
+    if a.reduce == "rccl":
+        from sparsearray_amd.device import set_spare_cus
+        other = 32 if a.spare_cus == 0 else 0
+        set_spare_cus(other)
+        try:
+            variants[f"rccl_spare_cus_{other}"] = {"ms_per_step": region(step, a.steps)}
+        finally:
+            set_spare_cus(a.spare_cus)
+    if a.compare_reducers and a.reduce != "peer":
+        sc2 = par.ShardedCrossprod(A, a.K, None, a.cbw, a.wpb, a.logr, reducer="peer", spare_cus=a.spare_cus)
+
+        def step2():
+            sc2.step(Y)
+            if with_colsums:
+                par.sharded_colsums_rows(A)
+
+        def region2():
+            sc2.wait()
+        # (the peer reducer has its own wait; `region` calls the main finish, which is idle here)
+        step2(); region2(); torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step2()
+        region2(); torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t = torch.tensor([(time.perf_counter() - t0) / a.steps * 1e3], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        same = bool(torch.allclose(sc2.result(), sc.result(), rtol=1e-11, atol=1e-11))
+        variants["peer_copies"] = {"ms_per_step": float(t.item()), "same_result": same}
+        sc2.close()
+        del sc2
+    d["variants"] = variants
+    return d
 
 
 def host_cores() -> int:
@@ -264,6 +337,12 @@ def main():
     kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs]))
     res_t = result()
     checksum = [float(res_t.sum().item()), float(res_t.abs().sum().item())]
+    diag = None
+    if world > 1 and a.path == "pbc":
+        # (a failure here must not leave the other ranks inside a collective: let it end the process with a
+        # non-zero status -- torch.distributed.run then ends the job -- rather than be caught on one rank)
+        diag = multi_gpu_diagnostics(a, dist, par, dev, sc, A, Y, step, finish, kern_ms, elapsed / a.steps * 1e3,
+                                     with_colsums)
 
     if rank != 0:
         if world > 1:
@@ -318,6 +397,8 @@ def main():
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "kernel_ms": kern_ms},
     }
+    if diag is not None:
+        res["multi_gpu"] = diag
     if layout_ms is not None:
         res["config"]["layout"] = (f"PBC cbw=40 wpb=4 logR={g_logr} (gather kernel)" if kernel_name.startswith("crossprod_pbc_gather")
                                    else "PBC cbw=40 wpb=16 logR=7 (LDS-DMA kernel)") if a.cbw == 0 else \

@@ -281,6 +281,11 @@ int svt_dev_crossprod_csc_dense(const svt_dev_csc *A, const void *Y,
 typedef struct svt_dev_pbc svt_dev_pbc;
 svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB, int logR);
 void svt_dev_pbc_release(svt_dev_pbc *P);
+/* Layout buffers come from a stream-ordered pool of the library's own (one per device) that keeps up to 3 GiB of
+   released memory for the next build; svt_dev_pbc_release() frees behind the last product of every stream that
+   used the layout (events, no device-wide synchronisation).  svt_dev_pbc_trim() hands everything the pools hold
+   but no layout uses back to the driver -- e.g. before another allocator of the process needs the memory. */
+void svt_dev_pbc_trim(void);
 /* Device bytes held by a layout (records + tile table + flags). */
 size_t svt_dev_pbc_bytes(const svt_dev_pbc *P);
 size_t svt_dev_crossprod_pbc_ws_bytes(const svt_dev_pbc *P, int K);
@@ -360,6 +365,15 @@ int svt_dev_rowsums_prepared(const svt_dev_csc *A, int na_rm, int64_t inner,
    this level. */
 int svt_dev_rowsum(const svt_dev_csc *A, const int *group, int ngroup,
 		   int na_rm, double *out, void *stream);
+/* The same for an (operand, grouping) pair used more than once: svt_dev_rowsum_prepare() writes the group of
+   every nonzero -- a 16-bit 0-based id, NA -> the last group (src/rowsum_methods.c:51-54) -- into `gid`
+   (svt_dev_rowsum_gid_bytes(A) bytes, device memory); svt_dev_rowsum_prepared() then streams 10 bytes per
+   nonzero (value + id) and looks nothing up.  1 <= ngroup <= 20480 (a column's sums live in LDS). */
+size_t svt_dev_rowsum_gid_bytes(const svt_dev_csc *A);
+int svt_dev_rowsum_prepare(const svt_dev_csc *A, const int *group, int ngroup, void *gid, size_t gid_bytes,
+			   void *stream);
+int svt_dev_rowsum_prepared(const svt_dev_csc *A, const void *gid, int ngroup, int na_rm, double *out,
+			    void *stream);
 
 /* Thread control (C_get_num_procs / C_get_max_threads / C_set_max_threads,
    src/thread_control.c:47-66; R/thread-control.R sets the team size around every

@@ -21,7 +21,7 @@ EXPORTS = [
     "svt_crossprod2_SVT_SVT", "svt_crossprod1_SVT",
     "svt_matmul_SVT_mat", "svt_matmul_SVT_SVT",
     "svt_colMedians_SVT", "svt_rowMedians_SVT", "svt_dev_colmedians_ws_bytes", "svt_dev_colmedians",
-    "svt_resident_set_limit", "svt_resident_clear", "svt_resident_stats", "svt_dev_pbc_bytes", "svt_dev_pbc_set_spare_cus", "svt_dev_pbc_spare_cus", "svt_dev_pbc_set_gather_pacing", "svt_dev_matmul_csc_csc_ws_bytes", "svt_dev_matmul_csc_csc", "svt_dev_rowsums_prepare", "svt_dev_rowsums_prepared", "svt_dev_matmul_csc_csc_prepare", "svt_dev_matmul_csc_csc_prepared",
+    "svt_resident_set_limit", "svt_resident_clear", "svt_resident_stats", "svt_dev_pbc_bytes", "svt_dev_pbc_set_spare_cus", "svt_dev_pbc_spare_cus", "svt_dev_pbc_set_gather_pacing", "svt_dev_matmul_csc_csc_ws_bytes", "svt_dev_matmul_csc_csc", "svt_dev_rowsums_prepare", "svt_dev_rowsums_prepared", "svt_dev_rowsum_gid_bytes", "svt_dev_rowsum_prepare", "svt_dev_rowsum_prepared", "svt_dev_matmul_csc_csc_prepare", "svt_dev_matmul_csc_csc_prepared",
     "svt_summarize_SVT", "svt_colStats_out_Rtype", "svt_colStats_SVT",
     "svt_rowStats_SVT", "svt_rowsum_SVT", "svt_colsum_SVT",
     "svt_rowsum_dgCMatrix", "svt_colsum_dgCMatrix",
@@ -29,7 +29,7 @@ EXPORTS = [
     "svt_upload", "svt_wrap_device_csc", "svt_release",
     "svt_dev_crossprod_ws_bytes", "svt_dev_crossprod_csc_dense",
     "svt_dev_dense_prepare", "svt_dev_crossprod_prepared",
-    "svt_dev_pbc_build", "svt_dev_pbc_release",
+    "svt_dev_pbc_build", "svt_dev_pbc_release", "svt_dev_pbc_trim",
     "svt_dev_crossprod_pbc_ws_bytes", "svt_dev_crossprod_pbc", "svt_dev_crossprod_pbc_phase", "svt_dev_crossprod_pbc_from",
     "svt_get_num_procs", "svt_get_max_threads", "svt_set_max_threads", "svt_dev_aperm_ws_bytes", "svt_dev_aperm", "svt_aperm_SVT", "svt_transpose_2D_SVT", "svt_dev_transpose_ws_bytes", "svt_dev_transpose", "svt_dev_colstats", "svt_dev_rowstats_ws_bytes", "svt_dev_rowsums", "svt_dev_rowsum",
 ]

@@ -65,6 +65,13 @@ struct svt_dev_pbc {
 	int64_t *tile_ptr;     // [ngroups*npanels + 1]
 	int *col_has_na;       // [ncol]
 	int64_t max_leaf_nnz;  // the longest leaf (a dense column with more non-finite entries than that makes every cell NaN / NA)
+	// streams that have read the layout, each with an event behind its last product: svt_dev_pbc_release()
+	// frees behind those events instead of synchronising the device (a handle is used from one host thread)
+	mutable hipStream_t use_s[4];
+	mutable hipEvent_t use_ev[4];
+	mutable int nuse;
+	mutable bool use_overflow;  // more than 4 streams: release falls back to hipDeviceSynchronize()
+	int device;
 };
 
 #define PCH 256            // panels per build chunk
@@ -509,31 +516,89 @@ __global__ void pbc_build_finish_kernel(int64_t *__restrict__ tile_ptr, int64_t 
 	for (int x = threadIdx.x; x < PBC_SLACK * 4; x += blockDim.x) slack[x] = 0u;
 }
 
-// The layout's buffers come from the device's stream-ordered pool (stream 0), which keeps what is freed:
-// hipMalloc of the 1.4 GB record array of BASELINE config 2 maps pages for ~0.5 ms on every build, and a
-// build used to spend as long in allocation and its five synchronous calls as in its kernels
-// (2.24 ms for 1.1 ms of kernels).
+// The layout's buffers come from a stream-ordered pool of the library's own, one per device, which keeps what
+// is freed up to PBC_POOL_KEEP bytes: hipMalloc of the 1.4 GB record array of BASELINE config 2 maps pages
+// for ~0.5 ms on every build, and a build used to spend as long in allocation and its five synchronous calls
+// as in its kernels (2.24 ms for 1.1 ms of kernels).  Not the device's default pool and not "keep everything":
+// memory the pool holds is invisible to torch's caching allocator, so what it may keep is bounded (a rebuild of
+// a config-2 layout stays warm; a 6-12 GB layout of config 4 goes back to the driver when it is released) and
+// svt_dev_pbc_trim() returns all of it.
+#define PBC_POOL_KEEP ((uint64_t) 3 << 30)
+#define PBC_MAX_DEV 16
+static hipMemPool_t g_pbc_pool[PBC_MAX_DEV];
+static bool g_pbc_pool_ok[PBC_MAX_DEV];
+
+static hipMemPool_t pbc_pool(int dev)
+{
+	if (dev < 0 || dev >= PBC_MAX_DEV)
+		return NULL;
+	if (!g_pbc_pool_ok[dev]) {
+		hipMemPoolProps props;
+		memset(&props, 0, sizeof(props));
+		props.allocType = hipMemAllocationTypePinned;
+		props.handleTypes = hipMemHandleTypeNone;
+		props.location.type = hipMemLocationTypeDevice;
+		props.location.id = dev;
+		hipMemPool_t pool = NULL;
+		if (hipMemPoolCreate(&pool, &props) != hipSuccess) {
+			(void) hipGetLastError();
+			return NULL;
+		}
+		uint64_t keep = PBC_POOL_KEEP;
+		(void) hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+		g_pbc_pool[dev] = pool;
+		g_pbc_pool_ok[dev] = true;
+	}
+	return g_pbc_pool[dev];
+}
+
 static hipError_t pbc_alloc(void **p, size_t n)
 {
-	static bool pool_ready = false;
-	if (!pool_ready) {
-		int dev = 0;
-		hipMemPool_t pool;
-		if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
-			uint64_t keep = ~(uint64_t) 0;
-			(void) hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-		}
-		pool_ready = true;
-	}
-	return hipMallocAsync(p, n ? n : 16, 0);
+	int dev = 0;
+	(void) hipGetDevice(&dev);
+	hipMemPool_t pool = pbc_pool(dev);
+	if (pool == NULL)
+		return hipMallocAsync(p, n ? n : 16, 0);
+	return hipMallocFromPoolAsync(p, n ? n : 16, pool, 0);
 }
 static void pbc_free(void *p) { if (p) (void) hipFreeAsync(p, 0); }
+
+// Returns what the layout pools hold but no layout uses to the driver (all devices this process built on).
+extern "C" void svt_dev_pbc_trim(void)
+{
+	for (int d = 0; d < PBC_MAX_DEV; d++)
+		if (g_pbc_pool_ok[d])
+			(void) hipMemPoolTrimTo(g_pbc_pool[d], 0);
+}
+
+static void pbc_note_use(const svt_dev_pbc *P, hipStream_t s)
+{
+	int slot = -1;
+	for (int i = 0; i < P->nuse; i++)
+		if (P->use_s[i] == s) slot = i;
+	if (slot < 0) {
+		if (P->nuse == 4) { P->use_overflow = true; return; }
+		hipEvent_t ev;
+		if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { P->use_overflow = true; return; }
+		slot = P->nuse++;
+		P->use_s[slot] = s;
+		P->use_ev[slot] = ev;
+	}
+	(void) hipEventRecord(P->use_ev[slot], s);
+}
 
 extern "C" void svt_dev_pbc_release(svt_dev_pbc *h)
 {
 	if (h == NULL) return;
-	// (as hipFree() did implicitly: products on other streams may still be reading the layout)
-	(void) hipDeviceSynchronize();
+	// products on other streams may still be reading the layout: the frees (stream 0, stream-ordered) go
+	// behind the event each such stream recorded after its last product -- no device-wide synchronisation,
+	// which would also stall a collective or a peer copy in flight when a plan is dropped
+	if (h->use_overflow)
+		(void) hipDeviceSynchronize();
+	for (int i = 0; i < h->nuse; i++) {
+		(void) hipStreamWaitEvent(0, h->use_ev[i], 0);
+		(void) hipEventDestroy(h->use_ev[i]);
+	}
 	pbc_free(h->rec);
 	pbc_free(h->tile_ptr);
 	pbc_free(h->col_has_na);
@@ -2256,11 +2321,27 @@ int launch_dense_prepare_flag(const CrossprodArgs &a, int *any, hipStream_t s);
 // later ones are computed (their cells of `out` written); the cells of earlier leaves are left
 // alone.  Unary crossprod(x) needs only the leaves c >= k of dense column k (the reference's
 // compute_sym_dotprods_*, src/SparseMatrix_mult.c:263-296, computes ncol^2 / 2 dot products).
+static int pbc_phase_impl(const svt_dev_pbc *P, const svt_dev_csc *A,
+			  const double *Y, int64_t ldY, int K, int tr_y,
+			  double *out, int64_t out_stride_c,
+			  int64_t out_stride_k, void *ws, size_t ws_bytes,
+			  void *stream, int phase, int64_t first_col);
 static int pbc_phase(const svt_dev_pbc *P, const svt_dev_csc *A,
 		     const double *Y, int64_t ldY, int K, int tr_y,
 		     double *out, int64_t out_stride_c,
 		     int64_t out_stride_k, void *ws, size_t ws_bytes,
 		     void *stream, int phase, int64_t first_col)
+{
+	const int rc = pbc_phase_impl(P, A, Y, ldY, K, tr_y, out, out_stride_c, out_stride_k, ws, ws_bytes, stream,
+				      phase, first_col);
+	pbc_note_use(P, (hipStream_t) stream);
+	return rc;
+}
+static int pbc_phase_impl(const svt_dev_pbc *P, const svt_dev_csc *A,
+			  const double *Y, int64_t ldY, int K, int tr_y,
+			  double *out, int64_t out_stride_c,
+			  int64_t out_stride_k, void *ws, size_t ws_bytes,
+			  void *stream, int phase, int64_t first_col)
 {
 	hipStream_t s = (hipStream_t) stream;
 	if (P->ncol <= 0 || K <= 0)

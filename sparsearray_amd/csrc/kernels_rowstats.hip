@@ -989,6 +989,63 @@ rowsum_f64_cols_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__res
 	}
 }
 
+// rowsum(x, group) with the group of every NONZERO known in advance (svt_dev_rowsum_prepare, include/svt_hip.h):
+// what a call streams is 10 bytes per nonzero -- the value and a 16-bit 0-based group id beside it -- instead of
+// 12 bytes plus one 64-byte L2 sector for the lookup group[row] that bounds the kernel above (the lookups of a
+// wavefront go to ~50 different lines of the table; tools/micro/rowsum_probe.hip).  One wavefront per column, C
+// columns per workgroup, accumulators in LDS, no window and no barrier inside the walk.  Same rules as
+// compute_rowsum_doubles (src/rowsum_methods.c:44-64): NA group -> last group (folded into the ids), na.rm skips
+// NaN and NA values.
+__global__ void __launch_bounds__(256)
+rowsum_gid_kernel(const int32_t *__restrict__ row_idx, int64_t nnz, const int *__restrict__ group, int ngroup,
+		  uint16_t *__restrict__ gid)
+{
+	for (int64_t k = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) * 2; k < nnz;
+	     k += (int64_t) gridDim.x * blockDim.x * 2) {
+		// two ids per thread: one 4-byte store
+		const int g0 = group[row_idx[k]];
+		const uint32_t a = (uint32_t) ((g0 == NA_INT ? ngroup : g0) - 1);
+		if (k + 1 < nnz) {
+			const int g1 = group[row_idx[k + 1]];
+			const uint32_t b = (uint32_t) ((g1 == NA_INT ? ngroup : g1) - 1);
+			*(uint32_t *) (gid + k) = a | (b << 16);
+		} else
+			gid[k] = (uint16_t) a;
+	}
+}
+
+template <bool NARM>
+__global__ void __launch_bounds__(1024)
+rowsum_f64_gid_kernel(const int64_t *__restrict__ col_ptr, const double *__restrict__ val,
+		      const uint16_t *__restrict__ gid, int64_t ncol, int ngroup, double *__restrict__ out, int C)
+{
+	extern __shared__ double acc[];                 // [C][ngroup]
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const int64_t j = (int64_t) blockIdx.x * C + w;
+	for (int g = threadIdx.x; g < C * ngroup; g += C * 64) acc[g] = 0.0;
+	__syncthreads();
+	double *mine = acc + w * ngroup;
+	if (j < ncol) {
+		const int64_t beg = col_ptr[j], end = col_ptr[j + 1];
+		// four chunks of 64 nonzeros in flight per wavefront
+		for (int64_t k = beg + lane; k < end; k += 256) {
+			double v[4];
+			uint16_t g[4];
+#pragma unroll
+			for (int u = 0; u < 4; u++)
+				if (k + 64 * u < end) { v[u] = val[k + 64 * u]; g[u] = gid[k + 64 * u]; }
+#pragma unroll
+			for (int u = 0; u < 4; u++)
+				if (k + 64 * u < end && !(NARM && v[u] != v[u])) atomicAdd(&mine[g[u]], v[u]);
+		}
+	}
+	__syncthreads();
+	for (int g = threadIdx.x; g < C * ngroup; g += C * 64) {
+		const int64_t jj = (int64_t) blockIdx.x * C + g / ngroup;
+		if (jj < ncol) out[jj * (int64_t) ngroup + g % ngroup] = acc[g];
+	}
+}
+
 // columns per workgroup of rowsum_f64_cols_kernel (0: the operand does not suit it)
 static int rowsum_cols_per_wg(const GroupSumArgs &a)
 {
@@ -1038,6 +1095,51 @@ int launch_rowsum_lds(const GroupSumArgs &a, hipStream_t s)
 	}
 	hipLaunchKernelGGL(rowsum_f64_lds_kernel, dim3((unsigned) a.ncol), dim3(256),
 			   (size_t) a.ngroup * 8, s, a);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+// The 16-bit group id of every nonzero (gid: nnz ids); needs ngroup <= 65535.
+int launch_rowsum_gid(const GroupSumArgs &a, int64_t nnz, uint16_t *gid, hipStream_t s)
+{
+	if (nnz <= 0)
+		return 0;
+	int64_t nb = (nnz / 2 + 255) / 256;
+	if (nb > 256 * 32) nb = 256 * 32;
+	hipLaunchKernelGGL(rowsum_gid_kernel, dim3((unsigned) nb), dim3(256), 0, s, a.row_idx, nnz, a.group, a.ngroup, gid);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+// rowsum on prepared ids; every cell of out (ngroup x ncol) is written.  Returns 1 when the shape does not
+// suit the kernel (the caller then runs the unprepared product).
+int launch_rowsum_prepared(const GroupSumArgs &a, const uint16_t *gid, hipStream_t s)
+{
+	if (a.ncol <= 0 || a.ngroup <= 0)
+		return 0;
+	const int64_t cap = (int64_t) (160 * 1024) / ((int64_t) a.ngroup * 8);
+	if (cap < 1 || a.col_ptr64 == NULL)
+		return 1;
+	int C = cap > 16 ? 16 : (int) cap;
+	{       // as rowsum_cols_per_wg(): the fullest last round of workgroups
+		int best = C; int64_t best_cost = -1;
+		for (int c = C; c >= (C >= 4 ? 4 : 1); c--) {
+			const int64_t nwg = (a.ncol + c - 1) / c, rounds = (nwg + 255) / 256, cost = rounds * c;
+			if (best_cost < 0 || cost < best_cost) { best = c; best_cost = cost; }
+		}
+		C = best;
+	}
+	const size_t lds = (size_t) C * a.ngroup * 8;
+	const dim3 grid((unsigned) ((a.ncol + C - 1) / C));
+	if (a.na_rm) {
+		(void) hipFuncSetAttribute((const void *) rowsum_f64_gid_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+		hipLaunchKernelGGL(rowsum_f64_gid_kernel<true>, grid, dim3(C * 64), lds, s, a.col_ptr64, (const double *) a.val,
+				   gid, a.ncol, a.ngroup, (double *) a.out, C);
+	} else {
+		(void) hipFuncSetAttribute((const void *) rowsum_f64_gid_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+		hipLaunchKernelGGL(rowsum_f64_gid_kernel<false>, grid, dim3(C * 64), lds, s, a.col_ptr64, (const double *) a.val,
+				   gid, a.ncol, a.ngroup, (double *) a.out, C);
+	}
 	HIP_TRY(hipGetLastError());
 	return 0;
 }

@@ -182,8 +182,13 @@ int launch_spmm_product(SpmmArgs a, int64_t a_nnz, int64_t b_nnz, const void *ws
 {
 	if (a.nrow <= 0 || a.K <= 0)
 		return 0;
+	// the kernel counts the nonzeros of a workgroup's columns of B in 32 bits
+	if (b_nnz >= (int64_t) 2147483647)
+		return svt_set_error("sparse x sparse product: the second operand holds 2^31 nonzeros or more");
 	int ps, KW; int64_t npan;
 	spmm_shape(a.nrow, a.K, &ps, &npan, &KW);
+	if (npan >= (int64_t) 2147483647)
+		return svt_set_error("sparse x sparse product: too many row panels for one launch");
 	spmm_scan_values(a.b_val, a.b_type, b_nnz, a.flag, s);
 	const int64_t P = (int64_t) 1 << ps;
 	a.pt = (const int32_t *) ws; a.npan = npan; a.ps = ps;

@@ -200,6 +200,8 @@ struct GroupSumArgs {
 size_t groupsum_scratch_bytes(int Rtype, int64_t out_len);
 int launch_rowsum(const GroupSumArgs &a, hipStream_t s);
 int launch_rowsum_lds(const GroupSumArgs &a, hipStream_t s);   // f64, ngroup <= 8192
+int launch_rowsum_gid(const GroupSumArgs &a, int64_t nnz, uint16_t *gid, hipStream_t s);
+int launch_rowsum_prepared(const GroupSumArgs &a, const uint16_t *gid, hipStream_t s);   // f64, ngroup * 8 <= LDS
 int launch_colsum(const GroupSumArgs &a, hipStream_t s);
 
 struct CrossprodArgs {

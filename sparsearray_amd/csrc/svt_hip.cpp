@@ -937,6 +937,46 @@ extern "C" int svt_dev_rowsum(const svt_dev_csc *A, const int *group, int ngroup
 	return launch_rowsum(a, (hipStream_t) stream);
 }
 
+// rowsum(x, group) for a (x, group) pair that is used more than once: the group of every nonzero, as a 16-bit
+// 0-based id (NA -> ngroup - 1), is written to `gid` (svt_dev_rowsum_gid_bytes(A) bytes) once; the prepared call
+// then streams values and ids -- 10 bytes per nonzero, no lookup in the group table.
+extern "C" size_t svt_dev_rowsum_gid_bytes(const svt_dev_csc *A)
+{
+	return (size_t) (A->nnz > 0 ? A->nnz : 1) * 2 + 16;
+}
+
+extern "C" int svt_dev_rowsum_prepare(const svt_dev_csc *A, const int *group, int ngroup, void *gid,
+				      size_t gid_bytes, void *stream)
+{
+	if (ngroup < 1 || ngroup > 65535)
+		return svt_set_error("svt_dev_rowsum_prepare: between 1 and 65535 groups");
+	if (gid_bytes < svt_dev_rowsum_gid_bytes(A))
+		return svt_set_error("svt_dev_rowsum_prepare: id buffer too small");
+	GroupSumArgs a;
+	memset(&a, 0, sizeof(a));
+	a.row_idx = A->row_idx; a.group = group; a.ngroup = ngroup;
+	return launch_rowsum_gid(a, A->nnz, (uint16_t *) gid, (hipStream_t) stream);
+}
+
+extern "C" int svt_dev_rowsum_prepared(const svt_dev_csc *A, const void *gid, int ngroup, int na_rm,
+				       double *out, void *stream)
+{
+	if (A->Rtype != SVT_REALSXP)
+		return svt_set_error("svt_dev_rowsum: f64 input only");
+	if (ngroup < 1 || ngroup > 65535)
+		return svt_set_error("svt_dev_rowsum_prepared: between 1 and 65535 groups");
+	if ((int64_t) ngroup * 8 > 160 * 1024)
+		return svt_set_error("svt_dev_rowsum_prepared: more groups than a workgroup's LDS holds (20480)");
+	GroupSumArgs a;
+	memset(&a, 0, sizeof(a));
+	a.col_ptr64 = A->col_ptr; a.val = A->val; a.Rtype = A->Rtype; a.nrow = A->nrow; a.ncol = A->ncol;
+	a.ngroup = ngroup; a.na_rm = na_rm; a.out = out;
+	const int rc = launch_rowsum_prepared(a, (const uint16_t *) gid, (hipStream_t) stream);
+	if (rc > 0)
+		return svt_set_error("svt_dev_rowsum_prepared: unsupported shape");
+	return rc;
+}
+
 // ==================================================================================
 // Host level: crossprod
 // ==================================================================================

@@ -72,6 +72,10 @@ def _lib():
         lib.svt_dev_rowsums_prepare.argtypes = [c_void_p, c_int64, c_void_p, c_size_t, c_void_p]
         lib.svt_dev_rowsums_prepared.argtypes = [c_void_p, c_int, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]
         lib.svt_dev_rowsum.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]
+        lib.svt_dev_rowsum_gid_bytes.restype = c_size_t
+        lib.svt_dev_rowsum_gid_bytes.argtypes = [c_void_p]
+        lib.svt_dev_rowsum_prepare.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]
+        lib.svt_dev_rowsum_prepared.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]
         lib.svt_colStats_out_Rtype.argtypes = [c_int, c_int]
         lib.svt_dev_transpose_ws_bytes.restype = c_size_t
         lib.svt_dev_transpose_ws_bytes.argtypes = [c_int64, c_int64]
@@ -223,6 +227,12 @@ class PbcPlan:
             pass
 
 
+def trim_layout_pool() -> None:
+    """Returns the memory the layout pools keep for the next build to the driver (svt_dev_pbc_trim)."""
+    _lib().svt_dev_pbc_trim.restype = None
+    _lib().svt_dev_pbc_trim()
+
+
 def set_spare_cus(n: int) -> None:
     """CUs the LDS-DMA product kernel leaves idle from now on (0 = none; include/svt_hip.h:
     svt_dev_pbc_set_spare_cus) -- room for a collective's kernels beside the product."""
@@ -299,17 +309,19 @@ class SpmmPlan:
         self.A = A
         self.ws = torch.empty(_lib().svt_dev_matmul_csc_csc_ws_bytes(A.handle), dtype=torch.uint8, device=A.val.device)
         _check(_lib().svt_dev_matmul_csc_csc_prepare(A.handle, self.ws.data_ptr(), self.ws.numel(), _stream()))
-        self.flag = torch.zeros(1, dtype=torch.int32, device=A.val.device)
 
     def run(self, B: DeviceCSC, out=None):
-        """Returns (out, not_finite) like matmul_csc_csc()."""
+        """Returns (out, not_finite) like matmul_csc_csc(); the flag tensor is this call's own."""
         A = self.A
         assert A.ncol == B.nrow
         if out is None:
             out = torch.empty((B.ncol, A.nrow), dtype=torch.float64, device=A.val.device)
+        # (products are asynchronous: a flag tensor shared between runs would show a later product's verdict to
+        # whoever reads an earlier one late)
+        flag = torch.zeros(1, dtype=torch.int32, device=A.val.device)
         _check(_lib().svt_dev_matmul_csc_csc_prepared(A.handle, B.handle, out.data_ptr(), A.nrow, self.ws.data_ptr(),
-                                                      self.ws.numel(), self.flag.data_ptr(), _stream()))
-        return out, self.flag
+                                                      self.ws.numel(), flag.data_ptr(), _stream()))
+        return out, flag
 
 
 def rowsums(A: DeviceCSC, na_rm=False, inner=1, out=None, ws=None):
@@ -347,3 +359,25 @@ def rowsum(A: DeviceCSC, group: torch.Tensor, ngroup: int, na_rm=False, out=None
     _check(_lib().svt_dev_rowsum(A.handle, group.data_ptr(), int(ngroup), int(na_rm),
                                  out.data_ptr(), _stream()))
     return out
+
+
+class RowsumPlan:
+    """rowsum(A, group) for a pair used more than once: the 16-bit group id of every nonzero is computed once
+    (svt_dev_rowsum_prepare), a call then streams 10 bytes per nonzero and looks nothing up
+    (svt_dev_rowsum_prepared; src/rowsum_methods.c:44-64 for the rules)."""
+
+    def __init__(self, A: DeviceCSC, group: torch.Tensor, ngroup: int):
+        assert group.dtype == torch.int32 and group.numel() == A.nrow
+        self.A, self.ngroup = A, int(ngroup)
+        self.gid = torch.empty(_lib().svt_dev_rowsum_gid_bytes(A.handle), dtype=torch.uint8, device=A.val.device)
+        _check(_lib().svt_dev_rowsum_prepare(A.handle, group.data_ptr(), self.ngroup, self.gid.data_ptr(),
+                                             self.gid.numel(), _stream()))
+
+    def run(self, na_rm=False, out=None):
+        """(ncol, ngroup) C-contiguous = the column-major ngroup x ncol result, like rowsum()."""
+        A = self.A
+        if out is None:
+            out = torch.empty((A.ncol, self.ngroup), dtype=torch.float64, device=A.val.device)
+        _check(_lib().svt_dev_rowsum_prepared(A.handle, self.gid.data_ptr(), self.ngroup, int(na_rm),
+                                              out.data_ptr(), _stream()))
+        return out

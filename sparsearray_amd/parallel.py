@@ -224,8 +224,19 @@ class PeerReducer:
         self.world, self.me = _world(group), _rank(group)
         self.cuda = torch.device(device).type == "cuda"
         self.shape = tuple(shape)
-        # (handles travel as bytes through all_gather_object: host tensors are shared by file name, not by descriptor)
+        # (handles travel as bytes through all_gather_object: host tensors are shared by file name, not by descriptor --
+        # the process-wide strategy is switched only while the windows are made and opened, and put back)
+        strategy = tmp.get_sharing_strategy()
         tmp.set_sharing_strategy("file_system")
+        try:
+            self._open_windows(shape, dtype, device, group, nbuf, pickle, ForkingPickler)
+        finally:
+            tmp.set_sharing_strategy(strategy)
+        self.gen = [0] * nbuf          # generation of the last push / sum of every buffer
+        self.pending = [False] * nbuf
+        self.closed = False
+
+    def _open_windows(self, shape, dtype, device, group, nbuf, pickle, ForkingPickler):
         self.staging = torch.zeros((nbuf, self.world) + self.shape, dtype=dtype, device=device)
         self.flags = torch.zeros((2, nbuf), dtype=torch.int64)          # [pushed | consumed][buffer], host memory
         if not self.cuda:
@@ -261,8 +272,19 @@ class PeerReducer:
                 self.peer_pushed.append(None); self.peer_consumed.append(None)
         if self.world > 1:
             dist.barrier(group=group)          # every rank has opened every window before anyone's tensors can go away
-        self.gen = [0] * nbuf          # generation of the last push / sum of every buffer
-        self.pending = [False] * nbuf
+
+    def close(self):
+        """Collective: every rank drops its views of the peers' windows (the IPC mappings and the shared-memory
+        files behind the host counters go with them), after a barrier that says nobody is still copying."""
+        if getattr(self, "closed", True):
+            return
+        if self.cuda:
+            torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier(group=self.group)
+        self.peer_staging = self.peer_flags = self.peer_pushed = self.peer_consumed = None
+        self.staging = self.flags = None
+        self.closed = True
 
     def _spin(self, flags, row, b, want):
         import time
@@ -402,6 +424,13 @@ class ShardedCrossprod:
     def result(self) -> torch.Tensor:
         self.wait()
         return self.outs[(self.stepno - 1) % len(self.outs)]
+
+    def close(self):
+        """Collective when the peer reducer is in use: finishes what is pending and closes its windows."""
+        self.wait()
+        if self.peer is not None:
+            self.peer.close()
+            self.peer = None
 
 
 def sharded_colsums_rows(A_local, group=None, local: Optional[Callable] = None) -> torch.Tensor:

@@ -278,8 +278,16 @@ def test_bench_strong_scaling_rehearsal_same_problem(hip):
     torch.cuda.empty_cache()
     common = ["--nrow", "262144", "--ncol", "4000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras"]
     one = _bench_line(common, 1, 0)
-    two = _bench_line(common + ["--spare-cus", "32"], 2, 29700 + os.getpid() % 200)   # and CUs left to the collective
-    assert two["config"]["spare_cus"] == 32
+    two = _bench_line(common + ["--spare-cus", "32", "--compare-reducers"], 2, 29700 + os.getpid() % 200)
+    assert two["config"]["spare_cus"] == 32                   # CUs left to the collective
+    # the N > 1 line says why it scales the way it does
+    m = two["multi_gpu"]
+    assert m["backend"] == "gloo" and m["world_size"] == 2 and m["reducer"] == "rccl" and m["spare_cus"] == 32
+    assert len(m["kernel_ms_per_rank"]) == 2 and min(m["kernel_ms_per_rank"]) > 0
+    assert m["allreduce_alone_ms"] > 0 and m["product_alone_ms"] > 0 and 0.0 <= m["overlap_fraction"] <= 1.0
+    assert m["allreduce_bytes"] == 4000 * 128 * 8
+    assert m["variants"]["rccl_spare_cus_0"]["ms_per_step"] > 0
+    assert m["variants"]["peer_copies"]["ms_per_step"] > 0 and m["variants"]["peer_copies"]["same_result"]
     peer = _bench_line(common + ["--reduce", "peer"], 2, 29950 + os.getpid() % 200)     # PeerReducer instead of all-reduce
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and peer["n_gpus"] == 2
     c = peer["config"]["result_checksum"]
