@@ -402,12 +402,15 @@ int svt_dev_transpose(const svt_dev_csc *A, int64_t *out_col_ptr, int32_t *out_r
    products, added as the lane groups get to them; exact for integer operands below 2^53).  A non-finite
    value or an NA in either operand changes what the reference computes (its dirty-leaf loops multiply the
    implicit zeros too): then `*not_finite` (device int, may be NULL; the second int of `ws` holds the same flag)
-   is set and `out` must be recomputed by the dense route (svt_matmul_SVT_SVT does).  Every cell of the
-   A->nrow x B->ncol result is written; ws: svt_dev_matmul_csc_csc_ws_bytes(A) bytes.  Asynchronous.
-   What depends on A alone -- the table of run bounds (one pass over its offsets) and the scan of its values --
+   is set and `out` must be recomputed by the dense route (svt_matmul_SVT_SVT does; a launch that finds the flag
+   up already leaves `out` alone).  Otherwise every cell of the A->nrow x B->ncol result is written; ws:
+   svt_dev_matmul_csc_csc_ws_bytes(A) bytes.  Asynchronous.
+   What depends on A alone -- the table of run bounds and a look at all its values, one pass over the operand --
    can be done once per operand: svt_dev_matmul_csc_csc_prepare(A, ws) fills `ws`, which
    svt_dev_matmul_csc_csc_prepared() then only reads (plus its second int, the flag of the last product), as the
-   panel-blocked layout serves crossprod(A, Y); svt_dev_matmul_csc_csc() is the two in a row. */
+   panel-blocked layout serves crossprod(A, Y).  svt_dev_matmul_csc_csc() does the same work for ONE product and
+   less of it: its table pass looks only at the leaves of A that no column of B refers to, the product kernel at
+   every value it reads (all of B, the other leaves of A); the `ws` it leaves is not a prepared one. */
 size_t svt_dev_matmul_csc_csc_ws_bytes(const svt_dev_csc *A);
 int svt_dev_matmul_csc_csc(const svt_dev_csc *A, const svt_dev_csc *B, double *out, int64_t ldo,
 			   void *ws, size_t ws_bytes, int *not_finite, void *stream);

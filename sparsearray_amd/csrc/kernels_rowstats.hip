@@ -239,15 +239,22 @@ rowpanel_table_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__rest
 // scattered form spends 222 us of a 0.65 ms rowSums at BASELINE config 2 on write
 // amplification).  LDS: (npan + 1) * 64 bytes.
 #define PT_LEAVES 16
+// SCAN (the sparse x sparse product, kernels_spmm.hip): the pass also looks at the VALUES of the leaves it walks
+// -- all of them (skip == NULL) or those with skip[j] == 0 -- and raises *flag at a NaN / Inf / NA (doubles) or an
+// NA_integer_ (ints): one stream over the operand instead of two.  SCAN: 0 none, 1 doubles, 2 ints.
+template <int SCAN>
 __global__ void __launch_bounds__(PT_LEAVES * 64)
 rowpanel_table16_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__ row_idx,
-			int64_t ncol, int64_t npan, int ps, int32_t *__restrict__ pt)
+			int64_t ncol, int64_t npan, int ps, int32_t *__restrict__ pt,
+			const void *__restrict__ val, const uint8_t *__restrict__ skip, int *__restrict__ flag)
 {
 	extern __shared__ int32_t tab[];            // [npan + 1][PT_LEAVES]
 	const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const int64_t j0 = (int64_t) blockIdx.x * PT_LEAVES, j = j0 + w;
 	if (j < ncol) {
 		const int64_t beg = col_ptr[j], end = col_ptr[j + 1];
+		const bool look = SCAN != 0 && (skip == NULL || skip[j] == 0);
+		bool bad = false;
 		int carry = -1;                         // panel of the element before this trip
 		for (int64_t k0 = beg; k0 < end; k0 += 4 * 64) {
 			int32_t r[4];
@@ -255,6 +262,23 @@ rowpanel_table16_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__re
 			for (int u = 0; u < 4; u++) {       // four coalesced loads in flight
 				const int64_t k = k0 + u * 64 + lane;
 				r[u] = k < end ? row_idx[k] : 0x7FFFFFFF;
+			}
+			if (SCAN == 1 && look) {
+				double x[4];
+#pragma unroll
+				for (int u = 0; u < 4; u++) {
+					const int64_t k = k0 + u * 64 + lane;
+					x[u] = k < end ? ((const double *) val)[k] : 0.0;
+				}
+#pragma unroll
+				for (int u = 0; u < 4; u++) bad |= !(fabs(x[u]) <= 1.7976931348623157e308);
+			}
+			if (SCAN == 2 && look) {
+#pragma unroll
+				for (int u = 0; u < 4; u++) {
+					const int64_t k = k0 + u * 64 + lane;
+					bad |= k < end && ((const int *) val)[k] == NA_INT;
+				}
 			}
 #pragma unroll
 			for (int u = 0; u < 4; u++) {
@@ -268,6 +292,7 @@ rowpanel_table16_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__re
 						tab[(int64_t) q * PT_LEAVES + w] = (int32_t) (k - beg);
 			}
 		}
+		if (SCAN != 0 && __ballot(bad) != 0 && lane == 0) *flag = 1;
 		const int64_t pl = end > beg ? row_idx[end - 1] >> ps : -1;
 		for (int64_t q = pl + 1 + lane; q <= npan; q += 64)
 			tab[q * PT_LEAVES + w] = (int32_t) (end - beg);
@@ -574,15 +599,37 @@ void launch_rowpanel_table(const int64_t *col_ptr, const int32_t *row_idx, int64
 			   int64_t npan, int ps, int32_t *pt, hipStream_t s)
 {
 	if (ncol > 0 && (size_t) (npan + 1) * PT_LEAVES * 4 <= 64 * 1024) {
-		hipLaunchKernelGGL(rowpanel_table16_kernel, dim3((unsigned) ((ncol + PT_LEAVES - 1) / PT_LEAVES)),
+		hipLaunchKernelGGL(rowpanel_table16_kernel<0>, dim3((unsigned) ((ncol + PT_LEAVES - 1) / PT_LEAVES)),
 				   dim3(PT_LEAVES * 64), (size_t) (npan + 1) * PT_LEAVES * 4, s,
-				   col_ptr, row_idx, ncol, npan, ps, pt);
+				   col_ptr, row_idx, ncol, npan, ps, pt, (const void *) NULL, (const uint8_t *) NULL, (int *) NULL);
 	} else if (ncol > 0) {                      // very tall arrays: the table rows do not fit LDS
 		// (grid == ncol selects the workgroup-per-leaf form; never equal to (ncol+3)/4 for ncol > 1)
 		const bool wide = nnz_hint / ncol >= 1024 && ncol > 1;
 		hipLaunchKernelGGL(rowpanel_table_kernel, dim3((unsigned) (wide ? ncol : (ncol + 3) / 4)),
 				   dim3(256), 0, s, col_ptr, row_idx, ncol, npan, ps, pt);
 	}
+}
+
+// The same pass, looking at the values of the leaves with skip[j] == 0 (all leaves: skip == NULL) on its way:
+// *flag = 1 at a non-finite double / an NA.  Returns false when the shape takes the plain table kernel (the
+// caller then scans the values in a pass of its own).
+bool launch_rowpanel_table_scan(const int64_t *col_ptr, const int32_t *row_idx, const void *val, int Rtype,
+				int64_t ncol, int64_t nnz_hint, int64_t npan, int ps, int32_t *pt,
+				const uint8_t *skip, int *flag, hipStream_t s)
+{
+	if (ncol > 0 && (size_t) (npan + 1) * PT_LEAVES * 4 <= 64 * 1024) {
+		const dim3 grid((unsigned) ((ncol + PT_LEAVES - 1) / PT_LEAVES));
+		const size_t lds = (size_t) (npan + 1) * PT_LEAVES * 4;
+		if (Rtype == SVT_REALSXP)
+			hipLaunchKernelGGL(rowpanel_table16_kernel<1>, grid, dim3(PT_LEAVES * 64), lds, s, col_ptr, row_idx,
+					   ncol, npan, ps, pt, val, skip, flag);
+		else
+			hipLaunchKernelGGL(rowpanel_table16_kernel<2>, grid, dim3(PT_LEAVES * 64), lds, s, col_ptr, row_idx,
+					   ncol, npan, ps, pt, val, skip, flag);
+		return true;
+	}
+	launch_rowpanel_table(col_ptr, row_idx, ncol, nnz_hint, npan, ps, pt, s);
+	return false;
 }
 
 // `ws`: rowstats_panel_ws_bytes() bytes.

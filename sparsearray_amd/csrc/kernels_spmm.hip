@@ -26,8 +26,13 @@
 // 0.95; 4096 x 2 1.01; 64 lanes per run 0.97; the dense route 2.35-2.45 ms + 2.2 ms t(A) + 2.0 ms layout once per A.
 //
 // A non-finite value or an NA ANYWHERE in either operand changes what the reference computes (its dirty-leaf
-// loops multiply the implicit zeros too, src/SparseVec_dotprod.c:48-65): a scan of all values (0.8 GB at
-// config 3: 0.16 of the call's ~0.8 ms) raises *flag and the caller takes the dense route.
+// loops multiply the implicit zeros too, src/SparseVec_dotprod.c:48-65): *flag goes up and the caller takes the
+// dense route.  Who looks at which values (round 4; a separate scan of all of A was 0.15 of a 0.85 ms call):
+//   * the product kernel at every value it reads anyway -- all of B, and the leaves of A that some column of B
+//     refers to;
+//   * the pass that builds the table of run bounds (it streams A's offsets) at the values of the leaves of A
+//     that NO column of B refers to (28 % of them at config 3: a byte map of the referenced leaves is made from
+//     B's offsets first) -- or at all of them when the table is prepared for any B (SpmmPlan).
 #include "svt_common.h"
 
 #define SPMM_NT 1024
@@ -36,13 +41,27 @@
 #define SPMM_U 4
 #endif
 
-size_t spmm_ws_bytes(int64_t nrow, int64_t ninner)
+static size_t spmm_table_bytes(int64_t nrow, int64_t ninner)
 {
 	// the table of run bounds for the shortest panels this file uses (64 rows)
 	int ps = 13;
 	while (ps > 6 && ((int64_t) 1 << ps) >= 2 * (nrow > 0 ? nrow : 1)) ps--;
 	const int64_t npan = (nrow + ((int64_t) 1 << ps) - 1) >> ps;
-	return (size_t) (ninner > 0 ? ninner : 1) * (size_t) (npan + 1) * 4 + 256;
+	return ((size_t) (ninner > 0 ? ninner : 1) * (size_t) (npan + 1) * 4 + 255) / 256 * 256;
+}
+
+// [table of run bounds][byte map of the leaves of A that B refers to]
+size_t spmm_ws_bytes(int64_t nrow, int64_t ninner)
+{
+	return spmm_table_bytes(nrow, ninner) + (size_t) (ninner > 0 ? ninner : 1) + 256;
+}
+
+// ref[j] = 1 for every leaf j of A that a nonzero of B sits in row j of
+__global__ void __launch_bounds__(256)
+spmm_ref_kernel(const int32_t *__restrict__ b_idx, int64_t b_nnz, uint8_t *__restrict__ ref)
+{
+	for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < b_nnz; i += (int64_t) gridDim.x * blockDim.x)
+		ref[b_idx[i]] = 1;
 }
 
 template <typename T> __device__ inline bool spmm_bad(T v);
@@ -80,6 +99,9 @@ spmm_csc_csc_kernel(SpmmArgs a, int KW, int G)
 {
 	extern __shared__ double acc[];                 // [KW][P]
 	const int tid = threadIdx.x;
+	// an earlier pass has found a value that voids the result: the caller takes the dense route
+	if (*(volatile const int *) a.flag != 0)
+		return;
 	const int P = 1 << a.ps;
 	const int64_t q = blockIdx.x, r0 = q << a.ps;
 	const int64_t k0 = (int64_t) blockIdx.y * KW;
@@ -104,6 +126,7 @@ spmm_csc_csc_kernel(SpmmArgs a, int KW, int G)
 	const TA *__restrict__ av = (const TA *) a.a_val;
 	const TB *__restrict__ bv = (const TB *) a.b_val;
 	const int32_t *__restrict__ pt0 = a.pt + q * a.ninner, *__restrict__ pt1 = pt0 + a.ninner;
+	bool bad = false;
 	// SPMM_U pairs per group in flight: their bounds are fetched together, then their runs
 	for (int t0 = grp; t0 < npairs; t0 += SPMM_U * ngrp) {
 		int64_t xb[SPMM_U], xe[SPMM_U];
@@ -122,6 +145,7 @@ spmm_csc_csc_kernel(SpmmArgs a, int KW, int G)
 				const int64_t base = a.a_ptr[j];
 				xb[u] = base + pt0[j] + sl; xe[u] = base + pt1[j];
 				bval[u] = (double) b; kkof[u] = kk;
+				bad |= spmm_bad<TB>(b);
 			}
 		}
 		bool more = true;
@@ -135,12 +159,14 @@ spmm_csc_csc_kernel(SpmmArgs a, int KW, int G)
 #pragma unroll
 			for (int u = 0; u < SPMM_U; u++)
 				if (xb[u] < xe[u]) {
+					bad |= spmm_bad<TA>(v[u]);
 					atomicAdd(&acc[kkof[u] * P + r[u]], (double) v[u] * bval[u]);
 					xb[u] += G;
 					more |= xb[u] < xe[u];
 				}
 		}
 	}
+	if (__ballot(bad) != 0 && (tid & 63) == 0) *a.flag = 1;
 	__syncthreads();
 	for (int kk = 0; kk < kw; kk++) {
 		double *__restrict__ dst = a.out + (k0 + kk) * a.ldo + r0;
@@ -170,14 +196,37 @@ int launch_spmm_prepare(const SpmmArgs &a, int64_t a_nnz, void *ws, hipStream_t 
 		return 0;
 	int ps, KW; int64_t npan;
 	spmm_shape(a.nrow, 1, &ps, &npan, &KW);
-	spmm_scan_values(a.a_val, a.a_type, a_nnz, a.flag, s);
-	launch_rowpanel_table(a.a_ptr, a.a_idx, a.ninner, a_nnz, npan, ps, (int32_t *) ws, s);
+	if (!launch_rowpanel_table_scan(a.a_ptr, a.a_idx, a.a_val, a.a_type, a.ninner, a_nnz, npan, ps, (int32_t *) ws,
+					NULL, a.flag, s))
+		spmm_scan_values(a.a_val, a.a_type, a_nnz, a.flag, s);
 	HIP_TRY(hipGetLastError());
 	return 0;
 }
 
-// The product on a prepared A (ws as left by launch_spmm_prepare); B's values are scanned here (raises *flag).
-// Every cell of out[0 .. nrow) x [0 .. K) is written.
+// The same for ONE product with B: only the leaves of A that B does not refer to are looked at here -- the
+// product kernel sees the values of the others.
+int launch_spmm_prepare_for(const SpmmArgs &a, int64_t a_nnz, int64_t b_nnz, void *ws, hipStream_t s)
+{
+	if (a.nrow <= 0)
+		return 0;
+	int ps, KW; int64_t npan;
+	spmm_shape(a.nrow, 1, &ps, &npan, &KW);
+	uint8_t *ref = (uint8_t *) ws + spmm_table_bytes(a.nrow, a.ninner);
+	HIP_TRY(hipMemsetAsync(ref, 0, (size_t) (a.ninner > 0 ? a.ninner : 1), s));
+	if (b_nnz > 0) {
+		int64_t nb = (b_nnz + 255) / 256;
+		if (nb > 1024) nb = 1024;
+		hipLaunchKernelGGL(spmm_ref_kernel, dim3((unsigned) nb), dim3(256), 0, s, a.b_idx, b_nnz, ref);
+	}
+	if (!launch_rowpanel_table_scan(a.a_ptr, a.a_idx, a.a_val, a.a_type, a.ninner, a_nnz, npan, ps, (int32_t *) ws,
+					ref, a.flag, s))
+		spmm_scan_values(a.a_val, a.a_type, a_nnz, a.flag, s);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+// The product on a prepared A (ws as left by launch_spmm_prepare / _prepare_for); it looks at every value it reads
+// (raises *flag).  Every cell of out[0 .. nrow) x [0 .. K) is written unless *flag was up already.
 int launch_spmm_product(SpmmArgs a, int64_t a_nnz, int64_t b_nnz, const void *ws, hipStream_t s)
 {
 	if (a.nrow <= 0 || a.K <= 0)
@@ -189,7 +238,6 @@ int launch_spmm_product(SpmmArgs a, int64_t a_nnz, int64_t b_nnz, const void *ws
 	spmm_shape(a.nrow, a.K, &ps, &npan, &KW);
 	if (npan >= (int64_t) 2147483647)
 		return svt_set_error("sparse x sparse product: too many row panels for one launch");
-	spmm_scan_values(a.b_val, a.b_type, b_nnz, a.flag, s);
 	const int64_t P = (int64_t) 1 << ps;
 	a.pt = (const int32_t *) ws; a.npan = npan; a.ps = ps;
 	// lanes per run: the largest power of two <= half its mean length (81 nonzeros at config 3: three trips of

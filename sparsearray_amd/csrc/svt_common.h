@@ -160,6 +160,9 @@ size_t rowstats_panel_ws_bytes(int64_t nrow, int64_t ncol);
 int launch_rowstats_panel(const RowStatsArgs &a, void *ws, hipStream_t s);      // LDS row panels
 void launch_rowpanel_table(const int64_t *col_ptr, const int32_t *row_idx, int64_t ncol, int64_t nnz_hint,
 			   int64_t npan, int ps, int32_t *pt, hipStream_t s);
+bool launch_rowpanel_table_scan(const int64_t *col_ptr, const int32_t *row_idx, const void *val, int Rtype,
+				int64_t ncol, int64_t nnz_hint, int64_t npan, int ps, int32_t *pt,
+				const uint8_t *skip, int *flag, hipStream_t s);
 
 // sparse x sparse product by row panels (kernels_spmm.hip)
 struct SpmmArgs {
@@ -171,6 +174,7 @@ struct SpmmArgs {
 };
 size_t spmm_ws_bytes(int64_t nrow, int64_t ninner);
 int launch_spmm_prepare(const SpmmArgs &a, int64_t a_nnz, void *ws, hipStream_t s);
+int launch_spmm_prepare_for(const SpmmArgs &a, int64_t a_nnz, int64_t b_nnz, void *ws, hipStream_t s);
 int launch_spmm_product(SpmmArgs a, int64_t a_nnz, int64_t b_nnz, const void *ws, hipStream_t s);
 
 size_t transpose_ws_bytes(int64_t nrow, int64_t nnz);

@@ -851,9 +851,24 @@ extern "C" int svt_dev_matmul_csc_csc(const svt_dev_csc *A, const svt_dev_csc *B
 {
 	if (A->ncol != B->nrow)
 		return svt_set_error("svt_dev_matmul_csc_csc: non-conformable operands");
-	if (svt_dev_matmul_csc_csc_prepare(A, ws, ws_bytes, stream))
+	if (ws_bytes < svt_dev_matmul_csc_csc_ws_bytes(A))
+		return svt_set_error("svt_dev_matmul_csc_csc: workspace too small");
+	if (ldo < A->nrow)
+		return svt_set_error("svt_dev_matmul_csc_csc: leading dimension of the result too small");
+	// one product: the table pass looks only at the leaves of A that B does not refer to, the product kernel at
+	// the values it reads (kernels_spmm.hip); ws[0] is left as "not known for A alone" -- this ws is not a
+	// prepared one afterwards
+	hipStream_t s = (hipStream_t) stream;
+	HIP_TRY(hipMemsetAsync(ws, 0, 8, s));
+	int *flag = (int *) ws + 1;
+	const SpmmArgs a = spmm_args(A, B, out, ldo, flag);
+	if (launch_spmm_prepare_for(a, A->nnz, B->nnz, (char *) ws + 256, s))
 		return -1;
-	return svt_dev_matmul_csc_csc_prepared(A, B, out, ldo, ws, ws_bytes, not_finite, stream);
+	if (launch_spmm_product(a, A->nnz, B->nnz, (char *) ws + 256, s))
+		return -1;
+	if (not_finite != NULL)
+		HIP_TRY(hipMemcpyAsync(not_finite, flag, 4, hipMemcpyDeviceToDevice, s));
+	return 0;
 }
 
 static int aperm_args(int ndim, const int *perm, int *perm0)
@@ -1496,17 +1511,19 @@ extern "C" int svt_matmul_SVT_SVT(const svt_view *x, const svt_view *y, double *
 	const int64_t Rpp_nops = view_nzcount(x) * out_ncol;
 	CscGuard X(x);
 	if (X.h == NULL) return -1;
+	CscGuard Y(y);                                  // (one upload of y for both routes)
+	if (Y.h == NULL) return -1;
 	// y much sparser than a dense matrix (<= 5 % filled), finite operands: the row-panel kernel on x itself,
 	// no transposition, no dense operand (kernels_spmm.hip); a non-finite value or an NA anywhere sends the
-	// product down the reference's route below
+	// product down the reference's route below.  The kernel adds the products of a cell in the order its lane
+	// groups get to them: doubles can differ in the last bits from run to run and from the reference's
+	// ascending-index order (inside the 1e-6 the contract allows; integer operands are exact below 2^53).
 	if (view_nzcount(y) * 20 <= (int64_t) y->dim[0] * y->dim[1]) {
-		CscGuard Ys(y);
-		if (Ys.h == NULL) return -1;
 		DevBuf Os, Ws;
 		int bad = 1;
 		if (Os.alloc(out_n * 8) || Ws.alloc(svt_dev_matmul_csc_csc_ws_bytes(X.h)))
 			return -1;
-		if (svt_dev_matmul_csc_csc(X.h, Ys.h, Os.as<double>(), out_nrow, Ws.p, Ws.bytes, NULL, 0))
+		if (svt_dev_matmul_csc_csc(X.h, Y.h, Os.as<double>(), out_nrow, Ws.p, Ws.bytes, NULL, 0))
 			return -1;
 		HIP_TRY(hipMemcpy(&bad, (char *) Ws.p + 4, 4, hipMemcpyDeviceToHost));
 		if (!bad)
@@ -1517,8 +1534,6 @@ extern "C" int svt_matmul_SVT_SVT(const svt_view *x, const svt_view *y, double *
 	OwnedCsc TX = { T, own_T };
 	if (T == NULL) return -1;
 	X.drop();
-	CscGuard Y(y);
-	if (Y.h == NULL) return -1;
 	DevBuf O;
 	if (O.alloc(out_n * 8) || O.zero())
 		return -1;

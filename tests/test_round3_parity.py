@@ -245,6 +245,24 @@ def test_rowsum_tall_operands(hip, oracle, ngroup, shape):
         b, ub = oracle.rowsum(x, grp, na_rm=na_rm)
         assert ua == ub
         assert_equal(a, b, tol=1e-9, atol=1e-12, what=f"rowsum ngroup={ngroup} na_rm={na_rm}")
+    # the prepared form: the 16-bit group id of every nonzero computed once (svt_dev_rowsum_prepare), then
+    # products that stream values + ids (svt_dev_rowsum_prepared) -- same rules, src/rowsum_methods.c:44-64
+    import torch
+    from sparsearray_amd.device import DeviceCSC, RowsumPlan
+    A = DeviceCSC.from_host(nrow, cp, ri, v)
+    ug = hip._compute_ugroup(grp, nrow, True)
+    gpos = hip._match(grp, ug)                         # 1-based positions, the NA group last (as R's match())
+    for na_as_int in (False, True):                    # ... and as NA_integer_ -> last group (src/rowsum_methods.c:51-54)
+        g32 = gpos.copy()
+        if na_as_int and ug[-1] is None:
+            g32[g32 == len(ug)] = -2147483648
+        plan = RowsumPlan(A, torch.as_tensor(g32, device="cuda"), len(ug))
+        for na_rm in (False, True):
+            got = plan.run(na_rm=na_rm)
+            torch.cuda.synchronize()
+            b, _ = oracle.rowsum(x, grp, na_rm=na_rm)
+            assert_equal(got.cpu().numpy().T, b, tol=1e-9, atol=1e-12,
+                         what=f"prepared rowsum ngroup={ngroup} na_rm={na_rm} NA as integer: {na_as_int}")
 
 
 # ---------------------------------------------------------------------------------------------
