@@ -242,43 +242,30 @@ rowpanel_table_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__rest
 // SCAN (the sparse x sparse product, kernels_spmm.hip): the pass also looks at the VALUES of the leaves it walks
 // -- all of them (skip == NULL) or those with skip[j] == 0 -- and raises *flag at a NaN / Inf / NA (doubles) or an
 // NA_integer_ (ints): one stream over the operand instead of two.  SCAN: 0 none, 1 doubles, 2 ints.
-template <int SCAN>
+// S wavefronts share a leaf (each a contiguous S-th of its offsets; a workgroup then holds 16 / S leaves): leaves
+// are the unit the chip is filled with, and 1e4 long leaves on 8192 wavefront slots are two rounds of which the
+// second is a quarter full (BASELINE config 2/3: 101 us; in quarters 5 rounds of a quarter the length).
+template <int SCAN, int S>
 __global__ void __launch_bounds__(PT_LEAVES * 64)
 rowpanel_table16_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__ row_idx,
 			int64_t ncol, int64_t npan, int ps, int32_t *__restrict__ pt,
 			const void *__restrict__ val, const uint8_t *__restrict__ skip, int *__restrict__ flag)
 {
-	extern __shared__ int32_t tab[];            // [npan + 1][PT_LEAVES]
+	extern __shared__ int32_t tab[];            // [npan + 1][L]
+	constexpr int L = PT_LEAVES / S;
 	const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const int64_t j0 = (int64_t) blockIdx.x * PT_LEAVES, j = j0 + w;
+	const int wl = w / S, sg = w % S;           // leaf of the workgroup, segment of the leaf
+	const int64_t j0 = (int64_t) blockIdx.x * L, j = j0 + wl;
 	if (j < ncol) {
 		const int64_t beg = col_ptr[j], end = col_ptr[j + 1];
-		const bool look = SCAN != 0 && (skip == NULL || skip[j] == 0);
-		bool bad = false;
-		int carry = -1;                         // panel of the element before this trip
-		for (int64_t k0 = beg; k0 < end; k0 += 4 * 64) {
+		const int64_t sb = beg + (end - beg) * sg / S, se = beg + (end - beg) * (sg + 1) / S;
+		int carry = sb > beg ? row_idx[sb - 1] >> ps : -1;     // panel of the element before this trip
+		for (int64_t k0 = sb; k0 < se; k0 += 4 * 64) {
 			int32_t r[4];
 #pragma unroll
 			for (int u = 0; u < 4; u++) {       // four coalesced loads in flight
 				const int64_t k = k0 + u * 64 + lane;
-				r[u] = k < end ? row_idx[k] : 0x7FFFFFFF;
-			}
-			if (SCAN == 1 && look) {
-				double x[4];
-#pragma unroll
-				for (int u = 0; u < 4; u++) {
-					const int64_t k = k0 + u * 64 + lane;
-					x[u] = k < end ? ((const double *) val)[k] : 0.0;
-				}
-#pragma unroll
-				for (int u = 0; u < 4; u++) bad |= !(fabs(x[u]) <= 1.7976931348623157e308);
-			}
-			if (SCAN == 2 && look) {
-#pragma unroll
-				for (int u = 0; u < 4; u++) {
-					const int64_t k = k0 + u * 64 + lane;
-					bad |= k < end && ((const int *) val)[k] == NA_INT;
-				}
+				r[u] = k < se ? row_idx[k] : 0x7FFFFFFF;
 			}
 #pragma unroll
 			for (int u = 0; u < 4; u++) {
@@ -287,20 +274,46 @@ rowpanel_table16_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__re
 				int prev = __shfl_up(p, 1, 64);
 				if (lane == 0) prev = carry;
 				carry = __shfl(p, 63, 64);
-				if (k < end)
+				if (k < se)
 					for (int q = prev + 1; q <= p; q++)
-						tab[(int64_t) q * PT_LEAVES + w] = (int32_t) (k - beg);
+						tab[(int64_t) q * L + wl] = (int32_t) (k - beg);
 			}
 		}
-		if (SCAN != 0 && __ballot(bad) != 0 && lane == 0) *flag = 1;
-		const int64_t pl = end > beg ? row_idx[end - 1] >> ps : -1;
-		for (int64_t q = pl + 1 + lane; q <= npan; q += 64)
-			tab[q * PT_LEAVES + w] = (int32_t) (end - beg);
+		if (sg == S - 1) {
+			const int64_t pl = end > beg ? row_idx[end - 1] >> ps : -1;
+			for (int64_t q = pl + 1 + lane; q <= npan; q += 64)
+				tab[q * L + wl] = (int32_t) (end - beg);
+		}
+	}
+	if (SCAN != 0) {
+		// the values of the workgroup's leaves that are looked at here, shared out over ALL its wavefronts (a
+		// wavefront that scanned its own leaf alone would hold the others back)
+		bool bad = false;
+		for (int l = 0; l < L && j0 + l < ncol; l++) {
+			if (skip != NULL && skip[j0 + l] != 0)
+				continue;
+			const int64_t b = col_ptr[j0 + l], e = col_ptr[j0 + l + 1];
+			for (int64_t k = b + threadIdx.x; k < e; k += 4 * PT_LEAVES * 64) {
+				if (SCAN == 1) {
+					double x[4];
+#pragma unroll
+					for (int u = 0; u < 4; u++)
+						x[u] = k + u * PT_LEAVES * 64 < e ? ((const double *) val)[k + u * PT_LEAVES * 64] : 0.0;
+#pragma unroll
+					for (int u = 0; u < 4; u++) bad |= !(fabs(x[u]) <= 1.7976931348623157e308);
+				} else {
+#pragma unroll
+					for (int u = 0; u < 4; u++)
+						bad |= k + u * PT_LEAVES * 64 < e && ((const int *) val)[k + u * PT_LEAVES * 64] == NA_INT;
+				}
+			}
+		}
+		if (__ballot(bad) != 0 && lane == 0) *flag = 1;
 	}
 	__syncthreads();
-	const int64_t n = (npan + 1) * PT_LEAVES;
+	const int64_t n = (npan + 1) * L;
 	for (int64_t t = threadIdx.x; t < n; t += PT_LEAVES * 64) {
-		const int64_t q = t / PT_LEAVES, l = t % PT_LEAVES;
+		const int64_t q = t / L, l = t % L;
 		if (j0 + l < ncol)
 			pt[q * ncol + j0 + l] = tab[t];
 	}
@@ -594,14 +607,47 @@ rowstats_whole_kernel(RowStatsArgs a, int G)
 	}
 }
 
+// wavefronts per leaf of rowpanel_table16_kernel: the split (1, 2 or 4) with the fewest leaf-times of rounds on 8192
+// wavefront slots; short leaves are not split
+static int rowpanel_split(int64_t ncol, int64_t nnz_hint)
+{
+	if (ncol <= 0 || nnz_hint / ncol < 2048)
+		return 1;
+	int best = 1;
+	double best_t = 1e30;
+	for (int sp = 1; sp <= 4; sp *= 2) {
+		const int64_t nwg = (ncol * sp + PT_LEAVES - 1) / PT_LEAVES, rounds = (nwg + 511) / 512;
+		const double t = (double) rounds / sp;
+		if (t < best_t - 1e-9) { best_t = t; best = sp; }
+	}
+	return best;
+}
+
+template <int SCAN>
+static void launch_table16(const int64_t *col_ptr, const int32_t *row_idx, int64_t ncol, int64_t nnz_hint, int64_t npan,
+			   int ps, int32_t *pt, const void *val, const uint8_t *skip, int *flag, hipStream_t s)
+{
+	const int sp = rowpanel_split(ncol, nnz_hint);
+	const int L = PT_LEAVES / sp;
+	const dim3 grid((unsigned) ((ncol + L - 1) / L));
+	const size_t lds = (size_t) (npan + 1) * L * 4;
+	if (sp == 4)
+		hipLaunchKernelGGL((rowpanel_table16_kernel<SCAN, 4>), grid, dim3(PT_LEAVES * 64), lds, s, col_ptr, row_idx,
+				   ncol, npan, ps, pt, val, skip, flag);
+	else if (sp == 2)
+		hipLaunchKernelGGL((rowpanel_table16_kernel<SCAN, 2>), grid, dim3(PT_LEAVES * 64), lds, s, col_ptr, row_idx,
+				   ncol, npan, ps, pt, val, skip, flag);
+	else
+		hipLaunchKernelGGL((rowpanel_table16_kernel<SCAN, 1>), grid, dim3(PT_LEAVES * 64), lds, s, col_ptr, row_idx,
+				   ncol, npan, ps, pt, val, skip, flag);
+}
+
 // pt[q * ncol + j] = number of offsets of leaf j below q << ps, q = 0 .. npan ((npan + 1) * ncol entries)
 void launch_rowpanel_table(const int64_t *col_ptr, const int32_t *row_idx, int64_t ncol, int64_t nnz_hint,
 			   int64_t npan, int ps, int32_t *pt, hipStream_t s)
 {
 	if (ncol > 0 && (size_t) (npan + 1) * PT_LEAVES * 4 <= 64 * 1024) {
-		hipLaunchKernelGGL(rowpanel_table16_kernel<0>, dim3((unsigned) ((ncol + PT_LEAVES - 1) / PT_LEAVES)),
-				   dim3(PT_LEAVES * 64), (size_t) (npan + 1) * PT_LEAVES * 4, s,
-				   col_ptr, row_idx, ncol, npan, ps, pt, (const void *) NULL, (const uint8_t *) NULL, (int *) NULL);
+		launch_table16<0>(col_ptr, row_idx, ncol, nnz_hint, npan, ps, pt, NULL, NULL, NULL, s);
 	} else if (ncol > 0) {                      // very tall arrays: the table rows do not fit LDS
 		// (grid == ncol selects the workgroup-per-leaf form; never equal to (ncol+3)/4 for ncol > 1)
 		const bool wide = nnz_hint / ncol >= 1024 && ncol > 1;
@@ -618,14 +664,10 @@ bool launch_rowpanel_table_scan(const int64_t *col_ptr, const int32_t *row_idx, 
 				const uint8_t *skip, int *flag, hipStream_t s)
 {
 	if (ncol > 0 && (size_t) (npan + 1) * PT_LEAVES * 4 <= 64 * 1024) {
-		const dim3 grid((unsigned) ((ncol + PT_LEAVES - 1) / PT_LEAVES));
-		const size_t lds = (size_t) (npan + 1) * PT_LEAVES * 4;
 		if (Rtype == SVT_REALSXP)
-			hipLaunchKernelGGL(rowpanel_table16_kernel<1>, grid, dim3(PT_LEAVES * 64), lds, s, col_ptr, row_idx,
-					   ncol, npan, ps, pt, val, skip, flag);
+			launch_table16<1>(col_ptr, row_idx, ncol, nnz_hint, npan, ps, pt, val, skip, flag, s);
 		else
-			hipLaunchKernelGGL(rowpanel_table16_kernel<2>, grid, dim3(PT_LEAVES * 64), lds, s, col_ptr, row_idx,
-					   ncol, npan, ps, pt, val, skip, flag);
+			launch_table16<2>(col_ptr, row_idx, ncol, nnz_hint, npan, ps, pt, val, skip, flag, s);
 		return true;
 	}
 	launch_rowpanel_table(col_ptr, row_idx, ncol, nnz_hint, npan, ps, pt, s);

@@ -40,6 +40,9 @@
 #ifndef SPMM_U
 #define SPMM_U 4
 #endif
+#ifndef SPMM_T
+#define SPMM_T 1
+#endif
 
 static size_t spmm_table_bytes(int64_t nrow, int64_t ninner)
 {
@@ -148,22 +151,34 @@ spmm_csc_csc_kernel(SpmmArgs a, int KW, int G)
 				bad |= spmm_bad<TB>(b);
 			}
 		}
+		// SPMM_T trips of every pair's run fetched together.  Measured at config 3 (a run holds ~2.5 trips of 32
+		// lanes): T = 1 0.60 ms (54 VGPRs, two workgroups per CU); T = 3 0.875 (82 VGPRs: one workgroup per CU);
+		// T = 2 held to 64 VGPRs 0.95 (20 of them spilled) -- the round trips in a row are not what the kernel waits for.
 		bool more = true;
 		while (more) {
-			TA v[SPMM_U];
-			int r[SPMM_U];
+			TA v[SPMM_U][SPMM_T];
+			int r[SPMM_U][SPMM_T];
 #pragma unroll
 			for (int u = 0; u < SPMM_U; u++)
-				if (xb[u] < xe[u]) { v[u] = av[xb[u]]; r[u] = (int) (a.a_idx[xb[u]] - r0); }
+#pragma unroll
+				for (int t = 0; t < SPMM_T; t++) {
+					const int64_t x = xb[u] + (int64_t) t * G;
+					if (x < xe[u]) { v[u][t] = av[x]; r[u][t] = (int) (a.a_idx[x] - r0); }
+				}
 			more = false;
 #pragma unroll
-			for (int u = 0; u < SPMM_U; u++)
+			for (int u = 0; u < SPMM_U; u++) {
+#pragma unroll
+				for (int t = 0; t < SPMM_T; t++)
+					if (xb[u] + (int64_t) t * G < xe[u]) {
+						bad |= spmm_bad<TA>(v[u][t]);
+						atomicAdd(&acc[kkof[u] * P + r[u][t]], (double) v[u][t] * bval[u]);
+					}
 				if (xb[u] < xe[u]) {
-					bad |= spmm_bad<TA>(v[u]);
-					atomicAdd(&acc[kkof[u] * P + r[u]], (double) v[u] * bval[u]);
-					xb[u] += G;
+					xb[u] += (int64_t) SPMM_T * G;
 					more |= xb[u] < xe[u];
 				}
+			}
 		}
 	}
 	if (__ballot(bad) != 0 && (tid & 63) == 0) *a.flag = 1;
