@@ -431,7 +431,14 @@ def main():
         ):
             ms = timed(fn)
             ex[name] = {"ms": ms, "GNZ/s": nnz / ms / 1e6, "GB/s": nbytes / ms / 1e6}
-        from sparsearray_amd.device import RowSumsPlan
+        from sparsearray_amd.device import RowSumsPlan, RowsumPlan
+        # rowsum with the 16-bit group id of every nonzero computed once per (operand, grouping): 10 B/nz streamed
+        rwp = RowsumPlan(A, grp, 1000)
+        rw_o = rwp.run()
+        ex["rowsum_1e3_groups"]["with_group_ids_prepared_once_ms"] = timed(lambda: rwp.run(out=rw_o))
+        ex["rowsum_1e3_groups"]["prepare_ms_once_per_operand_and_grouping"] = timed(lambda: RowsumPlan(A, grp, 1000), 3)
+        ex["rowsum_1e3_groups"]["same_result"] = bool(torch.allclose(rw_o, rowsum(A, grp, 1000), rtol=1e-12, atol=1e-13))
+        del rwp, rw_o
         rsp = RowSumsPlan(A)
         rs_out2 = torch.empty(lrow, dtype=torch.float64, device=dev)
         ms = timed(lambda: rsp.run(out=rs_out2))
