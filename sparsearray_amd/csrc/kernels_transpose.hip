@@ -135,16 +135,21 @@ int launch_exclusive_scan_i64(int64_t *data, int64_t n, void *ws, hipStream_t s)
 #define T3_CAP 4096               // nonzeros a pass-3 workgroup ranks in one round (more: round by round, straight to memory)
 #define T3_STAGE 2048             // of which the LDS image of the output holds this many at a time
 
+// Batched form (round 4): `nslab` independent matrices of srow x scol that follow one another in the operand's
+// columns (slab s = columns [s * scol, (s + 1) * scol)), each transposed on its own -- aperm(x, c(2, 1, 3, ...)) of an
+// N-d array; nfb / ncoarse / ngroups count per slab, the table is ordered (slab, coarse, group, fine).  One matrix:
+// nslab = 1, srow = nrow, scol = ncol.
 struct T2Shape {
 	int fbits;                // log2(F)
-	int64_t nfb;              // fine buckets
+	int64_t nfb;              // fine buckets (per slab)
 	int64_t ncoarse;
 	int64_t ngroups;
+	int64_t nslab, srow, scol;
 };
 
-__device__ inline int64_t t2_slot(const T2Shape &sh, int64_t fb, int64_t g)
+__device__ inline int64_t t2_slot(const T2Shape &sh, int64_t sl, int64_t fb, int64_t g)
 {
-	return ((fb / T2_NFINE) * sh.ngroups + g) * T2_NFINE + (fb % T2_NFINE);
+	return (((sl * sh.ncoarse + fb / T2_NFINE) * sh.ngroups + g) * T2_NFINE) + (fb % T2_NFINE);
 }
 
 // pass 1: workgroup = 16 columns (16 divides the group size), one per wavefront (coalesced along the column); counts by fine bucket in
@@ -158,11 +163,15 @@ transpose_count_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__res
 {
 	extern __shared__ uint32_t hist[];              // [T1_HIST / 2]
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-	const int64_t c = (int64_t) blockIdx.x * (T1_NT / 64) + w;
-	const int64_t g = ((int64_t) blockIdx.x * (T1_NT / 64)) / T2_NT;          // (16 divides 128: one group per workgroup)
+	const int64_t wps = (sh.scol + T1_NT / 64 - 1) / (T1_NT / 64);            // workgroups per slab
+	const int64_t sl = (int64_t) blockIdx.x / wps, bl = (int64_t) blockIdx.x % wps;
+	const int64_t cl = bl * (T1_NT / 64) + w;                                  // column inside the slab
+	const bool have = cl < sh.scol;
+	const int64_t c = sl * sh.scol + cl;
+	const int64_t g = (bl * (T1_NT / 64)) / T2_NT;                            // (16 divides 256: one group per workgroup)
 	const int cshift = sh.fbits + 4;                // log2(rows per coarse bucket)
 	int64_t beg = 0, end = 0;
-	if (c < ncol) { beg = col_ptr[c]; end = col_ptr[c + 1]; }
+	if (have) { beg = col_ptr[c]; end = col_ptr[c + 1]; }
 	for (int64_t w0 = 0; w0 < sh.nfb; w0 += T1_HIST) {          // (one sweep unless there are > 32768 fine buckets)
 		const int64_t w1 = w0 + T1_HIST < sh.nfb ? w0 + T1_HIST : sh.nfb;
 		for (int x = threadIdx.x; x < (int) ((w1 - w0 + 1) >> 1); x += T1_NT) hist[x] = 0;
@@ -181,7 +190,7 @@ transpose_count_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__res
 					const int64_t fb = (int64_t) r >> sh.fbits;
 					if (fb >= w0 && fb < w1) atomicAdd(&hist[(fb - w0) >> 1], 1u << (16 * (int) ((fb - w0) & 1)));
 				}
-				if (w0 == 0 && c < ncol) {
+				if (w0 == 0 && have) {
 					// coarse buckets that start at position k: those after the previous entry's, up to this one's
 					int32_t rp = __shfl_up(r, 1, SVT_WAVE);
 					const int32_t last_prev = __shfl(r4[u > 0 ? u - 1 : 0], 63, SVT_WAVE);      // (all lanes take part)
@@ -192,7 +201,7 @@ transpose_count_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__res
 				}
 			}
 		}
-		if (w0 == 0 && c < ncol && lane == 0) {
+		if (w0 == 0 && have && lane == 0) {
 			// (a column whose length is a multiple of 64 -- or zero -- has not closed its last buckets)
 			if (((end - beg) & 63) == 0) {
 				const int64_t ip = end > beg ? ((int64_t) row_idx[end - 1] >> cshift) : -1;
@@ -202,7 +211,7 @@ transpose_count_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__res
 		__syncthreads();
 		for (int x = threadIdx.x; x < (int) (w1 - w0); x += T1_NT) {
 			const uint32_t n = (hist[x >> 1] >> (16 * (x & 1))) & 0xFFFFu;
-			if (n) atomicAdd(table + t2_slot(sh, w0 + x, g), (unsigned long long) n);
+			if (n) atomicAdd(table + t2_slot(sh, sl, w0 + x, g), (unsigned long long) n);
 		}
 		__syncthreads();
 	}
@@ -338,13 +347,16 @@ transpose_scatter_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__r
 	__shared__ T s_val[T2_CAP];
 	__shared__ uint8_t s_row[T2_CAP];
 	const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-	const int64_t g = (int64_t) blockIdx.x % sh.ngroups, i0 = ((int64_t) blockIdx.x / sh.ngroups) * T2_CPW;
-	const int64_t c = g * T2_NT + t;
+	const int64_t wps = sh.ngroups * ((sh.ncoarse + T2_CPW - 1) / T2_CPW);     // workgroups per slab
+	const int64_t sl = (int64_t) blockIdx.x / wps, bl = (int64_t) blockIdx.x % wps;
+	const int64_t g = bl % sh.ngroups, i0 = (bl / sh.ngroups) * T2_CPW;
+	const bool have = g * T2_NT + t < sh.scol;
+	const int64_t c = sl * sh.scol + g * T2_NT + t;
 	// where this column's runs of the workgroup's T2_CPW coarse buckets start (recorded by pass 1)
 	uint32_t cs[T2_CPW + 1];
 #pragma unroll
 	for (int q = 0; q <= T2_CPW; q++)
-		cs[q] = (c < ncol && i0 + q <= sh.ncoarse) ? cstart[c * (sh.ncoarse + 1) + i0 + q] : 0u;
+		cs[q] = (have && i0 + q <= sh.ncoarse) ? cstart[c * (sh.ncoarse + 1) + i0 + q] : 0u;
 #pragma unroll 1
 	for (int q = 0; q < T2_CPW; q++) {
 	const int64_t i = i0 + q;
@@ -352,7 +364,7 @@ transpose_scatter_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__r
 	if (q > 0) __syncthreads();                     // the previous bucket's image has left
 	const int64_t r_lo = (i * T2_NFINE) << sh.fbits;
 	int64_t a = 0, b = 0;
-	if (c < ncol) {
+	if (have) {
 #pragma unroll
 		for (int qq = 0; qq < T2_CPW; qq++) if (qq == q) { a = cs[qq]; b = cs[qq + 1]; }
 	}
@@ -377,7 +389,7 @@ transpose_scatter_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__r
 		__syncthreads();
 	}
 	const int32_t n = ppre[T2_NT];
-	const int64_t base = table[(i * sh.ngroups + g) * T2_NFINE];     // start of the workgroup's stretch
+	const int64_t base = table[((sl * sh.ncoarse + i) * sh.ngroups + g) * T2_NFINE];     // start of the workgroup's stretch
 	if (n <= T2_CAP) {
 		for (int32_t x = ppre[t]; x < ppre[t + 1]; x++) owner[x] = (uint8_t) t;
 		__syncthreads();
@@ -466,11 +478,11 @@ transpose_finish_kernel(const int64_t *__restrict__ table, T2Shape sh, int64_t n
 	T *s_val = (T *) (s_idx + T3_STAGE);
 	const int t = threadIdx.x, lane = t & 63, w = t >> 6;
 	const int F = 1 << sh.fbits;
-	const int64_t fb = blockIdx.x, ci = fb / T2_NFINE;
+	const int64_t sl = (int64_t) blockIdx.x / sh.nfb, fb = (int64_t) blockIdx.x % sh.nfb, ci = fb / T2_NFINE;
 	const int sf = (int) (fb % T2_NFINE);
 	// the pieces of this fine bucket, one per group: starts, sizes, then the prefix of the sizes
 	for (int g = t; g < ng; g += T3_NT) {
-		const int64_t slot = (ci * ng + g) * T2_NFINE + sf;
+		const int64_t slot = ((sl * sh.ncoarse + ci) * ng + g) * T2_NFINE + sf;
 		const int64_t p0 = table[slot];
 		pa[g] = p0;
 		ppre[g + 1] = (int32_t) (table[slot + 1] - p0);
@@ -495,15 +507,15 @@ transpose_finish_kernel(const int64_t *__restrict__ table, T2Shape sh, int64_t n
 	}
 	__syncthreads();
 	const int32_t n = ppre[ng];
-	const int64_t b0 = fb_base[fb];                 // first output position of the bucket's rows
+	const int64_t b0 = fb_base[sl * sh.nfb + fb];   // first output position of the bucket's rows
 	const bool staged = n <= T3_CAP;
 	auto bins_done = [&]() {
 		__syncthreads();
 		split_scan_bins(L.binstart, F, [&](int r, int32_t off) {
 			const int64_t row = (fb << sh.fbits) + r;
-			if (row < nrow) out_ptr[row] = b0 + off;
+			if (row < sh.srow) out_ptr[sl * sh.srow + row] = b0 + off;
 		});
-		if (fb == sh.nfb - 1 && t == 0) out_ptr[nrow] = nnz;
+		if (sl == sh.nslab - 1 && fb == sh.nfb - 1 && t == 0) out_ptr[sh.nslab * sh.srow] = nnz;
 		__syncthreads();
 	};
 	if (!staged || n == 0) {
@@ -568,8 +580,10 @@ __global__ void transpose_fb_base_kernel(const int64_t *__restrict__ table, T2Sh
 {
 	// one wavefront per coarse bucket: sizes of its 16 fine buckets summed over the groups, then a prefix
 	const int lane = threadIdx.x & 63;
+	// (ci counts over all slabs: the pieces of one (slab, coarse bucket) pair are contiguous in the table)
 	const int64_t ci = (int64_t) blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-	if (ci >= sh.ncoarse) return;
+	if (ci >= sh.nslab * sh.ncoarse) return;
+	const int64_t sl = ci / sh.ncoarse, cil = ci % sh.ncoarse;
 	const int64_t ng = sh.ngroups;
 	int64_t acc[T2_NFINE];
 #pragma unroll
@@ -587,17 +601,20 @@ __global__ void transpose_fb_base_kernel(const int64_t *__restrict__ table, T2Sh
 	for (int s = 0; s < T2_NFINE; s++) {
 		int64_t v = acc[s];
 		for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, SVT_WAVE);
-		const int64_t fb = ci * T2_NFINE + s;
-		if (lane == 0 && fb < sh.nfb) fb_base[fb] = run;
+		const int64_t fb = cil * T2_NFINE + s;
+		if (lane == 0 && fb < sh.nfb) fb_base[sl * sh.nfb + fb] = run;
 		run += v;
 	}
-	if (ci == sh.ncoarse - 1 && lane == 0) fb_base[sh.nfb] = nnz;
+	if (ci == sh.nslab * sh.ncoarse - 1 && lane == 0) fb_base[sh.nslab * sh.nfb] = nnz;
 }
 
 // the bucketed form applies to this operand: fills *sh
-static bool t2_shape(int64_t nrow, int64_t ncol, int64_t nnz, T2Shape *sh)
+static bool t2_shape(int64_t nrow, int64_t ncol, int64_t nnz_all, T2Shape *sh, int64_t nslab = 1)
 {
-	if (nrow <= 0 || ncol <= 0 || nnz <= 0)
+	if (nrow <= 0 || ncol <= 0 || nnz_all <= 0 || nslab <= 0)
+		return false;
+	const int64_t nnz = nnz_all / nslab;            // (per slab; nrow, ncol are a slab's)
+	if (nnz <= 0)
 		return false;
 	const double per_row = (double) nnz / (double) nrow, per_col = (double) nnz / (double) ncol;
 	// the largest F <= 64 with ~3000 nonzeros per fine bucket (pass 3 ranks 4096 per round) and ~1500 per
@@ -612,8 +629,11 @@ static bool t2_shape(int64_t nrow, int64_t ncol, int64_t nnz, T2Shape *sh)
 	sh->nfb = (nrow + ((int64_t) 1 << fbits) - 1) >> fbits;
 	sh->ncoarse = (sh->nfb + T2_NFINE - 1) / T2_NFINE;
 	sh->ngroups = (ncol + T2_NT - 1) / T2_NT;
-	const double ntab = (double) sh->ncoarse * (double) sh->ngroups * T2_NFINE;
-	const double nwg = (double) sh->ncoarse * (double) sh->ngroups;
+	sh->nslab = nslab; sh->srow = nrow; sh->scol = ncol;
+	const double ntab = (double) nslab * (double) sh->ncoarse * (double) sh->ngroups * T2_NFINE;
+	const double nwg = (double) nslab * (double) sh->ncoarse * (double) sh->ngroups;
+	if ((double) nslab * (double) sh->nfb >= 2.0e9 || (double) nslab * (double) ncol >= 2.0e9)
+		return false;
 	if ((double) (sh->ncoarse + 1) * (double) ncol > 2.0 * (double) nnz + 32.0)     // (the table of coarse-bucket starts)
 		return false;
 	return ntab < 1.0e8 && nwg < 2.0e9 && sh->ngroups <= 6000;      // (pass 3 keeps one int per group in LDS)
@@ -789,10 +809,10 @@ static int launch_transpose_bucketed(const int64_t *col_ptr, const int32_t *row_
 				     int64_t nrow, int64_t ncol, int64_t nnz, const T2Shape &sh, int64_t *out_ptr,
 				     int32_t *out_idx, T *out_val, void *ws, size_t reserve, hipStream_t s)
 {
-	const int64_t ntab = sh.ncoarse * sh.ngroups * T2_NFINE + 1;
+	const int64_t ntab = sh.nslab * sh.ncoarse * sh.ngroups * T2_NFINE + 1;
 	char *p = (char *) ws;
 	int64_t *table = (int64_t *) p;            p += t2_a((size_t) ntab, 8);
-	int64_t *fb_base = (int64_t *) p;          p += t2_a((size_t) (sh.nfb + 1), 8);
+	int64_t *fb_base = (int64_t *) p;          p += t2_a((size_t) (sh.nslab * sh.nfb + 1), 8);
 	void *scan_ws = p;
 	p = (char *) ws + reserve;
 	int32_t *col1 = (int32_t *) p;             p += t2_a((size_t) nnz, 4);
@@ -803,19 +823,19 @@ static int launch_transpose_bucketed(const int64_t *col_ptr, const int32_t *row_
 	const size_t hist_b = (size_t) ((sh.nfb < T1_HIST ? sh.nfb : T1_HIST) + 1) / 2 * 4;
 	(void) hipFuncSetAttribute((const void *) transpose_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
 				   T1_HIST * 2);
-	hipLaunchKernelGGL(transpose_count_kernel, dim3((unsigned) ((ncol + T1_NT / 64 - 1) / (T1_NT / 64))), dim3(T1_NT),
+	hipLaunchKernelGGL(transpose_count_kernel, dim3((unsigned) (sh.nslab * ((sh.scol + T1_NT / 64 - 1) / (T1_NT / 64)))), dim3(T1_NT),
 			   hist_b, s, col_ptr, row_idx, ncol, sh, (unsigned long long *) table, cstart);
 	if (launch_exclusive_scan_i64(table, ntab, scan_ws, s))
 		return -1;
-	hipLaunchKernelGGL(transpose_fb_base_kernel, dim3((unsigned) ((sh.ncoarse + 3) / 4)), dim3(256), 0, s,
+	hipLaunchKernelGGL(transpose_fb_base_kernel, dim3((unsigned) ((sh.nslab * sh.ncoarse + 3) / 4)), dim3(256), 0, s,
 			   table, sh, nnz, fb_base);
-	hipLaunchKernelGGL(transpose_scatter_kernel<T>, dim3((unsigned) (sh.ngroups * ((sh.ncoarse + T2_CPW - 1) / T2_CPW))), dim3(T2_NT), 0, s,
+	hipLaunchKernelGGL(transpose_scatter_kernel<T>, dim3((unsigned) (sh.nslab * sh.ngroups * ((sh.ncoarse + T2_CPW - 1) / T2_CPW))), dim3(T2_NT), 0, s,
 			   col_ptr, row_idx, val, nrow, ncol, sh, table, cstart, col1, rlow1, val1);
 	const size_t lds = ((sizeof(SplitLds<T3_NT, T3_ITEMS, 64>) + 15) & ~(size_t) 15) + (size_t) sh.ngroups * 8 +
 			   (size_t) ((sh.ngroups + 1 + 3) & ~(int64_t) 3) * 4 + (size_t) T3_STAGE * 4 + (size_t) T3_STAGE * sizeof(T);
 	(void) hipFuncSetAttribute((const void *) transpose_finish_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
 				   (int) lds);
-	hipLaunchKernelGGL(transpose_finish_kernel<T>, dim3((unsigned) sh.nfb), dim3(T3_NT), lds, s, table, sh, nrow, nnz,
+	hipLaunchKernelGGL(transpose_finish_kernel<T>, dim3((unsigned) (sh.nslab * sh.nfb)), dim3(T3_NT), lds, s, table, sh, nrow, nnz,
 			   col1, rlow1, val1, fb_base, out_ptr, out_idx, out_val);
 	HIP_TRY(hipGetLastError());
 	return 0;
@@ -838,6 +858,7 @@ int launch_transpose(const int64_t *col_ptr, const int32_t *row_idx, const void 
 		const int64_t ntab = sh.ncoarse * sh.ngroups * T2_NFINE + 1;
 		bucketed = t2_a((size_t) ntab, 8) + t2_a((size_t) (sh.nfb + 1), 8) + exclusive_scan_ws_bytes(ntab) <= reserve;
 	}
+	// (one matrix: t2_shape() has left nslab = 1, srow = nrow, scol = ncol)
 	if (!bucketed)
 		return launch_transpose_sorted(col_ptr, row_idx, val, Rtype, nrow, ncol, nnz, out_ptr, out_idx, out_val, ws, s);
 	if (Rtype == SVT_REALSXP)
@@ -1181,6 +1202,26 @@ aperm_slab_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict
 	if (g == nslab - 1 && tid == 0) out_ptr[nslab * d0] = nnz;
 }
 
+// aperm(x, c(2, 1, 3, ...)): the first two axes change places inside every slab of the remaining ones -- prod(dim[2..])
+// independent transpositions of dim[0] x dim[1] matrices that follow one another in the operand's leaves: the bucketed
+// transposition, batched (T2Shape).  Returns the workspace it needs (0: the shape does not suit it) and fills *sh, *reserve.
+static size_t aperm_swap01_bytes(int64_t nnz, const int64_t *dim, int ndim, T2Shape *sh, size_t *reserve)
+{
+	if (ndim < 3 || nnz <= 0 || nnz >= ((int64_t) 1 << 31))
+		return 0;
+	double ns = 1.0;
+	for (int a = 2; a < ndim; a++) ns *= (double) dim[a];
+	if (ns < 1.0 || ns > 1.0e9)
+		return 0;
+	if (!t2_shape(dim[0], dim[1], nnz, sh, (int64_t) ns))
+		return 0;
+	const int64_t ntab = sh->nslab * sh->ncoarse * sh->ngroups * T2_NFINE + 1;
+	const size_t res = t2_a((size_t) ntab, 8) + t2_a((size_t) (sh->nslab * sh->nfb + 1), 8) + exclusive_scan_ws_bytes(ntab) + 256;
+	const size_t cst = t2_a((size_t) (sh->ncoarse + 1) * (size_t) (sh->nslab * sh->scol), 4);
+	if (reserve) *reserve = (res + 255) / 256 * 256;
+	return (res + 255) / 256 * 256 + t2_a((size_t) nnz, 4) + t2_a((size_t) nnz, 1) + t2_a((size_t) nnz, 8) + cst + 512;
+}
+
 size_t aperm_ws_bytes(int64_t nnz, const int64_t *dim, int ndim)
 {
 	const size_t n = (size_t) (nnz > 0 ? nnz : 1);
@@ -1196,7 +1237,11 @@ size_t aperm_ws_bytes(int64_t nnz, const int64_t *dim, int ndim)
 					 (const uint32_t *) NULL, (uint32_t *) NULL, (size_t) nnz, 0u, 32u);
 	const size_t need64 = 2 * a8 + 2 * a4 + aperm_sort_tmp(nnz, aperm_bits(dim, ndim));
 	const size_t need32 = 5 * a4 + hint_bytes(nnz) + t32;
-	return (need64 > need32 ? need64 : need32) + scan_b + 256;
+	T2Shape sh;
+	const size_t swap01 = aperm_swap01_bytes(nnz, dim, ndim, &sh, NULL);
+	size_t need = need64 > need32 ? need64 : need32;
+	if (swap01 > need) need = swap01;
+	return need + scan_b + 256;
 }
 
 int launch_aperm(const int64_t *col_ptr, const int32_t *row_idx, const void *val, int Rtype,
@@ -1254,6 +1299,20 @@ int launch_aperm(const int64_t *col_ptr, const int32_t *row_idx, const void *val
 					   (const int32_t *) val, new_nleaves, lm, out_ptr, out_idx, (int32_t *) out_val);
 		HIP_TRY(hipGetLastError());
 		return 0;
+	}
+	// the first two axes change places, the others stay: one batched bucketed transposition, no sort
+	{
+		bool swap01 = ndim >= 3 && perm[0] == 1 && perm[1] == 0;
+		for (int a = 2; a < ndim && swap01; a++) swap01 = perm[a] == a;
+		T2Shape sh;
+		size_t reserve = 0;
+		if (swap01 && aperm_swap01_bytes(nnz, dim, ndim, &sh, &reserve) > 0) {
+			if (Rtype == SVT_REALSXP)
+				return launch_transpose_bucketed<double>(col_ptr, row_idx, (const double *) val, dim[0], ncol, nnz, sh,
+									 out_ptr, out_idx, (double *) out_val, ws, reserve, s);
+			return launch_transpose_bucketed<int32_t>(col_ptr, row_idx, (const int32_t *) val, dim[0], ncol, nnz, sh,
+								  out_ptr, out_idx, (int32_t *) out_val, ws, reserve, s);
+		}
 	}
 	// slab form (see aperm_slab_kernel): new axis 0 = an old outer axis of <= 1024 entries, new axis 1 = the old
 	// rows, slabs of a few thousand nonzeros.  The largest slab is read back (one synchronisation of the

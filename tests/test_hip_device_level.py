@@ -221,6 +221,36 @@ def test_device_aperm(hip, perm):
 
 
 @pytest.mark.parametrize("dim,nnz,perm,dtype", [
+    ((3000, 2500, 5), 750_000, (2, 1, 3), "double"),       # F = 16 rows, 10 groups of 256 columns (the last of 196)
+    ((3000, 2500, 5), 750_000, (2, 1, 3), "integer"),
+    ((1234, 777, 3, 2), 400_000, (2, 1, 3, 4), "double"),  # 4-d: six slabs, ragged groups and buckets
+    ((5000, 300, 7), 900_000, (2, 1, 3), "double"),        # tall slabs
+    ((700, 40, 23), 20000, (2, 1, 3), "double"),           # too few nonzeros per column and bucket: the key sort
+])
+def test_device_aperm_first_two_axes_swapped(hip, dim, nnz, perm, dtype):
+    """aperm(x, c(2, 1, 3, ...)): every slab of the remaining axes is a matrix transposed on its own -- the bucketed
+    transposition, batched over the slabs (no library sort; src/SparseArray_aperm.c:892-929 in the reference) --
+    against numpy; one slab is emptied, one column of another holds no nonzero."""
+    rng = np.random.default_rng(46)
+    a = np.zeros(dim, order="F")
+    idx = rng.choice(a.size, size=nnz, replace=False)
+    a.reshape(-1, order="F")[idx] = rng.normal(size=nnz) if dtype == "double" else rng.integers(1, 1000, size=nnz)
+    a[(slice(None), slice(None)) + (1,) + (0,) * (len(dim) - 3)] = 0      # an empty slab
+    a[(slice(None), 7) + (0,) * (len(dim) - 2)] = 0                       # an empty column
+    x = SVT_SparseArray.from_dense(a, dtype, lacunar=False)
+    cp, ri, v = x.to_csc()
+    A = _dev(cp, ri, v, dim[0])
+    T, new_dim = A.aperm(dim, perm)
+    torch.cuda.synchronize()
+    want = SVT_SparseArray.from_dense(np.asfortranarray(np.transpose(a, [q - 1 for q in perm])), dtype, lacunar=False)
+    wcp, wri, wv = want.to_csc()
+    assert new_dim == want.dim
+    assert np.array_equal(T.col_ptr.cpu().numpy(), wcp)
+    assert np.array_equal(T.row_idx.cpu().numpy(), wri)
+    assert np.array_equal(T.val.cpu().numpy(), wv)
+
+
+@pytest.mark.parametrize("dim,nnz,perm,dtype", [
     ((700, 40, 23), 20000, (3, 1, 2), "integer"),          # slabs of ~500 nonzeros
     ((5000, 9, 64), 30000, (3, 1, 2), "double"),           # ~3300 per slab, 64 old leaves each
     ((300, 6, 5, 4), 9000, (3, 1, 2, 4), "double"),        # 4-d: slabs over two remaining axes
