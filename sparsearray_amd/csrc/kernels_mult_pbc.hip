@@ -1383,12 +1383,14 @@ crossprod_pbc_gather2_kernel(const uint4 *__restrict__ rec, const int64_t *__res
 //   * at every tile start a wavefront publishes its tile count and looks at a snapshot of the counts of
 //     the XCD's other wavefronts: it does not run more than `dsync` tiles ahead of the slowest one that has
 //     started.  All the XCD's wavefronts then gather from a window of (dsync + 1) panels that stays in its
-//     L2 (the first gather of a line brings it in for the other 255).  The protocol only paces: a
-//     wavefront that waits in vain (a spin budget) stops looking, and no result depends on it.
+//     L2 (the first gather of a line brings it in for the other 255).  A wavefront more than 8 tiles behind is
+//     not waited for (workgroups that could only start late -- CUs held by a collective's kernels at launch --
+//     pace themselves among each other).  The protocol only paces: a wavefront that waits in vain (a spin
+//     budget) stops looking, and no result depends on it.
 // ---------------------------------------------------------------------------
 #include "pbgx_asm.inc"       // PBGX_PASS_TXT, generated by tools/gen_pbgx_asm.py
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-#define PBGX_CLOBBERS "scc", "vcc", "memory", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s85", "s86", "s87", "s88", "s89", "s94", "s95"
+#define PBGX_CLOBBERS "scc", "vcc", "memory", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s85", "s86", "s87", "s88", "s89", "s90", "s94", "s95"
 #define PBGX_OPS                                                                       \
 	[lo] "+s"(lo_), [nb] "+s"(nb_), [step] "+s"(step), [dsync] "+s"(dsync),          \
 	[t0] "=&v"(t0_), [t1] "=&v"(t1_), [t2] "=&v"(t2_), [t3] "=&v"(t3_),              \

@@ -47,7 +47,7 @@
 static size_t spmm_table_bytes(int64_t nrow, int64_t ninner)
 {
 	// the table of run bounds for the shortest panels this file uses (64 rows)
-	int ps = 13;
+	int ps = 12;                                    // (the shortest full panels spmm_shape() picks)
 	while (ps > 6 && ((int64_t) 1 << ps) >= 2 * (nrow > 0 ? nrow : 1)) ps--;
 	const int64_t npan = (nrow + ((int64_t) 1 << ps) - 1) >> ps;
 	return ((size_t) (ninner > 0 ? ninner : 1) * (size_t) (npan + 1) * 4 + 255) / 256 * 256;
@@ -65,6 +65,24 @@ spmm_ref_kernel(const int32_t *__restrict__ b_idx, int64_t b_nnz, uint8_t *__res
 {
 	for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < b_nnz; i += (int64_t) gridDim.x * blockDim.x)
 		ref[b_idx[i]] = 1;
+}
+
+static int g_spmm_ps = 13, g_spmm_nt = SPMM_NT, g_spmm_kw = 16;
+static void spmm_knobs(void)
+{
+	static bool done = false;
+	if (done) return;
+	done = true;
+	// (tuning build only.  Round 4 at config 3, prepared product: 8192 rows x 1024 threads 0.64 ms; 4096 x 512 0.72;
+	// 4096 x 1024 0.78; 4096 x 256 0.90; 2048 x 512 0.88; 2048 x 256 1.03 -- shorter panels = shorter runs, a larger table)
+#ifdef SVT_TUNING
+	if (getenv("SVT_SPMM_PS")) g_spmm_ps = atoi(getenv("SVT_SPMM_PS"));
+	if (getenv("SVT_SPMM_NT")) g_spmm_nt = atoi(getenv("SVT_SPMM_NT"));
+	if (getenv("SVT_SPMM_KW")) g_spmm_kw = atoi(getenv("SVT_SPMM_KW"));
+#endif
+	if (g_spmm_kw < 1) g_spmm_kw = 1;
+	if (g_spmm_ps < 7 || g_spmm_ps > 13) g_spmm_ps = 13;
+	if (g_spmm_nt != 256 && g_spmm_nt != 512 && g_spmm_nt != 1024) g_spmm_nt = SPMM_NT;
 }
 
 template <typename T> __device__ inline bool spmm_bad(T v);
@@ -110,7 +128,8 @@ spmm_csc_csc_kernel(SpmmArgs a, int KW, int G)
 	const int64_t k0 = (int64_t) blockIdx.y * KW;
 	const int kw = (int) (a.K - k0 < KW ? a.K - k0 : KW);
 	const int np = (int) (a.nrow - r0 < P ? a.nrow - r0 : P);
-	for (int x = tid; x < kw * P; x += SPMM_NT) acc[x] = 0.0;
+	const int NT = blockDim.x;
+	for (int x = tid; x < kw * P; x += NT) acc[x] = 0.0;
 	// the pairs of the workgroup's columns, flattened: pair t belongs to column kk with pre[kk] <= t < pre[kk + 1]
 	__shared__ int64_t bbeg[17];
 	__shared__ int32_t pre[17];
@@ -125,7 +144,7 @@ spmm_csc_csc_kernel(SpmmArgs a, int KW, int G)
 	}
 	__syncthreads();
 	const int npairs = pre[kw];
-	const int grp = tid / G, sl = tid % G, ngrp = SPMM_NT / G;
+	const int grp = tid / G, sl = tid % G, ngrp = NT / G;
 	const TA *__restrict__ av = (const TA *) a.a_val;
 	const TB *__restrict__ bv = (const TB *) a.b_val;
 	const int32_t *__restrict__ pt0 = a.pt + q * a.ninner, *__restrict__ pt1 = pt0 + a.ninner;
@@ -185,18 +204,20 @@ spmm_csc_csc_kernel(SpmmArgs a, int KW, int G)
 	__syncthreads();
 	for (int kk = 0; kk < kw; kk++) {
 		double *__restrict__ dst = a.out + (k0 + kk) * a.ldo + r0;
-		for (int x = tid; x < np; x += SPMM_NT) dst[x] = acc[kk * P + x];
+		for (int x = tid; x < np; x += NT) dst[x] = acc[kk * P + x];
 	}
 }
 
 // Shape of the launch for an operand with nrow rows (shared by the preparation and the product)
 static void spmm_shape(int64_t nrow, int64_t K, int *ps_out, int64_t *npan_out, int *KW_out)
 {
-	int ps = 13;                                    // 8192-row panels; shorter operands: one or two panels
+	spmm_knobs();
+	int ps = g_spmm_ps;                             // 8192-row panels; shorter operands: one or two panels
 	while (ps > 6 && ((int64_t) 1 << ps) >= 2 * nrow) ps--;
 	const int64_t P = (int64_t) 1 << ps, npan = (nrow + P - 1) >> ps;
 	int KW = (int) (SPMM_LDS / (P * 8));
 	if (KW > 16) KW = 16;
+	if (KW > g_spmm_kw) KW = g_spmm_kw;
 	if (KW > K) KW = (int) K;
 	if (KW < 1) KW = 1;
 	// with few panels: fewer columns per workgroup, so that the grid fills the chip
@@ -268,7 +289,7 @@ int launch_spmm_product(SpmmArgs a, int64_t a_nnz, int64_t b_nnz, const void *ws
 		return svt_set_error("sparse x sparse product: too many columns for one launch");
 #define SPMM_GO(TA, TB) do { \
 		(void) hipFuncSetAttribute((const void *) spmm_csc_csc_kernel<TA, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); \
-		hipLaunchKernelGGL((spmm_csc_csc_kernel<TA, TB>), grid, dim3(SPMM_NT), lds, s, a, KW, G); } while (0)
+		hipLaunchKernelGGL((spmm_csc_csc_kernel<TA, TB>), grid, dim3(g_spmm_nt), lds, s, a, KW, G); } while (0)
 	if (a.a_type == SVT_REALSXP && a.b_type == SVT_REALSXP) SPMM_GO(double, double);
 	else if (a.a_type == SVT_INTSXP && a.b_type == SVT_INTSXP) SPMM_GO(int, int);
 	else if (a.a_type == SVT_REALSXP && a.b_type == SVT_INTSXP) SPMM_GO(double, int);

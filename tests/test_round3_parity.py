@@ -376,6 +376,36 @@ def test_sparse_x_sparse_by_row_panels(hip, oracle, shape, dtype):
     assert_equal(hip.matmul(x, y), want, tol=1e-12, atol=1e-13, what="x %*% y")
 
 
+def test_sparse_x_sparse_integer_sums_close_to_2_53(hip, oracle):
+    """Integer operands whose cell sums come within a factor of four of 2^53: every product (< 2^49) and every
+    partial sum is still an exact double, so the order in which the lane groups add (kernels_spmm.hip) cannot show --
+    bit for bit with the oracle's ascending order (the reference adds integer products in double,
+    src/SparseVec_dotprod.c:73-92).  Past 2^53 the reference itself rounds in its own order; not tested, stated."""
+    from test_hip_device_level import _dev
+    from sparsearray_amd.device import matmul_csc_csc
+    nrow, ninner, K = 6000, 160, 9
+    cpa, ria, va = random_csc(nrow, ninner, 0.5, seed=87)
+    cpb, rib, vb = random_csc(ninner, K, 0.1, seed=88)
+    rng = np.random.default_rng(89)
+    lo, hi = int(2 ** 23.5), int(2 ** 24.5)
+    va = (rng.integers(lo, hi, len(va)) * rng.choice([-1, 1], len(va))).astype(np.int32)
+    vb = rng.integers(lo, hi, len(vb)).astype(np.int32)            # one sign: the sums do not cancel
+    x = SVT_SparseArray.from_csc((nrow, ninner), "integer", cpa, ria, va)
+    y = SVT_SparseArray.from_csc((ninner, K), "integer", cpb, rib, vb)
+    want = oracle.matmul(x, y)
+    top = np.abs(np.asarray(want)).max()
+    # the bound that makes the order irrelevant, and "close": sums of |products| stay below 2^53, the largest cell above 2^51
+    pos = np.abs(va.astype(np.float64))
+    xa = SVT_SparseArray.from_csc((nrow, ninner), "double", cpa, ria, pos)
+    ya = SVT_SparseArray.from_csc((ninner, K), "double", cpb, rib, vb.astype(np.float64))
+    assert np.asarray(oracle.matmul(xa, ya)).max() < 2.0 ** 53
+    assert top > 2.0 ** 51
+    out, flag = matmul_csc_csc(_dev(cpa, ria, va, nrow), _dev(cpb, rib, vb, ninner))
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0
+    assert_identical(out.cpu().numpy().T, want, what="integer sums close to 2^53")
+
+
 def test_sparse_x_sparse_not_finite_takes_the_dense_route(hip, oracle):
     """A non-finite value or an NA in either operand: the flag goes up, and the entry point returns the
     reference's result (its dirty-leaf loops multiply the implicit zeros too)."""

@@ -22,7 +22,7 @@ batch reaches the D stage the boundary code runs -- nothing in it waits for the 
 The protocol is a pacing hint only: results never depend on it.
 
 Register map: accumulators v[64:143] (lo) and v[144:223] (hi), y sets v[224:239] / v[240:255], snapshot
-v[56:59]; s[36:83] record blocks, s85 M0 save, s[86:87] pb, s[88:89] touch pointer, s94 / s95 scratch.
+v[56:59]; s[36:83] record blocks, s85 M0 save, s[86:87] pb, s[88:89] touch pointer, s90 / s94 / s95 scratch.
 
 Measured at one rank's share of BASELINE config 4 (round 4, tools/debug/config4_pacing.py): an L2 touch of the
 panel ahead by the wavefronts themselves (one dword per 128-byte line, spread over the XCD's wavefronts) bought
@@ -33,6 +33,7 @@ import os
 
 BLK = {"A": 36, "B": 52, "C": 68}
 RECTOUCH = int(os.environ.get("PBGX_RECTOUCH", "2048"))   # 0: no L2 touch of the record stream
+FAR = 8                                                    # tiles behind beyond which a wavefront is not waited for
 YSET = {"a": 224, "b": 240}
 out = []
 nlab = [0]
@@ -48,9 +49,14 @@ def load(blk):
 
 
 def snapshot_min():
-    # v56..v59 = entries; 0 = not started -> wraps to the maximum and is ignored
+    # v56..v59 = entries; 0 = not started -> wraps to the maximum and is ignored; so is a wavefront more than FAR
+    # tiles behind (s90 = the smallest entry - 1 that still counts): it gathers from rows that left this XCD's L2
+    # long ago, nothing is gained by waiting for it -- workgroups that START late (CUs held by another kernel at
+    # launch, e.g. a collective's) pace themselves among each other and do not hold the others back
     for v in (56, 57, 58, 59):
         e(f"v_add_u32 v{v}, -1, v{v}")
+        e(f"v_cmp_gt_u32 vcc, s90, v{v}")
+        e(f"v_cndmask_b32_e64 v{v}, v{v}, -1, vcc")
     e("v_min3_u32 %[vt], v56, v57, v58")
     e("v_min_u32 %[vt], %[vt], v59")
     e("v_cmp_gt_u32 vcc, s94, %[vt]")
@@ -83,6 +89,10 @@ def boundary(blk):
     e("s_cselect_b32 s94, 0, s94")
     e("s_max_u32 s94, s94, 1")
     e("s_sub_u32 s94, s94, 1")
+    e(f"s_sub_u32 s90, %[step], {FAR}")
+    e("s_cselect_b32 s90, 0, s90")
+    e("s_max_u32 s90, s90, 1")
+    e("s_sub_u32 s90, s90, 1")
     snapshot_min()
     e(f"s_cbranch_vccz 5{n}f")
     e("s_mov_b32 s95, %[spin]")
