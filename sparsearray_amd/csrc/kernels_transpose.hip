@@ -125,7 +125,7 @@ int launch_exclusive_scan_i64(int64_t *data, int64_t n, void *ws, hipStream_t s)
 // launch_transpose_sorted() below.
 // ---------------------------------------------------------------------------
 #define T2_NT 256                 // columns per group = threads per workgroup of pass 2
-#define T2_NFINE 16               // fine buckets per coarse bucket
+#define T2_NFINE_MAX 32           // fine buckets per coarse bucket: 16 or 32 (T2Shape::cbits = 4 or 5)
 #define T2_CAP 2048               // nonzeros a pass-2 workgroup assembles in LDS (more: straight to memory)
 #define T2_CPW 2                  // coarse buckets a pass-2 workgroup takes, one after the other (t(A) at config 2: 1 -> 2.06 ms, 2 -> 2.05, 4 -> 2.12, 8 -> 2.20, 16 -> 2.30)
 #define T1_NT 1024
@@ -145,11 +145,12 @@ struct T2Shape {
 	int64_t ncoarse;
 	int64_t ngroups;
 	int64_t nslab, srow, scol;
+	int cbits;                // log2(fine buckets per coarse bucket): 4, or 5 where that fills the pass-2 workgroups better
 };
 
 __device__ inline int64_t t2_slot(const T2Shape &sh, int64_t sl, int64_t fb, int64_t g)
 {
-	return (((sl * sh.ncoarse + fb / T2_NFINE) * sh.ngroups + g) * T2_NFINE) + (fb % T2_NFINE);
+	return ((((sl * sh.ncoarse + (fb >> sh.cbits)) * sh.ngroups + g) << sh.cbits)) + (fb & ((1 << sh.cbits) - 1));
 }
 
 // pass 1: workgroup = 16 columns (16 divides the group size), one per wavefront (coalesced along the column); counts by fine bucket in
@@ -169,7 +170,7 @@ transpose_count_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__res
 	const bool have = cl < sh.scol;
 	const int64_t c = sl * sh.scol + cl;
 	const int64_t g = (bl * (T1_NT / 64)) / T2_NT;                            // (16 divides 256: one group per workgroup)
-	const int cshift = sh.fbits + 4;                // log2(rows per coarse bucket)
+	const int cshift = sh.fbits + sh.cbits;         // log2(rows per coarse bucket)
 	int64_t beg = 0, end = 0;
 	if (have) { beg = col_ptr[c]; end = col_ptr[c + 1]; }
 	for (int64_t w0 = 0; w0 < sh.nfb; w0 += T1_HIST) {          // (one sweep unless there are > 32768 fine buckets)
@@ -339,7 +340,8 @@ transpose_scatter_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__r
 			 const int64_t *__restrict__ table, const uint32_t *__restrict__ cstart,
 			 int32_t *__restrict__ col1, uint8_t *__restrict__ rlow1, T *__restrict__ val1)
 {
-	__shared__ SplitLds<T2_NT, T2_ITEMS, T2_NFINE> L;
+	__shared__ SplitLds<T2_NT, T2_ITEMS, T2_NFINE_MAX> L;
+	const int nfine = 1 << sh.cbits;
 	__shared__ int64_t pa[T2_NT];                   // first position of every column's run
 	__shared__ int32_t ppre[T2_NT + 1];             // lengths of the runs, then their prefix
 	__shared__ uint8_t owner[T2_CAP];               // column (0 .. 255) of every element of the sequence
@@ -362,7 +364,7 @@ transpose_scatter_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__r
 	const int64_t i = i0 + q;
 	if (i >= sh.ncoarse) break;                     // (uniform)
 	if (q > 0) __syncthreads();                     // the previous bucket's image has left
-	const int64_t r_lo = (i * T2_NFINE) << sh.fbits;
+	const int64_t r_lo = (i << sh.cbits) << sh.fbits;
 	int64_t a = 0, b = 0;
 	if (have) {
 #pragma unroll
@@ -380,7 +382,7 @@ transpose_scatter_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__r
 			if (lane >= o) incl += x;
 		}
 		if (lane == 63) wsum[w] = incl;
-		if (t < T2_NFINE) { L.binstart[t] = 0; L.run[t] = 0; L.rtot[t] = 0; }
+		if (t < nfine) { L.binstart[t] = 0; L.run[t] = 0; L.rtot[t] = 0; }
 		__syncthreads();
 		int32_t off = 0;
 		for (int ww = 0; ww < w; ww++) off += wsum[ww];
@@ -389,7 +391,7 @@ transpose_scatter_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__r
 		__syncthreads();
 	}
 	const int32_t n = ppre[T2_NT];
-	const int64_t base = table[((sl * sh.ncoarse + i) * sh.ngroups + g) * T2_NFINE];     // start of the workgroup's stretch
+	const int64_t base = table[((sl * sh.ncoarse + i) * sh.ngroups + g) << sh.cbits];     // start of the workgroup's stretch
 	if (n <= T2_CAP) {
 		for (int32_t x = ppre[t]; x < ppre[t + 1]; x++) owner[x] = (uint8_t) t;
 		__syncthreads();
@@ -404,7 +406,7 @@ transpose_scatter_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__r
 			atomicAdd(&L.binstart[q >> sh.fbits], 1);
 		}
 		__syncthreads();
-		split_scan_bins(L.binstart, T2_NFINE, [](int, int32_t) {});
+		split_scan_bins(L.binstart, nfine, [](int, int32_t) {});
 		__syncthreads();
 	}
 	for (int32_t x0 = 0; x0 < n; x0 += T2_CAP) {
@@ -435,10 +437,10 @@ transpose_scatter_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__r
 #pragma unroll
 			for (int u = 0; u < T2_ITEMS; u++) if (valid[u]) atomicAdd(&L.binstart[key[u]], 1);
 			__syncthreads();
-			split_scan_bins(L.binstart, T2_NFINE, [](int, int32_t) {});
+			split_scan_bins(L.binstart, nfine, [](int, int32_t) {});
 			__syncthreads();
 		}
-		split_round<T2_NT, T2_ITEMS, T2_NFINE>(L, valid, key, 4, at);
+		split_round<T2_NT, T2_ITEMS, T2_NFINE_MAX>(L, valid, key, sh.cbits, at);
 #pragma unroll
 		for (int u = 0; u < T2_ITEMS; u++) {
 			if (!valid[u]) continue;
@@ -478,11 +480,11 @@ transpose_finish_kernel(const int64_t *__restrict__ table, T2Shape sh, int64_t n
 	T *s_val = (T *) (s_idx + T3_STAGE);
 	const int t = threadIdx.x, lane = t & 63, w = t >> 6;
 	const int F = 1 << sh.fbits;
-	const int64_t sl = (int64_t) blockIdx.x / sh.nfb, fb = (int64_t) blockIdx.x % sh.nfb, ci = fb / T2_NFINE;
-	const int sf = (int) (fb % T2_NFINE);
+	const int64_t sl = (int64_t) blockIdx.x / sh.nfb, fb = (int64_t) blockIdx.x % sh.nfb, ci = fb >> sh.cbits;
+	const int sf = (int) (fb & ((1 << sh.cbits) - 1));
 	// the pieces of this fine bucket, one per group: starts, sizes, then the prefix of the sizes
 	for (int g = t; g < ng; g += T3_NT) {
-		const int64_t slot = ((sl * sh.ncoarse + ci) * ng + g) * T2_NFINE + sf;
+		const int64_t slot = (((sl * sh.ncoarse + ci) * ng + g) << sh.cbits) + sf;
 		const int64_t p0 = table[slot];
 		pa[g] = p0;
 		ppre[g + 1] = (int32_t) (table[slot + 1] - p0);
@@ -585,23 +587,25 @@ __global__ void transpose_fb_base_kernel(const int64_t *__restrict__ table, T2Sh
 	if (ci >= sh.nslab * sh.ncoarse) return;
 	const int64_t sl = ci / sh.ncoarse, cil = ci % sh.ncoarse;
 	const int64_t ng = sh.ngroups;
-	int64_t acc[T2_NFINE];
+	const int nfine = 1 << sh.cbits;
+	int64_t acc[T2_NFINE_MAX];
 #pragma unroll
-	for (int s = 0; s < T2_NFINE; s++) acc[s] = 0;
-	const int64_t tot = ng * T2_NFINE;                // slots of this coarse bucket
+	for (int s = 0; s < T2_NFINE_MAX; s++) acc[s] = 0;
+	const int64_t tot = ng * nfine;                   // slots of this coarse bucket
 	const int64_t s0 = ci * tot;
 	for (int64_t x = lane; x < tot; x += 64) {
 		const int64_t sz = table[s0 + x + 1] - table[s0 + x];
-		const int s = (int) (x % T2_NFINE);
+		const int s = (int) (x & (nfine - 1));
 #pragma unroll
-		for (int q = 0; q < T2_NFINE; q++) if (q == s) acc[q] += sz;
+		for (int q = 0; q < T2_NFINE_MAX; q++) if (q == s) acc[q] += sz;
 	}
 	int64_t run = table[s0];
 #pragma unroll
-	for (int s = 0; s < T2_NFINE; s++) {
+	for (int s = 0; s < T2_NFINE_MAX; s++) {
+		if (s >= nfine) break;
 		int64_t v = acc[s];
 		for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, SVT_WAVE);
-		const int64_t fb = cil * T2_NFINE + s;
+		const int64_t fb = cil * nfine + s;
 		if (lane == 0 && fb < sh.nfb) fb_base[sl * sh.nfb + fb] = run;
 		run += v;
 	}
@@ -618,19 +622,26 @@ static bool t2_shape(int64_t nrow, int64_t ncol, int64_t nnz_all, T2Shape *sh, i
 		return false;
 	const double per_row = (double) nnz / (double) nrow, per_col = (double) nnz / (double) ncol;
 	// the largest F <= 64 with ~3000 nonzeros per fine bucket (pass 3 ranks 4096 per round) and ~1500 per
-	// pass-2 workgroup (it assembles 2048 in LDS)
-	int fbits = 6;
-	while (fbits > 0 && (ldexp(per_row, fbits) > 3520.0 ||
-			     (double) T2_NT * per_col * ldexp((double) T2_NFINE, fbits) / (double) nrow > 1536.0))
-		fbits--;
-	if (per_col * ldexp((double) T2_NFINE, fbits) / (double) nrow < 1.0)      // less than one nonzero per thread of pass 2
+	// pass-2 workgroup (it assembles 2048 in LDS); 32 fine buckets per coarse one where that costs no F (short
+	// columns: aperm(x, c(2, 1, 3)) at BASELINE config 5 fills a pass-2 workgroup with 1310 nonzeros instead of 655)
+	int fbits = -1, cbits = 4;
+	for (int cb = 5; cb >= 4; cb--) {
+		int fb = 6;
+		while (fb > 0 && (ldexp(per_row, fb) > 3520.0 ||
+				  (double) T2_NT * per_col * ldexp((double) (1 << cb), fb) / (double) nrow > 1536.0))
+			fb--;
+		if (fb > fbits) { fbits = fb; cbits = cb; }
+	}
+	const int nfine = 1 << cbits;
+	if (per_col * ldexp((double) nfine, fbits) / (double) nrow < 1.0)      // less than one nonzero per thread of pass 2
 		return false;
+	sh->cbits = cbits;
 	sh->fbits = fbits;
 	sh->nfb = (nrow + ((int64_t) 1 << fbits) - 1) >> fbits;
-	sh->ncoarse = (sh->nfb + T2_NFINE - 1) / T2_NFINE;
+	sh->ncoarse = (sh->nfb + nfine - 1) / nfine;
 	sh->ngroups = (ncol + T2_NT - 1) / T2_NT;
 	sh->nslab = nslab; sh->srow = nrow; sh->scol = ncol;
-	const double ntab = (double) nslab * (double) sh->ncoarse * (double) sh->ngroups * T2_NFINE;
+	const double ntab = (double) nslab * (double) sh->ncoarse * (double) sh->ngroups * nfine;
 	const double nwg = (double) nslab * (double) sh->ncoarse * (double) sh->ngroups;
 	if ((double) nslab * (double) sh->nfb >= 2.0e9 || (double) nslab * (double) ncol >= 2.0e9)
 		return false;
@@ -809,7 +820,7 @@ static int launch_transpose_bucketed(const int64_t *col_ptr, const int32_t *row_
 				     int64_t nrow, int64_t ncol, int64_t nnz, const T2Shape &sh, int64_t *out_ptr,
 				     int32_t *out_idx, T *out_val, void *ws, size_t reserve, hipStream_t s)
 {
-	const int64_t ntab = sh.nslab * sh.ncoarse * sh.ngroups * T2_NFINE + 1;
+	const int64_t ntab = ((sh.nslab * sh.ncoarse * sh.ngroups) << sh.cbits) + 1;
 	char *p = (char *) ws;
 	int64_t *table = (int64_t *) p;            p += t2_a((size_t) ntab, 8);
 	int64_t *fb_base = (int64_t *) p;          p += t2_a((size_t) (sh.nslab * sh.nfb + 1), 8);
@@ -855,7 +866,7 @@ int launch_transpose(const int64_t *col_ptr, const int32_t *row_idx, const void 
 	const size_t reserve = t2_reserve(nrow, nnz);
 	bool bucketed = t2_shape(nrow, ncol, nnz, &sh);
 	if (bucketed) {
-		const int64_t ntab = sh.ncoarse * sh.ngroups * T2_NFINE + 1;
+		const int64_t ntab = ((sh.ncoarse * sh.ngroups) << sh.cbits) + 1;
 		bucketed = t2_a((size_t) ntab, 8) + t2_a((size_t) (sh.nfb + 1), 8) + exclusive_scan_ws_bytes(ntab) <= reserve;
 	}
 	// (one matrix: t2_shape() has left nslab = 1, srow = nrow, scol = ncol)
@@ -1215,7 +1226,7 @@ static size_t aperm_swap01_bytes(int64_t nnz, const int64_t *dim, int ndim, T2Sh
 		return 0;
 	if (!t2_shape(dim[0], dim[1], nnz, sh, (int64_t) ns))
 		return 0;
-	const int64_t ntab = sh->nslab * sh->ncoarse * sh->ngroups * T2_NFINE + 1;
+	const int64_t ntab = ((sh->nslab * sh->ncoarse * sh->ngroups) << sh->cbits) + 1;
 	const size_t res = t2_a((size_t) ntab, 8) + t2_a((size_t) (sh->nslab * sh->nfb + 1), 8) + exclusive_scan_ws_bytes(ntab) + 256;
 	const size_t cst = t2_a((size_t) (sh->ncoarse + 1) * (size_t) (sh->nslab * sh->scol), 4);
 	if (reserve) *reserve = (res + 255) / 256 * 256;
