@@ -313,6 +313,11 @@ int svt_dev_pbc_spare_cus(void);
    (src/SparseMatrix_mult.c:131-152 walks leaf by leaf on the host). */
 void svt_dev_pbc_set_gather_pacing(int dsync, int spin);
 
+/* Products with many column blocks and no row split (A %*% Y on the layout of t(A)) are launched one round of
+   workgroups at a time, so that every round starts aligned and the dense tile its workgroups stage streams
+   through the XCDs' L2 once per round; on = 0: one launch.  Default 1.  Process-wide, tuning / measurement. */
+void svt_dev_pbc_set_round_launches(int on);
+
 /* The same, restricted to the leaves from `first_col` on (rounded down to the kernel's block of
    16 * CBW columns): cells of earlier leaves are not written.  What the unary crossprod(x) needs:
    of dense column k only the leaves c >= k (compute_sym_dotprods_*, src/SparseMatrix_mult.c:

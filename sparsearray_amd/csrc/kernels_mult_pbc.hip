@@ -2123,13 +2123,15 @@ static int64_t pbc_padded_rows(const svt_dev_pbc *P)
 // panels: dsync 0: 5.69 ms, 1: 4.77, 2: 4.73, 3: 4.80, no pacing at all: 7.9; with the L2 touch of the
 // record stream 1: 4.31, 2: 4.43; spin 16: 6.7 -- a wavefront that gives up never paces itself again.)
 static int g_pbgx_dsync = 1, g_pbgx_spin = 256;
+static int g_pbc_rounds = 1;        // 0: one launch whatever the number of column blocks (svt_dev_pbc_set_round_launches)
+extern "C" void svt_dev_pbc_set_round_launches(int on) { g_pbc_rounds = on; }
 extern "C" void svt_dev_pbc_set_gather_pacing(int dsync, int spin)
 {
 	g_pbgx_dsync = dsync;
 	g_pbgx_spin = spin < 1 ? 1 : spin;
 }
 
-static int pbgx_cus(void)
+static int pbc_cus(void)
 {
 	static int cus = 0;
 	if (cus == 0) {
@@ -2281,7 +2283,7 @@ static void launch_main(const svt_dev_pbc *P, const double *Y, int64_t ldY, int 
 
 template <int NV>
 static void launch_dma(const svt_dev_pbc *P, const double *Y, int64_t ldY, int K, int nsplit,
-		       int64_t pps, double *part, int64_t Kp, PbcFlags fl, hipStream_t s, int block0)
+		       int64_t pps, double *part, int64_t Kp, PbcFlags fl, hipStream_t s, int block0, int nb_launch = 0)
 {
 	const size_t lds = (size_t) 2 * PBC_DMA_BUF;
 	const int kt = (int) (Kp / 64);
@@ -2302,7 +2304,8 @@ static void launch_dma(const svt_dev_pbc *P, const double *Y, int64_t ldY, int K
 	auto kern = crossprod_pbc_dma_kernel<NV, 0>;
 #endif
 	(void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-	const int nb = (int) P->nblocks - block0;
+	int nb = (int) P->nblocks - block0;
+	if (nb_launch > 0 && nb_launch < nb) nb = nb_launch;
 	// with CUs kept free: 8 x per_xcd workgroups, packed XCD by XCD (see the kernel's decode)
 	const bool sparing = pbc_sparing(P, K);
 	const int per_xcd = (256 - g_pbc_spare_cus) / 8;
@@ -2403,7 +2406,7 @@ static int pbc_phase_impl(const svt_dev_pbc *P, const svt_dev_csc *A,
 				// persistent grid, one row range per XCD, paced (see crossprod_pbc_gatherx_kernel)
 				unsigned int *prog = (unsigned int *) ((char *) ws + PBC_PROG_OFFSET);
 				HIP_TRY(hipMemsetAsync(prog, 0, 8 * PBGX_PROG_ENTRIES * 4, s));
-				int nslots = (pbgx_cus() - g_pbc_spare_cus) / 8 * 2;
+				int nslots = (pbc_cus() - g_pbc_spare_cus) / 8 * 2;
 				if (nslots > PBGX_PROG_ENTRIES / 4) nslots = PBGX_PROG_ENTRIES / 4;
 				if (nslots < 2) nslots = 2;
 				const int nkt = (int) (Kp / 128);
@@ -2451,9 +2454,21 @@ static int pbc_phase_impl(const svt_dev_pbc *P, const svt_dev_csc *A,
 				hipLaunchKernelGGL(pbc_transpose_dense_kernel, tg, dim3(256), 0, s, Y, ldY, P->nrow, K,
 						   (double *) gen_ws);
 			}
-			if (nv == 1) launch_dma<1>(P, Yc, ldc, K, nsplit, pps, part, Kp, fl, s, block0);
-			else if (nv == 2) launch_dma<2>(P, Yc, ldc, K, nsplit, pps, part, Kp, fl, s, block0);
-			else launch_dma<3>(P, Yc, ldc, K, nsplit, pps, part, Kp, fl, s, block0);
+			// Many column blocks, no row split (A %*% Y on the layout of t(A): 1563 blocks x 2 dense tiles of
+			// 79 panels each): one launch per round of workgroups (a workgroup per CU).  In ONE launch the
+			// workgroups of later rounds start whenever a CU frees up, spread over all panel positions, and
+			// the 5 MB dense tile they all stage no longer fits the XCD's 4 MiB L2 (4030 cycles per panel in
+			// the first round, 4650 later); launch by launch every round starts aligned.
+			const int kt_ = (int) (Kp / 64);
+			int per_launch = 0;
+			if (nsplit == 1 && !pbc_sparing(P, K) && g_pbc_rounds != 0 &&
+			    (int64_t) (P->nblocks - block0) * kt_ >= 2 * pbc_cus())
+				per_launch = pbc_cus() / kt_ > 0 ? pbc_cus() / kt_ : 1;
+			for (int b0 = block0; b0 < (int) P->nblocks; b0 += per_launch > 0 ? per_launch : (int) P->nblocks) {
+				if (nv == 1) launch_dma<1>(P, Yc, ldc, K, nsplit, pps, part, Kp, fl, s, b0, per_launch);
+				else if (nv == 2) launch_dma<2>(P, Yc, ldc, K, nsplit, pps, part, Kp, fl, s, b0, per_launch);
+				else launch_dma<3>(P, Yc, ldc, K, nsplit, pps, part, Kp, fl, s, b0, per_launch);
+			}
 			HIP_TRY(hipGetLastError());
 			return 0;
 		}

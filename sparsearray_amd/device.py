@@ -249,6 +249,12 @@ def set_gather_pacing(dsync: int = 1, spin: int = 256) -> None:
     _lib().svt_dev_pbc_set_gather_pacing(int(dsync), int(spin))
 
 
+def set_round_launches(on: bool = True) -> None:
+    """One launch per round of workgroups for products with many column blocks (svt_dev_pbc_set_round_launches)."""
+    _lib().svt_dev_pbc_set_round_launches.restype = None
+    _lib().svt_dev_pbc_set_round_launches(int(bool(on)))
+
+
 def crossprod_csc_dense(A: DeviceCSC, Y: torch.Tensor) -> torch.Tensor:
     """crossprod(A, Y) for a dense Y given as a (K, nrow) C-contiguous tensor,
     i.e. the column-major nrow x K matrix R would hand over.  Returns the
