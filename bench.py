@@ -66,10 +66,12 @@ def parse():
     p.add_argument("--reduce", choices=["rccl", "peer"], default="rccl",
                    help="N > 1: rccl = all-reduce of the result (default); peer = peer-to-peer copies of the partials + "
                         "a local sum (sparsearray_amd/parallel.py, PeerReducer; no collective kernel)")
-    p.add_argument("--spare-cus", type=int, default=0,
-                   help="CUs the product kernel leaves idle (room for RCCL's kernels beside it); default 0 -- at N > 1 the "
-                        "line's `multi_gpu` object times the same steps with 32 CUs left idle as well, so that one run "
-                        "says whether the option pays on real RCCL (it costs +8 %% product time at an eighth of the rows)")
+    p.add_argument("--spare-cus", type=int, default=-1,
+                   help="CUs the product kernel leaves idle (room for RCCL's kernels beside it).  Default: 0 on one GPU; at "
+                        "N > 1 with the RCCL reducer the untimed warm-up times a few steps with 0 and with 32 and the timed steps "
+                        "run with the faster of the two (the product fills every CU's registers and LDS: whether a collective's "
+                        "kernels can run beside it is a property of the node, and leaving CUs idle costs +8 %% product time at an "
+                        "eighth of the rows); the line's `multi_gpu` object reports both")
     p.add_argument("--compare-reducers", action="store_true",
                    help="N > 1: after the timed steps, time the same steps with the peer-to-peer reducer as well "
                         "(`multi_gpu.variants`); the RCCL variants (0 and 32 spare CUs) are always there")
@@ -80,6 +82,9 @@ def parse():
     for k in ("nrow", "ncol", "density", "K"):
         if getattr(a, k) is None:
             setattr(a, k, c[k])
+    a.spare_auto = a.spare_cus < 0 and a.gpus > 1 and a.reduce == "rccl" and a.path == "pbc"
+    if a.spare_cus < 0:
+        a.spare_cus = 0
     return a
 
 
@@ -262,7 +267,7 @@ def main():
         del del_me, wcp, wri, wv
         torch.cuda.synchronize()
         t_l = time.perf_counter()
-        sc = par.ShardedCrossprod(A, K, None, a.cbw, a.wpb, a.logr, reducer=a.reduce, spare_cus=a.spare_cus)
+        sc = par.ShardedCrossprod(A, K, None, a.cbw, a.wpb, a.logr, reducer=a.reduce, spare_cus=a.spare_cus)   # (the plan serves any later setting)
         torch.cuda.synchronize()
         layout_ms = (time.perf_counter() - t_l) * 1e3
         auto_gather = (a.cbw, a.wpb, a.logr) == (0, 0, 0) and a.density * 40 * 128 < 12 and lrow >= 4096
@@ -307,6 +312,26 @@ def main():
         def result():
             return out
 
+    spare_tuned = None
+    if world > 1 and a.spare_auto:
+        # part of the untimed warm-up: the same steps with 0 and with 32 CUs left to the collective's kernels; every
+        # rank takes the setting with the smaller MAX-over-ranks time
+        from sparsearray_amd.device import set_spare_cus
+        spare_tuned = {}
+        for cand in (0, 32):
+            set_spare_cus(cand)
+            for _ in range(2):
+                step()
+            finish(); torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(4):
+                step()
+            finish(); torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            t = torch.tensor([(time.perf_counter() - t0) / 4 * 1e3], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            spare_tuned[cand] = float(t.item())
+        a.spare_cus = min(spare_tuned, key=spare_tuned.get)
+        set_spare_cus(a.spare_cus)
     for _ in range(a.warmup):
         step()
     finish()
@@ -406,6 +431,8 @@ def main():
         res["config"]["layout_build_ms_once_per_operand"] = layout_ms
         if a.spare_cus:
             res["config"]["spare_cus"] = a.spare_cus
+        if spare_tuned is not None:
+            res["config"]["spare_cus_chosen_in_warmup_from_ms_per_step"] = {str(k): v for k, v in spare_tuned.items()}
     if world == 1 and not a.no_extras and a.config == 2:
         def timed(fn, reps=5):
             fn(); torch.cuda.synchronize()

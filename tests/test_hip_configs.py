@@ -289,6 +289,11 @@ def test_bench_strong_scaling_rehearsal_same_problem(hip):
     assert m["variants"]["rccl_spare_cus_0"]["ms_per_step"] > 0
     assert m["variants"]["peer_copies"]["ms_per_step"] > 0 and m["variants"]["peer_copies"]["same_result"]
     peer = _bench_line(common + ["--reduce", "peer"], 2, 29950 + os.getpid() % 200)     # PeerReducer instead of all-reduce
+    auto = _bench_line(common, 2, 30200 + os.getpid() % 200)          # spare CUs chosen in the warm-up
+    tuned = auto["config"]["spare_cus_chosen_in_warmup_from_ms_per_step"]
+    assert set(tuned) == {"0", "32"} and auto["multi_gpu"]["spare_cus"] == int(min(tuned, key=tuned.get))
+    assert abs(auto["config"]["result_checksum"]["abs_sum"] - one["config"]["result_checksum"]["abs_sum"]) \
+        <= 1e-12 * one["config"]["result_checksum"]["abs_sum"]
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and peer["n_gpus"] == 2
     c = peer["config"]["result_checksum"]
     assert abs(c["abs_sum"] - one["config"]["result_checksum"]["abs_sum"]) <= 1e-12 * abs(c["abs_sum"])
