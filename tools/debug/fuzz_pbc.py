@@ -9,7 +9,7 @@ import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from sparsearray_amd import _hip
-from sparsearray_amd.device import CrossprodPlan, DeviceCSC, PbcPlan
+from sparsearray_amd.device import CrossprodPlan, DeviceCSC, PbcPlan, set_gather_pacing, set_spare_cus
 lib = _hip.init()
 
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
@@ -22,6 +22,16 @@ for case in range(ncases):
     K = int(rng.choice([1, 2, 7, 63, 64, 65, 100, 128, 129, 200]))
     kind = rng.integers(0, 5)
     dens = float(rng.choice([0.0005, 0.003, 0.01, 0.05, 0.3]))
+    # every fifth case: a shape the XCD-paced gather kernel takes (K a multiple of 128, >= 64 panels of >= 512 rows),
+    # with its pacing knobs and the number of idle CUs drawn as well
+    paced = case % 5 == 4
+    if paced:
+        nrow = int(rng.choice([65537, 70001, 140003]))
+        ncol = int(rng.choice([41, 640, 1283]))
+        K = int(rng.choice([128, 128, 256]))
+        dens = float(rng.choice([0.0005, 0.003, 0.01]))
+        set_gather_pacing(int(rng.choice([0, 1, 2, 1000000, -1])), int(rng.choice([1, 256])))
+        set_spare_cus(int(rng.choice([0, 0, 96])))
     cols = []
     for j in range(ncol):
         d = dens
@@ -53,12 +63,16 @@ for case in range(ncases):
     out_g = torch.full((K, ncol), 9.0, dtype=torch.float64, device=dev)
     # layout: the default LDS-DMA one, the gather one (needs >= 512-row panels to make sense), or by density
     lay = [(40, 16, 7), (40, 4, 10), (0, 0, 0), (40, 4, 9)][int(rng.integers(0, 4))]
+    if paced:
+        lay = [(40, 4, 9), (40, 4, 10), (32, 4, 9), (16, 4, 10), (40, 4, 11 if nrow > 132000 else 10)][int(rng.integers(0, 5))]
     if by_rows:
         PbcPlan(A, K, *lay).run(Yd.t().contiguous(), K, out_p, tr_y=True)
     else:
         PbcPlan(A, K, *lay).run(Yd, nrow, out_p)
     CrossprodPlan(A, K).run(Yd, nrow, out_g)
     torch.cuda.synchronize()
+    if paced:
+        set_gather_pacing(); set_spare_cus(0)
     same_class = bool((torch.isnan(out_p) == torch.isnan(out_g)).all()) and \
         bool(((out_p == float("inf")) == (out_g == float("inf"))).all()) and \
         bool(((out_p == float("-inf")) == (out_g == float("-inf"))).all())
