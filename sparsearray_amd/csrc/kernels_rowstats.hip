@@ -239,6 +239,7 @@ rowpanel_table_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__rest
 // scattered form spends 222 us of a 0.65 ms rowSums at BASELINE config 2 on write
 // amplification).  LDS: (npan + 1) * 64 bytes.
 #define PT_LEAVES 16
+#define PT_U 8                  // loads of 64 offsets a wavefront keeps in flight (4: 157 us for the pass at config 3, 8: see DESIGN.md)
 // SCAN (the sparse x sparse product, kernels_spmm.hip): the pass also looks at the VALUES of the leaves it walks
 // -- all of them (skip == NULL) or those with skip[j] == 0 -- and raises *flag at a NaN / Inf / NA (doubles) or an
 // NA_integer_ (ints): one stream over the operand instead of two.  SCAN: 0 none, 1 doubles, 2 ints.
@@ -260,15 +261,15 @@ rowpanel_table16_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__re
 		const int64_t beg = col_ptr[j], end = col_ptr[j + 1];
 		const int64_t sb = beg + (end - beg) * sg / S, se = beg + (end - beg) * (sg + 1) / S;
 		int carry = sb > beg ? row_idx[sb - 1] >> ps : -1;     // panel of the element before this trip
-		for (int64_t k0 = sb; k0 < se; k0 += 4 * 64) {
-			int32_t r[4];
+		for (int64_t k0 = sb; k0 < se; k0 += PT_U * 64) {
+			int32_t r[PT_U];
 #pragma unroll
-			for (int u = 0; u < 4; u++) {       // four coalesced loads in flight
+			for (int u = 0; u < PT_U; u++) {    // PT_U coalesced loads in flight
 				const int64_t k = k0 + u * 64 + lane;
 				r[u] = k < se ? row_idx[k] : 0x7FFFFFFF;
 			}
 #pragma unroll
-			for (int u = 0; u < 4; u++) {
+			for (int u = 0; u < PT_U; u++) {
 				const int64_t k = k0 + u * 64 + lane;
 				const int p = r[u] >> ps;
 				int prev = __shfl_up(p, 1, 64);
