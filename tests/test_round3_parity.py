@@ -531,3 +531,34 @@ def test_layout_build_count_pass_both_forms(hip, oracle, nrow):
     plan.run(Yd, nrow, out)
     torch.cuda.synchronize()
     assert_equal(out.cpu().numpy().T, want, tol=1e-9, atol=1e-11, what=f"nrow={nrow}")
+
+
+def test_layout_pool_is_bounded_and_trims(hip):
+    """Layout buffers come from the library's own stream-ordered pool: a released layout stays cached for the next
+    build (up to 3 GiB), svt_dev_pbc_trim() hands the cache back to the driver, and a plan can be dropped while a
+    product on another stream is still running (release behind events, no device-wide synchronisation)."""
+    import torch
+    from test_hip_device_level import _dev
+    from sparsearray_amd.device import PbcPlan, trim_layout_pool
+    cp, ri, v = random_csc(300_000, 2000, 0.01, seed=77)          # 6e6 nonzeros: ~80 MB of records
+    A = _dev(cp, ri, v, 300_000)
+    K = 64
+    Yd = torch.as_tensor(np.random.default_rng(78).uniform(-1, 1, (K, 300_000)), device="cuda")
+    out = torch.empty((K, 2000), dtype=torch.float64, device="cuda")
+    ref = None
+    side = torch.cuda.Stream()
+    for _ in range(3):
+        plan = PbcPlan(A, K)
+        with torch.cuda.stream(side):
+            plan.run(Yd, 300_000, out)
+        del plan                                                  # released while the product may still be in flight
+        side.synchronize()
+        if ref is None:
+            ref = out.clone()
+        assert torch.equal(out, ref)
+    torch.cuda.synchronize()
+    free_cached, _ = torch.cuda.mem_get_info()
+    trim_layout_pool()
+    torch.cuda.synchronize()
+    free_trimmed, _ = torch.cuda.mem_get_info()
+    assert free_trimmed >= free_cached + 50 * 2 ** 20             # the cached layout (~80 MB) went back
