@@ -608,6 +608,52 @@ rowstats_whole_kernel(RowStatsArgs a, int G)
 	}
 }
 
+// The same table for SHORT leaves (mean < 256 offsets: the 1.28e6 leaves of ~100 offsets of BASELINE config 5): 16 lanes per
+// leaf, 64 leaves per workgroup -- a wavefront per leaf leaves three quarters of its lanes idle and its table rows leave in
+// 64-byte pieces (0.45 ms of a 1.12 ms rowSums(dims = 2) at config 5); here a row of the LDS image is 256 bytes.
+#define PTS_LEAVES 64
+__global__ void __launch_bounds__(1024)
+rowpanel_table_short_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__ row_idx,
+			    int64_t ncol, int64_t npan, int ps, int32_t *__restrict__ pt)
+{
+	extern __shared__ int32_t tab[];            // [npan + 1][PTS_LEAVES]
+	const int g = threadIdx.x >> 4, sl = threadIdx.x & 15;
+	const int64_t j0 = (int64_t) blockIdx.x * PTS_LEAVES, j = j0 + g;
+	if (j < ncol) {
+		const int64_t beg = col_ptr[j], end = col_ptr[j + 1];
+		int carry = -1;                         // panel of the element before this trip
+		for (int64_t k0 = beg; k0 < end; k0 += 4 * 16) {
+			int32_t r[4];
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				const int64_t k = k0 + u * 16 + sl;
+				r[u] = k < end ? row_idx[k] : 0x7FFFFFFF;
+			}
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				const int64_t k = k0 + u * 16 + sl;
+				const int p = r[u] >> ps;
+				int prev = __shfl_up(p, 1, 16);
+				if (sl == 0) prev = carry;
+				carry = __shfl(p, 15, 16);
+				if (k < end)
+					for (int q = prev + 1; q <= p; q++)
+						tab[q * PTS_LEAVES + g] = (int32_t) (k - beg);
+			}
+		}
+		const int64_t pl = end > beg ? row_idx[end - 1] >> ps : -1;
+		for (int64_t q = pl + 1 + sl; q <= npan; q += 16)
+			tab[q * PTS_LEAVES + g] = (int32_t) (end - beg);
+	}
+	__syncthreads();
+	const int64_t n = (npan + 1) * PTS_LEAVES;
+	for (int64_t t = threadIdx.x; t < n; t += 1024) {
+		const int64_t q = t / PTS_LEAVES, l = t % PTS_LEAVES;
+		if (j0 + l < ncol)
+			pt[q * ncol + j0 + l] = tab[t];
+	}
+}
+
 // wavefronts per leaf of rowpanel_table16_kernel: the split (1, 2 or 4) with the fewest leaf-times of rounds on 8192
 // wavefront slots; short leaves are not split
 static int rowpanel_split(int64_t ncol, int64_t nnz_hint)
@@ -647,7 +693,10 @@ static void launch_table16(const int64_t *col_ptr, const int32_t *row_idx, int64
 void launch_rowpanel_table(const int64_t *col_ptr, const int32_t *row_idx, int64_t ncol, int64_t nnz_hint,
 			   int64_t npan, int ps, int32_t *pt, hipStream_t s)
 {
-	if (ncol > 0 && (size_t) (npan + 1) * PT_LEAVES * 4 <= 64 * 1024) {
+	if (ncol > 0 && nnz_hint / ncol < 256 && (size_t) (npan + 1) * PTS_LEAVES * 4 <= 64 * 1024) {
+		hipLaunchKernelGGL(rowpanel_table_short_kernel, dim3((unsigned) ((ncol + PTS_LEAVES - 1) / PTS_LEAVES)), dim3(1024),
+				   (size_t) (npan + 1) * PTS_LEAVES * 4, s, col_ptr, row_idx, ncol, npan, ps, pt);
+	} else if (ncol > 0 && (size_t) (npan + 1) * PT_LEAVES * 4 <= 64 * 1024) {
 		launch_table16<0>(col_ptr, row_idx, ncol, nnz_hint, npan, ps, pt, NULL, NULL, NULL, s);
 	} else if (ncol > 0) {                      // very tall arrays: the table rows do not fit LDS
 		// (grid == ncol selects the workgroup-per-leaf form; never equal to (ncol+3)/4 for ncol > 1)
