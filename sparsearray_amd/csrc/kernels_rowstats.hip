@@ -608,6 +608,79 @@ rowstats_whole_kernel(RowStatsArgs a, int G)
 	}
 }
 
+// The whole-column form as a persistent, pipelined loop (sums and NA counts of doubles / ints; at most 64 leaves of at
+// most ~128 nonzeros per output column -- rowSums(x, dims = 2) of BASELINE config 5): a workgroup owns a CU (160 KB of
+// LDS = its column's 2e4 cells) and with one workgroup per column nothing of the next column is in flight while the
+// current one leaves (zero the cells -> read 64 leaves -> write 160 KB, strictly in a row: 14.5 us per column, 1.13 ms).
+// Here a workgroup walks columns i, i + grid, ...: the leaf bounds and the (value, row) pairs of the NEXT column are
+// loaded into registers before the current column's cells are written out (and zeroed again in the same sweep).
+template <typename T>
+__global__ void __launch_bounds__(ROWPANEL_NT)
+rowstats_whole_pipe_kernel(RowStatsArgs a)
+{
+	extern __shared__ unsigned long long lds64[];   // nrow cells
+	constexpr int U = 4, TT = 2;                    // leaves per wavefront, trips of 64 lanes fetched ahead
+	const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63, w = tid >> 6, nw = NT >> 6;
+	const int np = (int) a.nrow;
+	const bool is_dbl = sizeof(T) == 8;
+	const bool narm = a.na_rm != 0;
+	const int oc = a.opcode;
+	double *accd = (double *) lds64;
+	const T *__restrict__ val = (const T *) a.val;
+	const int32_t *__restrict__ row = a.row_idx;
+	const double NAr = svt_na_real();
+	auto apply = [&](const T v, const int r) {
+		const bool miss = is_dbl ? (v != v) : ((int) v == NA_INT);
+		if (oc == SVT_OP_COUNTNAS) {
+			if (miss) atomicAdd(accd + r, 1.0);
+		} else if (!(miss && narm)) {
+			atomicAdd(accd + r, (!is_dbl && miss) ? NAr : (double) v);
+		}
+	};
+	int64_t kb[U], ke[U];
+	T v[U][TT];
+	int r[U][TT];
+	auto fetch = [&](const int64_t i) {
+#pragma unroll
+		for (int u = 0; u < U; u++) {
+			const int64_t s = w + (int64_t) u * nw;
+			kb[u] = ke[u] = 0;
+			if (s < a.nstrata) {
+				const int64_t j = i + s * a.inner;
+				kb[u] = a.col_ptr[j] + lane; ke[u] = a.col_ptr[j + 1];
+			}
+		}
+#pragma unroll
+		for (int u = 0; u < U; u++)
+#pragma unroll
+			for (int t = 0; t < TT; t++) {
+				const int64_t k = kb[u] + 64 * t;
+				if (k < ke[u]) { v[u][t] = val[k]; r[u][t] = (int) row[k]; }
+			}
+	};
+	int64_t i = blockIdx.x;
+	if (i < a.inner) fetch(i);
+	for (int x = tid; x < np; x += NT) accd[x] = 0.0;
+	__syncthreads();
+	for (; i < a.inner; i += gridDim.x) {
+#pragma unroll
+		for (int u = 0; u < U; u++) {
+#pragma unroll
+			for (int t = 0; t < TT; t++)
+				if (kb[u] + 64 * t < ke[u]) apply(v[u][t], r[u][t]);
+			for (int64_t k = kb[u] + 64 * TT; k < ke[u]; k += 64) apply(val[k], (int) row[k]);   // (leaves past 128 nonzeros)
+		}
+		__syncthreads();
+		const int64_t cell0 = i * a.nrow;
+		if (i + gridDim.x < a.inner) fetch(i + gridDim.x);              // in flight while this column leaves
+		for (int x = tid; x < np; x += NT) {
+			((double *) a.out)[cell0 + x] = accd[x];
+			accd[x] = 0.0;
+		}
+		__syncthreads();
+	}
+}
+
 // The same table for SHORT leaves (mean < 256 offsets: the 1.28e6 leaves of ~100 offsets of BASELINE config 5): 16 lanes per
 // leaf, 64 leaves per workgroup -- a wavefront per leaf leaves three quarters of its lanes idle and its table rows leave in
 // 64-byte pieces (0.45 ms of a 1.12 ms rowSums(dims = 2) at config 5); here a row of the LDS image is 256 bytes.
@@ -746,6 +819,19 @@ int launch_rowstats_panel(const RowStatsArgs &a, void *ws, hipStream_t s)
 			const void *fn = a.Rtype == SVT_REALSXP ? (const void *) rowstats_whole_kernel<double>
 								: (const void *) rowstats_whole_kernel<int>;
 			(void) hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_whole);
+			if ((oc == SVT_OP_SUM || oc == SVT_OP_COUNTNAS) && a.nstrata <= 4 * (ROWPANEL_NT / 64) && leaf_len <= 112.0 &&
+			    a.inner >= 1024) {
+				const void *fp = a.Rtype == SVT_REALSXP ? (const void *) rowstats_whole_pipe_kernel<double>
+									: (const void *) rowstats_whole_pipe_kernel<int>;
+				(void) hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_whole);
+				const unsigned ng = (unsigned) (a.inner < 256 ? a.inner : 256);       // one workgroup per CU
+				if (a.Rtype == SVT_REALSXP)
+					hipLaunchKernelGGL(rowstats_whole_pipe_kernel<double>, dim3(ng), dim3(ROWPANEL_NT), lds_whole, s, a);
+				else
+					hipLaunchKernelGGL(rowstats_whole_pipe_kernel<int>, dim3(ng), dim3(ROWPANEL_NT), lds_whole, s, a);
+				HIP_TRY(hipGetLastError());
+				return 0;
+			}
 			if (a.Rtype == SVT_REALSXP)
 				hipLaunchKernelGGL(rowstats_whole_kernel<double>, dim3((unsigned) a.inner), dim3(ROWPANEL_NT),
 						   lds_whole, s, a, G);

@@ -562,3 +562,22 @@ def test_layout_pool_is_bounded_and_trims(hip):
     torch.cuda.synchronize()
     free_trimmed, _ = torch.cuda.mem_get_info()
     assert free_trimmed >= free_cached + 50 * 2 ** 20             # the cached layout (~80 MB) went back
+
+
+def test_rowsums_whole_column_pipeline_long_leaves(hip, oracle):
+    """rowSums(x, dims = 2) / rowCountNAs through the persistent whole-column kernel (rowstats_whole_pipe_kernel: the next
+    column's leaves are fetched while the current column's cells leave): leaves longer than the two trips it fetches
+    ahead (300 and 1000 nonzeros), an empty leaf, NaN / NA values, na.rm -- src/SparseArray_matrixStats.c:774-913."""
+    shape = (9000, 1100, 6)
+    rng = np.random.default_rng(131)
+    a = np.where(rng.random(shape) < 0.01, rng.normal(size=shape), 0.0)
+    a[rng.choice(shape[0], 300, replace=False), 5, 2] = rng.normal(size=300)
+    a[rng.choice(shape[0], 1000, replace=False), 700, 0] = rng.normal(size=1000)
+    a[:, 9, 4] = 0.0
+    a[17, 5, 2] = np.nan
+    a[18, 700, 0] = NA_real
+    x = SVT_SparseArray.from_dense(np.asfortranarray(a), "double", lacunar=False)
+    for na_rm in (False, True):
+        assert_equal(hip.rowSums(x, dims=2, na_rm=na_rm), oracle.rowSums(x, dims=2, na_rm=na_rm), tol=1e-9, atol=1e-12,
+                     what=f"rowSums dims=2 na_rm={na_rm}")
+    assert_identical(hip.rowCountNAs(x, dims=2), oracle.rowCountNAs(x, dims=2), "rowCountNAs dims=2")
