@@ -614,9 +614,12 @@ rowstats_whole_kernel(RowStatsArgs a, int G)
 // current one leaves (zero the cells -> read 64 leaves -> write 160 KB, strictly in a row: 14.5 us per column, 1.13 ms).
 // Here a workgroup walks columns i, i + grid, ...: the leaf bounds and the (value, row) pairs of the NEXT column are
 // loaded into registers before the current column's cells are written out (and zeroed again in the same sweep).
-template <typename T>
+// ATOMIC: an output column has more leaves than one unit takes (64): its leaves are cut into chunks of 64, a workgroup takes a
+// contiguous range of (column, chunk) units, keeps adding into its LDS cells while the column stays the same and adds the cells
+// to `out` (zeroed by the launcher) when it changes -- rowSums(x, dims = 1) of an N-d array: one column, 1.28e6 leaves at config 5.
+template <typename T, bool ATOMIC>
 __global__ void __launch_bounds__(ROWPANEL_NT)
-rowstats_whole_pipe_kernel(RowStatsArgs a)
+rowstats_whole_pipe_kernel(RowStatsArgs a, int64_t nchunks)
 {
 	extern __shared__ unsigned long long lds64[];   // nrow cells
 	constexpr int U = 4, TT = 2;                    // leaves per wavefront, trips of 64 lanes fetched ahead
@@ -640,10 +643,11 @@ rowstats_whole_pipe_kernel(RowStatsArgs a)
 	int64_t kb[U], ke[U];
 	T v[U][TT];
 	int r[U][TT];
-	auto fetch = [&](const int64_t i) {
+	auto fetch = [&](const int64_t unit) {
+		const int64_t i = unit / nchunks, c = unit % nchunks;
 #pragma unroll
 		for (int u = 0; u < U; u++) {
-			const int64_t s = w + (int64_t) u * nw;
+			const int64_t s = c * (int64_t) (U * nw) + w + (int64_t) u * nw;
 			kb[u] = ke[u] = 0;
 			if (s < a.nstrata) {
 				const int64_t j = i + s * a.inner;
@@ -658,11 +662,12 @@ rowstats_whole_pipe_kernel(RowStatsArgs a)
 				if (k < ke[u]) { v[u][t] = val[k]; r[u][t] = (int) row[k]; }
 			}
 	};
-	int64_t i = blockIdx.x;
-	if (i < a.inner) fetch(i);
+	const int64_t total = a.inner * nchunks, per = (total + gridDim.x - 1) / gridDim.x;
+	const int64_t u0 = (int64_t) blockIdx.x * per, u1 = u0 + per < total ? u0 + per : total;
+	if (u0 < u1) fetch(u0);
 	for (int x = tid; x < np; x += NT) accd[x] = 0.0;
 	__syncthreads();
-	for (; i < a.inner; i += gridDim.x) {
+	for (int64_t unit = u0; unit < u1; unit++) {
 #pragma unroll
 		for (int u = 0; u < U; u++) {
 #pragma unroll
@@ -670,14 +675,20 @@ rowstats_whole_pipe_kernel(RowStatsArgs a)
 				if (kb[u] + 64 * t < ke[u]) apply(v[u][t], r[u][t]);
 			for (int64_t k = kb[u] + 64 * TT; k < ke[u]; k += 64) apply(val[k], (int) row[k]);   // (leaves past 128 nonzeros)
 		}
-		__syncthreads();
-		const int64_t cell0 = i * a.nrow;
-		if (i + gridDim.x < a.inner) fetch(i + gridDim.x);              // in flight while this column leaves
-		for (int x = tid; x < np; x += NT) {
-			((double *) a.out)[cell0 + x] = accd[x];
-			accd[x] = 0.0;
+		const int64_t i = unit / nchunks;
+		const bool flush = unit + 1 == u1 || (unit + 1) / nchunks != i;
+		if (flush) __syncthreads();
+		if (unit + 1 < u1) fetch(unit + 1);                             // in flight while this column leaves
+		if (flush) {
+			const int64_t cell0 = i * a.nrow;
+			for (int x = tid; x < np; x += NT) {
+				const double c = accd[x];
+				if (ATOMIC) { if (c != 0.0) atomicAdd((double *) a.out + cell0 + x, c); }
+				else ((double *) a.out)[cell0 + x] = c;
+				accd[x] = 0.0;
+			}
+			__syncthreads();
 		}
-		__syncthreads();
 	}
 }
 
@@ -805,6 +816,30 @@ int launch_rowstats_panel(const RowStatsArgs &a, void *ws, hipStream_t s)
 	const int oc = a.opcode;
 	const bool sumlike = oc == SVT_OP_SUM || oc == SVT_OP_COUNTNAS || oc == SVT_OP_CENTERED_X2_SUM ||
 		oc == SVT_OP_ANYNA;
+	// output columns of MANY short leaves, all rows in LDS (rowSums(x, dims = 1) of an N-d array, a 2-d operand of at most
+	// 20480 rows and short columns): the persistent whole-column kernel over (column, chunk of 64 leaves) units, cells added
+	// to a zeroed `out` when a workgroup's column changes
+	{
+		const size_t lds_w = (size_t) a.nrow * 8;
+		const double leaf_len = a.ncol > 0 ? (double) a.nnz_hint / (double) a.ncol : 0.0;
+		const int64_t spu = 4 * (ROWPANEL_NT / 64), nchunks = (a.nstrata + spu - 1) / spu;
+		if ((oc == SVT_OP_SUM || oc == SVT_OP_COUNTNAS) && !a.na_bg && a.nnz_hint > 0 && a.nstrata > spu &&
+		    a.nrow > (1 << ROWPANEL_BIG_SHIFT) && lds_w <= 160 * 1024 && leaf_len <= 112.0 && leaf_len >= 8.0 &&
+		    a.inner * nchunks >= 2048) {
+			if (a.table_mode == 1)
+				return 0;                       // (this form needs no table)
+			HIP_TRY(hipMemsetAsync(a.out, 0, (size_t) a.out_len * 8, s));
+			const void *fp = a.Rtype == SVT_REALSXP ? (const void *) rowstats_whole_pipe_kernel<double, true>
+								: (const void *) rowstats_whole_pipe_kernel<int, true>;
+			(void) hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_w);
+			if (a.Rtype == SVT_REALSXP)
+				hipLaunchKernelGGL((rowstats_whole_pipe_kernel<double, true>), dim3(256), dim3(ROWPANEL_NT), lds_w, s, a, nchunks);
+			else
+				hipLaunchKernelGGL((rowstats_whole_pipe_kernel<int, true>), dim3(256), dim3(ROWPANEL_NT), lds_w, s, a, nchunks);
+			HIP_TRY(hipGetLastError());
+			return 0;
+		}
+	}
 	// many output columns of few short leaves, all rows in LDS: the whole-column kernel
 	{
 		const size_t lds_whole = (size_t) a.nrow * (oc == SVT_OP_CENTERED_X2_SUM ? 16 : 8);
@@ -821,14 +856,14 @@ int launch_rowstats_panel(const RowStatsArgs &a, void *ws, hipStream_t s)
 			(void) hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_whole);
 			if ((oc == SVT_OP_SUM || oc == SVT_OP_COUNTNAS) && a.nstrata <= 4 * (ROWPANEL_NT / 64) && leaf_len <= 112.0 &&
 			    a.inner >= 1024) {
-				const void *fp = a.Rtype == SVT_REALSXP ? (const void *) rowstats_whole_pipe_kernel<double>
-									: (const void *) rowstats_whole_pipe_kernel<int>;
+				const void *fp = a.Rtype == SVT_REALSXP ? (const void *) rowstats_whole_pipe_kernel<double, false>
+									: (const void *) rowstats_whole_pipe_kernel<int, false>;
 				(void) hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_whole);
 				const unsigned ng = (unsigned) (a.inner < 256 ? a.inner : 256);       // one workgroup per CU
 				if (a.Rtype == SVT_REALSXP)
-					hipLaunchKernelGGL(rowstats_whole_pipe_kernel<double>, dim3(ng), dim3(ROWPANEL_NT), lds_whole, s, a);
+					hipLaunchKernelGGL((rowstats_whole_pipe_kernel<double, false>), dim3(ng), dim3(ROWPANEL_NT), lds_whole, s, a, (int64_t) 1);
 				else
-					hipLaunchKernelGGL(rowstats_whole_pipe_kernel<int>, dim3(ng), dim3(ROWPANEL_NT), lds_whole, s, a);
+					hipLaunchKernelGGL((rowstats_whole_pipe_kernel<int, false>), dim3(ng), dim3(ROWPANEL_NT), lds_whole, s, a, (int64_t) 1);
 				HIP_TRY(hipGetLastError());
 				return 0;
 			}

@@ -581,3 +581,31 @@ def test_rowsums_whole_column_pipeline_long_leaves(hip, oracle):
         assert_equal(hip.rowSums(x, dims=2, na_rm=na_rm), oracle.rowSums(x, dims=2, na_rm=na_rm), tol=1e-9, atol=1e-12,
                      what=f"rowSums dims=2 na_rm={na_rm}")
     assert_identical(hip.rowCountNAs(x, dims=2), oracle.rowCountNAs(x, dims=2), "rowCountNAs dims=2")
+
+
+@pytest.mark.parametrize("dtype", ["double", "integer"])
+def test_rowsums_of_many_short_leaves_per_output_column(hip, oracle, dtype):
+    """rowSums / rowCountNAs of a 4-d array over its last 3, 2 and 1 axes: 144000 / 9000 leaves per output column go through
+    the persistent whole-column kernel in chunks of 64 leaves whose cells are added to `out` (rowstats_whole_pipe_kernel
+    <T, true>), 60 leaves per column through its plain form -- against the oracle (src/SparseArray_matrixStats.c:774-913);
+    integer input bit for bit."""
+    shape = (8500, 16, 150, 60)
+    ncol = int(np.prod(shape[1:]))
+    cp, ri, v = random_csc(shape[0], ncol, 0.01, seed=141, dtype="double" if dtype == "double" else "int")
+    v = v.copy()
+    rng = np.random.default_rng(142)
+    hit = rng.choice(len(v), 12, replace=False)
+    if dtype == "double":
+        v[hit] = [np.nan, NA_real, np.inf, -np.inf, 1e300, -1e300, np.nan, NA_real, 3.5, -2.0, 0.25, 7.0]
+    else:
+        v[hit[:4]] = NA_integer
+    x = SVT_SparseArray.from_csc((shape[0], ncol), dtype, cp, ri, v)
+    x = SVT_SparseArray(shape, x.type, x.leaves)
+    for dims in (1, 2, 3):
+        for na_rm in (False, True):
+            got, want = hip.rowSums(x, dims=dims, na_rm=na_rm), oracle.rowSums(x, dims=dims, na_rm=na_rm)
+            if dtype == "integer":
+                assert_identical(got, want, f"rowSums dims={dims} na_rm={na_rm}")
+            else:
+                assert_equal(got, want, tol=1e-9, atol=1e-9, what=f"rowSums dims={dims} na_rm={na_rm}")
+        assert_identical(hip.rowCountNAs(x, dims=dims), oracle.rowCountNAs(x, dims=dims), f"rowCountNAs dims={dims}")
