@@ -166,19 +166,17 @@ prep_dense_rows128_kernel(const double *__restrict__ Y, int64_t ldY, int64_t nro
 }
 
 // ---- step 2 -------------------------------------------------------------------
+// (the work of one workgroup: four leaves x 64 dense columns; bx = block of leaves)
 template <typename T>
-__global__ void __launch_bounds__(256)
-crossprod_gather_kernel(const int64_t *__restrict__ col_ptr,
-			const int32_t *__restrict__ row_idx,
-			const T *__restrict__ val, int64_t ncol,
-			const double *__restrict__ Yt, int64_t Kp, int K,
-			ColFlags fl, double *__restrict__ out,
-			int64_t sc, int64_t sk, const int *__restrict__ run_flag)
+__device__ inline void crossprod_gather_block(const int64_t *__restrict__ col_ptr,
+					      const int32_t *__restrict__ row_idx,
+					      const T *__restrict__ val, int64_t ncol,
+					      const double *__restrict__ Yt, int64_t Kp, int K,
+					      ColFlags fl, double *__restrict__ out,
+					      int64_t sc, int64_t sk, int64_t bx)
 {
-	if (run_flag != NULL && *run_flag == 0)
-		return;
 	const int lane = threadIdx.x & 63;
-	const int64_t c = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
+	const int64_t c = bx * 4 + (threadIdx.x >> 6);
 	if (c >= ncol)
 		return;
 	const int k = blockIdx.y * KT + lane;
@@ -218,6 +216,25 @@ crossprod_gather_kernel(const int64_t *__restrict__ col_ptr,
 		if (col_nf > 0 || leaf_na) res = svt_na_real();
 	}
 	out[c * sc + (int64_t) k * sk] = res;
+}
+
+// Blocks of four leaves in a grid-stride loop: behind every panel product the kernel is enqueued with a flag that
+// is almost always clear, and a grid of one workgroup per block -- 250000 x 2 for the 1e6 leaves of t(A) at
+// BASELINE config 2b -- took 0.106 ms to find that out (5 % of that product); the grid is capped at 2048 x K / 64.
+template <typename T>
+__global__ void __launch_bounds__(256)
+crossprod_gather_kernel(const int64_t *__restrict__ col_ptr,
+			const int32_t *__restrict__ row_idx,
+			const T *__restrict__ val, int64_t ncol,
+			const double *__restrict__ Yt, int64_t Kp, int K,
+			ColFlags fl, double *__restrict__ out,
+			int64_t sc, int64_t sk, const int *__restrict__ run_flag)
+{
+	if (run_flag != NULL && *run_flag == 0)
+		return;
+	const int64_t nb = (ncol + 3) / 4;
+	for (int64_t bx = blockIdx.x; bx < nb; bx += gridDim.x)
+		crossprod_gather_block<T>(col_ptr, row_idx, val, ncol, Yt, Kp, K, fl, out, sc, sk, bx);
 }
 
 static ColFlags flags_of(void *ws, int64_t nrow, int64_t Kp)
@@ -316,7 +333,9 @@ static int crossprod_prepared(const CrossprodArgs &a, const int *run_flag, hipSt
 	const int64_t Kp = pad_k(a.K);
 	const double *Yt = (const double *) a.ws;
 	ColFlags fl = flags_of(a.ws, a.nrow, Kp);
-	dim3 grid((unsigned) ((a.ncol + 3) / 4), (unsigned) (Kp / KT));
+	// (gated launches find their flag clear almost always: a small grid; ungated ones fill the chip a few times over)
+	const int64_t nblk = (a.ncol + 3) / 4, cap = run_flag != NULL ? 2048 : 65536;
+	dim3 grid((unsigned) (nblk < cap ? nblk : cap), (unsigned) (Kp / KT));
 	if (a.Rtype == SVT_REALSXP)
 		hipLaunchKernelGGL(crossprod_gather_kernel<double>, grid, dim3(256), 0, s,
 				   a.col_ptr, a.row_idx, (const double *) a.val, a.ncol,
