@@ -191,7 +191,7 @@ def test_config3_rowsum_1e3_groups_full_size(config3):
 D5 = (20_000, 20_000, 64)
 
 
-@pytest.mark.parametrize("perm", [(1, 3, 2), (3, 1, 2), (2, 1, 3)])
+@pytest.mark.parametrize("perm", [(1, 3, 2), (3, 1, 2), (2, 1, 3), (2, 3, 1), (3, 2, 1)])
 def test_config5_aperm_full_size(hip, perm):
     """aperm(x, perm) on 1.28e8 nonzeros against a torch sort of the permuted linear indices:
     col_ptr, offsets and values bit for bit (src/SparseArray_aperm.c:892-970)."""

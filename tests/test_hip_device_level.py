@@ -226,6 +226,11 @@ def test_device_aperm(hip, perm):
     ((1234, 777, 3, 2), 400_000, (2, 1, 3, 4), "double"),  # 4-d: six slabs, ragged groups and buckets
     ((5000, 300, 7), 900_000, (2, 1, 3), "double"),        # tall slabs
     ((700, 40, 23), 20000, (2, 1, 3), "double"),           # too few nonzeros per column and bucket: the key sort
+    # 3-d: c(2,3,1) = c(2,1,3) then c(1,3,2), c(3,2,1) = c(2,1,3) then c(3,1,2) through an intermediate array
+    ((3000, 2500, 5), 750_000, (2, 3, 1), "double"),
+    ((3000, 2500, 5), 750_000, (3, 2, 1), "double"),
+    ((3000, 2500, 5), 750_000, (3, 2, 1), "integer"),
+    ((5000, 300, 7), 900_000, (2, 3, 1), "integer"),
 ])
 def test_device_aperm_first_two_axes_swapped(hip, dim, nnz, perm, dtype):
     """aperm(x, c(2, 1, 3, ...)): every slab of the remaining axes is a matrix transposed on its own -- the bucketed

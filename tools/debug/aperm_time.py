@@ -9,7 +9,8 @@ D = (20_000, 20_000, 64)
 dev = torch.device("cuda", 0)
 cp, ri, v = synth.random_device_csc(D[0], D[1] * D[2], 0.005, seed=5, device=dev)
 A = DeviceCSC(D[0], cp, ri, v)
-for perm in ((1, 3, 2), (3, 1, 2), (2, 1, 3)):
+perms = [tuple(int(c) for c in a) for a in sys.argv[1:]] or [(1, 3, 2), (3, 1, 2), (2, 1, 3), (2, 3, 1), (3, 2, 1)]
+for perm in perms:
     for _ in range(2):
         P, pdim = A.aperm(D, perm); del P
     torch.cuda.synchronize()

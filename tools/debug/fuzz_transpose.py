@@ -45,23 +45,29 @@ for case in range(ncases):
         v = torch.randn(lin.numel(), generator=g, device=dev, dtype=torch.float64)
     A = DeviceCSC(nrow, cp, ri, v)
     # every third case with columns that split into slabs: the operand read as an nrow x d2 x nslab array and
-    # aperm(x, c(2, 1, 3)) -- the batched form of the bucketed transposition -- against a sort of the permuted indices
+    # aperm(x, c(2, 1, 3)) -- the batched form of the bucketed transposition -- and the two permutations composed from it,
+    # against a sort of the permuted indices
     nslab = next((q for q in (7, 5, 4, 3, 2) if ncol % q == 0 and ncol // q >= 1), 0) if case % 3 == 2 else 0
     if nslab:
         d2 = ncol // nslab
-        P, new_dim = A.aperm((nrow, d2, nslab), (2, 1, 3))
-        torch.cuda.synchronize()
         j, sl = col % d2, col // d2
-        key = j + d2 * (ri.to(torch.int64) + nrow * sl)              # linear index in the permuted array
-        order = torch.sort(key, stable=True).indices
-        want_cp = torch.zeros(nrow * nslab + 1, dtype=torch.int64, device=dev)
-        want_cp[1:] = torch.cumsum(torch.bincount(ri.to(torch.int64) + nrow * sl, minlength=nrow * nslab), 0)
-        ok3 = new_dim == (d2, nrow, nslab) and torch.equal(P.col_ptr, want_cp) and \
-            torch.equal(P.row_idx, j[order].to(torch.int32)) and torch.equal(P.val, v[order])
-        if not ok3:
-            bad += 1
-            print(f"MISMATCH (aperm 2,1,3) case {case}: dim ({nrow}, {d2}, {nslab}) nnz {lin.numel()} kind {kind} int {is_int}", flush=True)
-        del P, key, order, want_cp, j, sl
+        subs, dims3 = [ri.to(torch.int64), j, sl], (nrow, d2, nslab)
+        for perm in ((2, 1, 3), (2, 3, 1), (3, 2, 1)):
+            P, new_dim = A.aperm(dims3, perm)
+            torch.cuda.synchronize()
+            ns = [subs[q - 1] for q in perm]
+            nd = tuple(dims3[q - 1] for q in perm)
+            key = ns[0] + nd[0] * (ns[1] + nd[1] * ns[2])                # linear index in the permuted array
+            order = torch.sort(key, stable=True).indices
+            want_cp = torch.zeros(nd[1] * nd[2] + 1, dtype=torch.int64, device=dev)
+            want_cp[1:] = torch.cumsum(torch.bincount(ns[1] + nd[1] * ns[2], minlength=nd[1] * nd[2]), 0)
+            ok3 = new_dim == nd and torch.equal(P.col_ptr, want_cp) and \
+                torch.equal(P.row_idx, ns[0][order].to(torch.int32)) and torch.equal(P.val, v[order])
+            if not ok3:
+                bad += 1
+                print(f"MISMATCH (aperm {perm}) case {case}: dim {dims3} nnz {lin.numel()} kind {kind} int {is_int}", flush=True)
+            del P, key, order, want_cp, ns
+        del j, sl, subs
     T = A.t()
     torch.cuda.synchronize()
     order = torch.sort(ri.to(torch.int64), stable=True).indices
