@@ -645,6 +645,10 @@ static bool t2_shape(int64_t nrow, int64_t ncol, int64_t nnz_all, T2Shape *sh, i
 	const double nwg = (double) nslab * (double) sh->ncoarse * (double) sh->ngroups;
 	if ((double) nslab * (double) sh->nfb >= 2.0e9 || (double) nslab * (double) ncol >= 2.0e9)
 		return false;
+	// many small slabs: a pass-3 workgroup per fine bucket needs a few hundred nonzeros to be worth its launch
+	// (slabs of 2e4 x 64 with 6400 nonzeros would make 6e6 workgroups of 20) -- the key sort takes those
+	if (nslab > 1 && ldexp(per_row, fbits) < 512.0)
+		return false;
 	if ((double) (sh->ncoarse + 1) * (double) ncol > 2.0 * (double) nnz + 32.0)     // (the table of coarse-bucket starts)
 		return false;
 	return ntab < 1.0e8 && nwg < 2.0e9 && sh->ngroups <= 6000;      // (pass 3 keeps one int per group in LDS)
