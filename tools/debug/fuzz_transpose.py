@@ -53,6 +53,8 @@ for case in range(ncases):
         j, sl = col % d2, col // d2
         subs, dims3 = [ri.to(torch.int64), j, sl], (nrow, d2, nslab)
         for perm in ((2, 1, 3), (2, 3, 1), (3, 2, 1)):
+            if dims3[perm[1] - 1] * dims3[perm[2] - 1] > 5e7:          # (new leaves: their pointers alone would be GBs)
+                continue
             P, new_dim = A.aperm(dims3, perm)
             torch.cuda.synchronize()
             ns = [subs[q - 1] for q in perm]
