@@ -9,7 +9,10 @@ Metric: GNZ/s = nonzeros of A streamed per second (whole job, all ranks).
 
     python bench.py --gpus N --steps K --warmup W [--scaling strong|weak] [--config 2|4]
 
-N > 1 is launched by torch.distributed.run, one rank per GPU (RCCL).  Default `--scaling strong`:
+N > 1 runs one rank per GPU under torch.distributed.run (RCCL): either the caller starts it that way (RANK / WORLD_SIZE
+in the environment), or `python bench.py --gpus N` starts its own ranks -- the parent spawns
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a fresh child process before it touches the GPU, relays
+rank 0's JSON line as its last line of output and exits with the child's status.  Default `--scaling strong`:
 the SAME 1e6 x 1e4 problem at every N -- the matrix is defined as 8 row blocks
 (sparsearray_amd/synth.py, random_device_csc_blocked), rank r owns blocks r*8/N .. (r+1)*8/N-1 of A
 and of Y (rows = the contracted dimension, sparsearray_amd/parallel.py), and the 10 MB ncol x K
@@ -177,10 +180,10 @@ def host_cores() -> int:
     return min(n, int(os.environ.get("SVT_BENCH_CPU_THREADS", "16")))
 
 
-def cpu_baseline(col_ptr, row_idx, val, Y, nrow, K, nleaves_sample):
+def cpu_baseline(col_ptr, row_idx, val, Y, nrow, K, nleaves_sample, threads=None):
     """The oracle (CPU restatement of the reference's C/OpenMP path) timed on
-    the host cores of this box, on the first `nleaves_sample` leaves of A
-    against all K dense columns."""
+    the host cores of this box (`threads` of them; default: all this job may use), on the first
+    `nleaves_sample` leaves of A against all K dense columns."""
     import ctypes
     from oracle import load_oracle
     from sparsearray_amd.svt import make_view_from_csc
@@ -193,7 +196,7 @@ def cpu_baseline(col_ptr, row_idx, val, Y, nrow, K, nleaves_sample):
     yh = np.ascontiguousarray(Y.cpu().numpy())          # (K, nrow) == col-major nrow x K
     view = make_view_from_csc((nrow, ns), "double", cp, ri, vv)
     out = np.zeros((K, ns), dtype=np.float64)
-    ncores = host_cores()
+    ncores = threads if threads else host_cores()
     lib.orc_set_max_threads(ncores)
     fn = lib.orc_crossprod2_SVT_mat
     fn.restype = ctypes.c_int
@@ -208,13 +211,55 @@ def cpu_baseline(col_ptr, row_idx, val, Y, nrow, K, nleaves_sample):
                       f"oracle C/OpenMP path, {dt:.2f} s wall"}, out, ns
 
 
+def launch_ranks(a) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a FRESH child process
+    (`python -m torch.distributed.run`; never an exec, and nothing in this process has touched the GPU yet), pass
+    the children's output through, print rank 0's JSON line last and return the launcher's exit status (a rank
+    that dies makes torch.distributed.run end the others and return non-zero)."""
+    import signal
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "4")          # (torch.distributed.run would set 1 and say so on stderr)
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, start_new_session=True)
+
+    def forward(sig, _frame):
+        try:
+            os.killpg(child.pid, sig)
+        except ProcessLookupError:
+            pass
+    for sg in (signal.SIGTERM, signal.SIGINT):
+        signal.signal(sg, forward)
+    line_json = None
+    for line in child.stdout:
+        t = line.strip()
+        if t.startswith("{") and '"metric"' in t:
+            line_json = t                           # held back: it must be the last line of this process
+        else:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+    rc = child.wait()
+    if line_json is not None:
+        print(line_json, flush=True)
+    elif rc == 0:
+        rc = 1                                      # the ranks ended without a result line
+    return rc if rc >= 0 else 128 - rc
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(a))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world == 1 and a.gpus > 1:
-        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but the launcher started {world} rank(s)")
     if a.same_device:
         local = 0
         os.environ["LOCAL_RANK"] = "0"          # (the HIP library binds to LOCAL_RANK)
@@ -425,6 +470,15 @@ def main():
         "roofline": {"bound": "hbm", "kernel": kernel_name,
                      "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                      "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_source,
+                     # priced against HBM as BASELINE.json asks; what the kernel actually waits for (DESIGN.md section 0,
+                     # profiles/r04_ceiling_work_corrected.txt, r03_dma_sq_counters.txt) is not HBM:
+                     "limiter": ("lds+issue (one LDS read of Y per record x 64 dense columns + scalar/vector issue in strict "
+                                 "alternation; HBM traffic is 1.09x algorithmic at 15 % of peak)"
+                                 if kernel_name == "crossprod_pbc_dma_kernel" else
+                                 "l2->cu gather (every nonzero fetches its row of Yt through the texture-address path)"
+                                 if kernel_name.startswith("crossprod_pbc_gather") else "l2 gather"),
+                     "fp64_frac": 2.0 * nnz * K / (kern_ms * 1e-3) / 78.6e12,
+                     "fp64_peak_TFLOPs": 78.6,
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "kernel_ms": kern_ms,
                      "kernel_ms_from": f"HIP events around the kernel on every {max(1, a.event_every)}-th of the timed steps"},
@@ -504,6 +558,28 @@ def main():
             ex["crossprod_whole_call"]["with_32_CUs_left_idle_same_result"] = bool(
                 torch.allclose(outs, result(), rtol=1e-11, atol=1e-11))
             del outs
+        # what ONE rank of an N-GPU strong-scaling run of this config computes per step (rank 0's row blocks of the same
+        # 8-block matrix, no collective), timed like the main loop: 1.77 / this = the scaling the result's all-reduce can
+        # only lower
+        if strong and (a.nrow, a.ncol) == (CONFIGS[2]["nrow"], CONFIGS[2]["ncol"]):
+            share = {}
+            for nshare in (2, 4, 8):
+                scp, sri, sv, (sr0, sr1) = synth.random_device_csc_blocked(nrow, ncol, a.density, seed=1, device=dev,
+                                                                           nblocks=8, first=0, last=8 // nshare)
+                sY = synth.random_dense_blocked(nrow, K, seed=101, device=dev, nblocks=8, first=0, last=8 // nshare)
+                sA = DeviceCSC(sr1 - sr0, scp, sri, sv)
+                ssc = par.ShardedCrossprod(sA, K, None, a.cbw, a.wpb, a.logr)
+                for _ in range(5):
+                    ssc.step(sY)
+                torch.cuda.synchronize()
+                t0_ = time.perf_counter()
+                for _ in range(50):
+                    ssc.step(sY)
+                torch.cuda.synchronize()
+                share[str(nshare)] = (time.perf_counter() - t0_) / 50 * 1e3
+                del ssc, sA, sY, scp, sri, sv
+            ex["rank_share_ms_per_step"] = share
+            ex["rank_share_speedup_before_the_collective"] = {k: res["ms_per_step"] / v for k, v in share.items()}
         # once-per-operand costs, steady state (second call: code objects loaded, allocator warm)
         def wall(fn, reps=3):
             best = 1e30
@@ -574,6 +650,40 @@ def main():
                                "max_abs_diff_vs_dense_route": float((out2 - out3).abs().max().item())}
         del plan_t, T, out2, out3, Bd, Bs, ws3
         res["extras"] = ex
+        # row f2 of SURVEY.md section 8: the .Call-shaped entry point on HOST leaves -- marshal (src/SVT_SparseArray_class.c:598-633
+        # walks the tree the same way) + PCIe both ways + layout build + product, and the same call with the operand
+        # kept resident on the device between calls (svt_resident_set_limit)
+        import ctypes
+        from sparsearray_amd import _hip as _hipmod
+        from sparsearray_amd.svt import make_view_from_csc
+        hl = _hipmod.init()
+        hcp, hri, hv = col_ptr.cpu().numpy(), row_idx.cpu().numpy(), val.cpu().numpy()
+        hview = make_view_from_csc((lrow, ncol), "double", hcp, hri, hv)
+        hy = np.ascontiguousarray(Y.cpu().numpy())            # (K, nrow) C-order = column-major nrow x K
+        hout = np.zeros((K, ncol))
+        hfn = hl.svt_crossprod2_SVT_mat
+        hfn.restype = ctypes.c_int
+        hfn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        hl.svt_resident_set_limit.argtypes = [ctypes.c_size_t]
+
+        def host_call():
+            t0_ = time.perf_counter()
+            rc_ = hfn(ctypes.addressof(hview), hy.ctypes.data, lrow, K, 14, 0, hout.ctypes.data)
+            assert rc_ == 0
+            return (time.perf_counter() - t0_) * 1e3
+        host_call()
+        cold = min(host_call() for _ in range(2))
+        hl.svt_resident_set_limit(8 << 30)
+        host_call()
+        resident = min(host_call() for _ in range(3))
+        hl.svt_resident_set_limit(0)
+        hl.svt_resident_clear()
+        herr = float(np.max(np.abs(hout - result().cpu().numpy()) / np.maximum(np.abs(hout), 1e-12)))
+        ex["host_entry_point_ms"] = {"svt_crossprod2_SVT_mat_cold": cold, "with_the_resident_cache": resident,
+                                     "bytes_over_pcie_cold": int(nnz * 12 + lrow * K * 8 + ncol * K * 8),
+                                     "GNZ/s_cold": nnz / cold / 1e6, "GNZ/s_resident": nnz / resident / 1e6,
+                                     "max_rel_diff_vs_device_level_result": herr}
+        del hcp, hri, hv, hy, hout, hview
     if world == 1 and not a.no_cpu_baseline:
         ns = max(1, min(ncol, int(1e8 / max(nnz / ncol, 1))))   # <= 1e8 nz x K: 10-30 core-seconds
         cb, ref_out, ns = cpu_baseline(col_ptr, row_idx, val, Y, lrow, K, ns)
@@ -581,6 +691,13 @@ def main():
         got = result()[:, :ns].cpu().numpy()
         err = np.max(np.abs(got - ref_out) / np.maximum(np.abs(ref_out), 1e-12))
         cb["max_rel_err_vs_gpu"] = float(err)
+        # the reference's DEFAULT team: min(omp_get_max_threads(), nprocs %/% 3), at least 1 (R/thread-control.R:46-57);
+        # a third of the sample so that both legs together stay within ~30 core-seconds
+        nthr3 = max(1, host_cores() // 3)
+        cb3, _, ns3 = cpu_baseline(col_ptr, row_idx, val, Y, lrow, K, max(1, ns // 3), threads=nthr3)
+        cb["at_reference_default_threads"] = {"value": cb3["value"], "unit": "GNZ/s", "cores": nthr3,
+                                              "rule": "min(OMP max threads, nprocs %/% 3), R/thread-control.R:46-57",
+                                              "sample": cb3["sample"]}
         res["cpu_baseline"] = cb
     print(json.dumps(res))
     if world > 1:

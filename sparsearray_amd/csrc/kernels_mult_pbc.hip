@@ -1863,7 +1863,9 @@ static DirtyWs dirty_ws_of(void *flag_block, void *tail, int64_t ncol, int64_t K
 	DirtyWs d;
 	(void) ncol;
 	d.flags = (int *) flag_block;
-	const bool in_block = 256 + Kp * 8 <= PBC_FLAG_BYTES - 1024;   // (the last KB: tuning builds' cycle counters)
+	// the counters must stay below the progress words of the paced gather kernel ([PBC_PROG_OFFSET, PBC_FLAG_BYTES): that kernel
+	// runs between the clear of phase 1 and the readers of phase 2) and below the tuning builds' cycle counters (the KB before them)
+	const bool in_block = 256 + Kp * 8 <= PBC_PROG_OFFSET - 1024;
 	d.col_nf = in_block ? (int *) ((char *) flag_block + 256) : (int *) tail;   // then phase 1 clears them with the flags
 	d.has_na = d.col_nf + Kp;
 	d.list = (uint2 *) (((uintptr_t) (in_block ? (char *) tail : (char *) (d.has_na + Kp)) + 15) & ~(uintptr_t) 15);

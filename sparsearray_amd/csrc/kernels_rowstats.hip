@@ -1263,12 +1263,17 @@ rowsum_gid_kernel(const int32_t *__restrict__ row_idx, int64_t nnz, const int *_
 	for (int64_t k = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) * 2; k < nnz;
 	     k += (int64_t) gridDim.x * blockDim.x * 2) {
 		// two ids per thread: one 4-byte store
+		// (the entry points have checked 1 <= group <= ngroup or NA, check_group, src/rowsum_methods.c:258-281; a caller of the
+		// device-level function that did not gets its stray ids folded into the last group, never an id past the LDS cells)
+		const uint32_t top = (uint32_t) (ngroup - 1);
 		const int g0 = group[row_idx[k]];
-		const uint32_t a = (uint32_t) ((g0 == NA_INT ? ngroup : g0) - 1);
+		uint32_t a = (uint32_t) ((g0 == NA_INT ? ngroup : g0) - 1);
+		a = a > top ? top : a;
 		if (k + 1 < nnz) {
 			const int g1 = group[row_idx[k + 1]];
-			const uint32_t b = (uint32_t) ((g1 == NA_INT ? ngroup : g1) - 1);
-			*(uint32_t *) (gid + k) = a | (b << 16);
+			uint32_t b = (uint32_t) ((g1 == NA_INT ? ngroup : g1) - 1);
+			b = b > top ? top : b;
+			*(uint32_t *) (gid + k) = (a & 0xFFFFu) | (b << 16);
 		} else
 			gid[k] = (uint16_t) a;
 	}
@@ -1364,8 +1369,9 @@ int launch_rowsum_gid(const GroupSumArgs &a, int64_t nnz, uint16_t *gid, hipStre
 {
 	if (nnz <= 0)
 		return 0;
-	int64_t nb = (nnz / 2 + 255) / 256;
+	int64_t nb = ((nnz + 1) / 2 + 255) / 256;
 	if (nb > 256 * 32) nb = 256 * 32;
+	if (nb < 1) nb = 1;
 	hipLaunchKernelGGL(rowsum_gid_kernel, dim3((unsigned) nb), dim3(256), 0, s, a.row_idx, nnz, a.group, a.ngroup, gid);
 	HIP_TRY(hipGetLastError());
 	return 0;

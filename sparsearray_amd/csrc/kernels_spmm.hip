@@ -47,7 +47,11 @@
 static size_t spmm_table_bytes(int64_t nrow, int64_t ninner)
 {
 	// the table of run bounds for the shortest panels this file uses (64 rows)
+#ifdef SVT_TUNING
+	int ps = 7;                                     // (tuning builds: SVT_SPMM_PS may shorten the panels down to 128 rows)
+#else
 	int ps = 12;                                    // (the shortest full panels spmm_shape() picks)
+#endif
 	while (ps > 6 && ((int64_t) 1 << ps) >= 2 * (nrow > 0 ? nrow : 1)) ps--;
 	const int64_t npan = (nrow + ((int64_t) 1 << ps) - 1) >> ps;
 	return ((size_t) (ninner > 0 ? ninner : 1) * (size_t) (npan + 1) * 4 + 255) / 256 * 256;
@@ -120,9 +124,6 @@ spmm_csc_csc_kernel(SpmmArgs a, int KW, int G)
 {
 	extern __shared__ double acc[];                 // [KW][P]
 	const int tid = threadIdx.x;
-	// an earlier pass has found a value that voids the result: the caller takes the dense route
-	if (*(volatile const int *) a.flag != 0)
-		return;
 	const int P = 1 << a.ps;
 	const int64_t q = blockIdx.x, r0 = q << a.ps;
 	const int64_t k0 = (int64_t) blockIdx.y * KW;
@@ -133,7 +134,12 @@ spmm_csc_csc_kernel(SpmmArgs a, int KW, int G)
 	// the pairs of the workgroup's columns, flattened: pair t belongs to column kk with pre[kk] <= t < pre[kk + 1]
 	__shared__ int64_t bbeg[17];
 	__shared__ int32_t pre[17];
+	__shared__ int stop;
 	if (tid == 0) {
+		// an earlier pass (or another workgroup of this launch) has found a value that voids the result: the caller takes
+		// the dense route.  ONE read per workgroup, shared through LDS: the wavefronts of a workgroup must agree, the
+		// flag can rise between their reads
+		stop = *(volatile const int *) a.flag;
 		int32_t run = 0;
 		for (int kk = 0; kk < kw; kk++) {
 			bbeg[kk] = a.b_ptr[k0 + kk];
@@ -143,6 +149,8 @@ spmm_csc_csc_kernel(SpmmArgs a, int KW, int G)
 		pre[kw] = run;
 	}
 	__syncthreads();
+	if (stop != 0)
+		return;
 	const int npairs = pre[kw];
 	const int grp = tid / G, sl = tid % G, ngrp = NT / G;
 	const TA *__restrict__ av = (const TA *) a.a_val;

@@ -307,3 +307,27 @@ def test_bench_strong_scaling_rehearsal_same_problem(hip):
         for key in ("metric", "value", "unit", "ms_per_step", "roofline", "dtype", "data", "config"):
             assert key in line
         assert line["roofline"]["bound"] == "hbm" and line["roofline"]["frac"] > 0
+
+
+def test_bench_starts_its_own_ranks(hip):
+    """`python3 bench.py --gpus 2 ...` started DIRECTLY (the shape of the driver's one-GPU command, no launcher, no
+    WORLD_SIZE in the environment): the parent spawns torch.distributed.run as a fresh child process before it touches
+    the GPU, the last line of its output is rank 0's JSON line, and a rank that dies gives a non-zero exit status
+    (the reference is single-process, R/thread-control.R:87-92)."""
+    torch.cuda.empty_cache()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    common = ["--nrow", "262144", "--ncol", "4000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device"] + common
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["multi_gpu"]["world_size"] == 2 and line["multi_gpu"]["backend"] == "gloo"
+    assert line["value"] > 0 and line["scaling"] == "strong"
+    # a rank that dies: without --same-device rank 1 asks for GPU 1 of a one-GPU box (on a larger node: a rank count
+    # that strong scaling refuses on every rank)
+    bad = ["--gpus", "2", "--backend", "gloo"] if torch.cuda.device_count() < 2 else ["--gpus", "3", "--backend", "gloo", "--same-device"]
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + bad + common, env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert p.returncode != 0
+    assert not p.stdout.strip().splitlines() or '"metric"' not in p.stdout.strip().splitlines()[-1]

@@ -536,6 +536,29 @@ def test_pbc_gather_xcd_paced_kernel_matches_oracle(hip, oracle, cfg):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
+def test_pbc_gather_xcd_paced_wide_dense_operand_nonfinite_high_column(hip, oracle):
+    """K = 1024 through the paced gather kernel with an Inf (no NA) in dense columns past 992: the per-column
+    counters of the non-finite fix-up must not share bytes with the kernel's progress words (ADVICE round 4:
+    with the counters inside the flag block, has_na[k] for k >= 993 sat on the progress words and the fix-up
+    wrote NA_real_ where the reference gives NaN / Inf; src/SparseVec_dotprod.c:48-65)."""
+    from sparsearray_amd.device import PbcPlan
+    logr, K = 9, 1024
+    nrow, ncol = (64 << logr) + 100, 333
+    cp, ri, v = random_csc(nrow, ncol, 0.002, seed=291)
+    x = SVT_SparseArray.from_csc((nrow, ncol), "double", cp, ri, v)
+    A = _dev(cp, ri, v, nrow)
+    plan = PbcPlan(A, K, 40, 4, logr)
+    y = np.random.default_rng(292).uniform(-1, 1, (nrow, K))
+    y[int(ri[cp[7]]), 1000] = np.inf           # on a nonzero of leaf 7
+    y[11, 1023] = -np.inf
+    y[nrow - 1, 995] = np.nan
+    y[5, 3] = np.inf
+    out = torch.full((K, ncol), 3.0, dtype=torch.float64, device="cuda")
+    plan.run(torch.as_tensor(np.ascontiguousarray(y.T), device="cuda"), nrow, out)
+    torch.cuda.synchronize()
+    assert_equal(out.cpu().numpy().T, oracle.crossprod(x, y), tol=1e-9, atol=1e-11, strict_na=True, what="K = 1024")
+
+
 def test_pbc_auto_layout_picks_by_density(hip, oracle):
     """svt_dev_pbc_build(A, 0, 0, 0): the gather layout below ~0.25 % density, the LDS-DMA layout
     above; same results either way."""

@@ -265,6 +265,28 @@ def test_rowsum_tall_operands(hip, oracle, ngroup, shape):
                          what=f"prepared rowsum ngroup={ngroup} na_rm={na_rm} NA as integer: {na_as_int}")
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("nnz", [1, 2, 3])
+def test_prepared_rowsum_tiny_operands(hip, nnz):
+    """RowsumPlan on operands with 1, 2, 3 nonzeros (the id kernel was launched with a grid of 0 blocks
+    for exactly one nonzero); compute_rowsum_doubles, src/rowsum_methods.c:44-64."""
+    import torch
+    from sparsearray_amd.device import DeviceCSC, RowsumPlan
+    nrow, ncol, ngroup = 9, 4, 3
+    ri = np.array([5, 2, 8][:nnz], dtype=np.int32)
+    v = np.array([1.5, -2.0, 4.0][:nnz])
+    cp = np.array([0, 0, 1, min(nnz, 2), nnz], dtype=np.int64)       # leaf 0 empty; leaves 1, 2, 3 hold up to one nonzero each
+    g32 = (np.arange(nrow, dtype=np.int32) % ngroup) + 1
+    A = DeviceCSC.from_host(nrow, cp, ri, v)
+    got = RowsumPlan(A, torch.as_tensor(g32, device="cuda"), ngroup).run()
+    torch.cuda.synchronize()
+    want = np.zeros((ncol, ngroup))
+    for j in range(ncol):
+        for k in range(cp[j], cp[j + 1]):
+            want[j, g32[ri[k]] - 1] += v[k]
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
 # ---------------------------------------------------------------------------------------------
 # the bucketed transposition: paths the random shapes of test_hip_device_level.py do not reach
 # ---------------------------------------------------------------------------------------------
