@@ -2,9 +2,11 @@
  * svt_hip_glue.c -- the host shim an R maintainer adds to SparseArray's src/ so that the package's
  * .Call entry points run on an MI355X through libsvt_hip.so (include/svt_hip.h of this repository).
  *
- * Not BUILT in this repository (no R in the image), but syntax- and type-checked against the reference's
- * own headers by tests/test_glue_compiles.py (gcc -fsyntax-only with a declarations-only stand-in for
- * Rdefines.h under tests/r_api_standin/).  It is the complete text of the binding,
+ * Not built into an R package in this repository (no R in the image), but syntax- and type-checked against
+ * the reference's own headers by tests/test_glue_compiles.py and compiled, linked and RUN on the CPU by
+ * tests/test_glue_executes.py (functional test-only stand-in for R's C API under tests/r_api_standin/, the
+ * svt_* symbols bound to the CPU oracle, all golden cases through the registered names).  It is the complete
+ * text of the binding,
  * one function per entry point registered in src/R_init_SparseArray.c:41-43,94,121-134:
  *
  *   C_crossprod2_SVT_mat/7  C_crossprod2_mat_SVT/7  C_crossprod2_SVT_SVT/8  C_crossprod1_SVT/5
@@ -387,21 +389,23 @@ SEXP C_summarize_SVT(SEXP x_dim, SEXP x_type, SEXP x_SVT, SEXP x_na_background,
 		hip_fail();
 	if (warn)
 		warning("NAs introduced by coercion of infinite values to integers");
-	/* same result shapes as _make_SEXP_from_summarize_result(): range -> 2 values, else 1 */
-	int n = opcode == SVT_OP_RANGE ? 2 : 1;
-	SEXP ans;
+	/* The library hands back the post-processed state (value(s) + their type); the R object is made from it
+	   by the reference's own _make_SEXP_from_summarize_result() (src/Rvector_summarization.c:1243-1303:
+	   sum / prod of integers -> integer when it fits, countNAs -> integer, any / all / anyNA -> logical,
+	   range -> 2 values) so that the two paths cannot disagree on the result's type. */
+	SummarizeOp sop = _make_SummarizeOp(opcode, Rtype, LOGICAL(na_rm)[0], REAL(center)[0]);
+	SummarizeResult res;
+	_init_SummarizeResult(&sop, &res);
+	res.out_Rtype = sexptype_of(out_Rtype);
+	res.outbuf_status = OUTBUF_IS_SET;
 	if (out_Rtype == SVT_REALSXP) {
-		ans = PROTECT(NEW_NUMERIC(n));
-		memcpy(REAL(ans), out_d, n * sizeof(double));
-	} else if (out_Rtype == SVT_INTSXP) {
-		ans = PROTECT(NEW_INTEGER(n));
-		memcpy(INTEGER(ans), out_i, n * sizeof(int));
+		res.outbuf.two_doubles[0] = out_d[0];
+		res.outbuf.two_doubles[1] = out_d[1];
 	} else {
-		ans = PROTECT(NEW_LOGICAL(n));
-		memcpy(LOGICAL(ans), out_i, n * sizeof(int));
+		res.outbuf.two_ints[0] = out_i[0];
+		res.outbuf.two_ints[1] = out_i[1];
 	}
-	UNPROTECT(1);
-	return ans;
+	return _make_SEXP_from_summarize_result(&sop, &res);
 }
 
 /* ------------------------------------------------------------------------------------------------ */

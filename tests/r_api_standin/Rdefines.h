@@ -3,14 +3,16 @@
  * integration/svt_hip_glue.c and the headers it includes name, so that
  *     gcc -fsyntax-only -Wall -I tests/r_api_standin -I <reference>/src -I include integration/svt_hip_glue.c
  * (tests/test_glue_compiles.py) can check the glue's syntax, types, arities and PROTECT discipline
- * against a compiler.  No definitions, nothing here is linked or shipped, and nothing is built from
- * it: it exists because the image has no R.  Written from R's documented API ("Writing R Extensions").
+ * against a compiler, and so that tests/test_glue_executes.py can RUN the glue on the CPU against the
+ * test-only definitions of r_standin.c (same directory).  Nothing here is shipped or linked into the
+ * product: it exists because the image has no R.  Written from R's documented API ("Writing R Extensions").
  */
 #ifndef SVT_TEST_RDEFINES_STANDIN_H
 #define SVT_TEST_RDEFINES_STANDIN_H
 
 #include <stddef.h>
 #include <limits.h>
+#include <string.h>     /* R's own headers pull it in; the reference's files rely on that */
 
 typedef struct SEXPREC *SEXP;
 typedef ptrdiff_t R_xlen_t;
@@ -86,6 +88,7 @@ Rboolean Rf_isReal(SEXP);
 Rboolean Rf_isNumeric(SEXP);
 Rboolean Rf_isString(SEXP);
 Rboolean Rf_isMatrix(SEXP);
+Rboolean Rf_isBlankString(const char *);
 SEXPTYPE Rf_str2type(const char *);
 const char *Rf_type2char(SEXPTYPE);
 int Rf_asInteger(SEXP);
@@ -118,6 +121,7 @@ void R_CheckUserInterrupt(void);
 #define isNumeric Rf_isNumeric
 #define isString Rf_isString
 #define isMatrix Rf_isMatrix
+#define isBlankString Rf_isBlankString
 #define str2type Rf_str2type
 #define type2char Rf_type2char
 #define asInteger Rf_asInteger
