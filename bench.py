@@ -80,6 +80,10 @@ def parse():
                         "(`multi_gpu.variants`); the RCCL variants (0 and 32 spare CUs) are always there")
     p.add_argument("--event-every", type=int, default=4,
                    help="HIP events around the dominant kernel on every n-th timed step (roofline.kernel_ms = their mean)")
+    p.add_argument("--settle-ms", type=float, default=150.0,
+                   help="untimed: keep the GPU busy this long with plain streaming reads of Y (torch.sum) before the W warm-up "
+                        "steps, so that the W + K steps do not run while the clocks are still ramping up out of idle "
+                        "(tools/debug/whole_call_vs_step.py: the first ~20-40 ms after an idle gap run 3-9 %% slower); 0 = off")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extras", action="store_true")
     a = p.parse_args()
@@ -379,6 +383,13 @@ def main():
             spare_tuned[cand] = float(t.item())
         a.spare_cus = min(spare_tuned, key=spare_tuned.get)
         set_spare_cus(a.spare_cus)
+    if a.settle_ms > 0:
+        # out of idle: generating the inputs and building the layout leaves the GPU mostly waiting for the host
+        t_s = time.perf_counter()
+        while (time.perf_counter() - t_s) * 1e3 < a.settle_ms:
+            for _ in range(16):
+                torch.sum(Y)
+            torch.cuda.synchronize()
     for _ in range(a.warmup):
         step()
     finish()
@@ -490,6 +501,8 @@ def main():
                                    else "PBC cbw=40 wpb=16 logR=7 (LDS-DMA kernel)") if a.cbw == 0 else \
             f"PBC cbw={a.cbw} wpb={a.wpb} logR={a.logr}"
         res["config"]["layout_build_ms_once_per_operand"] = layout_ms
+        if a.settle_ms > 0:
+            res["config"]["untimed_settle_ms_before_the_warmup_steps"] = a.settle_ms
         if a.spare_cus:
             res["config"]["spare_cus"] = a.spare_cus
         if spare_tuned is not None:
@@ -536,7 +549,8 @@ def main():
         # the same product when the dense operand is not clean / not column-major
         plan0 = sc.plan
         outx = torch.zeros((K, ncol), dtype=torch.float64, device=dev)
-        t_clean = timed(lambda: plan0.run(Y, lrow, outx), 10)
+        timed(lambda: plan0.run(Y, lrow, outx), 30)          # (out of the idle gap the allocations above left)
+        t_clean = timed(lambda: plan0.run(Y, lrow, outx), 20)
         Yp = Y.clone(); Yp[5, lrow // 8 + 1] = float("inf")
         t_inf = timed(lambda: plan0.run(Yp, lrow, outx), 10)
         Yp[7, :] = float("nan")

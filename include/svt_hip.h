@@ -282,8 +282,10 @@ typedef struct svt_dev_pbc svt_dev_pbc;
 svt_dev_pbc *svt_dev_pbc_build(const svt_dev_csc *A, int CBW, int WPB, int logR);
 void svt_dev_pbc_release(svt_dev_pbc *P);
 /* Layout buffers come from a stream-ordered pool of the library's own (one per device) that keeps up to 3 GiB of
-   released memory for the next build; svt_dev_pbc_release() frees behind the last product of every stream that
-   used the layout (events, no device-wide synchronisation).  svt_dev_pbc_trim() hands everything the pools hold
+   released memory for the next build; svt_dev_pbc_release() frees behind the work of every stream that has run a
+   product with the layout (an event recorded on each of them at release time: no device-wide synchronisation, and
+   nothing put on the stream per product; a stream destroyed before the handle is released makes the release
+   synchronise the device instead).  svt_dev_pbc_trim() hands everything the pools hold
    but no layout uses back to the driver -- e.g. before another allocator of the process needs the memory. */
 void svt_dev_pbc_trim(void);
 /* Device bytes held by a layout (records + tile table + flags). */
@@ -315,7 +317,9 @@ void svt_dev_pbc_set_gather_pacing(int dsync, int spin);
 
 /* Products with many column blocks and no row split (A %*% Y on the layout of t(A)) are launched one round of
    workgroups at a time, so that every round starts aligned and the dense tile its workgroups stage streams
-   through the XCDs' L2 once per round; on = 0: one launch.  Default 1.  Process-wide, tuning / measurement. */
+   through the XCDs' L2 once per round, and the last, partly filled round (54 of 256 CUs at BASELINE config 2b) is cut by
+   rows into 256 / its size splits whose partial sums are added in split order (round 5); on = 2: per round, the last round
+   whole; on = 0: one launch.  Default 1.  Process-wide, tuning / measurement. */
 void svt_dev_pbc_set_round_launches(int on);
 
 /* The same, restricted to the leaves from `first_col` on (rounded down to the kernel's block of

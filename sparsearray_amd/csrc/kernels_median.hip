@@ -9,54 +9,33 @@
 // NA rule (:714-719): na.rm drops NA/NaN from the nonzeros (the padding keeps its
 // size); otherwise any NA/NaN gives NA_real_.  n == 0 gives NA_real_ (:721-722).
 //
-// Device: the nonzero values of the columns that need it are copied as f64 keys with every
-// NA/NaN turned into one canonical positive NaN (sorts last), sorted per column by rocprim's
-// segmented radix sort, and one thread per column picks the order statistics by three
-// binary searches (first key >= 0, first key > 0, first NaN).
-// Most columns of a sparse matrix never get that far: when the middle ranks fall among the
-// zeros (fewer than half of the column's values positive, fewer than half negative) the
-// median is 0, which a counting pass over the values decides (median_count_kernel); only
-// the other columns keep a non-empty segment for the sort.
-// Roofline: HBM; algorithmic bytes = 8 per nonzero for the count pass, 8 + 8 for the key
-// copy, and 16 per sort pass for the columns that need one.
+// Device (round 5: no library sort): a counting pass (one wavefront per column) finds the
+// negatives, positives and NA/NaN among the stored values.  Most columns of a sparse matrix
+// are decided there: when the middle ranks fall among the zeros (fewer than half of the
+// column's values positive, fewer than half negative) the median is 0.  For the other
+// columns one workgroup per column SELECTS the one or two order statistics it needs from
+// the column where it lies -- a most-significant-digit-first radix select over the
+// order-preserving 64-bit image of the doubles (digits of 11, 11, 11, 11, 10, 10 bits: six
+// counting passes over the column with a histogram in LDS; the second middle value, when n
+// is even, costs one more pass: it is the same key again or the smallest key above it).
+// Nothing is copied and nothing is sorted (rounds 2-4: a key copy + rocprim's segmented
+// radix sort of 64-bit keys, eight read + write passes over the values).
+// Roofline: HBM; algorithmic bytes = 8 per nonzero for the count pass and up to 7 x 8 per
+// nonzero of an undecided column (short columns stay in the L2 between the passes).
 #include "svt_common.h"
 
 #include <string.h>
-#include <rocprim/rocprim.hpp>
-
-// Keys of the columns that need a sort (a wavefront per column; the others -- at BASELINE config 2
-// all of them -- return at once: copying every value cost 0.3 ms of a 0.55 ms colMedians there).
-template <typename T>
-__global__ void __launch_bounds__(256)
-median_key_kernel(const int64_t *__restrict__ col_ptr, const T *__restrict__ val, int64_t ncol,
-		  const int64_t *__restrict__ seg_b, const int64_t *__restrict__ seg_e,
-		  double *__restrict__ keys)
-{
-	const int lane = threadIdx.x & 63;
-	const int64_t j = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
-	if (j >= ncol || seg_e[j] == seg_b[j]) return;
-	const int64_t beg = col_ptr[j], end = col_ptr[j + 1];
-	for (int64_t k = beg + lane; k < end; k += 64) {
-		double d;
-		if (sizeof(T) == 8) {
-			d = (double) val[k];
-		} else {
-			const int v = (int) val[k];
-			d = v == NA_INT ? NAN : (double) v;
-		}
-		if (d != d) d = __longlong_as_double(0x7FF8000000000000LL);
-		keys[k] = d;
-	}
-}
 
 // One wavefront per column: negatives, positives, NA/NaN among the stored values.  Writes the
 // result where no order statistic of the nonzeros is needed (NA rule, empty column, both middle
-// ranks among the zeros) and gives every other column its sort segment [seg_b, seg_e).
+// ranks among the zeros); every other column gets todo[j] = 1 and its counts (cnt_neg, cnt_valid):
+// decided by median_select_kernel.
 template <typename T>
 __global__ void __launch_bounds__(256)
 median_count_kernel(const int64_t *__restrict__ col_ptr, const T *__restrict__ val, int64_t nrow,
 		    int64_t ncol, int na_rm, double *__restrict__ out,
-		    int64_t *__restrict__ seg_b, int64_t *__restrict__ seg_e)
+		    int64_t *__restrict__ cnt_neg, int64_t *__restrict__ cnt_pos, int64_t *__restrict__ cnt_nan,
+		    int *__restrict__ todo)
 {
 	const int lane = threadIdx.x & 63;
 	const int64_t j = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -87,59 +66,197 @@ median_count_kernel(const int64_t *__restrict__ col_ptr, const T *__restrict__ v
 	neg = __shfl(neg, 0, 64); pos = __shfl(pos, 0, 64); nan = __shfl(nan, 0, 64);
 	if (lane != 0) return;
 	const int64_t len = end - beg, v = len - nan, padding = nrow - len, n = v + padding;
-	int64_t b = beg, e = beg;                        // empty segment: nothing to sort
+	int undecided = 0;
 	if ((!na_rm && nan > 0) || n == 0) {
 		out[j] = svt_na_real();
 	} else {
 		const int64_t z = v - neg - pos + padding;   // stored + implicit zeros
 		const int64_t lo = (n - 1) >> 1, hi = n >> 1;
 		if (lo >= neg && hi < neg + z) out[j] = 0.0;
-		else { out[j] = -1.0; e = end; }             // decided by median_pick_kernel
+		else undecided = 1;                          // decided by median_select_kernel
 	}
-	seg_b[j] = b; seg_e[j] = e;
+	cnt_neg[j] = neg; cnt_pos[j] = pos; cnt_nan[j] = nan; todo[j] = undecided;
 }
 
-__global__ void median_pick_kernel(const int64_t *__restrict__ col_ptr, const double *__restrict__ keys,
-				   int64_t nrow, int64_t ncol, int na_rm, double *__restrict__ out,
-				   const int64_t *__restrict__ seg_e)
+// ---- radix select -----------------------------------------------------------------------------------
+#define MSEL_NT 256
+#define MSEL_BINS 2048
+
+template <typename T>
+__device__ inline bool msel_key(T raw, unsigned long long *key)
 {
-	const int64_t j = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-	if (j >= ncol) return;
-	const int64_t beg = col_ptr[j], end = col_ptr[j + 1];
-	if (seg_e[j] != end || end == beg) return;       // decided by the counting pass
-	const double *__restrict__ s = keys + beg;
-	const int64_t len = end - beg;
-	// first NaN, first key >= 0, first key > 0
-	int64_t lo = 0, hi = len;
-	while (lo < hi) { const int64_t m = (lo + hi) >> 1; if (s[m] == s[m]) lo = m + 1; else hi = m; }
-	const int64_t v = lo;                            // valid (non-NA) stored values
-	if ((!na_rm && v < len)) { out[j] = svt_na_real(); return; }
-	const int64_t padding = nrow - len;
-	const int64_t n = v + padding;
-	if (n == 0) { out[j] = svt_na_real(); return; }
-	lo = 0; hi = v;
-	while (lo < hi) { const int64_t m = (lo + hi) >> 1; if (s[m] < 0.0) lo = m + 1; else hi = m; }
-	const int64_t a = lo;                            // negatives
-	hi = v;
-	while (lo < hi) { const int64_t m = (lo + hi) >> 1; if (s[m] <= 0.0) lo = m + 1; else hi = m; }
-	const int64_t z0 = lo - a, z = z0 + padding;     // stored zeros (not expected), all zeros
-	auto elem = [&](int64_t r) -> double {
-		if (r < a) return s[r];
-		if (r < a + z) return 0.0;
-		return s[a + z0 + (r - a - z)];
-	};
-	if (n & 1) out[j] = elem((n - 1) >> 1);
-	else out[j] = (elem((n >> 1) - 1) + elem(n >> 1)) * 0.5;     // (:707 mean of the two, :757)
+	double d;
+	if (sizeof(T) == 8) d = (double) raw;
+	else { const int v = (int) raw; d = v == NA_INT ? NAN : (double) v; }
+	if (d != d || d == 0.0)
+		return false;                            // NA / NaN, and a stored zero (it counts among the zeros)
+	*key = f64_to_ordered(d);
+	return true;
+}
+
+// Block-wide exclusive prefix of one count per thread (MSEL_NT threads); returns the thread's prefix, *total
+// = the sum.  wsum: 4 words of LDS.
+__device__ inline unsigned msel_block_scan(unsigned x, unsigned *wsum, unsigned *total)
+{
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	unsigned incl = x;
+	for (int o = 1; o < 64; o <<= 1) {
+		const unsigned t = __shfl_up(incl, o, 64);
+		if (lane >= o) incl += t;
+	}
+	if (lane == 63) wsum[w] = incl;
+	__syncthreads();
+	unsigned before = 0, all = 0;
+	for (int i = 0; i < MSEL_NT / 64; i++) {
+		const unsigned t = wsum[i];
+		if (i < w) before += t;
+		all += t;
+	}
+	__syncthreads();
+	*total = all;
+	return before + incl - x;
+}
+
+// The key of rank k (0-based, ascending) among the NONZERO, non-NA values of val[beg, end): six counting passes,
+// most significant digit first.  Called by all MSEL_NT threads of the workgroup with the same arguments.
+template <typename T>
+__device__ unsigned long long msel_select(const T *__restrict__ val, int64_t beg, int64_t end, unsigned k,
+					  unsigned *hist, unsigned *wsum, unsigned *found)
+{
+	unsigned long long prefix = 0;
+	int shift = 64;
+	for (int pass = 0; pass < 6; pass++) {
+		const int w = pass < 4 ? 11 : 10;
+		const int hi_shift = shift;              // bits [hi_shift, 64) of the key are fixed by `prefix`
+		shift -= w;
+		const unsigned nb = 1u << w, mask = nb - 1;
+		for (unsigned i = threadIdx.x; i < nb; i += MSEL_NT) hist[i] = 0;
+		__syncthreads();
+		// (four loads per thread in flight: a long column is walked by ONE workgroup)
+		for (int64_t i0 = beg; i0 < end; i0 += 4 * MSEL_NT) {
+			T raw[4];
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				const int64_t i = i0 + u * MSEL_NT + threadIdx.x;
+				raw[u] = i < end ? val[i] : (T) 0;       // (a zero is skipped by msel_key)
+			}
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				unsigned long long key;
+				if (!msel_key<T>(raw[u], &key))
+					continue;
+				if (pass == 0 || (key >> hi_shift) == (prefix >> hi_shift))
+					atomicAdd(&hist[(unsigned) (key >> shift) & mask], 1u);
+			}
+		}
+		__syncthreads();
+		// the digit whose bin holds rank k: a thread owns nb / MSEL_NT consecutive bins
+		const unsigned per = nb / MSEL_NT, b0 = threadIdx.x * per;
+		unsigned mine = 0;
+		for (unsigned i = 0; i < per; i++) mine += hist[b0 + i];
+		unsigned total;
+		const unsigned before = msel_block_scan(mine, wsum, &total);
+		if (k >= before && k < before + mine) {
+			unsigned run = before;
+			for (unsigned i = 0; i < per; i++) {
+				const unsigned c = hist[b0 + i];
+				if (k < run + c) { found[0] = b0 + i; found[1] = run; break; }
+				run += c;
+			}
+		}
+		__syncthreads();
+		prefix |= (unsigned long long) found[0] << shift;
+		k -= found[1];
+		__syncthreads();
+	}
+	return prefix;
+}
+
+// One workgroup per undecided column (grid-stride over the columns): the virtual sorted column is
+// [negatives | z zeros | positives]; rank r < neg is the r-th smallest stored value, rank r >= neg + z the
+// (r - z)-th smallest NONZERO stored value.
+template <typename T>
+__global__ void __launch_bounds__(MSEL_NT)
+median_select_kernel(const int64_t *__restrict__ col_ptr, const T *__restrict__ val, int64_t nrow, int64_t ncol,
+		     const int64_t *__restrict__ cnt_neg, const int64_t *__restrict__ cnt_pos,
+		     const int64_t *__restrict__ cnt_nan, const int *__restrict__ todo, double *__restrict__ out)
+{
+	__shared__ unsigned hist[MSEL_BINS];
+	__shared__ unsigned wsum[MSEL_NT / 64];
+	__shared__ unsigned found[2];
+	__shared__ unsigned long long red[2 * (MSEL_NT / 64)];
+	for (int64_t j = blockIdx.x; j < ncol; j += gridDim.x) {
+		if (!todo[j])
+			continue;                                // (the same answer in every thread)
+		const int64_t beg = col_ptr[j], end = col_ptr[j + 1];
+		const int64_t neg = cnt_neg[j], pos = cnt_pos[j];
+		const int64_t nz = neg + pos;                    // nonzero, non-NA stored values
+		// (columns holding NA / NaN come here only under na.rm: those entries are dropped, the padding keeps its size)
+		const int64_t len = end - beg, nan = cnt_nan[j];
+		const int64_t zeros = (nrow - len) + (len - nan - nz);   // implicit zeros + stored zeros
+		const int64_t n = nz + zeros;
+		const int64_t lo = (n - 1) >> 1, hi = n >> 1;
+		// rank in the virtual column -> rank among the nonzero stored values, or -1 for "a zero"
+		const int64_t klo = lo < neg ? lo : lo < neg + zeros ? -1 : lo - zeros;
+		const int64_t khi = hi < neg ? hi : hi < neg + zeros ? -1 : hi - zeros;
+		double vlo = 0.0, vhi = 0.0;
+		unsigned long long key_lo = 0;
+		if (klo >= 0) {
+			key_lo = msel_select<T>(val, beg, end, (unsigned) klo, hist, wsum, found);
+			vlo = ordered_to_f64(key_lo);
+		}
+		if (khi < 0) {
+			vhi = 0.0;
+		} else if (khi == klo) {
+			vhi = vlo;
+		} else if (klo >= 0) {
+			// khi == klo + 1: the same key again if ranks <= klo + 1 are all covered by keys <= key_lo, else the
+			// smallest key above it.  One pass: count of keys <= key_lo, minimum of the keys > key_lo.
+			unsigned long long cnt = 0, nxt = ~0ull;
+			for (int64_t i0 = beg; i0 < end; i0 += 4 * MSEL_NT) {
+				T raw[4];
+#pragma unroll
+				for (int u = 0; u < 4; u++) {
+					const int64_t i = i0 + u * MSEL_NT + threadIdx.x;
+					raw[u] = i < end ? val[i] : (T) 0;
+				}
+#pragma unroll
+				for (int u = 0; u < 4; u++) {
+					unsigned long long key;
+					if (!msel_key<T>(raw[u], &key))
+						continue;
+					if (key <= key_lo) cnt++;
+					else if (key < nxt) nxt = key;
+				}
+			}
+			const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+			for (int o = 32; o > 0; o >>= 1) {
+				cnt += __shfl_down(cnt, o, 64);
+				const unsigned long long t = __shfl_down(nxt, o, 64);
+				nxt = t < nxt ? t : nxt;
+			}
+			if (lane == 0) { red[w] = cnt; red[MSEL_NT / 64 + w] = nxt; }
+			__syncthreads();
+			cnt = 0; nxt = ~0ull;
+			for (int i = 0; i < MSEL_NT / 64; i++) {
+				cnt += red[i];
+				nxt = red[MSEL_NT / 64 + i] < nxt ? red[MSEL_NT / 64 + i] : nxt;
+			}
+			__syncthreads();
+			vhi = (int64_t) cnt > khi ? vlo : ordered_to_f64(nxt);
+		} else {
+			vhi = ordered_to_f64(msel_select<T>(val, beg, end, (unsigned) khi, hist, wsum, found));
+		}
+		if (threadIdx.x == 0)
+			out[j] = (n & 1) ? vlo : (vlo + vhi) * 0.5;          // (:707 mean of the two, :757)
+	}
 }
 
 size_t colmedians_ws_bytes(int64_t nnz, int64_t ncol)
 {
-	size_t tmp = 0;
-	const int64_t n = nnz > 0 ? nnz : 1;
-	(void) rocprim::segmented_radix_sort_keys(NULL, tmp, (const double *) NULL, (double *) NULL,
-						  (unsigned int) n, (unsigned int) (ncol > 0 ? ncol : 1),
-						  (const int64_t *) NULL, (const int64_t *) NULL);
-	return (size_t) n * 16 + tmp + (size_t) (ncol > 0 ? ncol : 1) * 16 + 1024;
+	(void) nnz;
+	// [negatives per column][positives per column][NA / NaN per column][undecided flag per column]
+	return (size_t) (ncol > 0 ? ncol : 1) * 28 + 1024;
 }
 
 int launch_colmedians(const int64_t *col_ptr, const void *val, int Rtype, int64_t nrow, int64_t ncol,
@@ -149,36 +266,25 @@ int launch_colmedians(const int64_t *col_ptr, const void *val, int Rtype, int64_
 		return 0;
 	if (nnz > 0x7FFFFFFFLL || ncol > 0x7FFFFFFFLL)
 		return svt_set_error("colMedians: more than 2^31-1 nonzeros or columns");
-	double *k_in = (double *) ws;
-	double *k_out = k_in + (nnz > 0 ? nnz : 1);
-	int64_t *seg_b = (int64_t *) (((uintptr_t) (k_out + (nnz > 0 ? nnz : 1)) + 255) & ~(uintptr_t) 255);
-	int64_t *seg_e = seg_b + ncol;
-	void *tmp = (void *) (((uintptr_t) (seg_e + ncol) + 255) & ~(uintptr_t) 255);
-	{
-		const unsigned nbc = (unsigned) ((ncol + 3) / 4);
-		if (Rtype == SVT_REALSXP)
-			hipLaunchKernelGGL(median_count_kernel<double>, dim3(nbc), dim3(256), 0, s, col_ptr,
-					   (const double *) val, nrow, ncol, na_rm, out, seg_b, seg_e);
-		else
-			hipLaunchKernelGGL(median_count_kernel<int>, dim3(nbc), dim3(256), 0, s, col_ptr,
-					   (const int *) val, nrow, ncol, na_rm, out, seg_b, seg_e);
+	int64_t *cnt_neg = (int64_t *) (((uintptr_t) ws + 255) & ~(uintptr_t) 255);
+	int64_t *cnt_pos = cnt_neg + ncol, *cnt_nan = cnt_pos + ncol;
+	int *todo = (int *) (cnt_nan + ncol);
+	const unsigned nbc = (unsigned) ((ncol + 3) / 4);
+	// the undecided columns, one workgroup each, a few rounds of them in flight
+	const unsigned nbs = (unsigned) (ncol < 4096 ? ncol : 4096);
+	if (Rtype == SVT_REALSXP) {
+		hipLaunchKernelGGL(median_count_kernel<double>, dim3(nbc), dim3(256), 0, s, col_ptr,
+				   (const double *) val, nrow, ncol, na_rm, out, cnt_neg, cnt_pos, cnt_nan, todo);
+		if (nnz > 0)
+			hipLaunchKernelGGL(median_select_kernel<double>, dim3(nbs), dim3(MSEL_NT), 0, s, col_ptr,
+					   (const double *) val, nrow, ncol, cnt_neg, cnt_pos, cnt_nan, todo, out);
+	} else {
+		hipLaunchKernelGGL(median_count_kernel<int>, dim3(nbc), dim3(256), 0, s, col_ptr,
+				   (const int *) val, nrow, ncol, na_rm, out, cnt_neg, cnt_pos, cnt_nan, todo);
+		if (nnz > 0)
+			hipLaunchKernelGGL(median_select_kernel<int>, dim3(nbs), dim3(MSEL_NT), 0, s, col_ptr,
+					   (const int *) val, nrow, ncol, cnt_neg, cnt_pos, cnt_nan, todo, out);
 	}
-	if (nnz > 0) {
-		const unsigned nb = (unsigned) ((ncol + 3) / 4);
-		if (Rtype == SVT_REALSXP)
-			hipLaunchKernelGGL(median_key_kernel<double>, dim3(nb), dim3(256), 0, s, col_ptr, (const double *) val,
-					   ncol, seg_b, seg_e, k_in);
-		else
-			hipLaunchKernelGGL(median_key_kernel<int>, dim3(nb), dim3(256), 0, s, col_ptr, (const int *) val,
-					   ncol, seg_b, seg_e, k_in);
-		size_t tmp_bytes = 0;
-		HIP_TRY(rocprim::segmented_radix_sort_keys(NULL, tmp_bytes, k_in, k_out, (unsigned int) nnz, (unsigned int) ncol,
-							   seg_b, seg_e));
-		HIP_TRY(rocprim::segmented_radix_sort_keys(tmp, tmp_bytes, k_in, k_out, (unsigned int) nnz, (unsigned int) ncol,
-							   seg_b, seg_e, 0u, 64u, s));
-	}
-	hipLaunchKernelGGL(median_pick_kernel, dim3((unsigned) ((ncol + 255) / 256)), dim3(256), 0, s,
-			   col_ptr, k_out, nrow, ncol, na_rm, out, seg_e);
 	HIP_TRY(hipGetLastError());
 	return 0;
 }

@@ -65,10 +65,9 @@ struct svt_dev_pbc {
 	int64_t *tile_ptr;     // [ngroups*npanels + 1]
 	int *col_has_na;       // [ncol]
 	int64_t max_leaf_nnz;  // the longest leaf (a dense column with more non-finite entries than that makes every cell NaN / NA)
-	// streams that have read the layout, each with an event behind its last product: svt_dev_pbc_release()
-	// frees behind those events instead of synchronising the device (a handle is used from one host thread)
+	// streams that have read the layout: svt_dev_pbc_release() records an event on each and frees behind
+	// those events instead of synchronising the device (a handle is used from one host thread)
 	mutable hipStream_t use_s[4];
-	mutable hipEvent_t use_ev[4];
 	mutable int nuse;
 	mutable bool use_overflow;  // more than 4 streams: release falls back to hipDeviceSynchronize()
 	int device;
@@ -576,34 +575,39 @@ extern "C" void svt_dev_pbc_trim(void)
 			(void) hipMemPoolTrimTo(g_pbc_pool[d], 0);
 }
 
+// A product notes its stream here (host side only: an event record per product put a barrier packet behind every
+// phase -- two 5.6 us bubbles per step, 4 % of the step at an eighth of the rows of config 2a,
+// profiles/r05_share_trace.txt); the events are recorded when the handle is released.
 static void pbc_note_use(const svt_dev_pbc *P, hipStream_t s)
 {
-	int slot = -1;
 	for (int i = 0; i < P->nuse; i++)
-		if (P->use_s[i] == s) slot = i;
-	if (slot < 0) {
-		if (P->nuse == 4) { P->use_overflow = true; return; }
-		hipEvent_t ev;
-		if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { P->use_overflow = true; return; }
-		slot = P->nuse++;
-		P->use_s[slot] = s;
-		P->use_ev[slot] = ev;
-	}
-	(void) hipEventRecord(P->use_ev[slot], s);
+		if (P->use_s[i] == s) return;
+	if (P->nuse == 4) { P->use_overflow = true; return; }
+	P->use_s[P->nuse++] = s;
 }
 
 extern "C" void svt_dev_pbc_release(svt_dev_pbc *h)
 {
 	if (h == NULL) return;
 	// products on other streams may still be reading the layout: the frees (stream 0, stream-ordered) go
-	// behind the event each such stream recorded after its last product -- no device-wide synchronisation,
-	// which would also stall a collective or a peer copy in flight when a plan is dropped
-	if (h->use_overflow)
-		(void) hipDeviceSynchronize();
-	for (int i = 0; i < h->nuse; i++) {
-		(void) hipStreamWaitEvent(0, h->use_ev[i], 0);
-		(void) hipEventDestroy(h->use_ev[i]);
+	// behind an event recorded NOW on every stream that has run a product with this handle (it covers all
+	// the work that stream has been given so far) -- no device-wide synchronisation, which would also stall
+	// a collective or a peer copy in flight when a plan is dropped.  A stream that no longer exists has
+	// finished its work; the runtime refuses the record and the device is synchronised instead.
+	bool sync = h->use_overflow;
+	for (int i = 0; i < h->nuse && !sync; i++) {
+		if (h->use_s[i] == (hipStream_t) 0)
+			continue;                                // the frees are ordered on stream 0 themselves
+		hipEvent_t ev;
+		if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { sync = true; break; }
+		if (hipEventRecord(ev, h->use_s[i]) != hipSuccess || hipStreamWaitEvent(0, ev, 0) != hipSuccess) {
+			(void) hipGetLastError();
+			sync = true;
+		}
+		(void) hipEventDestroy(ev);
 	}
+	if (sync)
+		(void) hipDeviceSynchronize();
 	pbc_free(h->rec);
 	pbc_free(h->tile_ptr);
 	pbc_free(h->col_has_na);
@@ -1545,7 +1549,7 @@ crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restric
 			 int64_t npanels, const double *__restrict__ Y, int64_t ldY, int64_t nrow,
 			 int K, int64_t ncol, int CBW, int nfull, int nblocks, int block0,
 			 int64_t panels_per_split, double *__restrict__ part, int64_t Kp,
-			 PbcFlags fl, int rt_lines, int rt_ahead, int stag_mode)
+			 PbcFlags fl, int rt_lines, int rt_ahead, int stag_mode, int64_t part_ld, int64_t part_c0)
 {
 	extern __shared__ double ylds[];            // 2 buffers x [64][129]
 	const int tid = threadIdx.x;
@@ -1769,9 +1773,13 @@ crossprod_pbc_dma_kernel(const uint4 *__restrict__ rec, const int64_t *__restric
 		{       // wavefront w stores row w of the 16: one contiguous run, 16 bytes per lane where the row
 			// is aligned (the epilogue took 35k cycles per workgroup with 8-byte stores and an integer
 			// division per element: a tenth of a 79-panel workgroup of A %*% Y)
-			double *__restrict__ dstrow = part + ((int64_t) split * Kp + k0 + q * 16 + w) * ncol + cwg0;
+			// (part_ld / part_c0: the partials of a launch that covers only the column blocks from part_c0 on are
+			// kept in a buffer of part_ld columns per row -- the row-split last round of A %*% Y)
+			double *__restrict__ dstrow = part + ((int64_t) split * Kp + k0 + q * 16 + w) * part_ld + (cwg0 - part_c0);
 			const double *__restrict__ src = ylds + w * LS;
 			if ((((uintptr_t) dstrow) & 15) == 0) {
+				// (non-temporal stores here were measured in round 5: the kernel that sums the partials reads them
+				// back slower, 16.6 -> 22.5 us at an eighth of the rows of config 2a, the product kernel gains nothing)
 				for (int cc = lane2 * 2; cc < nvalid; cc += 128) {
 					if (cc + 1 < nvalid) *(double2 *) (dstrow + cc) = *(const double2 *) (src + cc);
 					else dstrow[cc] = src[cc];
@@ -2130,7 +2138,8 @@ static int64_t pbc_padded_rows(const svt_dev_pbc *P)
 // panels: dsync 0: 5.69 ms, 1: 4.77, 2: 4.73, 3: 4.80, no pacing at all: 7.9; with the L2 touch of the
 // record stream 1: 4.31, 2: 4.43; spin 16: 6.7 -- a wavefront that gives up never paces itself again.)
 static int g_pbgx_dsync = 1, g_pbgx_spin = 256;
-static int g_pbc_rounds = 1;        // 0: one launch whatever the number of column blocks (svt_dev_pbc_set_round_launches)
+static int g_pbc_rounds = 1;        // 0: one launch whatever the number of column blocks; 1: one launch per round of workgroups, the
+                                    // last (partly filled) round cut by rows; 2: per round, last round whole (svt_dev_pbc_set_round_launches)
 extern "C" void svt_dev_pbc_set_round_launches(int on) { g_pbc_rounds = on; }
 extern "C" void svt_dev_pbc_set_gather_pacing(int dsync, int spin)
 {
@@ -2290,8 +2299,10 @@ static void launch_main(const svt_dev_pbc *P, const double *Y, int64_t ldY, int 
 
 template <int NV>
 static void launch_dma(const svt_dev_pbc *P, const double *Y, int64_t ldY, int K, int nsplit,
-		       int64_t pps, double *part, int64_t Kp, PbcFlags fl, hipStream_t s, int block0, int nb_launch = 0)
+		       int64_t pps, double *part, int64_t Kp, PbcFlags fl, hipStream_t s, int block0, int nb_launch = 0,
+		       int64_t part_ld = -1, int64_t part_c0 = 0)
 {
+	if (part_ld < 0) part_ld = P->ncol;
 	const size_t lds = (size_t) 2 * PBC_DMA_BUF;
 	const int kt = (int) (Kp / 64);
 	// L2 touches of the record stream: ~1.5 tiles' worth of 128-byte lines
@@ -2314,13 +2325,51 @@ static void launch_dma(const svt_dev_pbc *P, const double *Y, int64_t ldY, int K
 	int nb = (int) P->nblocks - block0;
 	if (nb_launch > 0 && nb_launch < nb) nb = nb_launch;
 	// with CUs kept free: 8 x per_xcd workgroups, packed XCD by XCD (see the kernel's decode)
-	const bool sparing = pbc_sparing(P, K);
+	const bool sparing = pbc_sparing(P, K) && part_c0 == 0 && part_ld == P->ncol;
 	const int per_xcd = (256 - g_pbc_spare_cus) / 8;
 	const int nfull = sparing ? -per_xcd : nsplit & ~7;
 	const int64_t nwg = sparing ? (int64_t) 8 * per_xcd : (int64_t) nsplit * kt * nb;
 	hipLaunchKernelGGL(kern, dim3((unsigned) nwg), dim3(1024), lds, s,
 			   P->rec, P->tile_ptr, P->npanels, Y, ldY, P->nrow, K, P->ncol, P->CBW, nfull,
-			   nb, block0, pps, part, Kp, fl, rt_lines, rt_ahead, g_pbc_stagger);
+			   nb, block0, pps, part, Kp, fl, rt_lines, rt_ahead, g_pbc_stagger, part_ld, part_c0);
+}
+
+// out[k][c0 + c] = sum over the row splits of tail[(t * Kp + k) * ld + c], in split order (the row-split last round of a
+// product without row splits: launch code below); leaves holding an R NA are patched by pbc_nafix_kernel afterwards
+__global__ void __launch_bounds__(256)
+pbc_tail_reduce_kernel(const double *__restrict__ tail, int nsplit, int64_t Kp, int K, int64_t ld, int64_t ncols,
+		       double *__restrict__ out, int64_t out_ld, int64_t c0)
+{
+	const int64_t c = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) * 2;
+	const int k = blockIdx.y;
+	if (c >= ncols || k >= K)
+		return;
+	// (ld and c0 are multiples of 16 * CBW = even, rows of `out` start 16-byte aligned when out_ld is even)
+	if (c + 1 < ncols && ((out_ld | c0) & 1) == 0 && (((uintptr_t) out) & 15) == 0 && (((uintptr_t) tail) & 15) == 0) {
+		double2 a = make_double2(0.0, 0.0);
+		for (int t = 0; t < nsplit; t++) {
+			const double2 v = *(const double2 *) (tail + ((int64_t) t * Kp + k) * ld + c);
+			a.x += v.x; a.y += v.y;
+		}
+		*(double2 *) (out + (int64_t) k * out_ld + c0 + c) = a;
+		return;
+	}
+	for (int64_t cc = c; cc < c + 2 && cc < ncols; cc++) {
+		double a = 0.0;
+		for (int t = 0; t < nsplit; t++) a += tail[((int64_t) t * Kp + k) * ld + cc];
+		out[(int64_t) k * out_ld + c0 + cc] = a;
+	}
+}
+
+// three word ranges to zero (a NULL range is skipped)
+__global__ void __launch_bounds__(256)
+pbc_clear_kernel(uint32_t *__restrict__ a, int na, uint32_t *__restrict__ b, int nb, uint32_t *__restrict__ c, int nc)
+{
+	for (int i = threadIdx.x; i < na; i += blockDim.x) a[i] = 0u;
+	if (b != NULL)
+		for (int i = threadIdx.x; i < nb; i += blockDim.x) b[i] = 0u;
+	if (c != NULL)
+		for (int i = threadIdx.x; i < nc; i += blockDim.x) c[i] = 0u;
 }
 
 int launch_crossprod_general_if(const CrossprodArgs &a, const int *flag, bool counters_cleared, hipStream_t s);
@@ -2387,11 +2436,16 @@ static int pbc_phase_impl(const svt_dev_pbc *P, const svt_dev_csc *A,
 	const bool direct = nsplit == 1 && Kp == K && out_stride_c == 1 && out_stride_k == P->ncol;
 	if (direct) part = out;
 	if (phase == 1) {
-		if ((char *) dw.col_nf == (char *) ws + 256) {
-			HIP_TRY(hipMemsetAsync(ws, 0, 256 + (size_t) Kp * 8, s));
-		} else {
-			HIP_TRY(hipMemsetAsync(ws, 0, 256, s));
-			HIP_TRY(hipMemsetAsync(dw.col_nf, 0, (size_t) Kp * 8, s));
+		// flags, the per-column counters and (paced gather kernel) the progress words: ONE small kernel.  A
+		// hipMemsetAsync() between two kernels costs a step 5 us of blit kernel plus a 5-6 us bubble in front of it
+		// (profiles/r05_share_trace.txt: the runtime orders its blit kernels behind a barrier packet) -- 4 % of the
+		// step at an eighth of the rows of config 2a
+		{
+			const bool paced = gath && P->rec != NULL && pbgx_ok(P, K);
+			hipLaunchKernelGGL(pbc_clear_kernel, dim3(1), dim3(256), 0, s,
+					   (uint32_t *) ws, 64, (uint32_t *) dw.col_nf, (int) (Kp * 2),
+					   paced ? (uint32_t *) ((char *) ws + PBC_PROG_OFFSET) : (uint32_t *) NULL,
+					   8 * PBGX_PROG_ENTRIES);
 		}
 		if (P->rec == NULL) {
 			// no nonzero at all (no record stream was built): the general kernels
@@ -2411,8 +2465,7 @@ static int pbc_phase_impl(const svt_dev_pbc *P, const svt_dev_csc *A,
 				return -1;
 			if (pbgx_ok(P, K)) {
 				// persistent grid, one row range per XCD, paced (see crossprod_pbc_gatherx_kernel)
-				unsigned int *prog = (unsigned int *) ((char *) ws + PBC_PROG_OFFSET);
-				HIP_TRY(hipMemsetAsync(prog, 0, 8 * PBGX_PROG_ENTRIES * 4, s));
+				unsigned int *prog = (unsigned int *) ((char *) ws + PBC_PROG_OFFSET);     // (cleared with the flags)
 				int nslots = (pbc_cus() - g_pbc_spare_cus) / 8 * 2;
 				if (nslots > PBGX_PROG_ENTRIES / 4) nslots = PBGX_PROG_ENTRIES / 4;
 				if (nslots < 2) nslots = 2;
@@ -2471,10 +2524,44 @@ static int pbc_phase_impl(const svt_dev_pbc *P, const svt_dev_csc *A,
 			if (nsplit == 1 && !pbc_sparing(P, K) && g_pbc_rounds != 0 &&
 			    (int64_t) (P->nblocks - block0) * kt_ >= 2 * pbc_cus())
 				per_launch = pbc_cus() / kt_ > 0 ? pbc_cus() / kt_ : 1;
-			for (int b0 = block0; b0 < (int) P->nblocks; b0 += per_launch > 0 ? per_launch : (int) P->nblocks) {
-				if (nv == 1) launch_dma<1>(P, Yc, ldc, K, nsplit, pps, part, Kp, fl, s, b0, per_launch);
-				else if (nv == 2) launch_dma<2>(P, Yc, ldc, K, nsplit, pps, part, Kp, fl, s, b0, per_launch);
-				else launch_dma<3>(P, Yc, ldc, K, nsplit, pps, part, Kp, fl, s, b0, per_launch);
+			// The last round: `rem` column blocks (54 of 256 CUs busy at config 2b) are cut by rows so that they fill
+			// the chip -- ts row splits of a quarter of the panels each instead of one more full round; their partial
+			// sums go to the (unused: the product writes `out` directly) partials area of the workspace and are summed in
+			// split order behind them.  12.2 rounds then cost 12 + 1 / ts instead of 13.
+			int tail_blocks = 0, ts = 1;
+			int64_t tpps = pps;
+			if (per_launch > 0 && direct && g_pbc_rounds == 1) {
+				const int rem = (int) ((P->nblocks - block0) % per_launch);
+				if (rem > 0 && rem * kt_ * 2 <= pbc_cus()) {
+					ts = pbc_cus() / (rem * kt_);
+					if (ts > 8) ts = 8;
+					while (ts > 1 && P->npanels / ts < 8) ts--;
+					tpps = (P->npanels + ts - 1) / ts;
+					ts = (int) ((P->npanels + tpps - 1) / tpps);
+					const int64_t tcols = (int64_t) rem * 16 * P->CBW;
+					if (ts > 1 && (int64_t) ts * tcols <= P->ncol)      // (fits the partials area: Kp * ncol doubles)
+						tail_blocks = rem;
+				}
+			}
+			const int last_full = (int) P->nblocks - tail_blocks;
+			for (int b0 = block0; b0 < last_full; b0 += per_launch > 0 ? per_launch : (int) P->nblocks) {
+				const int nbl = per_launch > 0 ? (b0 + per_launch <= last_full ? per_launch : last_full - b0)
+							       : tail_blocks > 0 ? last_full - b0 : 0;
+				if (nv == 1) launch_dma<1>(P, Yc, ldc, K, nsplit, pps, part, Kp, fl, s, b0, nbl);
+				else if (nv == 2) launch_dma<2>(P, Yc, ldc, K, nsplit, pps, part, Kp, fl, s, b0, nbl);
+				else launch_dma<3>(P, Yc, ldc, K, nsplit, pps, part, Kp, fl, s, b0, nbl);
+			}
+			if (tail_blocks > 0) {
+				double *tail = (double *) ((char *) ws + PBC_FLAG_BYTES);
+				const int64_t c0 = (int64_t) last_full * 16 * P->CBW;
+				const int64_t tld = (int64_t) tail_blocks * 16 * P->CBW;
+				const int64_t tcols = P->ncol - c0;                  // (the last block may be short)
+				if (nv == 1) launch_dma<1>(P, Yc, ldc, K, ts, tpps, tail, Kp, fl, s, last_full, tail_blocks, tld, c0);
+				else if (nv == 2) launch_dma<2>(P, Yc, ldc, K, ts, tpps, tail, Kp, fl, s, last_full, tail_blocks, tld, c0);
+				else launch_dma<3>(P, Yc, ldc, K, ts, tpps, tail, Kp, fl, s, last_full, tail_blocks, tld, c0);
+				dim3 tg((unsigned) ((tcols + 511) / 512), (unsigned) K);
+				hipLaunchKernelGGL(pbc_tail_reduce_kernel, tg, dim3(256), 0, s, tail, ts, Kp, K, tld, tcols,
+						   out, P->ncol, c0);
 			}
 			HIP_TRY(hipGetLastError());
 			return 0;

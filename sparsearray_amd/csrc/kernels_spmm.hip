@@ -120,17 +120,23 @@ static void spmm_scan_values(const void *val, int Rtype, int64_t n, int *flag, h
 
 template <typename TA, typename TB>
 __global__ void __launch_bounds__(SPMM_NT)
-spmm_csc_csc_kernel(SpmmArgs a, int KW, int G)
+spmm_csc_csc_kernel(SpmmArgs a, int KW, int G, int nkb, int order)
 {
 	extern __shared__ double acc[];                 // [KW][P]
 	const int tid = threadIdx.x;
 	const int P = 1 << a.ps;
-	const int64_t q = blockIdx.x, r0 = q << a.ps;
-	const int64_t k0 = (int64_t) blockIdx.y * KW;
+	// 1-D grid of npan x nkb workgroups (nkb = blocks of KW result columns).  order 0 (the product's): panels fastest.
+	// order 1: the column blocks of a panel are neighbours in launch order -- the workgroups in flight then cover a few
+	// panels of A for ALL columns of B, so that the runs of A several columns of B name (1.28 reads per nonzero of A at
+	// config 3) could come from the caches: measured in round 5, no gain (0.608 against 0.599 ms prepared; tuning knob)
+	const int64_t L = blockIdx.x;
+	const int64_t q = order ? L / nkb : L % a.npan, kb = order ? L % nkb : L / a.npan;
+	const int64_t r0 = q << a.ps;
+	const int64_t k0 = kb * KW;
 	const int kw = (int) (a.K - k0 < KW ? a.K - k0 : KW);
 	const int np = (int) (a.nrow - r0 < P ? a.nrow - r0 : P);
 	const int NT = blockDim.x;
-	for (int x = tid; x < kw * P; x += NT) acc[x] = 0.0;
+	for (int x = tid * 2; x < kw * P; x += NT * 2) *(double2 *) (acc + x) = make_double2(0.0, 0.0);   // (P is even)
 	// the pairs of the workgroup's columns, flattened: pair t belongs to column kk with pre[kk] <= t < pre[kk + 1]
 	__shared__ int64_t bbeg[17];
 	__shared__ int32_t pre[17];
@@ -212,7 +218,19 @@ spmm_csc_csc_kernel(SpmmArgs a, int KW, int G)
 	__syncthreads();
 	for (int kk = 0; kk < kw; kk++) {
 		double *__restrict__ dst = a.out + (k0 + kk) * a.ldo + r0;
-		for (int x = tid; x < np; x += NT) dst[x] = acc[kk * P + x];
+		if ((((uintptr_t) dst) & 15) == 0) {
+			// the result is written once and not read again by this launch: 16-byte non-temporal stores, so that the
+			// 1 GB of it does not push A's runs out of the caches
+			typedef double d2 __attribute__((ext_vector_type(2)));
+			for (int x = tid * 2; x < np; x += NT * 2) {
+				if (x + 1 < np) {
+					const d2 v = *(const d2 *) (acc + kk * P + x);
+					__builtin_nontemporal_store(v, (d2 *) (dst + x));
+				} else
+					dst[x] = acc[kk * P + x];
+			}
+		} else
+			for (int x = tid; x < np; x += NT) dst[x] = acc[kk * P + x];
 	}
 }
 
@@ -292,12 +310,20 @@ int launch_spmm_product(SpmmArgs a, int64_t a_nnz, int64_t b_nnz, const void *ws
 		while (G > 8 && run < 2.0 * G) G >>= 1;
 	}
 	const size_t lds = (size_t) KW * P * 8;
-	dim3 grid((unsigned) npan, (unsigned) ((a.K + KW - 1) / KW));
-	if (grid.y > 65535)
-		return svt_set_error("sparse x sparse product: too many columns for one launch");
+	const int64_t nkb = (a.K + KW - 1) / KW;
+	if (npan * nkb >= (int64_t) 2147483647)
+		return svt_set_error("sparse x sparse product: too many workgroups for one launch");
+	dim3 grid((unsigned) (npan * nkb));
+	static int order = -1;
+	if (order < 0) {
+		order = 0;
+#ifdef SVT_TUNING
+		if (getenv("SVT_SPMM_ORDER")) order = atoi(getenv("SVT_SPMM_ORDER")) != 0;
+#endif
+	}
 #define SPMM_GO(TA, TB) do { \
 		(void) hipFuncSetAttribute((const void *) spmm_csc_csc_kernel<TA, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); \
-		hipLaunchKernelGGL((spmm_csc_csc_kernel<TA, TB>), grid, dim3(g_spmm_nt), lds, s, a, KW, G); } while (0)
+		hipLaunchKernelGGL((spmm_csc_csc_kernel<TA, TB>), grid, dim3(g_spmm_nt), lds, s, a, KW, G, (int) nkb, order); } while (0)
 	if (a.a_type == SVT_REALSXP && a.b_type == SVT_REALSXP) SPMM_GO(double, double);
 	else if (a.a_type == SVT_INTSXP && a.b_type == SVT_INTSXP) SPMM_GO(int, int);
 	else if (a.a_type == SVT_REALSXP && a.b_type == SVT_INTSXP) SPMM_GO(double, int);

@@ -249,10 +249,12 @@ def set_gather_pacing(dsync: int = 1, spin: int = 256) -> None:
     _lib().svt_dev_pbc_set_gather_pacing(int(dsync), int(spin))
 
 
-def set_round_launches(on: bool = True) -> None:
-    """One launch per round of workgroups for products with many column blocks (svt_dev_pbc_set_round_launches)."""
+def set_round_launches(on=True) -> None:
+    """One launch per round of workgroups for products with many column blocks (svt_dev_pbc_set_round_launches):
+    False / 0 = one launch, True / 1 = per round with the partly filled last round cut by rows (default), 2 = per
+    round with the last round whole."""
     _lib().svt_dev_pbc_set_round_launches.restype = None
-    _lib().svt_dev_pbc_set_round_launches(int(bool(on)))
+    _lib().svt_dev_pbc_set_round_launches(int(on))
 
 
 def crossprod_csc_dense(A: DeviceCSC, Y: torch.Tensor) -> torch.Tensor:

@@ -559,6 +559,43 @@ def test_pbc_gather_xcd_paced_wide_dense_operand_nonfinite_high_column(hip, orac
     assert_equal(out.cpu().numpy().T, oracle.crossprod(x, y), tol=1e-9, atol=1e-11, strict_na=True, what="K = 1024")
 
 
+def test_pbc_many_column_blocks_last_round_cut_by_rows(hip, oracle):
+    """A product with many column blocks and no row split (the shape of A %*% Y on the layout of t(A), BASELINE config 2b):
+    one launch per round of workgroups, and the last, partly filled round cut by rows with its partial sums added in
+    split order (round 5).  Against the oracle, against the single launch, with a short last column block, a ragged
+    last panel, an NA in a leaf of the last round and non-finite entries in Y (the fix-up reads the flags of all launches);
+    src/SparseMatrix_mult.c:131-152 over src/SparseVec_dotprod.c:28-65."""
+    from sparsearray_amd.device import PbcPlan, set_round_launches
+    nrow, K = 8192 + 70, 128
+    ncol = (128 * 2 + 27) * 640 - 100
+    cp, ri, v = random_csc(nrow, ncol, 0.002, seed=391)
+    v = v.copy()
+    v[cp[ncol - 300]] = NA_real                               # a leaf of the last round
+    x = SVT_SparseArray.from_csc((nrow, ncol), "double", cp, ri, v)
+    A = _dev(cp, ri, v, nrow)
+    plan = PbcPlan(A, K)
+    y = np.random.default_rng(392).uniform(-1, 1, (nrow, K))
+    outs = {}
+    try:
+        for poison in (0, 1):
+            if poison:
+                y[int(ri[cp[ncol - 5]]), 7] = np.inf          # on a nonzero of a leaf of the last round
+                y[nrow - 1, 100] = np.nan
+            Yd = torch.as_tensor(np.ascontiguousarray(y.T), device="cuda")
+            want = oracle.crossprod(x, y)
+            for mode in (1, 2, 0):
+                set_round_launches(mode)
+                out = torch.full((K, ncol), 3.0, dtype=torch.float64, device="cuda")
+                plan.run(Yd, nrow, out)
+                torch.cuda.synchronize()
+                assert_equal(out.cpu().numpy().T, want, tol=1e-9, atol=1e-11, strict_na=True, what=f"mode {mode} poison {poison}")
+                outs[(poison, mode)] = out
+            # rounds do not change a sum; the row-split round adds the same products in another order
+            assert torch.equal(outs[(poison, 2)].nan_to_num(1.5), outs[(poison, 0)].nan_to_num(1.5))
+    finally:
+        set_round_launches(1)
+
+
 def test_pbc_auto_layout_picks_by_density(hip, oracle):
     """svt_dev_pbc_build(A, 0, 0, 0): the gather layout below ~0.25 % density, the LDS-DMA layout
     above; same results either way."""

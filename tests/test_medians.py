@@ -107,3 +107,64 @@ def test_hip_colmedians_long_columns(hip):
     x = SVT_SparseArray.from_dense(np.asfortranarray(a), "double")
     for na_rm in (False, True):
         assert_equal(hip.colMedians(x, na_rm=na_rm), _dense_colmedians(a, na_rm), tol=1e-15, strict_na=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("type_", ["double", "integer"])
+def test_hip_colmedians_radix_select_against_numpy(hip, type_):
+    """The per-column radix select (round 5, kernels_median.hip) against the plain definition on columns where the
+    median is an order statistic of the stored values: dense-ish columns of every length class (shorter than one
+    sweep of the workgroup, ragged, several sweeps), heavy duplicates (the second middle value is the same key),
+    values that differ only in their low bits (the last digits of the select decide), mostly negative / mostly
+    positive columns, +-Inf, and NA / NaN entries under na.rm (R/SparseArray-matrixStats.R:690-784)."""
+    rng = np.random.default_rng(66)
+    cols = []
+    nrow = 5000
+    for j in range(96):
+        col = np.zeros(nrow)
+        fill = [1.0, 0.97, 0.8, 0.6, 0.51, 0.3][j % 6]
+        m = rng.random(nrow) < fill
+        kind = (j // 6) % 5
+        if kind == 0:
+            v = rng.normal(size=nrow)
+        elif kind == 1:
+            v = rng.integers(-3, 4, nrow).astype(np.float64)                    # duplicates
+        elif kind == 2:
+            v = 1.0 + rng.integers(0, 1 << 20, nrow) * 2.0 ** -52               # same exponent, low mantissa bits
+        elif kind == 3:
+            v = -np.abs(rng.normal(size=nrow)) - (j % 3)                         # negative majority
+        else:
+            v = np.abs(rng.normal(size=nrow)) * 1e200 * (1 if j % 2 else -1)
+        if type_ == "integer":
+            v = np.round(v * (1000 if kind != 2 else 1)).clip(-2e9, 2e9)
+        col[m] = v[m]
+        cols.append(col)
+    a = np.stack(cols, axis=1)
+    short = np.zeros((nrow, 6))                                                # few stored values among many zeros
+    short[:3, 0] = [5, 6, 7]
+    short[:nrow // 2 + 1, 1] = 2.0
+    short[: nrow // 2, 2] = -2.0; short[nrow // 2:, 2] = 3.0
+    short[:, 3] = np.arange(nrow) - 100.0
+    short[:, 4] = np.where(np.arange(nrow) % 2 == 0, -1.0, 1.0)
+    short[:, 5] = 7.0
+    a = np.concatenate([a, short], axis=1)
+    if type_ == "double":
+        a[17, 3] = np.inf; a[18, 3] = -np.inf; a[5, 9] = np.nan; a[6, 10] = NA_real; a[:40, 11] = np.nan
+        x = SVT_SparseArray.from_dense(np.asfortranarray(a), "double")
+        dense = a
+    else:
+        ai = a.astype(np.int32)
+        ai[5, 9] = NA_integer; ai[:40, 11] = NA_integer
+        x = SVT_SparseArray.from_dense(np.asfortranarray(ai), "integer")
+        dense = ai.astype(np.float64); dense[ai == NA_integer] = np.nan
+    for na_rm in (False, True):
+        got = hip.colMedians(x, na_rm=na_rm)
+        want = _dense_colmedians(dense, na_rm)
+        assert_equal(got, want, tol=0, strict_na=True, what=f"{type_} na_rm={na_rm}")
+    # a tall column: many sweeps of one workgroup, all six digit passes with survivors
+    tall = rng.normal(size=(300_000, 3))
+    tall[:, 1] = np.round(tall[:, 1], 1)
+    tall[rng.random(tall.shape) < 0.2] = 0.0
+    xt = SVT_SparseArray.from_dense(np.asfortranarray(tall if type_ == "double" else np.round(tall * 100).astype(np.int32)), type_)
+    td = tall if type_ == "double" else np.round(tall * 100)
+    assert_equal(hip.colMedians(xt), _dense_colmedians(td, False), tol=0, strict_na=True, what="tall")

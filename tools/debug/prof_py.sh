@@ -1,8 +1,8 @@
 #!/bin/bash
 # rocprofv3 kernel trace of one python script of this repository; prints per-kernel averages.
 #   bash tools/debug/prof_py.sh tools/debug/rowstats_time.py [min_calls]
+R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
 D=$R/gpurun_out/prof_py
 rm -rf $D
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 $R/$1 $3 > $R/gpurun_out/prof_py.log 2>&1 < /dev/null

@@ -1,6 +1,6 @@
 #!/bin/bash
+R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
   tag=$(echo $c | tr ' ' '_')
   timeout -k 10 200 rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmc_t_$tag -- python3 $R/tools/debug/t_only.py > /dev/null 2>&1

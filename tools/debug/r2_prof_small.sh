@@ -1,6 +1,6 @@
 #!/bin/bash
+R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_small -- python3 $R/bench.py --nrow 125056 --steps 50 --warmup 5 --no-cpu-baseline --no-extras > /dev/null 2>&1
 f=$(find $R/gpurun_out/prof_small -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'

@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of product-kernel variants built into side libraries (libsvt_hip_<tag>.so), same box, same process order
 #   TAGS="a b a b" [EXTRAS=1] bash tools/debug/r2_rot.sh      (EXTRAS=1: also the A %*% Y time of the bench extras)
-cd $GRAFT_REPO_ROOT
+cd ${GRAFT_REPO_ROOT:-.}
 cp sparsearray_amd/libsvt_hip.so /tmp/base.so
 for tag in ${TAGS:-rot0 rot1 rot5 rot0 rot1 rot5}; do
   cp sparsearray_amd/libsvt_hip_$tag.so sparsearray_amd/libsvt_hip.so
