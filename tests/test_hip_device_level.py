@@ -570,7 +570,9 @@ def test_pbc_many_column_blocks_last_round_cut_by_rows(hip, oracle):
     ncol = (128 * 2 + 27) * 640 - 100
     cp, ri, v = random_csc(nrow, ncol, 0.002, seed=391)
     v = v.copy()
-    v[cp[ncol - 300]] = NA_real                               # a leaf of the last round
+    c_na, c_inf = ncol - 8000, ncol - 7000                    # leaves of the last round (random_csc() leaves the last
+    assert cp[c_na + 1] > cp[c_na] and cp[c_inf + 1] > cp[c_inf]   # ~2 % of the columns of a large operand empty)
+    v[cp[c_na]] = NA_real
     x = SVT_SparseArray.from_csc((nrow, ncol), "double", cp, ri, v)
     A = _dev(cp, ri, v, nrow)
     plan = PbcPlan(A, K)
@@ -579,7 +581,7 @@ def test_pbc_many_column_blocks_last_round_cut_by_rows(hip, oracle):
     try:
         for poison in (0, 1):
             if poison:
-                y[int(ri[cp[ncol - 5]]), 7] = np.inf          # on a nonzero of a leaf of the last round
+                y[int(ri[cp[c_inf]]), 7] = np.inf             # on a nonzero of a leaf of the last round
                 y[nrow - 1, 100] = np.nan
             Yd = torch.as_tensor(np.ascontiguousarray(y.T), device="cuda")
             want = oracle.crossprod(x, y)
