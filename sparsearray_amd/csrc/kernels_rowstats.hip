@@ -1173,7 +1173,15 @@ int launch_rowsum(const GroupSumArgs &a, hipStream_t s)
 __global__ void group16_kernel(const int *__restrict__ g, int64_t n, int ngroup, uint16_t *__restrict__ g16)
 {
 	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n) { int v = g[i]; if (v == NA_INT) v = ngroup; g16[i] = (uint16_t) (v - 1); }
+	// (check_group, src/rowsum_methods.c:15-37, has refused ids outside 1 .. ngroup at the entry points; a caller of the
+	// device level that did not gets them folded into the last group: the kernels index LDS cells with the id)
+	if (i < n) {
+		int v = g[i];
+		if (v == NA_INT) v = ngroup;
+		unsigned u = (unsigned) (v - 1);
+		if (u > (unsigned) (ngroup - 1)) u = (unsigned) (ngroup - 1);
+		g16[i] = (uint16_t) u;
+	}
 }
 __global__ void __launch_bounds__(256)
 rowsum_f64_lds16_kernel(GroupSumArgs a, const uint16_t *__restrict__ g16)
@@ -1364,11 +1372,58 @@ int launch_rowsum_lds(const GroupSumArgs &a, hipStream_t s)
 	return 0;
 }
 
+// The same ids by the walk of rowsum_f64_cols_kernel (round 5): a wavefront per column, 16 columns per workgroup, all of
+// them inside the same window of ROWSUM_WIN rows at a time, looking up the 16-bit copy of the table -- the lookups of
+// the whole chip then go to one band of 96 KB of it instead of all over 4 MB of int32 while the offsets stream through
+// the same L2.  The flat kernel above took longer than an unprepared rowsum() call (0.62 against 0.52 ms at config 3).
+__global__ void __launch_bounds__(1024)
+rowsum_gid_cols_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__restrict__ row_idx, int64_t ncol,
+		       int64_t nrow, const uint16_t *__restrict__ g16, uint16_t *__restrict__ gid, int C)
+{
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const int64_t j = (int64_t) blockIdx.x * C + w;
+	const bool have = j < ncol;
+	const int64_t beg = have ? col_ptr[j] : 0, end = have ? col_ptr[j + 1] : 0;
+	int64_t k = beg;
+	int32_t r = k + lane < end ? row_idx[k + lane] : 0x7FFFFFFF;
+	for (int64_t R = ROWSUM_WIN; ; R += ROWSUM_WIN) {
+		const int32_t Rc = R < 0x7FFFFFFF ? (int32_t) R : 0x7FFFFFFF;
+		for (;;) {
+			const bool in = r < Rc;
+			const int cnt = __popcll(__ballot(in));
+			const int64_t kn = k + cnt;             // (the rows of a column ascend: the lanes inside the window are the first cnt)
+			const int32_t rn = kn + lane < end ? row_idx[kn + lane] : 0x7FFFFFFF;
+			if (in) gid[k + lane] = g16[r];
+			k = kn; r = rn;
+			if (cnt < 64) break;
+		}
+		if (R >= nrow) break;
+		__syncthreads();
+	}
+}
+
 // The 16-bit group id of every nonzero (gid: nnz ids); needs ngroup <= 65535.
 int launch_rowsum_gid(const GroupSumArgs &a, int64_t nnz, uint16_t *gid, hipStream_t s)
 {
 	if (nnz <= 0)
 		return 0;
+	if (a.col_ptr64 != NULL && a.ncol >= 64 && a.nrow >= 65536 && a.ngroup >= 1 && a.ngroup < 65535) {
+		// (group16_kernel folds NA into the last group as the flat kernel does; stray ids are the caller's: check_group)
+		uint16_t *g16 = NULL;
+		HIP_TRY(hipMallocAsync((void **) &g16, (size_t) a.nrow * 2 + 16, s));
+		hipLaunchKernelGGL(group16_kernel, dim3((unsigned) ((a.nrow + 255) / 256)), dim3(256), 0, s,
+				   a.group, a.nrow, a.ngroup, g16);
+		int C = 16; int64_t best = -1;
+		for (int c = 16; c >= 8; c--) {             // the fullest last round of workgroups
+			const int64_t nwg = (a.ncol + c - 1) / c, cost = (nwg + 255) / 256 * c;
+			if (best < 0 || cost < best) { best = cost; C = c; }
+		}
+		hipLaunchKernelGGL(rowsum_gid_cols_kernel, dim3((unsigned) ((a.ncol + C - 1) / C)), dim3(C * 64), 0, s,
+				   a.col_ptr64, a.row_idx, a.ncol, a.nrow, g16, gid, C);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipFreeAsync(g16, s));
+		return 0;
+	}
 	int64_t nb = ((nnz + 1) / 2 + 255) / 256;
 	if (nb > 256 * 32) nb = 256 * 32;
 	if (nb < 1) nb = 1;

@@ -17,7 +17,7 @@
 
 #include "svt_scan.h"
 
-#include <rocprim/rocprim.hpp>
+#include "svt_sort.h"
 
 // ---------------------------------------------------------------------------
 // Exclusive scan of an int64 array (svt_scan.h)
@@ -730,15 +730,6 @@ __global__ void transpose_gather_kernel(const int64_t *__restrict__ col_ptr, int
 	out_val[i] = val[k];
 }
 
-static size_t sort_tmp_bytes(int64_t nnz, int end_bit)
-{
-	size_t b = 0;
-	(void) rocprim::radix_sort_pairs(NULL, b, (const int32_t *) NULL, (int32_t *) NULL,
-					 (const uint32_t *) NULL, (uint32_t *) NULL,
-					 (size_t) nnz, 0u, (unsigned) end_bit);
-	return b;
-}
-
 static int key_bits(int64_t nrow)
 {
 	int b = 1;
@@ -751,11 +742,13 @@ static size_t hint_bytes(int64_t nnz)
 	return ((size_t) ((nnz >> HINT_SHIFT) + 2) * 4 + 255) / 256 * 256;
 }
 
-// [sorted rows nnz*4][positions nnz*4][sorted positions nnz*4][column hints][radix-sort temp]
+// [sorted rows nnz*4][positions nnz*4][sorted positions nnz*4][second buffers of the sort's passes 2 * nnz*4][column hints]
+// [the sort's histograms]
 static size_t transpose_sorted_ws_bytes(int64_t nrow, int64_t nnz)
 {
+	(void) nrow;
 	const size_t a = ((size_t) (nnz > 0 ? nnz : 1) * 4 + 255) / 256 * 256;
-	return 3 * a + hint_bytes(nnz) + sort_tmp_bytes(nnz, key_bits(nrow)) + 256;
+	return 5 * a + hint_bytes(nnz) + svt_sort_ws_bytes(nnz) + 256;
 }
 
 static int launch_transpose_sorted(const int64_t *col_ptr, const int32_t *row_idx, const void *val, int Rtype,
@@ -773,16 +766,18 @@ static int launch_transpose_sorted(const int64_t *col_ptr, const int32_t *row_id
 	int32_t *srows = (int32_t *) ws;
 	uint32_t *pos = (uint32_t *) ((char *) ws + a);
 	uint32_t *perm = (uint32_t *) ((char *) ws + 2 * a);
-	uint32_t *hint = (uint32_t *) ((char *) ws + 3 * a);
-	void *tmp = (char *) ws + 3 * a + hint_bytes(nnz);
+	uint32_t *ktmp = (uint32_t *) ((char *) ws + 3 * a), *ptmp = (uint32_t *) ((char *) ws + 4 * a);
+	uint32_t *hint = (uint32_t *) ((char *) ws + 5 * a);
+	void *tmp = (char *) ws + 5 * a + hint_bytes(nnz);
 	const int bits = key_bits(nrow);
-	size_t tb = sort_tmp_bytes(nnz, bits);
 	const unsigned nb = (unsigned) ((nnz + 255) / 256);
 	const unsigned nb8 = (unsigned) (((nnz + 255) / 256 + 7) / 8 * 8);      // whole rounds over the 8 XCDs (xcd_chunk)
 	hipLaunchKernelGGL(iota_u32_kernel, dim3(nb), dim3(256), 0, s, pos, nnz);
 	const int64_t nblk = (nnz >> HINT_SHIFT) + 1;
 	hipLaunchKernelGGL(col_hint_kernel, dim3((unsigned) ((nblk + 1 + 255) / 256)), dim3(256), 0, s, col_ptr, ncol, nblk, hint);
-	HIP_TRY(rocprim::radix_sort_pairs(tmp, tb, row_idx, srows, pos, perm, (size_t) nnz, 0u, (unsigned) bits, s));
+	// stable sort of (row, position) by row: positions ascend inside a row = (row, column) order
+	if (svt_sort_pairs<uint32_t>((const uint32_t *) row_idx, (uint32_t *) srows, ktmp, pos, perm, ptmp, nnz, bits, tmp, s))
+		return -1;
 	hipLaunchKernelGGL(row_bounds_kernel, dim3(nbr), dim3(256), 0, s, srows, nnz, nrow, out_ptr);
 	if (Rtype == SVT_REALSXP)
 		hipLaunchKernelGGL(transpose_gather_kernel<double>, dim3(nb8), dim3(256), 0, s, col_ptr, ncol,
@@ -1086,15 +1081,6 @@ static int aperm_bits(const int64_t *dim, int ndim)
 	return b;
 }
 
-static size_t aperm_sort_tmp(int64_t nnz, int bits)
-{
-	size_t b = 0;
-	(void) rocprim::radix_sort_pairs(NULL, b, (const unsigned long long *) NULL,
-					 (unsigned long long *) NULL, (const uint32_t *) NULL,
-					 (uint32_t *) NULL, (size_t) nnz, 0u, (unsigned) bits);
-	return b;
-}
-
 // [keys nnz*8][sorted keys nnz*8][pos nnz*4][sorted pos nnz*4][sort temp]
 // ---- slab form: the new leading axis is an old outer axis q of small extent, the old rows become new
 // axis 1 (aperm(x, c(3, 1, 2)) of a 2e4 x 2e4 x 64 array).  For every index of the remaining axes (a slab)
@@ -1252,9 +1238,91 @@ static size_t aperm_via_bytes(int64_t nnz, const int64_t *dim, int ndim)
 	return t2_a((size_t) nly + 1, 8) + t2_a((size_t) nnz, 4) + t2_a((size_t) nnz, 8);
 }
 
+// General permutation of an array with three or more axes (round 5; rounds 1-4: a device-wide key sort):
+//   A  aperm(x, c(1, q, others))   old axis q = perm[0] next to the rows; axis 1 stays: whole leaves move (no step when q = 2)
+//   B  aperm(., c(2, 1, 3, ...))   the first two axes change places: the batched bucketed transposition
+//   C  aperm(., c(1, ...))         the remaining axes into their final order: whole leaves move (no step when they are in order)
+// through up to two intermediate arrays in the workspace.  aperm_general_plan() fills the steps for a given perm and returns
+// false when the shape does not suit (leaf counts past 2^31, or a first-two-axes matrix the bucketed transposition refuses):
+// those arrays take the library's own radix sort of (new linear index, position) pairs (svt_sort.h).
+struct ApermPlan3 {
+	bool a_id, c_id;
+	int pa[8], pc[8];
+	int64_t dim_a[8], dim_b[8];
+	int64_t leaves_a, leaves_b;
+};
+
+static size_t aperm_inter_bytes(int64_t leaves, int64_t nnz)
+{
+	return t2_a((size_t) leaves + 1, 8) + t2_a((size_t) (nnz > 0 ? nnz : 1), 4) + t2_a((size_t) (nnz > 0 ? nnz : 1), 8);
+}
+
+static bool aperm_general_plan(int64_t nnz, const int64_t *dim, int ndim, const int *perm, ApermPlan3 *pl)
+{
+	if (ndim < 3 || perm[0] == 0 || nnz <= 0)
+		return false;
+	const int q = perm[0];
+	pl->pa[0] = 0; pl->pa[1] = q;
+	for (int a = 1, i = 2; a < ndim; a++)
+		if (a != q) pl->pa[i++] = a;
+	pl->a_id = q == 1;
+	double la = 1.0, lb = 1.0;
+	for (int i = 0; i < ndim; i++) pl->dim_a[i] = dim[pl->pa[i]];
+	for (int i = 0; i < ndim; i++) pl->dim_b[i] = i == 0 ? pl->dim_a[1] : i == 1 ? pl->dim_a[0] : pl->dim_a[i];
+	for (int i = 1; i < ndim; i++) { la *= (double) pl->dim_a[i]; lb *= (double) pl->dim_b[i]; }
+	if (la >= 2147483646.0 || lb >= 2147483646.0 || la < 1.0 || lb < 1.0)
+		return false;
+	pl->leaves_a = (int64_t) la; pl->leaves_b = (int64_t) lb;
+	// axes of the array after step B, by old axis: l2 = (q, 0, pa[2], pa[3], ...)
+	pl->c_id = true;
+	pl->pc[0] = 0;
+	for (int a = 1; a < ndim; a++) {
+		int at = -1;
+		for (int i = 1; i < ndim; i++) {
+			const int old_axis = i == 1 ? 0 : pl->pa[i];
+			if (old_axis == perm[a]) at = i;
+		}
+		if (at < 0)
+			return false;
+		pl->pc[a] = at;
+		if (at != a) pl->c_id = false;
+	}
+	T2Shape sh;
+	return aperm_swap01_bytes(nnz, pl->dim_a, ndim, &sh, NULL) > 0;
+}
+
+// Workspace of the three-step form over all permutations of `dim`: the two intermediates + the largest step.
+static size_t aperm_general_bytes(int64_t nnz, const int64_t *dim, int ndim)
+{
+	if (ndim < 3 || nnz <= 0)
+		return 0;
+	size_t need = 0;
+	for (int q = 1; q < ndim; q++) {
+		int perm[8];
+		perm[0] = q; perm[1] = 0;
+		for (int a = 1, i = 2; a < ndim; a++)
+			if (a != q) perm[i++] = a;
+		ApermPlan3 pl;
+		if (!aperm_general_plan(nnz, dim, ndim, perm, &pl))
+			continue;
+		T2Shape sh;
+		size_t step = aperm_swap01_bytes(nnz, pl.dim_a, ndim, &sh, NULL);
+		const size_t sa = exclusive_scan_ws_bytes(pl.leaves_a + 1) + 256, sb = exclusive_scan_ws_bytes(pl.leaves_b + 1) + 256;
+		if (sa > step) step = sa;
+		if (sb > step) step = sb;
+		const size_t tot = aperm_inter_bytes(pl.leaves_a, nnz) + aperm_inter_bytes(pl.leaves_b, nnz) + step + 512;
+		if (tot > need) need = tot;
+	}
+	return need;
+}
+
 size_t aperm_ws_bytes(int64_t nnz, const int64_t *dim, int ndim)
 {
 	size_t need = aperm_ws_core(nnz, dim, ndim);
+	{
+		const size_t gen = aperm_general_bytes(nnz, dim, ndim);
+		if (gen > need) need = gen;
+	}
 	const size_t via = aperm_via_bytes(nnz, dim, ndim);
 	if (via > 0) {
 		const int64_t dimy[3] = {dim[1], dim[0], dim[2]};
@@ -1274,11 +1342,9 @@ static size_t aperm_ws_core(int64_t nnz, const int64_t *dim, int ndim)
 	size_t scan_b = 0;
 	if (nl < 2147483646.0)
 		scan_b = exclusive_scan_ws_bytes((int64_t) nl + 1);
-	size_t t32 = 0;
-	(void) rocprim::radix_sort_pairs(NULL, t32, (const uint32_t *) NULL, (uint32_t *) NULL,
-					 (const uint32_t *) NULL, (uint32_t *) NULL, (size_t) nnz, 0u, 32u);
-	const size_t need64 = 2 * a8 + 2 * a4 + aperm_sort_tmp(nnz, aperm_bits(dim, ndim));
-	const size_t need32 = 5 * a4 + hint_bytes(nnz) + t32;
+	const size_t t32 = svt_sort_ws_bytes(nnz);
+	const size_t need64 = 3 * a8 + 3 * a4 + t32;
+	const size_t need32 = 7 * a4 + hint_bytes(nnz) + t32;
 	T2Shape sh;
 	const size_t swap01 = aperm_swap01_bytes(nnz, dim, ndim, &sh, NULL);
 	size_t need = need64 > need32 ? need64 : need32;
@@ -1433,25 +1499,58 @@ int launch_aperm(const int64_t *col_ptr, const int32_t *row_idx, const void *val
 			}
 		}
 	}
+	// the general form: leaf-preserving step, first two axes swapped, leaf-preserving step (aperm_general_plan)
+	{
+		ApermPlan3 pl;
+		if (aperm_general_plan(nnz, dim, ndim, perm, &pl)) {
+			char *p = (char *) ws;
+			const int64_t *cp_a = col_ptr; const int32_t *ri_a = row_idx; const void *v_a = val;
+			int64_t ncol_a = ncol;
+			int64_t *xcp = NULL; int32_t *xri = NULL; void *xv = NULL;
+			if (!pl.a_id) {
+				xcp = (int64_t *) p; p += t2_a((size_t) pl.leaves_a + 1, 8);
+				xri = (int32_t *) p; p += t2_a((size_t) nnz, 4);
+				xv = p;              p += t2_a((size_t) nnz, 8);
+			}
+			int64_t *ycp = out_ptr; int32_t *yri = out_idx; void *yv = out_val;
+			if (!pl.c_id) {
+				ycp = (int64_t *) p; p += t2_a((size_t) pl.leaves_b + 1, 8);
+				yri = (int32_t *) p; p += t2_a((size_t) nnz, 4);
+				yv = p;              p += t2_a((size_t) nnz, 8);
+			}
+			void *sub = p;
+			if (!pl.a_id) {
+				const int rc = launch_aperm(col_ptr, row_idx, val, Rtype, ncol, nnz, dim, ndim, pl.pa, xcp, xri, xv, sub, s);
+				if (rc) return rc;
+				cp_a = xcp; ri_a = xri; v_a = xv; ncol_a = pl.leaves_a;
+			}
+			int pb[8];
+			for (int a = 0; a < ndim; a++) pb[a] = a == 0 ? 1 : a == 1 ? 0 : a;
+			int rc = launch_aperm(cp_a, ri_a, v_a, Rtype, ncol_a, nnz, pl.dim_a, ndim, pb, ycp, yri, yv, sub, s);
+			if (rc) return rc;
+			if (!pl.c_id)
+				rc = launch_aperm(ycp, yri, yv, Rtype, pl.leaves_b, nnz, pl.dim_b, ndim, pl.pc, out_ptr, out_idx, out_val, sub, s);
+			return rc;
+		}
+	}
 	if (new_nleaves < ((int64_t) 1 << 31) - 1) {
 		const size_t a4 = ((size_t) nnz * 4 + 255) / 256 * 256;
 		uint32_t *keys = (uint32_t *) ws, *skeys = (uint32_t *) ((char *) ws + a4);
 		uint32_t *pos = (uint32_t *) ((char *) ws + 2 * a4), *spos = (uint32_t *) ((char *) ws + 3 * a4);
 		int32_t *newrow = (int32_t *) ((char *) ws + 4 * a4);
-		uint32_t *hint = (uint32_t *) ((char *) ws + 5 * a4);
-		void *tmp = (char *) ws + 5 * a4 + hint_bytes(nnz);
+		uint32_t *ktmp = (uint32_t *) ((char *) ws + 5 * a4), *ptmp = (uint32_t *) ((char *) ws + 6 * a4);
+		uint32_t *hint = (uint32_t *) ((char *) ws + 7 * a4);
+		void *tmp = (char *) ws + 7 * a4 + hint_bytes(nnz);
 		int bits = 1;
 		while (bits < 32 && ((int64_t) 1 << bits) < new_nleaves) bits++;
-		size_t tb = 0;
-		(void) rocprim::radix_sort_pairs(NULL, tb, (const uint32_t *) NULL, (uint32_t *) NULL,
-						 (const uint32_t *) NULL, (uint32_t *) NULL, (size_t) nnz, 0u, (unsigned) bits);
 		const unsigned nb = (unsigned) ((nnz + 255) / 256);
 		const unsigned nb8 = (unsigned) (((nnz + 255) / 256 + 7) / 8 * 8);
 		const int64_t nblk = (nnz >> HINT_SHIFT) + 1;
 		hipLaunchKernelGGL(col_hint_kernel, dim3((unsigned) ((nblk + 1 + 255) / 256)), dim3(256), 0, s, col_ptr, ncol, nblk, hint);
 		hipLaunchKernelGGL(aperm_key32_kernel, dim3(nb), dim3(256), 0, s, col_ptr, row_idx, hint, ncol, nnz, d,
 				   keys, pos, newrow);
-		HIP_TRY(rocprim::radix_sort_pairs(tmp, tb, keys, skeys, pos, spos, (size_t) nnz, 0u, (unsigned) bits, s));
+		if (svt_sort_pairs<uint32_t>(keys, skeys, ktmp, pos, spos, ptmp, nnz, bits, tmp, s))
+			return -1;
 		hipLaunchKernelGGL(aperm_ptr_fill_kernel, dim3((unsigned) ((nnz + 1 + 255) / 256)), dim3(256), 0, s,
 				   skeys, nnz, new_nleaves, out_ptr);
 		if (Rtype == SVT_REALSXP)
@@ -1469,13 +1568,15 @@ int launch_aperm(const int64_t *col_ptr, const int32_t *row_idx, const void *val
 	unsigned long long *skeys = (unsigned long long *) ((char *) ws + a8);
 	uint32_t *pos = (uint32_t *) ((char *) ws + 2 * a8);
 	uint32_t *spos = (uint32_t *) ((char *) ws + 2 * a8 + a4);
-	void *tmp = (char *) ws + 2 * a8 + 2 * a4;
+	unsigned long long *ktmp = (unsigned long long *) ((char *) ws + 2 * a8 + 2 * a4);
+	uint32_t *ptmp = (uint32_t *) ((char *) ws + 3 * a8 + 2 * a4);
+	void *tmp = (char *) ws + 3 * a8 + 3 * a4;
 	const int bits = aperm_bits(dim, ndim);
-	size_t tb = aperm_sort_tmp(nnz, bits);
 	const unsigned nb = (unsigned) ((nnz + 255) / 256);
 	const unsigned nb8 = (unsigned) (((nnz + 255) / 256 + 7) / 8 * 8);
 	hipLaunchKernelGGL(aperm_key_kernel, dim3(nb), dim3(256), 0, s, col_ptr, row_idx, ncol, nnz, d, keys, pos);
-	HIP_TRY(rocprim::radix_sort_pairs(tmp, tb, keys, skeys, pos, spos, (size_t) nnz, 0u, (unsigned) bits, s));
+	if (svt_sort_pairs<unsigned long long>(keys, skeys, ktmp, pos, spos, ptmp, nnz, bits, tmp, s))
+		return -1;
 	hipLaunchKernelGGL(aperm_bounds_kernel, dim3(nbl), dim3(256), 0, s, skeys, nnz, new_nleaves, new_dim0, out_ptr);
 	if (Rtype == SVT_REALSXP)
 		hipLaunchKernelGGL(aperm_gather_kernel<double>, dim3(nb8), dim3(256), 0, s, skeys, spos,

@@ -289,6 +289,66 @@ def test_device_aperm_slab_form(hip, dim, nnz, perm, dtype):
     assert np.array_equal(T.val.cpu().numpy(), wv)
 
 
+@pytest.mark.parametrize("dim,nnz,perm,dtype", [
+    # general permutations of arrays with four and five axes (round 5): a leaf-preserving step, the first two axes
+    # swapped (batched bucketed transposition), a leaf-preserving step -- no sort
+    ((1500, 900, 4, 3), 1_500_000, (2, 4, 1, 3), "double"),     # q = 2: no first step
+    ((1500, 900, 4, 3), 1_500_000, (3, 1, 4, 2), "double"),     # dim[2] = 4: slab form refused? (perm[1] == 1: slab form takes it)
+    ((1500, 4, 900, 3), 1_500_000, (3, 2, 4, 1), "double"),     # q = 3: all three steps
+    ((1500, 4, 900, 3), 1_500_000, (3, 4, 2, 1), "integer"),
+    ((1200, 5, 3, 700, 2), 1_200_000, (4, 5, 1, 3, 2), "double"),   # five axes
+    ((1200, 5, 3, 700, 2), 1_200_000, (4, 1, 2, 3, 5), "double"),   # q = 4, the rest in order after the swap? (no last step)
+    # shapes the bucketed transposition refuses: the library's own radix sort of (new leaf, position) pairs
+    ((300, 6, 5, 4), 9000, (2, 4, 3, 1), "double"),
+    ((300, 6, 5, 4), 9000, (4, 3, 2, 1), "integer"),
+    ((40, 30, 20, 10, 3), 50_000, (5, 3, 1, 4, 2), "double"),
+])
+def test_device_aperm_general_permutations(hip, dim, nnz, perm, dtype):
+    """aperm() of 4-d / 5-d arrays for permutations that are none of the special forms, against numpy's transpose
+    (C_aperm_SVT, src/SparseArray_aperm.c:892-970)."""
+    rng = np.random.default_rng(47)
+    a = np.zeros(dim, order="F")
+    idx = rng.choice(a.size, size=nnz, replace=False)
+    a.reshape(-1, order="F")[idx] = rng.normal(size=nnz) if dtype == "double" else rng.integers(1, 1000, size=nnz)
+    if dtype == "integer":
+        a = a.astype(np.int32)
+    x = SVT_SparseArray.from_dense(a, dtype, lacunar=False)
+    cp, ri, v = x.to_csc()
+    A = _dev(cp, ri, v, dim[0])
+    T, new_dim = A.aperm(dim, perm)
+    torch.cuda.synchronize()
+    want = SVT_SparseArray.from_dense(np.asfortranarray(np.transpose(a, [q - 1 for q in perm])), dtype, lacunar=False)
+    wcp, wri, wv = want.to_csc()
+    assert new_dim == want.dim
+    assert np.array_equal(T.col_ptr.cpu().numpy(), wcp)
+    assert np.array_equal(T.row_idx.cpu().numpy(), wri)
+    assert np.array_equal(T.val.cpu().numpy(), wv)
+
+
+def test_transpose_shapes_for_the_own_radix_sort(hip):
+    """t() of operands the bucketed transposition does not take (less than one nonzero per column and coarse bucket):
+    the library's own least-significant-digit radix sort (svt_sort.h; rounds 1-4: rocprim) -- one, two, three and four
+    passes of 8 bits over the row index, a ragged last tile, empty columns; against a stable host sort."""
+    from sparsearray_amd.device import DeviceCSC
+    rng = np.random.default_rng(48)
+    for nrow, ncol, nnz in ((200, 70_000, 30_000), (60_000, 50_000, 41_000), (3_000_000, 9_000, 10_000),
+                            (20_000_000, 3_000, 70_001), (100, 5, 3)):
+        lin = np.sort(rng.choice(nrow * ncol, size=nnz, replace=False))
+        col, row = lin // nrow, (lin % nrow).astype(np.int32)
+        cp = np.zeros(ncol + 1, dtype=np.int64)
+        np.add.at(cp, col + 1, 1)
+        cp = np.cumsum(cp)
+        v = rng.normal(size=nnz)
+        T = DeviceCSC.from_host(nrow, cp, row, v).t()
+        torch.cuda.synchronize()
+        order = np.argsort(row, kind="stable")
+        tcp = np.zeros(nrow + 1, dtype=np.int64)
+        np.cumsum(np.bincount(row, minlength=nrow), out=tcp[1:])
+        assert np.array_equal(T.col_ptr.cpu().numpy(), tcp), (nrow, ncol)
+        assert np.array_equal(T.row_idx.cpu().numpy(), col[order].astype(np.int32)), (nrow, ncol)
+        assert np.array_equal(T.val.cpu().numpy(), v[order]), (nrow, ncol)
+
+
 def test_device_matmul_through_transpose(hip, oracle):
     """x %*% y = crossprod(t(x), y) (R/SparseMatrix-mult.R:195-215) with everything on the
     device: transpose, panel-blocked layout of t(x), product; many column blocks, one row split."""
