@@ -1247,6 +1247,8 @@ static size_t aperm_via_bytes(int64_t nnz, const int64_t *dim, int ndim)
 // those arrays take the library's own radix sort of (new linear index, position) pairs (svt_sort.h).
 struct ApermPlan3 {
 	bool a_id, c_id;
+	bool swap_ok;             // step B as the batched bucketed transposition
+	bool slab_first;          // steps A + B in one: aperm(x, c(q, 1, others)) by the slab form (one workgroup per slab), tried first
 	int pa[8], pc[8];
 	int64_t dim_a[8], dim_b[8];
 	int64_t leaves_a, leaves_b;
@@ -1273,6 +1275,11 @@ static bool aperm_general_plan(int64_t nnz, const int64_t *dim, int ndim, const 
 	if (la >= 2147483646.0 || lb >= 2147483646.0 || la < 1.0 || lb < 1.0)
 		return false;
 	pl->leaves_a = (int64_t) la; pl->leaves_b = (int64_t) lb;
+	// a leaf-preserving step reads and writes every leaf pointer a few times: with many more leaves than nonzeros (a short
+	// new leading axis: 4e8 leaves of at most 64 entries for aperm(x, c(4,3,2,1)) of a 2e4 x 2e3 x 10 x 64 array) the
+	// steps cost more than the sort of the nonzeros (41 against 28 ms there)
+	if (la > 2.0 * (double) nnz + 1024.0 || lb > 2.0 * (double) nnz + 1024.0)
+		return false;
 	// axes of the array after step B, by old axis: l2 = (q, 0, pa[2], pa[3], ...)
 	pl->c_id = true;
 	pl->pc[0] = 0;
@@ -1288,12 +1295,18 @@ static bool aperm_general_plan(int64_t nnz, const int64_t *dim, int ndim, const 
 		if (at != a) pl->c_id = false;
 	}
 	T2Shape sh;
-	return aperm_swap01_bytes(nnz, pl->dim_a, ndim, &sh, NULL) > 0;
+	pl->swap_ok = aperm_swap01_bytes(nnz, pl->dim_a, ndim, &sh, NULL) > 0;
+	// many small slabs (which the batched transposition refuses) are what the slab form is for; it serves a request
+	// that still has a step C to do -- c(q, 1, others) itself has met the slab form on its way here
+	pl->slab_first = !pl->c_id && dim[q] <= 1024 && dim[0] < ((int64_t) 1 << 30) &&
+			 (double) nnz / (lb / (double) dim[0]) <= 0.9 * 8192.0;
+	return pl->swap_ok || pl->slab_first;
 }
 
 // Workspace of the three-step form over all permutations of `dim`: the two intermediates + the largest step.
-static size_t aperm_general_bytes(int64_t nnz, const int64_t *dim, int ndim)
+static size_t aperm_general_bytes(int64_t nnz, const int64_t *dim, int ndim, size_t *inter_max)
 {
+	*inter_max = 0;
 	if (ndim < 3 || nnz <= 0)
 		return 0;
 	size_t need = 0;
@@ -1310,8 +1323,9 @@ static size_t aperm_general_bytes(int64_t nnz, const int64_t *dim, int ndim)
 		const size_t sa = exclusive_scan_ws_bytes(pl.leaves_a + 1) + 256, sb = exclusive_scan_ws_bytes(pl.leaves_b + 1) + 256;
 		if (sa > step) step = sa;
 		if (sb > step) step = sb;
-		const size_t tot = aperm_inter_bytes(pl.leaves_a, nnz) + aperm_inter_bytes(pl.leaves_b, nnz) + step + 512;
-		if (tot > need) need = tot;
+		const size_t inter = aperm_inter_bytes(pl.leaves_a, nnz) + aperm_inter_bytes(pl.leaves_b, nnz) + 512;
+		if (inter > *inter_max) *inter_max = inter;
+		if (inter + step > need) need = inter + step;
 	}
 	return need;
 }
@@ -1320,8 +1334,11 @@ size_t aperm_ws_bytes(int64_t nnz, const int64_t *dim, int ndim)
 {
 	size_t need = aperm_ws_core(nnz, dim, ndim);
 	{
-		const size_t gen = aperm_general_bytes(nnz, dim, ndim);
-		if (gen > need) need = gen;
+		// (a step of the general form may itself fall back to the forms that aperm_ws_core() sizes: the intermediates
+		// come on top of the larger of the two)
+		size_t inter = 0;
+		const size_t gen = aperm_general_bytes(nnz, dim, ndim, &inter);
+		if (gen > need + inter) need = gen; else need += inter;
 	}
 	const size_t via = aperm_via_bytes(nnz, dim, ndim);
 	if (via > 0) {
@@ -1519,6 +1536,16 @@ int launch_aperm(const int64_t *col_ptr, const int32_t *row_idx, const void *val
 				yv = p;              p += t2_a((size_t) nnz, 8);
 			}
 			void *sub = p;
+			if (pl.slab_first) {
+				// c(q, 1, others) in one go (slab form; if a slab turns out too long the call takes the two steps, or the
+				// sort, itself), then the leaf-preserving step
+				int p1[8];
+				p1[0] = perm[0]; p1[1] = 0;
+				for (int a = 2; a < ndim; a++) p1[a] = pl.pa[a];
+				int rc = launch_aperm(col_ptr, row_idx, val, Rtype, ncol, nnz, dim, ndim, p1, ycp, yri, yv, sub, s);
+				if (rc) return rc;
+				return launch_aperm(ycp, yri, yv, Rtype, pl.leaves_b, nnz, pl.dim_b, ndim, pl.pc, out_ptr, out_idx, out_val, sub, s);
+			}
 			if (!pl.a_id) {
 				const int rc = launch_aperm(col_ptr, row_idx, val, Rtype, ncol, nnz, dim, ndim, pl.pa, xcp, xri, xv, sub, s);
 				if (rc) return rc;

@@ -969,7 +969,8 @@ extern "C" int svt_dev_rowsum_prepare(const svt_dev_csc *A, const int *group, in
 		return svt_set_error("svt_dev_rowsum_prepare: id buffer too small");
 	GroupSumArgs a;
 	memset(&a, 0, sizeof(a));
-	a.row_idx = A->row_idx; a.group = group; a.ngroup = ngroup;
+	a.col_ptr64 = A->col_ptr; a.row_idx = A->row_idx; a.nrow = A->nrow; a.ncol = A->ncol;
+	a.group = group; a.ngroup = ngroup;
 	return launch_rowsum_gid(a, A->nnz, (uint16_t *) gid, (hipStream_t) stream);
 }
 
