@@ -1846,11 +1846,12 @@ pbc_transpose_dense_kernel(const double *__restrict__ Yin, int64_t ldY, int64_t 
 // rewrites the cells of the dirty columns by the rule above.  The clean columns are never
 // touched.  A column with more non-finite entries than the longest leaf has nonzeros is NaN / NA in every
 // cell without looking at its entries (a column of NAs).  More than PBC_DIRTY_CAP listed entries, more than
-// PBC_DIRTY_COLS listed columns, or a column between PBC_DIRTY_LIGHT and the longest leaf: the general
-// kernels redo the whole product as before.
+// PBC_DIRTY_COLS listed columns, or a column between PBC_DIRTY_LIGHT and the longest leaf: the leaf's wavefront
+// walks its nonzeros once per such column, counts the non-finite y it meets and sums on the way (round 5; rounds
+// 2-4 redid the WHOLE product with the general kernels in those cases, behind two gate launches per product).
 // ---------------------------------------------------------------------------
 #define PBC_DIRTY_CAP 8192
-#define PBC_DIRTY_COLS 16
+#define PBC_DIRTY_COLS 256    // light dense columns that get a slot (hit counters of a wavefront in LDS)
 #define PBC_DIRTY_LIGHT 256     // a dense column lists at most this many of its non-finite entries
 struct DirtyWs {
 	int *flags;          // the flag block: [0] product kernel saw a non-finite y, [2] run the general
@@ -2016,28 +2017,35 @@ __global__ void pbc_nafix_kernel(const int *__restrict__ col_has_na, int K, int6
 	pbc_dirty_scan_tail(ds, blockIdx.x, gridDim.x);
 }
 
-// Rank of every dirty column among the dirty ones (slot[k], in LDS) and the decision between the
-// fix-up and the general kernels, recomputed by every workgroup from the scan's counters (K <= a few
-// hundred entries).  Returns true for "general kernels".
-// Classes of a dirty column k (nf = its non-finite entries): light (nf <= PBC_DIRTY_LIGHT: all listed, gets a
-// slot), saturated (nf > the longest leaf: no leaf can have a nonzero on every non-finite row, every cell is NaN
-// or NA -- a column of NAs, the common case, costs no more than a single Inf), anything in between: general kernels.
-__device__ inline bool pbc_dirty_plan(int K, const DirtyWs &d, int *slot_lds, int64_t max_leaf_nnz)
+// Class of every dirty dense column k (nf = its non-finite entries), recomputed by every workgroup from the scan's
+// counters (K <= a few hundred entries): slot_lds[k] =
+//   s >= 0   light (nf <= PBC_DIRTY_LIGHT, all of its entries listed): hit counter s of the wavefront;
+//   -1       saturated (nf > the longest leaf: no leaf can have a nonzero on every non-finite row, every cell is NaN or
+//            NA -- a column of NAs, the common case, costs no more than a single Inf);
+//   -2       anything else (between the list and the longest leaf; more light columns than slots; more entries than
+//            the list holds): the leaf's wavefront walks its nonzeros and looks at y itself.
+// Returns the number of slots in use.  (Rounds 2-4 sent the -2 cases through the general kernels for the WHOLE product,
+// 35 ms at config 2a, behind two more gate launches per product; round 5: one walk of the leaf per such column.)
+__device__ inline int pbc_dirty_classes(int K, const DirtyWs &d, int *slot_lds, int64_t max_leaf_nnz)
 {
-	__shared__ int s_general;
+	__shared__ int s_nslots;
 	if (threadIdx.x == 0) {
-		int n = 0, general = d.flags[3] > PBC_DIRTY_CAP;
+		int n = 0;
+		const bool listed_all = d.flags[3] <= PBC_DIRTY_CAP;
 		for (int k = 0; k < K; k++) {
 			const int nf = d.col_nf[k];
-			slot_lds[k] = -1;
-			if (nf == 0) continue;
-			if (nf <= PBC_DIRTY_LIGHT) slot_lds[k] = n++;
-			else if ((int64_t) nf <= max_leaf_nnz) general = 1;
+			int cls = -1;
+			if (nf > 0) {
+				if (nf <= PBC_DIRTY_LIGHT && listed_all && n < PBC_DIRTY_COLS) cls = n++;
+				else if ((int64_t) nf > max_leaf_nnz) cls = -1;
+				else cls = -2;
+			}
+			slot_lds[k] = cls;
 		}
-		s_general = (general || n > PBC_DIRTY_COLS) ? 1 : 0;
+		s_nslots = n;
 	}
 	__syncthreads();
-	return s_general != 0;
+	return s_nslots;
 }
 
 // step 2: one wavefront per leaf c.
@@ -2058,19 +2066,14 @@ pbc_dirty_leaf_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__rest
 	extern __shared__ int slot_lds[];                       // [K] + [PBC_DIRTY_WPB][PBC_DIRTY_COLS]
 	if (d.flags[0] == 0)                                    // (the same answer in every workgroup)
 		return;
-	// the general kernels' per-column counters: they run (next launches) only if flags[2] gets set below
-	if (blockIdx.x == 0)
-		for (int i = threadIdx.x; i < n_gen_counters; i += blockDim.x) gen_counters[i] = 0;
-	if (pbc_dirty_plan(K, d, slot_lds, max_leaf_nnz)) {     // (the same answer in every workgroup)
-		if (blockIdx.x == 0 && threadIdx.x == 0) d.flags[2] = 1;    // read by the general kernels' gate
-		return;
-	}
+	(void) gen_counters; (void) n_gen_counters;
+	const int nslots = pbc_dirty_classes(K, d, slot_lds, max_leaf_nnz);      // (the same answer in every workgroup)
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	int *hits = slot_lds + K + w * PBC_DIRTY_COLS;
 	int n = d.flags[3];
-	if (n > PBC_DIRTY_CAP) n = PBC_DIRTY_CAP;               // (the plan sent that case to the general kernels)
+	if (n > PBC_DIRTY_CAP) n = 0;                            // (the list is incomplete: no column has a slot, all are walked)
 	for (int64_t c = (int64_t) blockIdx.x * PBC_DIRTY_WPB + w; c < ncol; c += (int64_t) gridDim.x * PBC_DIRTY_WPB) {
-		if (lane < PBC_DIRTY_COLS) hits[lane] = 0;
+		for (int i = lane; i < nslots; i += 64) hits[i] = 0;
 		__builtin_amdgcn_wave_barrier();
 		const int64_t beg = col_ptr[c], end = col_ptr[c + 1];
 		for (int e = lane; e < n; e += 64) {
@@ -2095,18 +2098,29 @@ pbc_dirty_leaf_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__rest
 			if (nf == 0)
 				continue;
 			double *cell = out + c * sc + (int64_t) k * sk;
+			const int cls = slot_lds[k];
 			if (d.has_na[k] || leaf_na) {
 				if (lane == 0) *cell = svt_na_real();
-			} else if (slot_lds[k] < 0 || hits[slot_lds[k]] < nf) {
+			} else if (cls == -1 || (cls >= 0 && hits[cls] < nf)) {
 				if (lane == 0) *cell = *cell + NAN;
 			} else {
+				// every non-finite entry of the column sits on a nonzero of the leaf (cls >= 0), or that is still to be
+				// found out (cls == -2): one walk over the leaf's nonzeros gives the count of non-finite y met and the sum
 				const double *__restrict__ y = Y + (int64_t) k * cs;
 				double acc = 0.0;
-				for (int64_t i = beg + lane; i < end; i += 64)
-					acc += val[i] * y[(int64_t) row_idx[i] * rs];
-				for (int off = 32; off > 0; off >>= 1)
+				int met = 0;
+				for (int64_t i = beg + lane; i < end; i += 64) {
+					const double yy = y[(int64_t) row_idx[i] * rs];
+					met += svt_is_finite(yy) ? 0 : 1;
+					acc += val[i] * yy;
+				}
+				for (int off = 32; off > 0; off >>= 1) {
 					acc += __shfl_xor(acc, off, 64);
-				if (lane == 0) *cell = acc;
+					met += __shfl_xor(met, off, 64);
+				}
+				// (a non-finite entry on a row where the leaf holds nothing: 0 * Inf and 0 * NaN are NaN in the
+				// reference's walk over all rows, src/SparseVec_dotprod.c:48-65)
+				if (lane == 0) *cell = (cls == -2 && met < nf) ? acc + NAN : acc;
 			}
 		}
 		__builtin_amdgcn_wave_barrier();
@@ -2610,7 +2624,7 @@ static int pbc_phase_impl(const svt_dev_pbc *P, const svt_dev_csc *A,
 	HIP_TRY(hipGetLastError());
 	if (fast && P->rec != NULL) {
 		int n_gen_counters = 0;
-		int *gen_counters = crossprod_general_counters(gen_ws, A->nrow, K, &n_gen_counters);
+		int *gen_counters = NULL;
 		// one wavefront per leaf, at most ~8 wavefronts per CU's worth of workgroups in flight at a time
 		int64_t nwg = (P->ncol + PBC_DIRTY_WPB - 1) / PBC_DIRTY_WPB;
 		if (nwg > 4096) nwg = 4096;
@@ -2621,14 +2635,16 @@ static int pbc_phase_impl(const svt_dev_pbc *P, const svt_dev_csc *A,
 				   gen_counters, n_gen_counters);
 		HIP_TRY(hipGetLastError());
 	}
-	// General (slow-path) semantics for everything else that is not finite.
+	if (fast && P->rec != NULL)
+		return 0;                               // (round 5: the leaf kernel above handles every class of dirty column itself)
+	// General (slow-path) semantics for the layouts without the fix-up (register-staged kernels, no record stream).
 	CrossprodArgs a;
 	memset(&a, 0, sizeof(a));
 	a.col_ptr = A->col_ptr; a.row_idx = A->row_idx; a.val = A->val; a.Rtype = SVT_REALSXP;
 	a.nrow = A->nrow; a.ncol = A->ncol; a.Y = Y; a.ldY = ldY; a.K = K; a.tr_y = tr_y;
 	a.out = out; a.out_stride_c = out_stride_c; a.out_stride_k = out_stride_k;
 	a.ws = gen_ws; a.ws_bytes = gen_bytes;
-	return launch_crossprod_general_if(a, fast && P->rec != NULL ? dw.flags + 2 : fl.y_nonfinite, fast && P->rec != NULL, s);
+	return launch_crossprod_general_if(a, fl.y_nonfinite, false, s);
 }
 
 extern "C" int svt_dev_crossprod_pbc_phase(const svt_dev_pbc *P, const svt_dev_csc *A,

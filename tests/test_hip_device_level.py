@@ -708,6 +708,19 @@ def test_pbc_dirty_column_classes(hip, oracle):
     check(y, "between the list and the longest leaf")
     y = y0.copy(); y[:3000, 7] = np.inf; y[:, 8] = np.nan
     check(y, "in-between column beside a saturated one")
+    # round 5: every class is decided inside the leaf kernel (no general kernels behind the panel products)
+    rng = np.random.default_rng(104)
+    y = y0.copy()
+    for k in range(40):                                       # 40 light columns (round 4: more than 16 -> general kernels)
+        y[rng.integers(0, nrow, 3), k] = [np.inf, -np.inf, np.nan][k % 3]
+    y[rows9[:5], 41] = np.inf                                 # all five on nonzeros of leaf 9: that cell is summed again
+    y[int(ri[cp[3]]), 42] = NA_real
+    check(y, "40 light columns + one whose entries all sit on a leaf + an NA")
+    y = y0.copy()
+    for k in range(60):                                       # 60 x 200 = 12000 listed entries > the list's 8192: all walked
+        y[rng.choice(nrow, 200, replace=False), k] = np.inf
+    y[rows9[:300], 61] = -np.inf                              # in-between (300 > 256), every entry on a nonzero of leaf 9
+    check(y, "list overflow: every dirty column walked")
     check(y0, "clean again")
 
 
