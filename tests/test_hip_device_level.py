@@ -658,6 +658,51 @@ def test_pbc_many_column_blocks_last_round_cut_by_rows(hip, oracle):
         set_round_launches(1)
 
 
+def test_pbc_flags_between_products(hip, oracle):
+    """The flags and per-column counters of the non-finite fix-up live at the head of the workspace and are cleared by one
+    small kernel in front of every product.  Sequences that would show a stale flag: a non-finite product followed by a
+    clean one, a phase 1 whose phase 2 never came, two streams taking turns on one handle with a dirty and a clean
+    operand.  (Round 5 also built flag blocks of the library's own, kept zero between products so that the clear kernel
+    could go: all tests green, but the step at an eighth of the rows of config 2a did not get shorter -- 267.8 -> 267.0 us
+    on the kernel timeline: the product kernel's start absorbs what the 5 us kernel in front of it took -- dropped.)"""
+    from sparsearray_amd.device import PbcPlan
+    nrow, ncol, K = 30000, 1300, 128
+    cp, ri, v = random_csc(nrow, ncol, 0.01, seed=501)
+    x = SVT_SparseArray.from_csc((nrow, ncol), "double", cp, ri, v)
+    A = _dev(cp, ri, v, nrow)
+    plan = PbcPlan(A, K)
+    y = np.random.default_rng(502).uniform(-1, 1, (nrow, K))
+    yd = y.copy(); yd[int(ri[cp[11]]), 3] = np.inf; yd[17, 77] = np.nan; yd[:, 100] = NA_real
+    Yc = torch.as_tensor(np.ascontiguousarray(y.T), device="cuda")
+    Yd = torch.as_tensor(np.ascontiguousarray(yd.T), device="cuda")
+    want_c, want_d = oracle.crossprod(x, y), oracle.crossprod(x, yd)
+    out = torch.zeros((K, ncol), dtype=torch.float64, device="cuda")
+
+    def check(Y, want, what):
+        out.fill_(7.0)
+        plan.run(Y, nrow, out)
+        torch.cuda.synchronize()
+        assert_equal(out.cpu().numpy().T, want, tol=1e-9, atol=1e-11, strict_na=True, what=what)
+    for rep in range(3):
+        check(Yd, want_d, f"dirty {rep}")
+        check(Yc, want_c, f"clean after dirty {rep}")
+    plan.run_phase(1, Yd, nrow, out)                    # a phase 1 without its phase 2 ...
+    check(Yc, want_c, "clean after an orphaned dirty phase 1")
+    check(Yd, want_d, "dirty again")
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    o1 = torch.zeros_like(out); o2 = torch.zeros_like(out)
+    for rep in range(4):
+        with torch.cuda.stream(s1):
+            plan.run(Yd if rep % 2 == 0 else Yc, nrow, o1)
+        torch.cuda.synchronize()                        # (one plan = one workspace of partial sums: not both at once)
+        with torch.cuda.stream(s2):
+            plan.run(Yc if rep % 2 == 0 else Yd, nrow, o2)
+        torch.cuda.synchronize()
+        a, b = (want_d, want_c) if rep % 2 == 0 else (want_c, want_d)
+        assert_equal(o1.cpu().numpy().T, a, tol=1e-9, atol=1e-11, strict_na=True, what=f"stream 1, turn {rep}")
+        assert_equal(o2.cpu().numpy().T, b, tol=1e-9, atol=1e-11, strict_na=True, what=f"stream 2, turn {rep}")
+
+
 def test_pbc_auto_layout_picks_by_density(hip, oracle):
     """svt_dev_pbc_build(A, 0, 0, 0): the gather layout below ~0.25 % density, the LDS-DMA layout
     above; same results either way."""
