@@ -57,6 +57,30 @@ for case in range(ncases):
     for _ in range(npoison):
         r = int(rng.integers(0, nrow)) if rng.random() < 0.5 or len(ri) == 0 else int(ri[rng.integers(0, len(ri))])
         y[rng.integers(0, K), r] = rng.choice([np.inf, -np.inf, np.nan])
+    # round 5: the classes of dirty dense columns the fix-up decides inside its leaf kernel (rounds 2-4: general kernels)
+    pmode = int(rng.choice([0, 0, 0, 1, 2, 3, 4]))
+    if pmode == 1:                                           # many light columns: 1-3 entries in every second / every column
+        for k in range(0, K, int(rng.choice([1, 2]))):
+            for _ in range(int(rng.integers(1, 4))):
+                r = int(rng.integers(0, nrow)) if rng.random() < 0.5 or len(ri) == 0 else int(ri[rng.integers(0, len(ri))])
+                y[k, r] = rng.choice([np.inf, -np.inf, np.nan])
+        npoison += K
+    elif pmode == 2:                                         # one column between the list (256 entries) and a long leaf, or past it
+        cnt = int(min(nrow, rng.choice([257, 300, 1000, 3000])))
+        k = int(rng.integers(0, K))
+        if rng.random() < 0.5 and len(cols) and len(max(cols, key=len)) >= cnt:
+            y[k, max(cols, key=len)[:cnt]] = np.inf          # every entry on a nonzero of the longest leaf
+        else:
+            y[k, rng.choice(nrow, size=cnt, replace=False)] = rng.choice([np.inf, np.nan])
+        npoison += cnt
+    elif pmode == 3 and K >= 40:                             # more listed entries than the list holds (8192)
+        per = min(nrow, 8192 // K + 40, 250)
+        for k in range(K):
+            y[k, rng.choice(nrow, size=per, replace=False)] = np.inf
+        npoison += per * K
+    elif pmode == 4:                                         # a whole column
+        y[int(rng.integers(0, K)), :] = rng.choice([np.inf, np.nan])
+        npoison += nrow
     Yd = torch.as_tensor(y, device=dev)
     by_rows = bool(rng.integers(0, 2))
     out_p = torch.full((K, ncol), 7.0, dtype=torch.float64, device=dev)
@@ -84,7 +108,7 @@ for case in range(ncases):
         err = float("inf")
     worst = max(worst, err)
     flag = "" if err <= 1e-11 else "   <-- MISMATCH"
-    print(f"{case:4d} nrow {nrow:6d} ncol {ncol:5d} K {K:4d} kind {kind} dens {dens:<7g} nsplit {ns:2d} poison {npoison} by_rows {int(by_rows)} layout {lay} nnz {len(ri):8d}  err {err:.2e}{flag}", flush=True)
+    print(f"{case:4d} nrow {nrow:6d} ncol {ncol:5d} K {K:4d} kind {kind} dens {dens:<7g} nsplit {ns:2d} poison {npoison:6d} mode {pmode} by_rows {int(by_rows)} layout {lay} nnz {len(ri):8d}  err {err:.2e}{flag}", flush=True)
     if flag:
         bad = ~(((out_p - out_g).abs() / scale <= 1e-11) | (torch.isnan(out_p) & torch.isnan(out_g)) | (out_p == out_g))
         idx = bad.nonzero()[:5].tolist()
