@@ -309,6 +309,9 @@ int launch_spmm_product(SpmmArgs a, int64_t a_nnz, int64_t b_nnz, const void *ws
 		const double run = (double) a_nnz / ((double) a.ninner * (double) npan);
 		while (G > 8 && run < 2.0 * G) G >>= 1;
 	}
+#ifdef SVT_TUNING
+	if (getenv("SVT_SPMM_G")) G = atoi(getenv("SVT_SPMM_G"));
+#endif
 	const size_t lds = (size_t) KW * P * 8;
 	const int64_t nkb = (a.K + KW - 1) / KW;
 	if (npan * nkb >= (int64_t) 2147483647)

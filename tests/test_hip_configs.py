@@ -224,6 +224,39 @@ def test_config5_aperm_full_size(hip, perm):
     assert torch.equal(P.col_ptr, want_cp)
 
 
+def test_aperm_more_than_2e31_new_leaves(hip):
+    """aperm(x, c(3, 1, 2)) of a 50000 x 50000 x 2 array: 2.5e9 new leaves (20 GB of leaf pointers) -- past what the
+    composed route and the 32-bit keys take: 64-bit (new linear index) keys through the library's own radix sort
+    (svt_sort.h, five passes of 8 bits; rounds 1-4: rocprim).  Against a torch sort; src/SparseArray_aperm.c:892-970."""
+    from sparsearray_amd import synth
+    from sparsearray_amd.device import DeviceCSC
+    dev = torch.device("cuda", 0)
+    D = (50_000, 50_000, 2)
+    perm = (3, 1, 2)
+    cp, ri, v = synth.random_device_csc(D[0], D[1] * D[2], 2e-4, seed=55, device=dev)          # 1e6 nonzeros
+    A = DeviceCSC(D[0], cp, ri, v)
+    P, new_dim = A.aperm(D, perm)
+    torch.cuda.synchronize()
+    assert new_dim == (2, 50_000, 50_000)
+    leaf = torch.repeat_interleave(torch.arange(A.ncol, device=dev), cp[1:] - cp[:-1])
+    sub = [ri.long(), leaf % D[1], leaf // D[1]]
+    nsub = [sub[p - 1] for p in perm]
+    lin = nsub[0] + new_dim[0] * (nsub[1] + new_dim[1] * nsub[2])
+    order = torch.argsort(lin)
+    lin = lin[order]
+    assert torch.equal(P.row_idx, (lin % new_dim[0]).to(torch.int32))
+    assert torch.equal(P.val, v[order])
+    want_leaf = lin // new_dim[0]
+    # leaf pointers: 2.5e9 + 1 of them; compared through the positions where they step (all others repeat their neighbour)
+    nl = new_dim[1] * new_dim[2]
+    assert P.col_ptr.numel() == nl + 1 and int(P.col_ptr[0]) == 0 and int(P.col_ptr[-1]) == A.nnz
+    uq, first = torch.unique_consecutive(want_leaf, return_inverse=False, return_counts=True)
+    starts = torch.cumsum(first, 0) - first
+    assert torch.equal(P.col_ptr[uq], starts) and torch.equal(P.col_ptr[uq + 1], starts + first)
+    d = P.col_ptr[1:] - P.col_ptr[:-1]
+    assert int(d.min()) >= 0 and int((d != 0).sum()) == uq.numel()
+
+
 # ---------------------------------------------------------------------------
 # two ranks, one device: the HIP path under the sharding + collectives of parallel.py
 # ---------------------------------------------------------------------------
