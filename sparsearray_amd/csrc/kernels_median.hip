@@ -15,13 +15,14 @@
 // column's values positive, fewer than half negative) the median is 0.  For the other
 // columns one workgroup per column SELECTS the one or two order statistics it needs from
 // the column where it lies -- a most-significant-digit-first radix select over the
-// order-preserving 64-bit image of the doubles (digits of 11, 11, 11, 11, 10, 10 bits: six
-// counting passes over the column with a histogram in LDS; the second middle value, when n
-// is even, costs one more pass: it is the same key again or the smallest key above it).
-// Nothing is copied and nothing is sorted (rounds 2-4: a key copy + rocprim's segmented
-// radix sort of 64-bit keys, eight read + write passes over the values).
-// Roofline: HBM; algorithmic bytes = 8 per nonzero for the count pass and up to 7 x 8 per
-// nonzero of an undecided column (short columns stay in the L2 between the passes).
+// order-preserving 64-bit image of the doubles (digits of 11, 11, 11, 11, 10, 10 bits:
+// counting passes over the column with a histogram in LDS until the bin of the wanted rank
+// holds at most 1024 keys, which are then collected into LDS and ranked there; the second
+// middle value, when n is even, comes from the same candidates or is the smallest key above
+// their bin).  Nothing is copied and nothing is sorted (rounds 2-4: a key copy + rocprim's
+// segmented radix sort of 64-bit keys, eight read + write passes over the values).
+// Roofline: HBM; algorithmic bytes = 8 per nonzero for the count pass and typically 3 x 8
+// (at most 8 x 8) per nonzero of an undecided column (short columns stay in the L2).
 #include "svt_common.h"
 
 #include <string.h>
@@ -117,11 +118,20 @@ __device__ inline unsigned msel_block_scan(unsigned x, unsigned *wsum, unsigned 
 	return before + incl - x;
 }
 
-// The key of rank k (0-based, ascending) among the NONZERO, non-NA values of val[beg, end): six counting passes,
-// most significant digit first.  Called by all MSEL_NT threads of the workgroup with the same arguments.
+#define MSEL_CAND 1024        // candidates finished in LDS
+
+// The keys of ranks k and k + 1 (0-based, ascending) among the NONZERO, non-NA values of val[beg, end) -- *key1 only when
+// want_next (the caller knows that rank k + 1 exists).  Counting passes, most significant digit first (11, 11, 11, 11,
+// 10, 10 bits), until the bin that holds rank k has at most MSEL_CAND keys; those are then collected into LDS in one more
+// pass over the column (which also finds the smallest key ABOVE the bin, for rank k + 1 when k is the bin's last) and
+// ranked there.  Doubles of one sign and exponent differ in their mantissa: two counting passes (22 bits) leave
+// n / 1024 candidates of a column of n values -- three passes over the column instead of seven.
+// Called by all MSEL_NT threads of the workgroup with the same arguments.  Returns false when the keys never got few
+// enough (more than MSEL_CAND equal keys): *key0 is exact after the six passes, *key1 is then left to the caller.
 template <typename T>
-__device__ unsigned long long msel_select(const T *__restrict__ val, int64_t beg, int64_t end, unsigned k,
-					  unsigned *hist, unsigned *wsum, unsigned *found)
+__device__ bool msel_select(const T *__restrict__ val, int64_t beg, int64_t end, unsigned k, bool want_next,
+			    unsigned *hist, unsigned *wsum, unsigned *found, unsigned long long *cand,
+			    unsigned long long *key0, unsigned long long *key1)
 {
 	unsigned long long prefix = 0;
 	int shift = 64;
@@ -160,16 +170,78 @@ __device__ unsigned long long msel_select(const T *__restrict__ val, int64_t beg
 			unsigned run = before;
 			for (unsigned i = 0; i < per; i++) {
 				const unsigned c = hist[b0 + i];
-				if (k < run + c) { found[0] = b0 + i; found[1] = run; break; }
+				if (k < run + c) { found[0] = b0 + i; found[1] = run; found[2] = c; break; }
 				run += c;
 			}
 		}
 		__syncthreads();
 		prefix |= (unsigned long long) found[0] << shift;
 		k -= found[1];
+		const unsigned ncand = found[2];
 		__syncthreads();
+		if (ncand <= MSEL_CAND && shift > 0) {
+			// collect the bin's keys (bits [shift, 64) equal to the prefix) and the smallest key above the bin
+			if (threadIdx.x == 0) found[3] = 0;
+			__syncthreads();
+			unsigned long long above = ~0ull;
+			for (int64_t i0 = beg; i0 < end; i0 += 4 * MSEL_NT) {
+				T raw[4];
+#pragma unroll
+				for (int u = 0; u < 4; u++) {
+					const int64_t i = i0 + u * MSEL_NT + threadIdx.x;
+					raw[u] = i < end ? val[i] : (T) 0;
+				}
+#pragma unroll
+				for (int u = 0; u < 4; u++) {
+					unsigned long long key;
+					if (!msel_key<T>(raw[u], &key))
+						continue;
+					const unsigned long long hi = key >> shift, want = prefix >> shift;
+					if (hi == want) cand[atomicAdd(&found[3], 1u)] = key;
+					else if (hi > want && key < above) above = key;
+				}
+			}
+			if (want_next) {
+				const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+				for (int o = 32; o > 0; o >>= 1) {
+					const unsigned long long t = __shfl_down(above, o, 64);
+					above = t < above ? t : above;
+				}
+				// (hist is free again: its first words carry the wavefronts' minima)
+				if (lane == 0) ((unsigned long long *) hist)[wv] = above;
+			}
+			__syncthreads();
+			if (want_next) {
+				above = ~0ull;
+				for (int i = 0; i < MSEL_NT / 64; i++) {
+					const unsigned long long t = ((unsigned long long *) hist)[i];
+					above = t < above ? t : above;
+				}
+			}
+			// rank the candidates: cand[i] is the key of local rank k iff (keys below it) <= k < (keys below or equal)
+			if (threadIdx.x == 0) { found[0] = 0; found[1] = 0; }
+			__syncthreads();
+			unsigned long long *res = (unsigned long long *) (hist + 64);       // [0] key of rank k, [1] of rank k + 1
+			for (unsigned i = threadIdx.x; i < ncand; i += MSEL_NT) {
+				const unsigned long long mk = cand[i];
+				unsigned lt = 0, le = 0;
+				for (unsigned jx = 0; jx < ncand; jx++) {
+					const unsigned long long o = cand[jx];
+					lt += o < mk; le += o <= mk;
+				}
+				if (lt <= k && k < le) res[0] = mk;                     // (equal keys write the same value)
+				if (lt <= k + 1 && k + 1 < le) { res[1] = mk; found[1] = 1; }
+			}
+			__syncthreads();
+			*key0 = res[0];
+			*key1 = found[1] ? res[1] : above;      // rank k + 1 past the bin's last key: the smallest key above the bin
+			__syncthreads();
+			return true;
+		}
 	}
-	return prefix;
+	*key0 = prefix;
+	*key1 = 0;
+	return false;
 }
 
 // One workgroup per undecided column (grid-stride over the columns): the virtual sorted column is
@@ -183,8 +255,9 @@ median_select_kernel(const int64_t *__restrict__ col_ptr, const T *__restrict__ 
 {
 	__shared__ unsigned hist[MSEL_BINS];
 	__shared__ unsigned wsum[MSEL_NT / 64];
-	__shared__ unsigned found[2];
+	__shared__ unsigned found[4];
 	__shared__ unsigned long long red[2 * (MSEL_NT / 64)];
+	__shared__ unsigned long long cand[MSEL_CAND];
 	for (int64_t j = blockIdx.x; j < ncol; j += gridDim.x) {
 		if (!todo[j])
 			continue;                                // (the same answer in every thread)
@@ -200,15 +273,18 @@ median_select_kernel(const int64_t *__restrict__ col_ptr, const T *__restrict__ 
 		const int64_t klo = lo < neg ? lo : lo < neg + zeros ? -1 : lo - zeros;
 		const int64_t khi = hi < neg ? hi : hi < neg + zeros ? -1 : hi - zeros;
 		double vlo = 0.0, vhi = 0.0;
-		unsigned long long key_lo = 0;
+		unsigned long long key_lo = 0, key_next = 0;
+		bool have_next = false;
 		if (klo >= 0) {
-			key_lo = msel_select<T>(val, beg, end, (unsigned) klo, hist, wsum, found);
+			have_next = msel_select<T>(val, beg, end, (unsigned) klo, khi == klo + 1, hist, wsum, found, cand, &key_lo, &key_next);
 			vlo = ordered_to_f64(key_lo);
 		}
 		if (khi < 0) {
 			vhi = 0.0;
 		} else if (khi == klo) {
 			vhi = vlo;
+		} else if (klo >= 0 && have_next) {
+			vhi = ordered_to_f64(key_next);          // (both ranks from the same candidates)
 		} else if (klo >= 0) {
 			// khi == klo + 1: the same key again if ranks <= klo + 1 are all covered by keys <= key_lo, else the
 			// smallest key above it.  One pass: count of keys <= key_lo, minimum of the keys > key_lo.
@@ -245,7 +321,9 @@ median_select_kernel(const int64_t *__restrict__ col_ptr, const T *__restrict__ 
 			__syncthreads();
 			vhi = (int64_t) cnt > khi ? vlo : ordered_to_f64(nxt);
 		} else {
-			vhi = ordered_to_f64(msel_select<T>(val, beg, end, (unsigned) khi, hist, wsum, found));
+			unsigned long long key_hi = 0, unused = 0;
+			(void) msel_select<T>(val, beg, end, (unsigned) khi, false, hist, wsum, found, cand, &key_hi, &unused);
+			vhi = ordered_to_f64(key_hi);
 		}
 		if (threadIdx.x == 0)
 			out[j] = (n & 1) ? vlo : (vlo + vhi) * 0.5;          // (:707 mean of the two, :757)
