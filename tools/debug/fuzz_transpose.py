@@ -70,6 +70,41 @@ for case in range(ncases):
                 print(f"MISMATCH (aperm {perm}) case {case}: dim {dims3} nnz {lin.numel()} kind {kind} int {is_int}", flush=True)
             del P, key, order, want_cp, ns
         del j, sl, subs
+    # round 5: every fourth case the columns read as three or four further axes and a RANDOM permutation of all axes (the
+    # composed route: leaf-preserving step, first two axes swapped or slab form, leaf-preserving step; or the own radix sort)
+    if case % 4 == 1 and ncol >= 8:
+        facs, rest = [], ncol
+        for q in (2, 3, 5, 7, 2, 3):
+            if rest % q == 0 and rest // q >= 1 and len(facs) < 3:
+                facs.append(q); rest //= q
+        if len(facs) >= 2:
+            dimsN = (nrow, rest) + tuple(facs)
+            strides, st = [], 1
+            for dsz in dimsN[1:]:
+                strides.append(st); st *= dsz
+            subsN = [ri.to(torch.int64)] + [(col // stv) % dsz for stv, dsz in zip(strides, dimsN[1:])]
+            for _ in range(3):
+                perm = tuple(int(q) + 1 for q in rng.permutation(len(dimsN)))
+                nd = tuple(dimsN[q - 1] for q in perm)
+                nl = int(np.prod(nd[1:], dtype=np.int64))
+                if nl > 5e7:
+                    continue
+                P, new_dim = A.aperm(dimsN, perm)
+                torch.cuda.synchronize()
+                ns = [subsN[q - 1] for q in perm]
+                leafN = torch.zeros_like(ns[0]); mul = 1
+                for a in range(1, len(nd)):
+                    leafN = leafN + ns[a] * mul; mul *= nd[a]
+                order = torch.sort(ns[0] + nd[0] * leafN, stable=True).indices
+                want_cp = torch.zeros(nl + 1, dtype=torch.int64, device=dev)
+                want_cp[1:] = torch.cumsum(torch.bincount(leafN, minlength=nl), 0)
+                okN = new_dim == nd and torch.equal(P.col_ptr, want_cp) and \
+                    torch.equal(P.row_idx, ns[0][order].to(torch.int32)) and torch.equal(P.val, v[order])
+                if not okN:
+                    bad += 1
+                    print(f"MISMATCH (aperm {perm}) case {case}: dim {dimsN} nnz {lin.numel()} kind {kind} int {is_int}", flush=True)
+                del P, order, want_cp, leafN, ns
+            del subsN
     T = A.t()
     torch.cuda.synchronize()
     order = torch.sort(ri.to(torch.int64), stable=True).indices
