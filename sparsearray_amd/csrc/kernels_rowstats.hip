@@ -257,7 +257,9 @@ rowpanel_table16_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__re
 	const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const int wl = w / S, sg = w % S;           // leaf of the workgroup, segment of the leaf
 	const int64_t j0 = (int64_t) blockIdx.x * L, j = j0 + wl;
-	if (j < ncol) {
+	// (with a map of the leaves the product will ask for -- svt %*% svt2, skip[j] != 0 -- the others need no run bounds:
+	// their offsets are not read, only their values are looked at below: 0.11 GB less at BASELINE config 3)
+	if (j < ncol && (skip == NULL || skip[j] != 0)) {
 		const int64_t beg = col_ptr[j], end = col_ptr[j + 1];
 		const int64_t sb = beg + (end - beg) * sg / S, se = beg + (end - beg) * (sg + 1) / S;
 		int carry = sb > beg ? row_idx[sb - 1] >> ps : -1;     // panel of the element before this trip
@@ -315,7 +317,7 @@ rowpanel_table16_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__re
 	const int64_t n = (npan + 1) * L;
 	for (int64_t t = threadIdx.x; t < n; t += PT_LEAVES * 64) {
 		const int64_t q = t / L, l = t % L;
-		if (j0 + l < ncol)
+		if (j0 + l < ncol && (skip == NULL || skip[j0 + l] != 0))
 			pt[q * ncol + j0 + l] = tab[t];
 	}
 }
