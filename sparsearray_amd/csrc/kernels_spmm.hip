@@ -71,6 +71,18 @@ spmm_ref_kernel(const int32_t *__restrict__ b_idx, int64_t b_nnz, uint8_t *__res
 		ref[b_idx[i]] = 1;
 }
 
+// the same for a small B, zeroing the map first: ONE workgroup, one launch (a memset in front of the kernel above is a
+// blit kernel with a bubble before it: ~10 us of a 0.73 ms call)
+__global__ void __launch_bounds__(1024)
+spmm_ref_small_kernel(const int32_t *__restrict__ b_idx, int64_t b_nnz, uint8_t *__restrict__ ref, int64_t ninner,
+		      int *__restrict__ zero2)
+{
+	if (zero2 != NULL && threadIdx.x < 2) zero2[threadIdx.x] = 0;   // (the two flag words at the head of the workspace)
+	for (int64_t i = threadIdx.x; i < ninner; i += blockDim.x) ref[i] = 0;
+	__syncthreads();
+	for (int64_t i = threadIdx.x; i < b_nnz; i += blockDim.x) ref[b_idx[i]] = 1;
+}
+
 static int g_spmm_ps = 13, g_spmm_nt = SPMM_NT, g_spmm_kw = 16;
 static void spmm_knobs(void)
 {
@@ -267,18 +279,25 @@ int launch_spmm_prepare(const SpmmArgs &a, int64_t a_nnz, void *ws, hipStream_t 
 
 // The same for ONE product with B: only the leaves of A that B does not refer to are looked at here -- the
 // product kernel sees the values of the others.
-int launch_spmm_prepare_for(const SpmmArgs &a, int64_t a_nnz, int64_t b_nnz, void *ws, hipStream_t s)
+int launch_spmm_prepare_for(const SpmmArgs &a, int64_t a_nnz, int64_t b_nnz, void *ws, hipStream_t s, int *zero2)
 {
-	if (a.nrow <= 0)
+	if (a.nrow <= 0) {
+		if (zero2 != NULL) HIP_TRY(hipMemsetAsync(zero2, 0, 8, s));
 		return 0;
+	}
 	int ps, KW; int64_t npan;
 	spmm_shape(a.nrow, 1, &ps, &npan, &KW);
 	uint8_t *ref = (uint8_t *) ws + spmm_table_bytes(a.nrow, a.ninner);
-	HIP_TRY(hipMemsetAsync(ref, 0, (size_t) (a.ninner > 0 ? a.ninner : 1), s));
-	if (b_nnz > 0) {
-		int64_t nb = (b_nnz + 255) / 256;
-		if (nb > 1024) nb = 1024;
-		hipLaunchKernelGGL(spmm_ref_kernel, dim3((unsigned) nb), dim3(256), 0, s, a.b_idx, b_nnz, ref);
+	if (a.ninner <= ((int64_t) 1 << 18) && b_nnz <= ((int64_t) 1 << 18)) {
+		hipLaunchKernelGGL(spmm_ref_small_kernel, dim3(1), dim3(1024), 0, s, a.b_idx, b_nnz, ref, a.ninner, zero2);
+	} else {
+		if (zero2 != NULL) HIP_TRY(hipMemsetAsync(zero2, 0, 8, s));
+		HIP_TRY(hipMemsetAsync(ref, 0, (size_t) (a.ninner > 0 ? a.ninner : 1), s));
+		if (b_nnz > 0) {
+			int64_t nb = (b_nnz + 255) / 256;
+			if (nb > 1024) nb = 1024;
+			hipLaunchKernelGGL(spmm_ref_kernel, dim3((unsigned) nb), dim3(256), 0, s, a.b_idx, b_nnz, ref);
+		}
 	}
 	if (!launch_rowpanel_table_scan(a.a_ptr, a.a_idx, a.a_val, a.a_type, a.ninner, a_nnz, npan, ps, (int32_t *) ws,
 					ref, a.flag, s))

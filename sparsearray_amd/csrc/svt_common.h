@@ -174,7 +174,7 @@ struct SpmmArgs {
 };
 size_t spmm_ws_bytes(int64_t nrow, int64_t ninner);
 int launch_spmm_prepare(const SpmmArgs &a, int64_t a_nnz, void *ws, hipStream_t s);
-int launch_spmm_prepare_for(const SpmmArgs &a, int64_t a_nnz, int64_t b_nnz, void *ws, hipStream_t s);
+int launch_spmm_prepare_for(const SpmmArgs &a, int64_t a_nnz, int64_t b_nnz, void *ws, hipStream_t s, int *zero2);
 int launch_spmm_product(SpmmArgs a, int64_t a_nnz, int64_t b_nnz, const void *ws, hipStream_t s);
 
 size_t transpose_ws_bytes(int64_t nrow, int64_t nnz);

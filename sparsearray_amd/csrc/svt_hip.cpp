@@ -859,10 +859,10 @@ extern "C" int svt_dev_matmul_csc_csc(const svt_dev_csc *A, const svt_dev_csc *B
 	// the values it reads (kernels_spmm.hip); ws[0] is left as "not known for A alone" -- this ws is not a
 	// prepared one afterwards
 	hipStream_t s = (hipStream_t) stream;
-	HIP_TRY(hipMemsetAsync(ws, 0, 8, s));
 	int *flag = (int *) ws + 1;
 	const SpmmArgs a = spmm_args(A, B, out, ldo, flag);
-	if (launch_spmm_prepare_for(a, A->nnz, B->nnz, (char *) ws + 256, s))
+	// (the two flag words are zeroed by the first kernel of the pass: a memset in front of it is a blit kernel of its own)
+	if (launch_spmm_prepare_for(a, A->nnz, B->nnz, (char *) ws + 256, s, (int *) ws))
 		return -1;
 	if (launch_spmm_product(a, A->nnz, B->nnz, (char *) ws + 256, s))
 		return -1;
