@@ -249,3 +249,20 @@ def test_blocked_generator_is_rank_count_invariant():
             assert torch.equal(scp, cpa) and torch.equal(sri, ria) and torch.equal(sv, va)
             Ya = synth.random_dense_blocked(20000, 3, 9, "cpu", first=rank * per, last=(rank + 1) * per)
             assert torch.equal(Y[:, a0:a1], Ya)
+
+
+def test_bench_launcher_reports_dead_ranks():
+    """`python bench.py --gpus 2` started directly spawns its ranks as a child process (torch.distributed.run) and hands
+    their fate on: where the ranks cannot run -- no GPU in this container (and on a one-GPU box rank 1 has no device) --
+    the exit status is non-zero and no result line is printed."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs here: the ranks would run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--nrow", "4096",
+                        "--ncol", "500", "--steps", "1", "--warmup", "0", "--no-extras", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0
+    assert '"metric"' not in p.stdout
