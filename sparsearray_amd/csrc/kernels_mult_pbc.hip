@@ -1991,16 +1991,33 @@ __device__ inline void pbc_dirty_scan_tail(const DirtyScanArgs &ds, int64_t wg, 
 __global__ void pbc_reduce_kernel(const double *__restrict__ part, int nsplit, int64_t Kp,
 				  int K, int64_t ncol, const int *__restrict__ col_has_na,
 				  double *__restrict__ out, int64_t sc, int64_t sk, int64_t c_begin,
-				  const DirtyScanArgs ds)
+				  const DirtyScanArgs ds, int pairs)
 {
-	const int64_t c = c_begin + (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
 	const int k = blockIdx.y;
-	if (c < ncol && k < K) {
-		double s = 0.0;
-		for (int t = 0; t < nsplit; t++)
-			s += part[((int64_t) t * Kp + k) * ncol + c];
-		if (col_has_na[c]) s = svt_na_real();
-		out[c * sc + (int64_t) k * sk] = s;
+	if (pairs) {
+		// two leaves per thread, 16-byte loads and stores (ncol, c_begin even, unit stride of the result, aligned bases:
+		// checked by the launcher); the same additions in the same order per cell
+		const int64_t c = c_begin + ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) * 2;
+		if (c < ncol && k < K) {
+			double2 s = make_double2(0.0, 0.0);
+			for (int t = 0; t < nsplit; t++) {
+				const double2 v = *(const double2 *) (part + ((int64_t) t * Kp + k) * ncol + c);
+				s.x += v.x; s.y += v.y;
+			}
+			const int2 na = *(const int2 *) (col_has_na + c);
+			if (na.x) s.x = svt_na_real();
+			if (na.y) s.y = svt_na_real();
+			*(double2 *) (out + c + (int64_t) k * sk) = s;
+		}
+	} else {
+		const int64_t c = c_begin + (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+		if (c < ncol && k < K) {
+			double s = 0.0;
+			for (int t = 0; t < nsplit; t++)
+				s += part[((int64_t) t * Kp + k) * ncol + c];
+			if (col_has_na[c]) s = svt_na_real();
+			out[c * sc + (int64_t) k * sk] = s;
+		}
 	}
 	pbc_dirty_scan_tail(ds, (int64_t) blockIdx.y * gridDim.x + blockIdx.x, (int64_t) gridDim.x * gridDim.y);
 }
@@ -2617,9 +2634,12 @@ static int pbc_phase_impl(const svt_dev_pbc *P, const svt_dev_csc *A,
 		hipLaunchKernelGGL(pbc_nafix_kernel, dim3((unsigned) ((P->ncol - c_begin + 255) / 256)), dim3(256), 0, s,
 				   P->col_has_na, K, P->ncol, out, out_stride_c, out_stride_k, c_begin, ds);
 	} else {
-		dim3 rgrid((unsigned) ((P->ncol - c_begin + 255) / 256), (unsigned) K);
+		const int pairs = (P->ncol % 2 == 0 && c_begin % 2 == 0 && out_stride_c == 1 && out_stride_k % 2 == 0 &&
+				   (((uintptr_t) part | (uintptr_t) out) & 15) == 0 && ((uintptr_t) P->col_has_na & 7) == 0) ? 1 : 0;
+		const int64_t per_wg = pairs ? 512 : 256;
+		dim3 rgrid((unsigned) ((P->ncol - c_begin + per_wg - 1) / per_wg), (unsigned) K);
 		hipLaunchKernelGGL(pbc_reduce_kernel, rgrid, dim3(256), 0, s, part, nsplit, Kp, K, P->ncol,
-				   P->col_has_na, out, out_stride_c, out_stride_k, c_begin, ds);
+				   P->col_has_na, out, out_stride_c, out_stride_k, c_begin, ds, pairs);
 	}
 	HIP_TRY(hipGetLastError());
 	if (fast && P->rec != NULL) {
