@@ -427,6 +427,43 @@ int svt_dev_matmul_csc_csc_prepare(const svt_dev_csc *A, void *ws, size_t ws_byt
 int svt_dev_matmul_csc_csc_prepared(const svt_dev_csc *A, const svt_dev_csc *B, double *out, int64_t ldo,
 				    void *ws, size_t ws_bytes, int *not_finite, void *stream);
 
+/* crossprod(X, Y) for two sparse operands without a dense buffer (round 6; kernels_gram.hip):
+   out[c + j * ldo] = sum over the rows r where X[r, c] and Y[r, j] are both nonzero of X[r, c] * Y[r, j] -- for
+   finite operands the cell C_crossprod2_SVT_SVT / C_crossprod1_SVT form (src/SparseMatrix_mult.c:1037-1140: one
+   operand's leaves expanded into a dense buffer, ALL leaves of the other walked over it, :728-887; K11-K13
+   :263-296), without the multiply-adds against the buffer's zeros and without the order of its additions
+   (exact for integer operands below 2^53).
+     Xt    t(X) in the device layout (svt_dev_transpose): Xt->nrow = ncol(X), Xt->ncol = nrow(X) leaves.
+     Y     nrow(X) x ncol(Y).
+     sym   != 0: Y is X (Xt = t(Y)), the unary crossprod(x): the cells c <= j are formed and mirrored
+           (compute_sym_dotprods_*, :827-873, writes out[k] and out[k * ncol] from one dot product).
+   A non-finite value or an NA anywhere in either operand changes what the reference computes (its dirty-leaf
+   loops multiply the implicit zeros too): `*not_finite` (device int, may be NULL; the first int of `ws` holds
+   the same flag) is set and `out` must come from the dense-buffer route (svt_crossprod2_SVT_SVT /
+   svt_crossprod1_SVT do that).  ws: svt_dev_crossprod_csc_csc_ws_bytes(Xt) bytes.  Asynchronous. */
+size_t svt_dev_crossprod_csc_csc_ws_bytes(const svt_dev_csc *Xt);
+int svt_dev_crossprod_csc_csc(const svt_dev_csc *Xt, const svt_dev_csc *Y, int sym, double *out, int64_t ldo,
+			      void *ws, size_t ws_bytes, int *not_finite, void *stream);
+/* Results up to `one_block_max` (<= 10200, the default) cells tall keep a whole result column in one
+   workgroup's LDS; taller ones are cut into panels of 2^log2_panel (<= 13, the default) cells.  Negative /
+   out-of-range arguments restore the defaults.  Process-wide; tests and tuning (workspaces sized before a change
+   may be too small after it). */
+void svt_dev_crossprod_csc_csc_set_panel(int one_block_max, int log2_panel);
+
+/* The dense-buffer route of the same product on resident operands -- the reference's own form (one operand
+   densified 128 or more columns at a time, the panel / general product kernels against each chunk; the Lpp / Rpp
+   choice of src/SparseMatrix_mult.c:1077-1097; Y == X, the same handle: the unary form, ncol^2 / 2 dot products
+   + mirror): what the host entry points fall back to when an operand is not finite, and the yardstick the
+   sparse-aware kernel is measured against.  out: ncol(X) x ncol(Y) doubles, column-major (device).  Allocates
+   its buffers and synchronises the device: not for a launch path. */
+int svt_dev_crossprod_csc_csc_dense_buffer(const svt_dev_csc *X, const svt_dev_csc *Y, double *out);
+
+/* Route choice of svt_crossprod2_SVT_SVT / svt_crossprod1_SVT: the sparse-aware kernel above is taken when
+   (pairs of nonzeros that meet in a row, estimated as nnz(x) * nnz(y) / nrow) * cost < the multiply-adds of the
+   dense-buffer route (the reference's own Lpp_nops / Rpp_nops count, src/SparseMatrix_mult.c:1077-1078).
+   cost <= 0: never; a huge value: always.  Default: the ratio measured on one MI355X.  Process-wide. */
+void svt_sparse_crossprod_set_cost(double cost);
+
 /* aperm(x, perm) for an N-d operand (C_aperm_SVT, src/SparseArray_aperm.c:935-970;
    R/SparseArray-aperm.R).  `dim` are the array's ndim extents (dim[0] = A->nrow,
    prod(dim[1..]) = A->ncol), `perm` is 1-based as in R.  Output: the CSC layout of

@@ -1,0 +1,378 @@
+// crossprod(X, Y) for two SPARSE operands without a dense operand: out[c, j] = sum over the rows r where BOTH
+// X[r, c] and Y[r, j] are nonzero of X[r, c] * Y[r, j].
+//
+// The reference (C_crossprod2_SVT_SVT / C_crossprod1_SVT, src/SparseMatrix_mult.c:1037-1140) expands the leaves
+// of one operand, one at a time, into a dense buffer and walks ALL leaves of the other operand over it
+// (crossprod2_Lpp_* / crossprod2_Rpp_* :728-820, compute_sym_dotprods_* :827-873, the loops K11-K13 :263-296):
+// ncol(x) * nnz(y) multiply-adds, nearly all of them with the buffer's zeros.  With finite operands the cell is
+// the sum over the rows where both leaves hold a nonzero (the others add exact zeros), and that is all this
+// kernel multiplies: at BASELINE config-2 scale (crossprod(A), A 1e6 x 1e4 @ 1 %) 5e9 products for the upper
+// triangle where the dense-buffer route -- rounds 2-5: densify 128 columns, panel product, 79 times -- does 5e11.
+//
+// Form (column-wise Gustavson on t(X)): the workgroup that owns result column j keeps its cells out[., j] in LDS
+// and, for every nonzero (r, v) of Y[:, j], adds v * X[r, .] -- row r of X, i.e. LEAF r of t(X), a contiguous run
+// of (column, value) pairs -- into them (ds_add_f64; two rows can meet in a cell).  A group of G lanes takes one
+// nonzero of Y at a time.  t(X) is the caller's (svt_dev_transpose; for x %*% y the operand itself).
+//   * nx = ncol(X) <= 10200: all cells of a result column fit one workgroup's LDS (two workgroups per CU).
+//     Symmetric case (Y is X): only the cells c <= j are formed -- row r's pairs come in ascending column order,
+//     a lane stops at its first column > j, so the prefix needs no search -- and columns j and nx - 1 - j share a
+//     workgroup: nx + 1 cells, the same work for every workgroup (which keeps the workgroups in flight walking
+//     the same stretch of rows: the runs several of them name can then come from the memory-side cache).
+//   * wider results: panels of 8192 cells; the part of leaf r inside a panel comes from the table of run bounds
+//     that the row-panel kernels use (launch_rowpanel_table, kernels_rowstats.hip); symmetric: panels above the
+//     diagonal cell are skipped, the diagonal panel is cut as above.
+// The lower triangle of a symmetric result is the mirror image of the upper one (gram_mirror_kernel, 64 x 64
+// tiles through LDS), as compute_sym_dotprods_* writes out[k] and out[k * ncol] from one dot product.
+//
+// Not a sum in the reference's order: the additions of one cell come in the order the lane groups get to them
+// (last-bit differences between runs; integer operands are exact below 2^53).  A non-finite value or an NA
+// ANYWHERE in either operand changes what the reference computes (its dirty-leaf loops multiply the implicit
+// zeros too, src/SparseVec_dotprod.c:48-65; an NA_integer_ fills whole rows / columns, :684-724): *flag goes up
+// and the caller takes the dense-buffer route.  Every value of Y is looked at by the product itself, the values
+// of X by a scan in front of it (symmetric: X is Y).
+#include "svt_common.h"
+
+#define GRAM_NT 1024
+#define GRAM_U 4
+
+static int g_gram_one = 10200, g_gram_ps = 13;
+
+void gram_set_panel(int one_block_max, int log2_panel)
+{
+	g_gram_one = one_block_max < 0 ? 10200 : (one_block_max > 10200 ? 10200 : one_block_max);
+	g_gram_ps = log2_panel < 4 || log2_panel > 13 ? 13 : log2_panel;
+}
+
+template <typename T> __device__ inline bool gram_bad(T v);
+template <> __device__ inline bool gram_bad<double>(double v) { return !(fabs(v) <= 1.7976931348623157e308); }
+template <> __device__ inline bool gram_bad<int>(int v) { return v == NA_INT; }
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+gram_scan_values_kernel(const T *__restrict__ val, int64_t n, int *__restrict__ flag)
+{
+	bool bad = false;
+	for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t) gridDim.x * blockDim.x)
+		bad |= gram_bad<T>(val[i]);
+	if (__ballot(bad) != 0 && (threadIdx.x & 63) == 0) *flag = 1;
+}
+
+// MODE 0: one block of cells per result column; 1: the same, symmetric, columns j and nx - 1 - j per workgroup;
+//      2: panels of cells + table of run bounds; 3: the same, symmetric (cells c <= j only)
+template <typename TA, typename TB, int MODE>
+__global__ void __launch_bounds__(GRAM_NT)
+gram_kernel(GramArgs a, int G)
+{
+	extern __shared__ double acc[];
+	__shared__ int stop;
+	const int tid = threadIdx.x, NT = blockDim.x;
+	constexpr bool CUT = MODE == 1 || MODE == 3;      // entries at or past the task's last cell end a lane's walk
+	constexpr bool TABLE = MODE >= 2;
+	// the workgroup's tasks: result column, cells [clo, chi), where they sit in LDS
+	int ntask = 1;
+	int64_t tk[2] = { 0, 0 };
+	int clo[2] = { 0, 0 }, chi[2] = { 0, 0 }, off[2] = { 0, 0 };
+	int64_t q = 0;
+	if (MODE == 0) {
+		tk[0] = blockIdx.x; chi[0] = (int) a.nx;
+	} else if (MODE == 1) {
+		tk[0] = blockIdx.x; chi[0] = (int) tk[0] + 1;
+		tk[1] = a.nx - 1 - tk[0]; chi[1] = (int) tk[1] + 1; off[1] = chi[0];
+		if (tk[1] != tk[0]) ntask = 2;
+	} else {
+		const int64_t L = blockIdx.x;
+		q = L % a.npan; tk[0] = L / a.npan;
+		const int64_t c0 = q << a.ps;
+		int64_t c1 = c0 + ((int64_t) 1 << a.ps);
+		if (c1 > a.nx) c1 = a.nx;
+		if (MODE == 3 && c1 > tk[0] + 1) c1 = tk[0] + 1;
+		if (c1 <= c0)
+			return;                         // (a panel above the diagonal cell: the whole workgroup leaves)
+		clo[0] = (int) c0; chi[0] = (int) c1;
+	}
+	const int ncell = off[ntask - 1] + chi[ntask - 1] - clo[ntask - 1];
+	for (int x = tid; x < ncell; x += NT) acc[x] = 0.0;
+	if (tid == 0)
+		stop = *(volatile const int *) a.flag;  // (ONE read per workgroup: its wavefronts must agree)
+	__syncthreads();
+	if (stop != 0)
+		return;
+	const int grp = tid / G, sl = tid % G, ngrp = NT / G;
+	const TA *__restrict__ av = (const TA *) a.a_val;
+	const TB *__restrict__ bv = (const TB *) a.b_val;
+	const int32_t *__restrict__ pt0 = TABLE ? a.pt + q * a.nrow : NULL;
+	const int32_t *__restrict__ pt1 = TABLE ? pt0 + a.nrow : NULL;
+	bool bad = false;
+	for (int ti = 0; ti < ntask; ti++) {
+		const int64_t bb = a.b_ptr[tk[ti]];
+		const int64_t npairs = a.b_ptr[tk[ti] + 1] - bb;
+		const int lo = clo[ti], hi = chi[ti];
+		double *__restrict__ cell = acc + off[ti] - lo;
+		// GRAM_U nonzeros of Y per group in flight: their bounds are fetched together, then their runs
+		for (int64_t t0 = grp; t0 < npairs; t0 += (int64_t) GRAM_U * ngrp) {
+			int64_t xb[GRAM_U], xe[GRAM_U];
+			double bval[GRAM_U];
+#pragma unroll
+			for (int u = 0; u < GRAM_U; u++) {
+				const int64_t t = t0 + (int64_t) u * ngrp;
+				xb[u] = xe[u] = 0; bval[u] = 0.0;
+				if (t < npairs) {
+					const int64_t r = a.b_idx[bb + t];
+					const TB b = bv[bb + t];
+					const int64_t base = a.a_ptr[r];
+					if (TABLE) { xb[u] = base + pt0[r] + sl; xe[u] = base + pt1[r]; }
+					else { xb[u] = base + sl; xe[u] = a.a_ptr[r + 1]; }
+					bval[u] = (double) b;
+					bad |= gram_bad<TB>(b);
+				}
+			}
+			bool more = true;
+			while (more) {
+				TA v[GRAM_U];
+				int c[GRAM_U];
+#pragma unroll
+				for (int u = 0; u < GRAM_U; u++)
+					if (xb[u] < xe[u]) { c[u] = a.a_idx[xb[u]]; v[u] = av[xb[u]]; }
+				more = false;
+#pragma unroll
+				for (int u = 0; u < GRAM_U; u++)
+					if (xb[u] < xe[u]) {
+						if (!CUT || c[u] < hi) {
+							bad |= gram_bad<TA>(v[u]);
+							atomicAdd(&cell[c[u]], (double) v[u] * bval[u]);
+							xb[u] += G;
+							more |= xb[u] < xe[u];
+						} else
+							xe[u] = 0;      // (ascending columns: the lane's later entries are past the cut too)
+					}
+			}
+		}
+	}
+	if (__ballot(bad) != 0 && (tid & 63) == 0) *a.flag = 1;
+	__syncthreads();
+	for (int ti = 0; ti < ntask; ti++) {
+		double *__restrict__ dst = a.out + tk[ti] * a.ldo + clo[ti];
+		const double *__restrict__ src = acc + off[ti];
+		const int n = chi[ti] - clo[ti];
+		for (int x = tid; x < n; x += NT) dst[x] = src[x];
+	}
+}
+
+// The symmetric one-block form.  A lane group's walk of row r for result column j ends at the first column > j:
+// walks for one result column vary from nothing to the whole row, and a wavefront is as slow as its longest walk
+// (first version, one walk per slot: 24.3 ms at config-2 scale where the general form, which reads twice as much,
+// took 22.1).  Here a slot's unit of work is the t-th nonzero of column j TOGETHER with the t-th nonzero of
+// column n - 1 - j: a prefix of one row up to column j and a prefix of another up to column n - 1 - j, about one
+// row's length in all whatever j is.
+#define GRAM_SU 2
+template <typename T>
+__global__ void __launch_bounds__(GRAM_NT)
+gram_sym_kernel(GramArgs a, int G)
+{
+	extern __shared__ double acc[];
+	__shared__ int stop;
+	const int tid = threadIdx.x, NT = blockDim.x;
+	const int64_t k1 = blockIdx.x, k2 = a.nx - 1 - k1;
+	const int hi1 = (int) k1 + 1, hi2 = (int) k2 + 1, off2 = hi1;
+	const int ncell = k2 != k1 ? hi1 + hi2 : hi1;
+	for (int x = tid; x < ncell; x += NT) acc[x] = 0.0;
+	if (tid == 0)
+		stop = *(volatile const int *) a.flag;
+	__syncthreads();
+	if (stop != 0)
+		return;
+	const int grp = tid / G, sl = tid % G, ngrp = NT / G;
+	const T *__restrict__ av = (const T *) a.a_val;
+	const T *__restrict__ bv = (const T *) a.b_val;
+	const int64_t bb1 = a.b_ptr[k1], np1 = a.b_ptr[k1 + 1] - bb1;
+	const int64_t bb2 = a.b_ptr[k2], np2 = k2 != k1 ? a.b_ptr[k2 + 1] - bb2 : 0;
+	const int64_t nunits = np1 > np2 ? np1 : np2;
+	bool bad = false;
+	for (int64_t t0 = grp; t0 < nunits; t0 += (int64_t) GRAM_SU * ngrp) {
+		int64_t x[GRAM_SU], xe[GRAM_SU], x2[GRAM_SU], xe2[GRAM_SU];
+		double b[GRAM_SU], b2[GRAM_SU];
+		int hi[GRAM_SU], off[GRAM_SU];
+#pragma unroll
+		for (int u = 0; u < GRAM_SU; u++) {
+			const int64_t t = t0 + (int64_t) u * ngrp;
+			x[u] = xe[u] = x2[u] = xe2[u] = 0; b[u] = b2[u] = 0.0; hi[u] = hi1; off[u] = 0;
+			if (t < np1) {
+				const int64_t r = a.b_idx[bb1 + t];
+				const T w = bv[bb1 + t];
+				x[u] = a.a_ptr[r] + sl; xe[u] = a.a_ptr[r + 1];
+				b[u] = (double) w; bad |= gram_bad<T>(w);
+			}
+			if (t < np2) {
+				const int64_t r = a.b_idx[bb2 + t];
+				const T w = bv[bb2 + t];
+				x2[u] = a.a_ptr[r] + sl; xe2[u] = a.a_ptr[r + 1];
+				b2[u] = (double) w; bad |= gram_bad<T>(w);
+			}
+		}
+		bool more = true;
+		while (more) {
+			T v[GRAM_SU];
+			int c[GRAM_SU];
+#pragma unroll
+			for (int u = 0; u < GRAM_SU; u++) {
+				if (x[u] >= xe[u]) {            // this walk is over: on to the unit's second one (or to nothing)
+					x[u] = x2[u]; xe[u] = xe2[u]; b[u] = b2[u]; hi[u] = hi2; off[u] = off2;
+					x2[u] = xe2[u] = 0;
+				}
+				if (x[u] < xe[u]) { c[u] = a.a_idx[x[u]]; v[u] = av[x[u]]; }
+			}
+			more = false;
+#pragma unroll
+			for (int u = 0; u < GRAM_SU; u++) {
+				if (x[u] < xe[u]) {
+					if (c[u] < hi[u]) {
+						bad |= gram_bad<T>(v[u]);
+						atomicAdd(&acc[off[u] + c[u]], (double) v[u] * b[u]);
+						x[u] += G;
+					} else
+						x[u] = xe[u];   // (ascending columns: the lane's later entries are past the cut too)
+				}
+				more |= x[u] < xe[u] || x2[u] < xe2[u];
+			}
+		}
+	}
+	if (__ballot(bad) != 0 && (tid & 63) == 0) *a.flag = 1;
+	__syncthreads();
+	{
+		double *__restrict__ dst = a.out + k1 * a.ldo;
+		for (int x = tid; x < hi1; x += NT) dst[x] = acc[x];
+	}
+	if (k2 != k1) {
+		double *__restrict__ dst = a.out + k2 * a.ldo;
+		for (int x = tid; x < hi2; x += NT) dst[x] = acc[off2 + x];
+	}
+}
+
+// out[j, i] = out[i, j] for i < j (n x n, column-major, leading dimension ld): 64 x 64 tiles through LDS, both
+// the reads and the writes run along columns
+__global__ void __launch_bounds__(256)
+gram_mirror_kernel(double *__restrict__ out, int64_t n, int64_t ld)
+{
+	__shared__ double tile[64][65];
+	const int64_t bi = blockIdx.x, bj = blockIdx.y;
+	if (bi > bj)
+		return;
+	const int tx = threadIdx.x & 63, ty0 = threadIdx.x >> 6;
+	const int64_t i = bi * 64 + tx;
+	for (int ty = ty0; ty < 64; ty += 4) {
+		const int64_t j = bj * 64 + ty;
+		if (i < n && j < n) tile[ty][tx] = out[i + j * ld];
+	}
+	__syncthreads();
+	const int64_t row = bj * 64 + tx;
+	for (int ty = ty0; ty < 64; ty += 4) {
+		const int64_t col = bi * 64 + ty;
+		if (row < n && col < n && row > col) out[row + col * ld] = tile[tx][ty];
+	}
+}
+
+int launch_gram_mirror(double *out, int64_t n, int64_t ld, hipStream_t s)
+{
+	if (n <= 1)
+		return 0;
+	const unsigned nt = (unsigned) ((n + 63) / 64);
+	if (nt > 65535)
+		return svt_set_error("sparse crossprod: result too wide to mirror");
+	hipLaunchKernelGGL(gram_mirror_kernel, dim3(nt, nt), dim3(256), 0, s, out, n, ld);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+// [256 bytes: flag words][table of run bounds, wide results only]
+size_t gram_ws_bytes(int64_t nx, int64_t nrow)
+{
+	size_t n = 256;
+	if (nx > g_gram_one) {
+		const int64_t npan = (nx + ((int64_t) 1 << g_gram_ps) - 1) >> g_gram_ps;
+		n += ((size_t) (nrow > 0 ? nrow : 1) * (size_t) (npan + 1) * 4 + 255) / 256 * 256;
+	}
+	return n;
+}
+
+int launch_gram(GramArgs a, int64_t a_nnz, int64_t b_nnz, void *ws, hipStream_t s)
+{
+	(void) b_nnz;
+	if (a.nx <= 0 || a.ny <= 0)
+		return 0;
+	int *flag = (int *) ws;
+	a.flag = flag;
+	HIP_TRY(hipMemsetAsync(flag, 0, 8, s));
+	if (!a.sym && a_nnz > 0) {                      // the values of X (symmetric: every value is some workgroup's Y value)
+		int64_t nb = (a_nnz + 256 * 8 - 1) / (256 * 8);
+		if (nb > 256 * 16) nb = 256 * 16;
+		if (a.a_type == SVT_REALSXP)
+			hipLaunchKernelGGL(gram_scan_values_kernel<double>, dim3((unsigned) nb), dim3(256), 0, s,
+					   (const double *) a.a_val, a_nnz, flag);
+		else
+			hipLaunchKernelGGL(gram_scan_values_kernel<int>, dim3((unsigned) nb), dim3(256), 0, s,
+					   (const int *) a.a_val, a_nnz, flag);
+	}
+	const bool one = a.nx <= g_gram_one;
+	int mode;
+	size_t lds;
+	int64_t nwg;
+	double run = a.nrow > 0 ? (double) a_nnz / (double) a.nrow : 0.0;        // mean length of a lane group's walk
+	if (one) {
+		mode = a.sym ? 1 : 0;
+		lds = (size_t) (a.nx + (a.sym ? 1 : 0)) * 8;
+		nwg = a.sym ? (a.nx + 1) / 2 : a.ny;
+		a.npan = 1; a.ps = 0; a.pt = NULL;
+	} else {
+		mode = a.sym ? 3 : 2;
+		a.ps = g_gram_ps;
+		a.npan = (a.nx + ((int64_t) 1 << a.ps) - 1) >> a.ps;
+		lds = ((size_t) 1 << a.ps) * 8;
+		nwg = a.npan * a.ny;
+		a.pt = (const int32_t *) ((char *) ws + 256);
+		launch_rowpanel_table(a.a_ptr, a.a_idx, a.nrow, a_nnz, a.npan, a.ps, (int32_t *) a.pt, s);
+		run /= (double) a.npan;
+	}
+	if (a.sym) run *= 0.5;
+	if (nwg >= (int64_t) 2147483647)
+		return svt_set_error("sparse crossprod: too many workgroups for one launch");
+	int G = 64;
+	while (G > 8 && run < 2.0 * G) G >>= 1;
+#ifdef SVT_TUNING
+	if (getenv("SVT_GRAM_G")) G = atoi(getenv("SVT_GRAM_G"));
+#endif
+	int nt = GRAM_NT;
+#ifdef SVT_TUNING
+	if (getenv("SVT_GRAM_NT")) nt = atoi(getenv("SVT_GRAM_NT"));
+#endif
+	const dim3 grid((unsigned) nwg);
+#define GRAM_GO(TA, TB, M) do { \
+		(void) hipFuncSetAttribute((const void *) gram_kernel<TA, TB, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); \
+		hipLaunchKernelGGL((gram_kernel<TA, TB, M>), grid, dim3(nt), lds, s, a, G); } while (0)
+#define GRAM_MODES(TA, TB) do { \
+		if (mode == 0) GRAM_GO(TA, TB, 0); else if (mode == 1) GRAM_GO(TA, TB, 1); \
+		else if (mode == 2) GRAM_GO(TA, TB, 2); else GRAM_GO(TA, TB, 3); } while (0)
+	int symk = 1;                                   // (tuning build: SVT_GRAM_SYMK=0 = the first, one-walk-per-slot form)
+#ifdef SVT_TUNING
+	if (getenv("SVT_GRAM_SYMK")) symk = atoi(getenv("SVT_GRAM_SYMK"));
+#endif
+	if (mode == 1 && symk && a.a_type == a.b_type) {
+		if (a.a_type == SVT_REALSXP) {
+			(void) hipFuncSetAttribute((const void *) gram_sym_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+			hipLaunchKernelGGL((gram_sym_kernel<double>), grid, dim3(nt), lds, s, a, G);
+		} else {
+			(void) hipFuncSetAttribute((const void *) gram_sym_kernel<int>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+			hipLaunchKernelGGL((gram_sym_kernel<int>), grid, dim3(nt), lds, s, a, G);
+		}
+	} else
+	if (a.a_type == SVT_REALSXP && a.b_type == SVT_REALSXP) GRAM_MODES(double, double);
+	else if (a.a_type == SVT_INTSXP && a.b_type == SVT_INTSXP) GRAM_MODES(int, int);
+	else if (a.a_type == SVT_REALSXP && a.b_type == SVT_INTSXP) GRAM_MODES(double, int);
+	else if (a.a_type == SVT_INTSXP && a.b_type == SVT_REALSXP) GRAM_MODES(int, double);
+	else return svt_set_error("sparse crossprod: unsupported operand types");
+#undef GRAM_MODES
+#undef GRAM_GO
+	HIP_TRY(hipGetLastError());
+	if (a.sym && launch_gram_mirror(a.out, a.nx, a.ldo, s))
+		return -1;
+	return 0;
+}

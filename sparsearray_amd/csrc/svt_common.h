@@ -177,6 +177,21 @@ int launch_spmm_prepare(const SpmmArgs &a, int64_t a_nnz, void *ws, hipStream_t 
 int launch_spmm_prepare_for(const SpmmArgs &a, int64_t a_nnz, int64_t b_nnz, void *ws, hipStream_t s, int *zero2);
 int launch_spmm_product(SpmmArgs a, int64_t a_nnz, int64_t b_nnz, const void *ws, hipStream_t s);
 
+// sparse x sparse crossprod without a dense operand (kernels_gram.hip)
+struct GramArgs {
+	const int64_t *a_ptr; const int32_t *a_idx; const void *a_val; int a_type;   // t(X): nrow leaves of (column of X, value)
+	int64_t nx, nrow;
+	const int64_t *b_ptr; const int32_t *b_idx; const void *b_val; int b_type; int64_t ny;   // Y: ny leaves of (row, value)
+	double *out; int64_t ldo;           // out[c + j * ldo]
+	int sym;                            // Y is X: cells c <= j, then mirrored
+	const int32_t *pt; int64_t npan; int ps;
+	int *flag;
+};
+void gram_set_panel(int one_block_max, int log2_panel);
+size_t gram_ws_bytes(int64_t nx, int64_t nrow);
+int launch_gram(GramArgs a, int64_t a_nnz, int64_t b_nnz, void *ws, hipStream_t s);
+int launch_gram_mirror(double *out, int64_t n, int64_t ld, hipStream_t s);
+
 size_t transpose_ws_bytes(int64_t nrow, int64_t nnz);
 int launch_transpose(const int64_t *col_ptr, const int32_t *row_idx, const void *val, int Rtype,
 		     int64_t nrow, int64_t ncol, int64_t nnz, int64_t *out_ptr, int32_t *out_idx,

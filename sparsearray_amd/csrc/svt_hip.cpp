@@ -871,6 +871,44 @@ extern "C" int svt_dev_matmul_csc_csc(const svt_dev_csc *A, const svt_dev_csc *B
 	return 0;
 }
 
+// crossprod(X, Y) of two sparse operands on t(X) and Y (kernels_gram.hip)
+extern "C" size_t svt_dev_crossprod_csc_csc_ws_bytes(const svt_dev_csc *Xt)
+{
+	return gram_ws_bytes(Xt->nrow, Xt->ncol);
+}
+
+extern "C" void svt_dev_crossprod_csc_csc_set_panel(int one_block_max, int log2_panel)
+{
+	gram_set_panel(one_block_max, log2_panel);
+}
+
+extern "C" int svt_dev_crossprod_csc_csc(const svt_dev_csc *Xt, const svt_dev_csc *Y, int sym, double *out,
+					 int64_t ldo, void *ws, size_t ws_bytes, int *not_finite, void *stream)
+{
+	if (Xt->ncol != Y->nrow)
+		return svt_set_error("svt_dev_crossprod_csc_csc: non-conformable operands");
+	if (sym && Xt->nrow != Y->ncol)
+		return svt_set_error("svt_dev_crossprod_csc_csc: the symmetric form needs t(Y) and Y");
+	if (ws_bytes < svt_dev_crossprod_csc_csc_ws_bytes(Xt))
+		return svt_set_error("svt_dev_crossprod_csc_csc: workspace too small");
+	if (ldo < Xt->nrow)
+		return svt_set_error("svt_dev_crossprod_csc_csc: leading dimension of the result too small");
+	if ((Xt->Rtype != SVT_REALSXP && Xt->Rtype != SVT_INTSXP) || (Y->Rtype != SVT_REALSXP && Y->Rtype != SVT_INTSXP))
+		return svt_set_error("svt_dev_crossprod_csc_csc: double or integer operands");
+	hipStream_t s = (hipStream_t) stream;
+	GramArgs a;
+	memset(&a, 0, sizeof(a));
+	a.a_ptr = Xt->col_ptr; a.a_idx = Xt->row_idx; a.a_val = Xt->val; a.a_type = Xt->Rtype;
+	a.nx = Xt->nrow; a.nrow = Xt->ncol;
+	a.b_ptr = Y->col_ptr; a.b_idx = Y->row_idx; a.b_val = Y->val; a.b_type = Y->Rtype; a.ny = Y->ncol;
+	a.out = out; a.ldo = ldo; a.sym = sym != 0;
+	if (launch_gram(a, Xt->nnz, Y->nnz, ws, s))
+		return -1;
+	if (not_finite != NULL)
+		HIP_TRY(hipMemcpyAsync(not_finite, ws, 4, hipMemcpyDeviceToDevice, s));
+	return 0;
+}
+
 static int aperm_args(int ndim, const int *perm, int *perm0)
 {
 	if (ndim < 1 || ndim > 8)
@@ -1319,6 +1357,72 @@ static int dev_crossprod_pp(const svt_dev_csc *other, const svt_dev_csc *pp,
 	return rc;
 }
 
+struct CscGuard;
+static svt_dev_csc *transposed_for(const CscGuard &A, int *owned);
+struct OwnedCsc {            // releases a handle only if this call built it
+	svt_dev_csc *t;
+	int own;
+	~OwnedCsc() { if (own) svt_release(t); }
+};
+
+// The sparse-aware route (kernels_gram.hip) multiplies only the pairs of nonzeros that meet in a row -- about
+// nnz(x) * nnz(y) / nrow of them (half that for the unary form), each an LDS atomic behind a gathered 12-byte read --
+// where the dense-buffer route below does `dense_ops` multiply-adds (the reference's Lpp_nops / Rpp_nops,
+// src/SparseMatrix_mult.c:1077-1078) at the panel kernels' rate.  Measured on one MI355X:
+// a gathered product costs about as much as g_gram_cost multiply-adds of the dense-buffer route.
+static double g_gram_cost = 24.0;
+extern "C" void svt_sparse_crossprod_set_cost(double products_per_gathered_product)
+{
+	g_gram_cost = products_per_gathered_product;      // <= 0: never the sparse-aware route; huge: always
+}
+
+static bool sparse_route_pays(int64_t nnz_x, int64_t nnz_y, int64_t nrow, double dense_ops, bool sym)
+{
+	if (g_gram_cost <= 0.0 || nrow <= 0 || nnz_x <= 0 || nnz_y <= 0)
+		return false;
+	double pairs = (double) nnz_x * (double) nnz_y / (double) nrow;
+	if (sym) { pairs *= 0.5; dense_ops *= 0.5; }
+	return pairs * g_gram_cost < dense_ops;
+}
+
+// 0: `O` holds the result; 1: a non-finite value or an NA took part (the caller takes the dense-buffer route, whose
+// dirty-leaf rules are the reference's); -1: error
+static int dev_crossprod_sparse(const CscGuard &X, const svt_dev_csc *Y, bool sym, double *O, int64_t ldo)
+{
+	int own_T = 1;
+	svt_dev_csc *T = transposed_for(X, &own_T);
+	OwnedCsc TX = { T, own_T };
+	if (T == NULL) return -1;
+	DevBuf Ws;
+	int bad = 1;
+	if (Ws.alloc(svt_dev_crossprod_csc_csc_ws_bytes(T)))
+		return -1;
+	if (svt_dev_crossprod_csc_csc(T, Y, sym ? 1 : 0, O, ldo, Ws.p, Ws.bytes, NULL, 0))
+		return -1;
+	HIP_TRY(hipMemcpy(&bad, Ws.p, 4, hipMemcpyDeviceToHost));
+	return bad ? 1 : 0;
+}
+
+// The dense-buffer route on resident operands (what the entry points below fall back to, and the yardstick of
+// tools/debug/sparse_crossprod_time.py): out = ncol(X) x ncol(Y), column-major, zeroed here.  Y == X (the same
+// handle): the unary form, half the dot products + mirror.  Allocates and synchronises.
+extern "C" int svt_dev_crossprod_csc_csc_dense_buffer(const svt_dev_csc *X, const svt_dev_csc *Y, double *out)
+{
+	if (X->nrow != Y->nrow)
+		return svt_set_error("svt_dev_crossprod_csc_csc_dense_buffer: non-conformable operands");
+	const int64_t nx = X->ncol, ny = Y->ncol;
+	if (nx == 0 || ny == 0) return 0;
+	HIP_TRY(hipMemset(out, 0, (size_t) nx * ny * 8));
+	if (X == Y) {
+		if (dev_crossprod_pp(X, X, out, 1, nx)) return -1;
+		if (launch_mirror_lower(out, nx, 0)) return -1;
+		HIP_TRY(hipDeviceSynchronize());
+		return 0;
+	}
+	const double Lpp = (double) Y->nnz * (double) nx, Rpp = (double) X->nnz * (double) ny;
+	return Lpp < Rpp ? dev_crossprod_pp(Y, X, out, nx, 1) : dev_crossprod_pp(X, Y, out, 1, nx);
+}
+
 static int64_t view_nzcount(const svt_view *x)   // _REC_nzcount_SVT, SVT_SparseArray_class.c:200-218
 {
 	int64_t t = 0;
@@ -1349,7 +1453,18 @@ extern "C" int svt_crossprod2_SVT_SVT(const svt_view *x, const svt_view *y, doub
 	CscGuard X(x), Y(y);
 	if (X.h == NULL || Y.h == NULL) return -1;
 	DevBuf O;
-	if (O.alloc(out_n * 8) || O.zero())
+	if (O.alloc(out_n * 8))
+		return -1;
+	// few pairs of nonzeros meet in a row: multiply only those (kernels_gram.hip); a non-finite value or an NA
+	// anywhere sends the product down the reference's route below
+	if (!x->svt_is_null && !y->svt_is_null &&
+	    sparse_route_pays(X.h->nnz, Y.h->nnz, in_nrow, (double) (Lpp_nops < Rpp_nops ? Lpp_nops : Rpp_nops), false)) {
+		const int st = dev_crossprod_sparse(X, Y.h, false, O.as<double>(), out_nrow);
+		if (st < 0) return -1;
+		if (st == 0)
+			return staged_download(out, O.p, out_n * 8) ? -1 : 0;
+	}
+	if (O.zero())
 		return -1;
 	int rc;
 	if (Lpp_nops < Rpp_nops)   // expand the columns of x, walk the leaves of y
@@ -1411,12 +1526,6 @@ static svt_dev_csc *transposed_for(const CscGuard &A, int *owned)
 			}
 	return T;
 }
-
-struct OwnedCsc {            // releases a handle only if this call built it
-	svt_dev_csc *t;
-	int own;
-	~OwnedCsc() { if (own) svt_release(t); }
-};
 
 // C_transpose_2D_SVT, src/SparseArray_aperm.c:395-423
 extern "C" int svt_transpose_2D_SVT(const svt_view *x, int64_t *out_col_ptr,
@@ -1561,7 +1670,15 @@ extern "C" int svt_crossprod1_SVT(const svt_view *x, double *out)
 	CscGuard X(x);
 	if (X.h == NULL) return -1;
 	DevBuf O;
-	if (O.alloc(out_n * 8) || O.zero())
+	if (O.alloc(out_n * 8))
+		return -1;
+	if (sparse_route_pays(X.h->nnz, X.h->nnz, x->dim[0], (double) X.h->nnz * (double) n, true)) {
+		const int st = dev_crossprod_sparse(X, X.h, true, O.as<double>(), n);
+		if (st < 0) return -1;
+		if (st == 0)
+			return staged_download(out, O.p, out_n * 8) ? -1 : 0;
+	}
+	if (O.zero())
 		return -1;
 	if (dev_crossprod_pp(X.h, X.h, O.as<double>(), 1, n))
 		return -1;

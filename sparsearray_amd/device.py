@@ -63,6 +63,12 @@ def _lib():
         lib.svt_dev_matmul_csc_csc_prepare.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p]
         lib.svt_dev_matmul_csc_csc_prepared.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_size_t,
                                                         c_void_p, c_void_p]
+        lib.svt_dev_crossprod_csc_csc_ws_bytes.restype = c_size_t
+        lib.svt_dev_crossprod_csc_csc_ws_bytes.argtypes = [c_void_p]
+        lib.svt_dev_crossprod_csc_csc.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_size_t,
+                                                  c_void_p, c_void_p]
+        lib.svt_dev_crossprod_csc_csc_set_panel.argtypes = [c_int, c_int]
+        lib.svt_dev_crossprod_csc_csc_set_panel.restype = None
         lib.svt_dev_colmedians_ws_bytes.restype = c_size_t
         lib.svt_dev_colmedians_ws_bytes.argtypes = [c_int64, c_int64]
         lib.svt_dev_colmedians.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
@@ -307,6 +313,41 @@ def matmul_csc_csc(A: DeviceCSC, B: DeviceCSC, out=None, ws=None):
     _check(_lib().svt_dev_matmul_csc_csc(A.handle, B.handle, out.data_ptr(), A.nrow, ws.data_ptr(), ws.numel(),
                                          flag.data_ptr(), _stream()))
     return out, flag
+
+
+def crossprod_csc_csc(Xt: DeviceCSC, Y: DeviceCSC, sym=False, out=None, ws=None):
+    """crossprod(X, Y) of two resident sparse operands without a dense buffer (include/svt_hip.h,
+    svt_dev_crossprod_csc_csc): ``Xt`` is t(X) (``X.t()``), ``sym`` says Y is X.  Returns (out, not_finite): out is the
+    (ncol(Y), ncol(X)) C-contiguous tensor that is the column-major ncol(X) x ncol(Y) matrix; not_finite a device
+    int32 tensor, nonzero when a non-finite value or an NA took part -- the result then has to come from the
+    dense-buffer route."""
+    assert Xt.ncol == Y.nrow
+    dev = Y.val.device
+    if out is None:
+        out = torch.empty((Y.ncol, Xt.nrow), dtype=torch.float64, device=dev)
+    if ws is None:
+        ws = torch.empty(_lib().svt_dev_crossprod_csc_csc_ws_bytes(Xt.handle), dtype=torch.uint8, device=dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    _check(_lib().svt_dev_crossprod_csc_csc(Xt.handle, Y.handle, int(bool(sym)), out.data_ptr(), Xt.nrow,
+                                            ws.data_ptr(), ws.numel(), flag.data_ptr(), _stream()))
+    return out, flag
+
+
+def crossprod_csc_csc_dense_buffer(X: DeviceCSC, Y: DeviceCSC, out=None):
+    """The dense-buffer route of crossprod(X, Y) on resident operands (svt_dev_crossprod_csc_csc_dense_buffer;
+    ``Y is X``: the unary form).  Allocates and synchronises inside.  Returns the (ncol(Y), ncol(X)) C-contiguous
+    tensor that is the column-major result."""
+    _lib().svt_dev_crossprod_csc_csc_dense_buffer.argtypes = [c_void_p, c_void_p, c_void_p]
+    if out is None:
+        out = torch.empty((Y.ncol, X.ncol), dtype=torch.float64, device=Y.val.device)
+    torch.cuda.synchronize()
+    _check(_lib().svt_dev_crossprod_csc_csc_dense_buffer(X.handle, X.handle if Y is X else Y.handle, out.data_ptr()))
+    return out
+
+
+def set_sparse_crossprod_panel(one_block_max=-1, log2_panel=-1) -> None:
+    """Cell-panel shape of crossprod_csc_csc() (svt_dev_crossprod_csc_csc_set_panel); defaults restored by -1."""
+    _lib().svt_dev_crossprod_csc_csc_set_panel(int(one_block_max), int(log2_panel))
 
 
 class SpmmPlan:

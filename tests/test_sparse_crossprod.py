@@ -1,0 +1,175 @@
+"""crossprod(x) / crossprod(x, y) of two sparse operands without a dense buffer (kernels_gram.hip,
+svt_dev_crossprod_csc_csc) against the CPU oracle's C_crossprod1_SVT / C_crossprod2_SVT_SVT
+(src/SparseMatrix_mult.c:1037-1140) and against the library's own dense-buffer route."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_equal, assert_identical, random_csc
+from sparsearray_amd import NA_integer, NA_real, SVT_SparseArray
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(cp, ri, v, nrow):
+    from sparsearray_amd.device import DeviceCSC
+    return DeviceCSC.from_host(nrow, cp, ri, v)
+
+
+def _ints(v, seed):
+    w = np.round(v * 1000).astype(np.int32)
+    w[w == 0] = 7
+    return w
+
+
+# (nrow, ncol, density): short and tall operands, rows with none / one / many nonzeros
+SHAPES = [(3000, 700, 0.05), (25000, 400, 0.07), (100, 60, 0.2), (50_000, 1300, 0.004), (64, 1, 0.5), (1, 9, 0.7),
+          (7000, 257, 0.3)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("dtype", ["double", "integer"])
+def test_unary_crossprod_device_level(oracle, shape, dtype):
+    """Symmetric form: cells c <= j in LDS, columns j and n - 1 - j per workgroup, mirrored."""
+    from sparsearray_amd.device import crossprod_csc_csc
+    nrow, ncol, d = shape
+    cp, ri, v = random_csc(nrow, ncol, d, seed=601)
+    if dtype == "integer":
+        v = _ints(v, 1)
+    x = SVT_SparseArray.from_csc((nrow, ncol), dtype, cp, ri, v)
+    want = np.asarray(oracle.crossprod(x))
+    A = _dev(cp, ri, v, nrow)
+    out, flag = crossprod_csc_csc(A.t(), A, sym=True)
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0
+    got = out.cpu().numpy().T
+    assert np.array_equal(got, got.T), "crossprod(x) must be bit-symmetric"
+    if dtype == "integer":
+        assert_identical(got, want, what="crossprod(x), integer")
+    else:
+        assert_equal(got, want, tol=1e-12, atol=1e-13, what="crossprod(x)")
+    # the general form on the same operands (no symmetry used) gives the same cells
+    out2, flag2 = crossprod_csc_csc(A.t(), A, sym=False)
+    torch.cuda.synchronize()
+    assert int(flag2.item()) == 0
+    assert_equal(out2.cpu().numpy().T, want, tol=1e-12, atol=1e-13, what="crossprod(x, x)")
+
+
+@pytest.mark.parametrize("shape", [(3000, 700, 90, 0.05, 0.02), (25000, 400, 650, 0.07, 0.2), (100, 60, 7, 0.2, 0.05),
+                                   (20_000, 50, 3, 0.3, 0.04), (70_001, 1200, 17, 0.004, 0.03), (500, 1, 1, 0.5, 0.5)])
+@pytest.mark.parametrize("types", [("double", "double"), ("integer", "integer")])
+def test_binary_crossprod_device_level(hip, oracle, shape, types):
+    from sparsearray_amd.device import crossprod_csc_csc
+    nrow, nx, ny, dx, dy = shape
+    cpx, rix, vx = random_csc(nrow, nx, dx, seed=611)
+    cpy, riy, vy = random_csc(nrow, ny, dy, seed=612)
+    if types[0] == "integer":
+        vx, vy = _ints(vx, 1), _ints(vy, 2)
+    x = SVT_SparseArray.from_csc((nrow, nx), types[0], cpx, rix, vx)
+    y = SVT_SparseArray.from_csc((nrow, ny), types[1], cpy, riy, vy)
+    want = np.asarray(oracle.crossprod(x, y))
+    X, Y = _dev(cpx, rix, vx, nrow), _dev(cpy, riy, vy, nrow)
+    out, flag = crossprod_csc_csc(X.t(), Y)
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0
+    got = out.cpu().numpy().T
+    if types[0] == "integer":
+        assert_identical(got, want, what="crossprod(x, y), integer")
+    else:
+        assert_equal(got, want, tol=1e-12, atol=1e-13, what="crossprod(x, y)")
+    # host entry points: whichever route they choose, the reference's result
+    assert_equal(hip.crossprod(x, y), want, tol=1e-12, atol=1e-13, what="host crossprod(x, y)")
+    assert_equal(hip.crossprod(y, x), want.T, tol=1e-12, atol=1e-13, what="host crossprod(y, x)")
+
+
+@pytest.mark.parametrize("panel", [(0, 6), (0, 9), (100, 8), (0, 13)])
+def test_wide_results_go_by_cell_panels(oracle, panel):
+    """Results taller than one workgroup's LDS: panels of cells + the table of run bounds (forced here on small
+    operands by shrinking the panel; the default is one block up to 10200 cells, panels of 8192 beyond)."""
+    from sparsearray_amd.device import crossprod_csc_csc, set_sparse_crossprod_panel
+    nrow, nx, ny = 4000, 777, 333
+    cpx, rix, vx = random_csc(nrow, nx, 0.03, seed=621)
+    cpy, riy, vy = random_csc(nrow, ny, 0.05, seed=622)
+    x = SVT_SparseArray.from_csc((nrow, nx), "double", cpx, rix, vx)
+    y = SVT_SparseArray.from_csc((nrow, ny), "double", cpy, riy, vy)
+    X, Y = _dev(cpx, rix, vx, nrow), _dev(cpy, riy, vy, nrow)
+    try:
+        set_sparse_crossprod_panel(*panel)
+        out, flag = crossprod_csc_csc(X.t(), Y)
+        outs, flags = crossprod_csc_csc(X.t(), X, sym=True)
+        torch.cuda.synchronize()
+    finally:
+        set_sparse_crossprod_panel(-1, -1)
+    assert int(flag.item()) == 0 and int(flags.item()) == 0
+    assert_equal(out.cpu().numpy().T, np.asarray(oracle.crossprod(x, y)), tol=1e-12, atol=1e-13, what="panels")
+    gs = outs.cpu().numpy().T
+    assert np.array_equal(gs, gs.T)
+    assert_equal(gs, np.asarray(oracle.crossprod(x)), tol=1e-12, atol=1e-13, what="panels, symmetric")
+
+
+def test_really_wide_result(oracle):
+    """12 000 result cells per column: two panels of 8192 with the default settings; against scipy."""
+    import scipy.sparse as sp
+    from sparsearray_amd.device import crossprod_csc_csc
+    nrow, ncol = 3000, 12_000
+    cp, ri, v = random_csc(nrow, ncol, 0.01, seed=631)
+    A = _dev(cp, ri, v, nrow)
+    out, flag = crossprod_csc_csc(A.t(), A, sym=True)
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0
+    got = out.cpu().numpy()
+    m = sp.csc_matrix((v, ri, cp), shape=(nrow, ncol))
+    want = (m.T @ m).toarray()
+    assert np.array_equal(got, got.T)
+    assert np.allclose(got, want, rtol=1e-12, atol=1e-12)
+
+
+def test_not_finite_raises_the_flag_and_the_entry_points_follow_the_reference(hip, oracle):
+    """A non-finite value or an NA anywhere: the flag goes up; svt_crossprod1_SVT / svt_crossprod2_SVT_SVT then
+    answer through the dense-buffer route, whose dirty-leaf rules are the reference's
+    (src/SparseMatrix_mult.c:632-724, 827-873)."""
+    from sparsearray_amd.device import crossprod_csc_csc
+    nrow, nx, ny = 3000, 90, 40
+    cpx, rix, vx = random_csc(nrow, nx, 0.05, seed=641)
+    cpy, riy, vy = random_csc(nrow, ny, 0.04, seed=642)
+    for which, poison in (("x", np.inf), ("y", np.nan), ("x", NA_real), ("y", -np.inf)):
+        vx2, vy2 = vx.copy(), vy.copy()
+        (vx2 if which == "x" else vy2)[5] = poison
+        x = SVT_SparseArray.from_csc((nrow, nx), "double", cpx, rix, vx2)
+        y = SVT_SparseArray.from_csc((nrow, ny), "double", cpy, riy, vy2)
+        X, Y = _dev(cpx, rix, vx2, nrow), _dev(cpy, riy, vy2, nrow)
+        _, flag = crossprod_csc_csc(X.t(), Y)
+        torch.cuda.synchronize()
+        assert int(flag.item()) == 1, (which, poison)
+        assert_equal(hip.crossprod(x, y), oracle.crossprod(x, y), tol=1e-12, atol=1e-13, strict_na=True,
+                     what=f"{which} {poison}")
+        op = x if which == "x" else y
+        O = X if which == "x" else Y
+        _, flag = crossprod_csc_csc(O.t(), O, sym=True)
+        torch.cuda.synchronize()
+        assert int(flag.item()) == 1
+        assert_equal(hip.crossprod(op), oracle.crossprod(op), tol=1e-12, atol=1e-13, strict_na=True,
+                     what=f"crossprod({which}) {poison}")
+    # integer NA
+    vxi = _ints(vx, 1)
+    vxi[11] = NA_integer
+    xi = SVT_SparseArray.from_csc((nrow, nx), "integer", cpx, rix, vxi)
+    Xi = _dev(cpx, rix, vxi, nrow)
+    _, flag = crossprod_csc_csc(Xi.t(), Xi, sym=True)
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 1
+    assert_equal(hip.crossprod(xi), oracle.crossprod(xi), tol=0, strict_na=True, what="integer NA")
+
+
+@pytest.mark.parametrize("shape", [(25000, 400, 0.07), (25000, 650, 0.2), (60_000, 900, 0.01)])
+def test_host_entry_points_choose_a_route(hip, oracle, shape):
+    """The reference's published benchmark shapes (inst/scripts/benchmark_crossprod.R:123-166: 25000 x 400 @ 0.07,
+    25000 x 650 @ 0.20) and a sparser one through svt_crossprod1_SVT and svt_crossprod2_SVT_SVT."""
+    nrow, ncol, d = shape
+    cp, ri, v = random_csc(nrow, ncol, d, seed=651)
+    x = SVT_SparseArray.from_csc((nrow, ncol), "double", cp, ri, v)
+    want = np.asarray(oracle.crossprod(x))
+    got = np.asarray(hip.crossprod(x))
+    assert np.array_equal(got, got.T)
+    assert_equal(got, want, tol=1e-12, atol=1e-12, what="crossprod(x)")
+    assert_equal(hip.crossprod(x, x), want, tol=1e-12, atol=1e-12, what="crossprod(x, x)")
