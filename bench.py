@@ -86,6 +86,8 @@ def parse():
                         "(tools/debug/whole_call_vs_step.py: the first ~20-40 ms after an idle gap run 3-9 %% slower); 0 = off")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extras", action="store_true")
+    p.add_argument("--no-sparse-crossprod", action="store_true",
+                   help="skip extras.sparse_crossprod (unary / SVT x SVT crossprod at the reference's published shapes and at config-2 scale)")
     a = p.parse_args()
     c = CONFIGS[a.config]
     for k in ("nrow", "ncol", "density", "K"):
@@ -213,6 +215,124 @@ def cpu_baseline(col_ptr, row_idx, val, Y, nrow, K, nleaves_sample, threads=None
     return {"value": nz / dt / 1e9, "unit": "GNZ/s", "cores": ncores, "kind": "port",
             "sample": f"first {ns} leaves of A ({nz} nnz) x all {K} dense columns, "
                       f"oracle C/OpenMP path, {dt:.2f} s wall"}, out, ns
+
+
+# The only operations the reference publishes timings for: unary crossprod(x) and SVT x SVT crossprod(x, y)
+# (inst/scripts/benchmark_crossprod.R:123-166; R `system.time()[["user.self"]]`: CPU seconds summed over the OpenMP
+# threads, machine and thread count unstated -- context, not a baseline).  Inputs: this repository's generator
+# at the script's shapes (rsparsematrix() under set.seed(333) is not reproducible without R).
+PUBLISHED_CPU_SECONDS = {"crossprod(svt1)": 0.224, "crossprod(svt1, svt1)": 0.381,
+                         "crossprod(svt1, svt2)": 0.641, "crossprod(svt2, svt1)": 0.608}
+
+
+def sparse_crossprod_extras(dev, A_big, timed):
+    """`extras.sparse_crossprod`: the four published cases through the host entry points (svt_crossprod1_SVT,
+    svt_crossprod2_SVT_SVT: marshal + PCIe + t(x) + product + result back) and at device level
+    (svt_dev_transpose + svt_dev_crossprod_csc_csc), the CPU oracle's wall time beside each at both thread
+    settings; and crossprod(A) at BASELINE config-2 scale (A = the bench operand) at device level with GB/s against
+    its algorithmic bytes (A once + the ncol x ncol result) next to the dense-buffer route of rounds 2-5."""
+    import ctypes
+    from oracle import load_oracle
+    from sparsearray_amd import _hip as _hipmod, synth
+    from sparsearray_amd.device import (DeviceCSC, crossprod_csc_csc, crossprod_csc_csc_dense_buffer, _lib as _dl)
+    from sparsearray_amd.svt import make_view_from_csc
+    hl, orc = _hipmod.init(), load_oracle()
+    for lib, pre in ((hl, "svt_"), (orc, "orc_")):
+        getattr(lib, pre + "crossprod1_SVT").argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        getattr(lib, pre + "crossprod2_SVT_SVT").argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    ops = {}
+    for name, (nr, nc, d, seed) in {"svt1": (25000, 400, 0.07, 11), "svt2": (25000, 650, 0.20, 12)}.items():
+        cp, ri, v = synth.random_device_csc(nr, nc, d, seed=seed, device=dev)
+        D = DeviceCSC(nr, cp, ri, v)
+        h = (cp.cpu().numpy(), ri.cpu().numpy(), v.cpu().numpy())
+        ops[name] = (D, make_view_from_csc((nr, nc), "double", *h), h)
+
+    def wall_ms(fn, reps=3):
+        fn()
+        best = 1e30
+        for _ in range(reps):
+            t0 = time.perf_counter(); fn(); best = min(best, (time.perf_counter() - t0) * 1e3)
+        return best
+    nthr, nthr3 = host_cores(), max(1, host_cores() // 3)
+    out = {"published": "inst/scripts/benchmark_crossprod.R:123-166 (CPU seconds over the OpenMP threads; machine and "
+                        "thread count unstated); inputs here: own generator at the same shapes and densities",
+           "cases": {}}
+    for label, xn, yn in (("crossprod(svt1)", "svt1", None), ("crossprod(svt1, svt1)", "svt1", "svt1"),
+                          ("crossprod(svt1, svt2)", "svt1", "svt2"), ("crossprod(svt2, svt1)", "svt2", "svt1")):
+        X, xv, _ = ops[xn]
+        Y, yv, _ = ops[yn] if yn else (None, None, None)
+        nx, ny = X.ncol, (Y.ncol if yn else X.ncol)
+        hres, ores = np.zeros((ny, nx)), np.zeros((ny, nx))
+
+        def call(lib, pre, res):
+            if yn is None:
+                rc = getattr(lib, pre + "crossprod1_SVT")(ctypes.addressof(xv), res.ctypes.data)
+            else:
+                rc = getattr(lib, pre + "crossprod2_SVT_SVT")(ctypes.addressof(xv), ctypes.addressof(yv), res.ctypes.data)
+            assert rc == 0
+        host_ms = wall_ms(lambda: call(hl, "svt_", hres))
+        orc.orc_set_max_threads(nthr)
+        cpu_ms = wall_ms(lambda: call(orc, "orc_", ores), 2)
+        orc.orc_set_max_threads(nthr3)
+        cpu3_ms = wall_ms(lambda: call(orc, "orc_", ores), 2)
+        orc.orc_set_max_threads(nthr)
+        scale = np.maximum(np.abs(ores), 1e-9)
+        o = torch.empty((ny, nx), dtype=torch.float64, device=dev)
+        t_ms = timed(lambda: X.t(), 5)
+        Xt = X.t()
+        ws = torch.empty(_dl().svt_dev_crossprod_csc_csc_ws_bytes(Xt.handle), dtype=torch.uint8, device=dev)
+        Yd = X if yn is None or yn == xn else Y
+        k_ms = timed(lambda: crossprod_csc_csc(Xt, Yd, sym=(yn is None), out=o, ws=ws), 10)
+        out["cases"][label] = {"host_entry_point_ms": host_ms, "device_level_ms": {"t(x)": t_ms, "product": k_ms},
+                               "cpu_oracle_wall_ms": {f"{nthr}_threads": cpu_ms, f"{nthr3}_threads_reference_default": cpu3_ms},
+                               "published_reference_cpu_seconds": PUBLISHED_CPU_SECONDS[label],
+                               "max_rel_err_host_vs_oracle": float(np.max(np.abs(hres - ores) / scale)),
+                               "max_rel_err_device_vs_oracle": float(np.max(np.abs(o.cpu().numpy() - ores) / scale))}
+        del o, Xt, ws
+    # config-2 scale
+    A = A_big
+    n = A.ncol
+    alg = A.nnz * 12 + (n + 1) * 8 + n * n * 8
+    t_ms = timed(lambda: A.t(), 3)
+    At = A.t()
+    o = torch.empty((n, n), dtype=torch.float64, device=dev)
+    ws = torch.empty(_dl().svt_dev_crossprod_csc_csc_ws_bytes(At.handle), dtype=torch.uint8, device=dev)
+    flag = [None]
+
+    def prod():
+        flag[0] = crossprod_csc_csc(At, A, sym=True, out=o, ws=ws)[1]
+    k_ms = timed(prod, 5)
+    sym_ok = bool(torch.equal(o, o.T))
+    # sampled cells against a dense product of the two columns
+    g = torch.Generator(device="cpu"); g.manual_seed(5)
+    worst = 0.0
+    for _ in range(24):
+        c, j = (int(x) for x in torch.randint(0, n, (2,), generator=g))
+        cols = []
+        for k in (c, j):
+            b, e = int(A.col_ptr[k]), int(A.col_ptr[k + 1])
+            dcol = torch.zeros(A.nrow, dtype=torch.float64, device=dev)
+            dcol[A.row_idx[b:e].long()] = A.val[b:e]
+            cols.append(dcol)
+        want, tot = float((cols[0] * cols[1]).sum()), float((cols[0] * cols[1]).abs().sum()) + 1e-300
+        worst = max(worst, abs(float(o[j, c]) - want) / tot)
+    del At, ws
+    o2 = torch.empty((n, n), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    crossprod_csc_csc_dense_buffer(A, A, out=o2)
+    torch.cuda.synchronize(); dense_ms = (time.perf_counter() - t0) * 1e3
+    out["crossprod(A)_config2_scale"] = {
+        "shape": [A.nrow, n], "nnz": A.nnz, "algorithmic_bytes": alg,
+        "device_level_ms": {"t(A)": t_ms, "product_incl_mirror": k_ms},
+        "GB/s_product": alg / k_ms / 1e6, "frac_of_8TB/s_product": alg / k_ms / 1e6 / 8000,
+        "GB/s_with_t(A)": alg / (k_ms + t_ms) / 1e6,
+        "G_pairs_of_nonzeros_per_s": float(((A.nnz / A.nrow) ** 2 / 2 * A.nrow) / k_ms / 1e6),
+        "not_finite_flag": int(flag[0].item()), "bit_symmetric": sym_ok,
+        "worst_sampled_err_over_sum_abs_terms": worst,
+        "dense_buffer_route_ms_rounds_2_to_5": dense_ms,
+        "max_abs_diff_vs_dense_buffer_route": float((o - o2).abs().max().item())}
+    del o, o2
+    return out
 
 
 def launch_ranks(a) -> int:
@@ -663,6 +783,8 @@ def main():
                                "dense_route_ms": ms_dense,
                                "max_abs_diff_vs_dense_route": float((out2 - out3).abs().max().item())}
         del plan_t, T, out2, out3, Bd, Bs, ws3
+        if not a.no_sparse_crossprod:
+            ex["sparse_crossprod"] = sparse_crossprod_extras(dev, A, timed)
         res["extras"] = ex
         # row f2 of SURVEY.md section 8: the .Call-shaped entry point on HOST leaves -- marshal (src/SVT_SparseArray_class.c:598-633
         # walks the tree the same way) + PCIe both ways + layout build + product, and the same call with the operand

@@ -458,11 +458,12 @@ void svt_dev_crossprod_csc_csc_set_panel(int one_block_max, int log2_panel);
    its buffers and synchronises the device: not for a launch path. */
 int svt_dev_crossprod_csc_csc_dense_buffer(const svt_dev_csc *X, const svt_dev_csc *Y, double *out);
 
-/* Route choice of svt_crossprod2_SVT_SVT / svt_crossprod1_SVT: the sparse-aware kernel above is taken when
-   (pairs of nonzeros that meet in a row, estimated as nnz(x) * nnz(y) / nrow) * cost < the multiply-adds of the
-   dense-buffer route (the reference's own Lpp_nops / Rpp_nops count, src/SparseMatrix_mult.c:1077-1078).
-   cost <= 0: never; a huge value: always.  Default: the ratio measured on one MI355X.  Process-wide. */
-void svt_sparse_crossprod_set_cost(double cost);
+/* Route choice of svt_crossprod2_SVT_SVT / svt_crossprod1_SVT: the sparse-aware kernel above is taken when its
+   estimated time -- pairs of nonzeros that meet in a row (nnz(x) * nnz(y) / nrow, half of it for the unary form)
+   at the measured gather rate, plus t(x) -- times `factor` is below that of the dense-buffer route (the reference's
+   own Lpp_nops / Rpp_nops count of multiply-adds, src/SparseMatrix_mult.c:1077-1078, at the measured rate of the
+   panel kernels).  factor < 0: never; 0: always; default 1.  Process-wide. */
+void svt_sparse_crossprod_set_cost(double factor);
 
 /* aperm(x, perm) for an N-d operand (C_aperm_SVT, src/SparseArray_aperm.c:935-970;
    R/SparseArray-aperm.R).  `dim` are the array's ndim extents (dim[0] = A->nrow,

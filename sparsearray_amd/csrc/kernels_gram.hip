@@ -163,9 +163,33 @@ gram_kernel(GramArgs a, int G)
 // (first version, one walk per slot: 24.3 ms at config-2 scale where the general form, which reads twice as much,
 // took 22.1).  Here a slot's unit of work is the t-th nonzero of column j TOGETHER with the t-th nonzero of
 // column n - 1 - j: a prefix of one row up to column j and a prefix of another up to column n - 1 - j, about one
-// row's length in all whatever j is.
-#define GRAM_SU 2
-template <typename T>
+// row's length in all whatever j is: 18.3 ms.  One unit per lane group in flight (more of them, or several entries per
+// lane and trip, only read further past the cuts: 2 units 15.0 ms, 4 units 21.1, two entries per lane 19.5; 32 lanes
+// per group 18.9, 8 lanes 16.3) on 12-byte records: 14.6 ms = 60 GB of prefixes + what the last trip of a walk reads
+// past its cut, at the rate the chip gathers 600-byte runs from HBM.
+// Records of t(X) for the symmetric form: (column, value) side by side, 12 bytes (8 for integer values) -- a
+// prefix of a row is then ONE run of memory instead of two (columns, values), read by one load per lane
+// AOS: 0 = t(X) as it is (two arrays), 1 = records.  (Measured at config-2 scale, symmetric form: two arrays 16.3 ms,
+// 12-byte records 14.6 incl. the 0.45 ms that makes them, 10-byte records with a 16-bit column -- the value at a 2-byte
+// boundary, global_load_dwordx2 at offset 2 -- 15.4.)
+template <typename T, int AOS> struct GramRec;
+template <> struct __attribute__((packed, aligned(4))) GramRec<double, 1> { int c; double v; };
+template <> struct __attribute__((packed, aligned(4))) GramRec<int, 1> { int c; int v; };
+template <> struct GramRec<double, 0> { int c; double v; };
+template <> struct GramRec<int, 0> { int c; int v; };
+
+template <typename T, int AOS>
+__global__ void __launch_bounds__(256)
+gram_pack_kernel(const int32_t *__restrict__ idx, const T *__restrict__ val, int64_t n, GramRec<T, AOS> *__restrict__ rec)
+{
+	for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t) gridDim.x * blockDim.x) {
+		GramRec<T, AOS> r;
+		r.c = idx[i]; r.v = val[i];
+		rec[i] = r;
+	}
+}
+
+template <typename T, int SU, int AOS, int TT>
 __global__ void __launch_bounds__(GRAM_NT)
 gram_sym_kernel(GramArgs a, int G)
 {
@@ -183,54 +207,72 @@ gram_sym_kernel(GramArgs a, int G)
 		return;
 	const int grp = tid / G, sl = tid % G, ngrp = NT / G;
 	const T *__restrict__ av = (const T *) a.a_val;
+	const GramRec<T, AOS> *__restrict__ rec = (const GramRec<T, AOS> *) a.a_val;      // (AOS)
 	const T *__restrict__ bv = (const T *) a.b_val;
-	const int64_t bb1 = a.b_ptr[k1], np1 = a.b_ptr[k1 + 1] - bb1;
-	const int64_t bb2 = a.b_ptr[k2], np2 = k2 != k1 ? a.b_ptr[k2 + 1] - bb2 : 0;
-	const int64_t nunits = np1 > np2 ? np1 : np2;
+	const int64_t bb1 = a.b_ptr[k1];
+	const int np1 = (int) (a.b_ptr[k1 + 1] - bb1);
+	const int64_t bb2 = a.b_ptr[k2];
+	const int np2 = k2 != k1 ? (int) (a.b_ptr[k2 + 1] - bb2) : 0;
+	const int nunits = np1 > np2 ? np1 : np2;
 	bool bad = false;
-	for (int64_t t0 = grp; t0 < nunits; t0 += (int64_t) GRAM_SU * ngrp) {
-		int64_t x[GRAM_SU], xe[GRAM_SU], x2[GRAM_SU], xe2[GRAM_SU];
-		double b[GRAM_SU], b2[GRAM_SU];
-		int hi[GRAM_SU], off[GRAM_SU];
+	// positions inside t(X) in 32 bits (the launcher sends operands with 2^31 nonzeros or more to gram_kernel);
+	// a lane takes TT consecutive entries per trip, a group G * TT
+	for (int t0 = grp; t0 < nunits; t0 += SU * ngrp) {
+		unsigned x[SU], xe[SU], x2[SU], xe2[SU];
+		double b[SU], b2[SU];
+		int second = 0;                                 // bit u: slot u is on its unit's second walk
 #pragma unroll
-		for (int u = 0; u < GRAM_SU; u++) {
-			const int64_t t = t0 + (int64_t) u * ngrp;
-			x[u] = xe[u] = x2[u] = xe2[u] = 0; b[u] = b2[u] = 0.0; hi[u] = hi1; off[u] = 0;
+		for (int u = 0; u < SU; u++) {
+			const int t = t0 + u * ngrp;
+			x[u] = xe[u] = x2[u] = xe2[u] = 0; b[u] = b2[u] = 0.0;
 			if (t < np1) {
 				const int64_t r = a.b_idx[bb1 + t];
 				const T w = bv[bb1 + t];
-				x[u] = a.a_ptr[r] + sl; xe[u] = a.a_ptr[r + 1];
+				x[u] = (unsigned) a.a_ptr[r] + sl * TT; xe[u] = (unsigned) a.a_ptr[r + 1];
 				b[u] = (double) w; bad |= gram_bad<T>(w);
 			}
 			if (t < np2) {
 				const int64_t r = a.b_idx[bb2 + t];
 				const T w = bv[bb2 + t];
-				x2[u] = a.a_ptr[r] + sl; xe2[u] = a.a_ptr[r + 1];
+				x2[u] = (unsigned) a.a_ptr[r] + sl * TT; xe2[u] = (unsigned) a.a_ptr[r + 1];
 				b2[u] = (double) w; bad |= gram_bad<T>(w);
 			}
 		}
 		bool more = true;
 		while (more) {
-			T v[GRAM_SU];
-			int c[GRAM_SU];
+			T v[SU][TT];
+			int c[SU][TT];
 #pragma unroll
-			for (int u = 0; u < GRAM_SU; u++) {
+			for (int u = 0; u < SU; u++) {
 				if (x[u] >= xe[u]) {            // this walk is over: on to the unit's second one (or to nothing)
-					x[u] = x2[u]; xe[u] = xe2[u]; b[u] = b2[u]; hi[u] = hi2; off[u] = off2;
+					x[u] = x2[u]; xe[u] = xe2[u]; b[u] = b2[u]; second |= 1 << u;
 					x2[u] = xe2[u] = 0;
 				}
-				if (x[u] < xe[u]) { c[u] = a.a_idx[x[u]]; v[u] = av[x[u]]; }
+#pragma unroll
+				for (int t = 0; t < TT; t++)
+					if (x[u] + t < xe[u]) {
+						if (AOS) { const GramRec<T, AOS> q = rec[x[u] + t]; c[u][t] = q.c; v[u][t] = q.v; }
+						else { c[u][t] = a.a_idx[x[u] + t]; v[u][t] = av[x[u] + t]; }
+					}
 			}
 			more = false;
 #pragma unroll
-			for (int u = 0; u < GRAM_SU; u++) {
+			for (int u = 0; u < SU; u++) {
 				if (x[u] < xe[u]) {
-					if (c[u] < hi[u]) {
-						bad |= gram_bad<T>(v[u]);
-						atomicAdd(&acc[off[u] + c[u]], (double) v[u] * b[u]);
-						x[u] += G;
-					} else
-						x[u] = xe[u];   // (ascending columns: the lane's later entries are past the cut too)
+					const bool sec = (second >> u) & 1;
+					const int hi = sec ? hi2 : hi1;
+					double *__restrict__ cell = acc + (sec ? off2 : 0);
+					bool over = false;      // (ascending columns: past the cut once, past it for good)
+#pragma unroll
+					for (int t = 0; t < TT; t++)
+						if (x[u] + t < xe[u] && !over) {
+							if (c[u][t] < hi) {
+								bad |= gram_bad<T>(v[u][t]);
+								atomicAdd(&cell[c[u][t]], (double) v[u][t] * b[u]);
+							} else
+								over = true;
+						}
+					x[u] = over ? xe[u] : x[u] + G * TT;
 				}
 				more |= x[u] < xe[u] || x2[u] < xe2[u];
 			}
@@ -283,14 +325,23 @@ int launch_gram_mirror(double *out, int64_t n, int64_t ld, hipStream_t s)
 	return 0;
 }
 
-// [256 bytes: flag words][table of run bounds, wide results only]
-size_t gram_ws_bytes(int64_t nx, int64_t nrow)
+static int g_gram_aos = 1, g_gram_su = 1;
+
+// does the symmetric one-block form (gram_sym_kernel) apply?  (32-bit positions inside t(X))
+static bool gram_sym_one(int64_t nx, int64_t a_nnz)
+{
+	return nx <= g_gram_one && a_nnz < (int64_t) 2147483647 - 64;
+}
+
+// [256 bytes: flag words][table of run bounds, wide results only | records of t(X), symmetric one-block form only]
+size_t gram_ws_bytes(int64_t nx, int64_t nrow, int64_t a_nnz)
 {
 	size_t n = 256;
 	if (nx > g_gram_one) {
 		const int64_t npan = (nx + ((int64_t) 1 << g_gram_ps) - 1) >> g_gram_ps;
 		n += ((size_t) (nrow > 0 ? nrow : 1) * (size_t) (npan + 1) * 4 + 255) / 256 * 256;
-	}
+	} else if (gram_sym_one(nx, a_nnz))
+		n += ((size_t) (a_nnz > 0 ? a_nnz : 1) * 12 + 255) / 256 * 256;
 	return n;
 }
 
@@ -351,18 +402,41 @@ int launch_gram(GramArgs a, int64_t a_nnz, int64_t b_nnz, void *ws, hipStream_t 
 #define GRAM_MODES(TA, TB) do { \
 		if (mode == 0) GRAM_GO(TA, TB, 0); else if (mode == 1) GRAM_GO(TA, TB, 1); \
 		else if (mode == 2) GRAM_GO(TA, TB, 2); else GRAM_GO(TA, TB, 3); } while (0)
-	int symk = 1;                                   // (tuning build: SVT_GRAM_SYMK=0 = the first, one-walk-per-slot form)
+	int symk = 1, aos = g_gram_aos, su = g_gram_su;  // (tuning build: SVT_GRAM_SYMK=0 = the first, one-walk-per-slot form)
 #ifdef SVT_TUNING
 	if (getenv("SVT_GRAM_SYMK")) symk = atoi(getenv("SVT_GRAM_SYMK"));
+	if (getenv("SVT_GRAM_AOS")) aos = atoi(getenv("SVT_GRAM_AOS"));
+	if (getenv("SVT_GRAM_SU")) su = atoi(getenv("SVT_GRAM_SU"));
+	int tt = 1;
+	if (getenv("SVT_GRAM_TT")) tt = atoi(getenv("SVT_GRAM_TT"));
+	(void) tt;
 #endif
-	if (mode == 1 && symk && a.a_type == a.b_type) {
-		if (a.a_type == SVT_REALSXP) {
-			(void) hipFuncSetAttribute((const void *) gram_sym_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-			hipLaunchKernelGGL((gram_sym_kernel<double>), grid, dim3(nt), lds, s, a, G);
-		} else {
-			(void) hipFuncSetAttribute((const void *) gram_sym_kernel<int>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-			hipLaunchKernelGGL((gram_sym_kernel<int>), grid, dim3(nt), lds, s, a, G);
+	(void) su;
+	if (mode == 1 && symk && a.a_type == a.b_type && gram_sym_one(a.nx, a_nnz)) {
+		if (aos && a_nnz > 0) {
+			void *rec = (char *) ws + 256;
+			int64_t nb = (a_nnz + 255) / 256;
+			if (nb > 256 * 32) nb = 256 * 32;
+#define GRAM_PACK(T, W) hipLaunchKernelGGL((gram_pack_kernel<T, W>), dim3((unsigned) nb), dim3(256), 0, s, a.a_idx, (const T *) a.a_val, a_nnz, (GramRec<T, W> *) rec)
+			if (a.a_type == SVT_REALSXP) GRAM_PACK(double, 1); else GRAM_PACK(int, 1);
+#undef GRAM_PACK
+			a.a_val = rec; a.a_idx = NULL;
 		}
+#define GRAM_SYM_GO(T, SU, AOS, TT) do { \
+		(void) hipFuncSetAttribute((const void *) gram_sym_kernel<T, SU, AOS, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); \
+		hipLaunchKernelGGL((gram_sym_kernel<T, SU, AOS, TT>), grid, dim3(nt), lds, s, a, G); } while (0)
+#ifdef SVT_TUNING
+#define GRAM_SYM_SU(T, AOS) do { \
+		if (su == 4) GRAM_SYM_GO(T, 4, AOS, 1); else if (su == 1 && tt == 2) GRAM_SYM_GO(T, 1, AOS, 2); \
+		else if (su == 1) GRAM_SYM_GO(T, 1, AOS, 1); \
+		else if (tt == 2) GRAM_SYM_GO(T, 2, AOS, 2); else GRAM_SYM_GO(T, 2, AOS, 1); } while (0)
+#else
+#define GRAM_SYM_SU(T, AOS) GRAM_SYM_GO(T, 1, AOS, 1)
+#endif
+		if (a.a_type == SVT_REALSXP) { if (aos) GRAM_SYM_SU(double, 1); else GRAM_SYM_SU(double, 0); }
+		else { if (aos) GRAM_SYM_SU(int, 1); else GRAM_SYM_SU(int, 0); }
+#undef GRAM_SYM_SU
+#undef GRAM_SYM_GO
 	} else
 	if (a.a_type == SVT_REALSXP && a.b_type == SVT_REALSXP) GRAM_MODES(double, double);
 	else if (a.a_type == SVT_INTSXP && a.b_type == SVT_INTSXP) GRAM_MODES(int, int);

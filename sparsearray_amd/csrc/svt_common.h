@@ -188,7 +188,7 @@ struct GramArgs {
 	int *flag;
 };
 void gram_set_panel(int one_block_max, int log2_panel);
-size_t gram_ws_bytes(int64_t nx, int64_t nrow);
+size_t gram_ws_bytes(int64_t nx, int64_t nrow, int64_t a_nnz);
 int launch_gram(GramArgs a, int64_t a_nnz, int64_t b_nnz, void *ws, hipStream_t s);
 int launch_gram_mirror(double *out, int64_t n, int64_t ld, hipStream_t s);
 

@@ -874,7 +874,7 @@ extern "C" int svt_dev_matmul_csc_csc(const svt_dev_csc *A, const svt_dev_csc *B
 // crossprod(X, Y) of two sparse operands on t(X) and Y (kernels_gram.hip)
 extern "C" size_t svt_dev_crossprod_csc_csc_ws_bytes(const svt_dev_csc *Xt)
 {
-	return gram_ws_bytes(Xt->nrow, Xt->ncol);
+	return gram_ws_bytes(Xt->nrow, Xt->ncol, Xt->nnz);
 }
 
 extern "C" void svt_dev_crossprod_csc_csc_set_panel(int one_block_max, int log2_panel)
@@ -1368,21 +1368,24 @@ struct OwnedCsc {            // releases a handle only if this call built it
 // The sparse-aware route (kernels_gram.hip) multiplies only the pairs of nonzeros that meet in a row -- about
 // nnz(x) * nnz(y) / nrow of them (half that for the unary form), each an LDS atomic behind a gathered 12-byte read --
 // where the dense-buffer route below does `dense_ops` multiply-adds (the reference's Lpp_nops / Rpp_nops,
-// src/SparseMatrix_mult.c:1077-1078) at the panel kernels' rate.  Measured on one MI355X:
-// a gathered product costs about as much as g_gram_cost multiply-adds of the dense-buffer route.
-static double g_gram_cost = 24.0;
-extern "C" void svt_sparse_crossprod_set_cost(double products_per_gathered_product)
+// src/SparseMatrix_mult.c:1077-1078).  Times measured on one MI355X (tools/debug/sparse_crossprod_time.py, round 6):
+// gathered pairs at 2.6e11 / s behind t(x) (2.5e-11 s per nonzero) and ~0.2 ms of launches; the dense-buffer route at
+// 3e12 multiply-adds / s behind ~1 ms of allocations, layout build and synchronisation.
+static double g_gram_cost = 1.0;
+extern "C" void svt_sparse_crossprod_set_cost(double factor)
 {
-	g_gram_cost = products_per_gathered_product;      // <= 0: never the sparse-aware route; huge: always
+	g_gram_cost = factor;      // the sparse-aware route's estimated time is multiplied by it; < 0: never that route; 0: always
 }
 
 static bool sparse_route_pays(int64_t nnz_x, int64_t nnz_y, int64_t nrow, double dense_ops, bool sym)
 {
-	if (g_gram_cost <= 0.0 || nrow <= 0 || nnz_x <= 0 || nnz_y <= 0)
+	if (g_gram_cost < 0.0 || nrow <= 0 || nnz_x <= 0 || nnz_y <= 0)
 		return false;
 	double pairs = (double) nnz_x * (double) nnz_y / (double) nrow;
 	if (sym) { pairs *= 0.5; dense_ops *= 0.5; }
-	return pairs * g_gram_cost < dense_ops;
+	const double t_sparse = 0.2e-3 + pairs / 2.6e11 + (double) nnz_x * 2.5e-11;
+	const double t_dense = 1.0e-3 + dense_ops / 3.0e12;
+	return t_sparse * g_gram_cost < t_dense;
 }
 
 // 0: `O` holds the result; 1: a non-finite value or an NA took part (the caller takes the dense-buffer route, whose

@@ -345,6 +345,14 @@ def crossprod_csc_csc_dense_buffer(X: DeviceCSC, Y: DeviceCSC, out=None):
     return out
 
 
+def set_sparse_crossprod_cost(factor=1.0) -> None:
+    """Route choice of the host entry points crossprod(x) / crossprod(x, y) (svt_sparse_crossprod_set_cost):
+    < 0 never the sparse-aware kernel, 0 always, 1 the measured model."""
+    _lib().svt_sparse_crossprod_set_cost.argtypes = [c_double]
+    _lib().svt_sparse_crossprod_set_cost.restype = None
+    _lib().svt_sparse_crossprod_set_cost(float(factor))
+
+
 def set_sparse_crossprod_panel(one_block_max=-1, log2_panel=-1) -> None:
     """Cell-panel shape of crossprod_csc_csc() (svt_dev_crossprod_csc_csc_set_panel); defaults restored by -1."""
     _lib().svt_dev_crossprod_csc_csc_set_panel(int(one_block_max), int(log2_panel))

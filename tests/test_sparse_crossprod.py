@@ -162,14 +162,49 @@ def test_not_finite_raises_the_flag_and_the_entry_points_follow_the_reference(hi
 
 
 @pytest.mark.parametrize("shape", [(25000, 400, 0.07), (25000, 650, 0.2), (60_000, 900, 0.01)])
-def test_host_entry_points_choose_a_route(hip, oracle, shape):
+@pytest.mark.parametrize("route", [1.0, 0.0, -1.0])
+def test_host_entry_points_choose_a_route(hip, oracle, shape, route):
     """The reference's published benchmark shapes (inst/scripts/benchmark_crossprod.R:123-166: 25000 x 400 @ 0.07,
-    25000 x 650 @ 0.20) and a sparser one through svt_crossprod1_SVT and svt_crossprod2_SVT_SVT."""
+    25000 x 650 @ 0.20) and a sparser one through svt_crossprod1_SVT and svt_crossprod2_SVT_SVT: with the measured
+    route model, with the sparse-aware kernel forced and with the dense-buffer route forced."""
+    from sparsearray_amd.device import set_sparse_crossprod_cost
     nrow, ncol, d = shape
     cp, ri, v = random_csc(nrow, ncol, d, seed=651)
     x = SVT_SparseArray.from_csc((nrow, ncol), "double", cp, ri, v)
+    cp2, ri2, v2 = random_csc(nrow, 37, 0.03, seed=652)
+    y = SVT_SparseArray.from_csc((nrow, 37), "double", cp2, ri2, v2)
     want = np.asarray(oracle.crossprod(x))
-    got = np.asarray(hip.crossprod(x))
+    want2 = np.asarray(oracle.crossprod(x, y))
+    try:
+        set_sparse_crossprod_cost(route)
+        got = np.asarray(hip.crossprod(x))
+        got_xx = np.asarray(hip.crossprod(x, x))
+        got2 = np.asarray(hip.crossprod(x, y))
+        got3 = np.asarray(hip.crossprod(y, x))
+    finally:
+        set_sparse_crossprod_cost(1.0)
     assert np.array_equal(got, got.T)
     assert_equal(got, want, tol=1e-12, atol=1e-12, what="crossprod(x)")
-    assert_equal(hip.crossprod(x, x), want, tol=1e-12, atol=1e-12, what="crossprod(x, x)")
+    assert_equal(got_xx, want, tol=1e-12, atol=1e-12, what="crossprod(x, x)")
+    assert_equal(got2, want2, tol=1e-12, atol=1e-12, what="crossprod(x, y)")
+    assert_equal(got3, want2.T, tol=1e-12, atol=1e-12, what="crossprod(y, x)")
+
+
+@pytest.mark.parametrize("lacunar", [True, False], ids=["lacunar", "plain"])
+def test_golden_unary_and_sparse_sparse_products_through_the_sparse_kernel(hip, lacunar):
+    """The reference's own test vectors (tests/testthat/test-SparseMatrix-mult.R:206-304 via tests/golden) for
+    crossprod() / tcrossprod() with the sparse-aware kernel forced wherever both operands are sparse and finite
+    (non-finite operands raise the flag and fall through to the dense-buffer route -- the NA / NaN / Inf cases of
+    those vectors check exactly that)."""
+    from helpers import check_case, golden_cases
+    from sparsearray_amd.device import set_sparse_crossprod_cost
+    n = 0
+    try:
+        set_sparse_crossprod_cost(0.0)
+        for case in golden_cases():
+            if case["fn"] in ("crossprod", "tcrossprod"):
+                check_case(hip, case, lacunar=lacunar, gpu=True)
+                n += 1
+    finally:
+        set_sparse_crossprod_cost(1.0)
+    assert n >= 200

@@ -29,14 +29,17 @@ def timed(fn, n=reps):
 
 
 ref = None
-for sym, env in [(True, {"SVT_GRAM_SYMK": "0"}), (True, {}), (True, {"SVT_GRAM_G": "8"}), (True, {"SVT_GRAM_G": "32"}),
-                 (True, {"SVT_GRAM_G": "64"}), (True, {"SVT_GRAM_NT": "512"}), (True, {"SVT_GRAM_NT": "512", "SVT_GRAM_G": "32"}),
-                 (False, {}), (False, {"SVT_GRAM_G": "16"}), (False, {"SVT_GRAM_G": "64"}), (False, {"SVT_GRAM_NT": "512"})]:
-    for k in ("SVT_GRAM_SYMK", "SVT_GRAM_G", "SVT_GRAM_NT"):
+KEYS = ("SVT_GRAM_SYMK", "SVT_GRAM_G", "SVT_GRAM_NT", "SVT_GRAM_SU", "SVT_GRAM_AOS", "SVT_GRAM_TT")
+CASES = [(True, {"SVT_GRAM_AOS": "1", "SVT_GRAM_SU": "1"}), (True, {"SVT_GRAM_AOS": "2", "SVT_GRAM_SU": "1"}),
+         (True, {"SVT_GRAM_AOS": "2", "SVT_GRAM_SU": "1", "SVT_GRAM_G": "8"}), (True, {"SVT_GRAM_AOS": "2", "SVT_GRAM_SU": "2"}),
+         (True, {"SVT_GRAM_AOS": "2", "SVT_GRAM_SU": "2", "SVT_GRAM_G": "8"}), (True, {"SVT_GRAM_AOS": "2", "SVT_GRAM_SU": "1", "SVT_GRAM_G": "32"}),
+         (True, {"SVT_GRAM_AOS": "0", "SVT_GRAM_SU": "1"}), (True, {})]
+for sym, env in CASES:
+    for k in KEYS:
         os.environ.pop(k, None)
     os.environ.update(env)
     ms = timed(lambda: crossprod_csc_csc(At, A, sym=sym, out=out, ws=ws))
     if ref is None:
         ref = out.clone()
     d = float((out - ref).abs().max())
-    print(f"sym={int(sym)} {str(env):60s} {ms:8.3f} ms   max |diff to first| {d:.2e}", flush=True)
+    print(f"sym={int(sym)} {str(env):70s} {ms:8.3f} ms   max |diff to first| {d:.2e}", flush=True)
