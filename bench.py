@@ -85,6 +85,10 @@ def parse():
                         "steps, so that the W + K steps do not run while the clocks are still ramping up out of idle "
                         "(tools/debug/whole_call_vs_step.py: the first ~20-40 ms after an idle gap run 3-9 %% slower); 0 = off")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--force-collectives", action="store_true",
+                   help="create the process group and run every collective even with ONE rank (an all-reduce of one rank is "
+                        "the identity): loads RCCL beside libsvt_hip.so and exercises the N > 1 code path on a one-GPU box; "
+                        "says nothing about scaling")
     p.add_argument("--no-extras", action="store_true")
     p.add_argument("--no-sparse-crossprod", action="store_true",
                    help="skip extras.sparse_crossprod (unary / SVT x SVT crossprod at the reference's published shapes and at config-2 scale)")
@@ -390,14 +394,20 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1:
+    coll = world > 1 or a.force_collectives         # are there collectives to run?
+    if coll:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29555")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if a.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(a.backend)
 
     from sparsearray_amd import parallel as par
+    if a.force_collectives:
+        par.force_collectives(True)
     from sparsearray_amd import synth
     from sparsearray_amd.device import (CrossprodPlan, DeviceCSC, PbcPlan, colmedians, colstats,
                                         rowsum, rowsums)
@@ -484,7 +494,7 @@ def main():
             return out
 
     spare_tuned = None
-    if world > 1 and a.spare_auto:
+    if coll and a.spare_auto:
         # part of the untimed warm-up: the same steps with 0 and with 32 CUs left to the collective's kernels; every
         # rank takes the setting with the smaller MAX-over-ranks time
         from sparsearray_amd.device import set_spare_cus
@@ -514,7 +524,7 @@ def main():
         step()
     finish()
     torch.cuda.synchronize()
-    if world > 1:
+    if coll:
         dist.barrier()
         torch.cuda.synchronize()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -528,11 +538,11 @@ def main():
         step(evs[i] if i % ev_every == ev_every - 1 else None)
     finish()
     torch.cuda.synchronize()
-    if world > 1:
+    if coll:
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if coll:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -545,14 +555,14 @@ def main():
     res_t = result()
     checksum = [float(res_t.sum().item()), float(res_t.abs().sum().item())]
     diag = None
-    if world > 1 and a.path == "pbc":
+    if coll and a.path == "pbc":
         # (a failure here must not leave the other ranks inside a collective: let it end the process with a
         # non-zero status -- torch.distributed.run then ends the job -- rather than be caught on one rank)
         diag = multi_gpu_diagnostics(a, dist, par, dev, sc, A, Y, step, finish, kern_ms, elapsed / a.steps * 1e3,
                                      with_colsums)
 
     if rank != 0:
-        if world > 1:
+        if coll:
             dist.destroy_process_group()
         return
 
@@ -627,7 +637,7 @@ def main():
             res["config"]["spare_cus"] = a.spare_cus
         if spare_tuned is not None:
             res["config"]["spare_cus_chosen_in_warmup_from_ms_per_step"] = {str(k): v for k, v in spare_tuned.items()}
-    if world == 1 and not a.no_extras and a.config == 2:
+    if world == 1 and not coll and not a.no_extras and a.config == 2:
         def timed(fn, reps=5):
             fn(); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -836,7 +846,7 @@ def main():
                                               "sample": cb3["sample"]}
         res["cpu_baseline"] = cb
     print(json.dumps(res))
-    if world > 1:
+    if coll:
         dist.destroy_process_group()
 
 

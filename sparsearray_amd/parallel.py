@@ -88,6 +88,23 @@ def _world(group=None) -> int:
     return dist.get_world_size(group) if dist.is_initialized() else 1
 
 
+_FORCE = False
+
+
+def force_collectives(on: bool = True) -> None:
+    """Run the collectives even in a group of ONE rank (the all-reduce of one rank is the identity): what a one-GPU
+    box can tell about the RCCL path -- that the library loads beside libsvt_hip.so, that the asynchronous all-reduce
+    and the two result buffers of `ShardedCrossprod` work against the real backend -- and nothing about scaling
+    (tests/test_rccl_one_rank.py; `bench.py --force-collectives`)."""
+    global _FORCE
+    _FORCE = bool(on)
+
+
+def _reduces(group=None) -> bool:
+    """Is there a collective to run?  More than one rank, or one rank with force_collectives()."""
+    return dist.is_initialized() and (dist.get_world_size(group) > 1 or _FORCE)
+
+
 def _rank(group=None) -> int:
     return dist.get_rank(group) if dist.is_initialized() else 0
 
@@ -96,7 +113,7 @@ def sharded_crossprod(local_crossprod: Callable[[], torch.Tensor], group=None) -
     """`local_crossprod()` returns this rank's ncol x K partial (any layout, the
     same on every rank); the sum over ranks is returned on every rank."""
     part = local_crossprod()
-    if _world(group) > 1:
+    if _reduces(group):
         dist.all_reduce(part, op=dist.ReduceOp.SUM, group=group)
     return part
 
@@ -104,7 +121,7 @@ def sharded_crossprod(local_crossprod: Callable[[], torch.Tensor], group=None) -
 def gather_columns(local: torch.Tensor, sizes: Sequence[int], group=None) -> torch.Tensor:
     """Concatenate per-rank result slices along dim 0 (col stats: one scalar per leaf; rowsum: one
     row of `ngroup` sums per leaf).  `sizes[r]` = leading extent of rank r's slice."""
-    if _world(group) == 1:
+    if not _reduces(group):
         return local
     tail = tuple(local.shape[1:])
     outs = [torch.empty((int(n),) + tail, dtype=local.dtype, device=local.device) for n in sizes]
@@ -179,8 +196,7 @@ def shard_axis_device(A, dim, axis: int, rank: int, world: int):
 def gather_axis(local: torch.Tensor, out_dim, axis: int, blocks, group=None) -> torch.Tensor:
     """Inverse of the cut for a result laid out like the array (R order over `out_dim`, rank r holding
     the slab blocks[r] of `axis`): all-gather of the slabs, then every slab goes to its place."""
-    world = _world(group)
-    if world == 1:
+    if not _reduces(group):
         return local
     out_dim = [int(d) for d in out_dim]
     inner = int(np.prod(out_dim[:axis], dtype=np.int64)) if axis > 0 else 1
@@ -368,7 +384,7 @@ class ShardedCrossprod:
         self.plan = PbcPlan(A_local, K, cbw, wpb, logr)
         dev = A_local.val.device
         world = _world(group)
-        nbuf = 2 if world > 1 else 1
+        nbuf = 2 if _reduces(group) else 1
         self.outs = [torch.zeros((self.K, A_local.ncol), dtype=torch.float64, device=dev) for _ in range(nbuf)]
         self.pending = [None] * nbuf
         self.stepno = 0
@@ -406,7 +422,7 @@ class ShardedCrossprod:
         self.plan.run_phase(2, Y_local, ld, target)
         if self.peer is not None:
             self.peer.push(i, target)
-        elif _world(self.group) > 1:
+        elif _reduces(self.group):
             self.pending[i] = dist.all_reduce(self.outs[i], op=dist.ReduceOp.SUM, group=self.group,
                                               async_op=True)
         return i
@@ -441,7 +457,7 @@ def sharded_colsums_rows(A_local, group=None, local: Optional[Callable] = None) 
     else:
         from .device import colstats
         part, _ = colstats(A_local, "sum")
-    if _world(group) > 1:
+    if _reduces(group):
         dist.all_reduce(part, op=dist.ReduceOp.SUM, group=group)
     return part
 
@@ -523,7 +539,7 @@ def sharded_crossprod_sparse(local_product: Callable, B_block, blocks_B, group=N
     ranges of A per rank)."""
     B_full = allgather_csc(*B_block, blocks_B, group)
     part = local_product(B_full)
-    if not gather_result or _world(group) == 1:
+    if not gather_result or not _reduces(group):
         return part
     return gather_columns(part.contiguous(), [b[1] - b[0] for b in (blocks_A or blocks_B)], group)
 
@@ -533,7 +549,7 @@ def sharded_colsum(local_colsum: Callable, group=None) -> torch.Tensor:
     leaves it holds into its own nrow x ngroup partial (src/rowsum_methods.c:204-255) and the partials
     are all-reduced.  (Integer input: int64 partials, NA / overflow flags reduced with MAX by the caller.)"""
     part = local_colsum()
-    if _world(group) > 1:
+    if _reduces(group):
         dist.all_reduce(part, op=dist.ReduceOp.SUM, group=group)
     return part
 
@@ -543,7 +559,7 @@ def sharded_rowsums_2d(local_rowsums: Callable, blocks=None, group=None) -> torc
     rank owns its nrow / N sums and they are all-gathered (no reduction).  `blocks` = None: sharded on
     leaves, the nrow partial sums are all-reduced (8 MB at BASELINE config 2)."""
     part = local_rowsums()
-    if _world(group) == 1:
+    if not _reduces(group):
         return part
     if blocks is not None:
         return gather_columns(part.contiguous(), [b[1] - b[0] for b in blocks], group)
