@@ -19,9 +19,22 @@
  *
  * Return convention (all int-returning functions):
  *     0   success
- *    -1   error; message in svt_last_error().  The R glue turns it into
+ *   < 0   (-1) error; message in svt_last_error().  The R glue turns it into
  *         error(), like the reference's own error() calls
  *         (e.g. src/SparseMatrix_mult.c:943-966).
+ *   > 0   (SVT_UNSUPPORTED = 1) not supported HERE: the device kernels do not take
+ *         this operand or operation -- 2^31 nonzeros or more in a transposition /
+ *         aperm / colMedians / the second operand of the row-panel product (an SVT's
+ *         total count is unbounded, R/SVT_SparseArray-class.R:13-23), too many strata
+ *         for the row-statistics counters, an opcode the R API never sends
+ *         (RANGE, SUM_X_X2, VAR2, SD2 for col / row statistics).  The reason is in
+ *         svt_last_error(); nothing the caller relies on has been written.  The R glue
+ *         answers it with the reference's own CPU body for that call
+ *         (integration/svt_hip_glue.c, HIP_STATUS) -- the same thing it does when the
+ *         library or the GPU is absent.  Inside the library a route that is refused
+ *         falls back to another one where there is one (the sparse-aware crossprod to
+ *         the dense-buffer route, the row-panel product to the transposition route);
+ *         only what no device route takes surfaces as > 0.
  * Warning conditions ("NAs introduced by coercion of infinite values to
  * integers", src/SparseArray_matrixStats.c:278-280; "NAs produced by integer
  * overflow", src/rowsum_methods.c:122-123) are reported through the
@@ -41,6 +54,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+#define SVT_UNSUPPORTED 1
 
 #define SVT_LGLSXP 10
 #define SVT_INTSXP 13

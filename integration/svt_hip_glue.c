@@ -22,7 +22,8 @@
  * steps: argument checks the reference makes before it allocates (they stay on the R side, with the
  * reference's own helpers) -> result allocation with the reference's helpers (dimnames included) ->
  * SVT flattened to an svt_view (pointers into R's vectors, nothing copied) -> one svt_* call ->
- * status < 0 becomes error(svt_last_error()), the warn / ovflow flags become warning() AFTER the
+ * status < 0 becomes error(svt_last_error()), status > 0 ("not supported here": e.g. 2^31 nonzeros or more in a
+ * transposition) hands the call to the reference's own body, the warn / ovflow flags become warning() AFTER the
  * compute, on the R thread (src/SparseArray_matrixStats.c:278-280, src/rowsum_methods.c:122-123).
  * libsvt_hip.so is dlopen()ed on first use; without it, or without an MI355X, every entry point
  * runs its _cpu body, so the package still loads anywhere.
@@ -116,6 +117,20 @@ static void hip_fail(void)     /* same role as the reference's error() calls: ne
 	error("%s", HIP_FN(svt_last_error)());
 }
 
+/* Status of an svt_* call (include/svt_hip.h): 0 done; < 0 error -> error(), as the reference's own error() calls;
+   > 0 "not supported here" (an operand past a size limit of the device kernels, an operation they do not
+   implement): what was PROTECTed for the device call is released and the reference's body computes the call. */
+#define HIP_STATUS(call, nprotect, cpu_call)        \
+	do {                                        \
+		int rc__ = (call);                  \
+		if (rc__ < 0)                       \
+			hip_fail();                 \
+		if (rc__ > 0) {                     \
+			UNPROTECT(nprotect);        \
+			return cpu_call;            \
+		}                                   \
+	} while (0)
+
 static int device_type(SEXPTYPE Rtype)
 {
 	return Rtype == REALSXP || Rtype == INTSXP || Rtype == LGLSXP;
@@ -207,8 +222,8 @@ SEXP C_crossprod2_SVT_mat(SEXP x_dim, SEXP x_type, SEXP x_SVT, SEXP y, SEXP tran
 		error("input objects are non-conformable");
 	SEXP ans = PROTECT(_new_Rmatrix0(REALSXP, INTEGER(x_dim)[1], tr_y ? y_nrow : y_ncol, ans_dimnames));
 	svt_view xv = make_view(x_dim, Rtype, x_SVT, 0);
-	if (HIP_FN(svt_crossprod2_SVT_mat)(&xv, DATAPTR(y), y_nrow, y_ncol, TYPEOF(y), tr_y, REAL(ans)) != 0)
-		hip_fail();
+	HIP_STATUS(HIP_FN(svt_crossprod2_SVT_mat)(&xv, DATAPTR(y), y_nrow, y_ncol, TYPEOF(y), tr_y, REAL(ans)), 1,
+		   C_crossprod2_SVT_mat_cpu(x_dim, x_type, x_SVT, y, transpose_y, ans_type, ans_dimnames));
 	UNPROTECT(1);
 	return ans;
 }
@@ -229,8 +244,8 @@ SEXP C_crossprod2_mat_SVT(SEXP x, SEXP y_dim, SEXP y_type, SEXP y_SVT, SEXP tran
 		error("input objects are non-conformable");
 	SEXP ans = PROTECT(_new_Rmatrix0(REALSXP, tr_x ? x_nrow : x_ncol, INTEGER(y_dim)[1], ans_dimnames));
 	svt_view yv = make_view(y_dim, Rtype, y_SVT, 0);
-	if (HIP_FN(svt_crossprod2_mat_SVT)(DATAPTR(x), x_nrow, x_ncol, TYPEOF(x), &yv, tr_x, REAL(ans)) != 0)
-		hip_fail();
+	HIP_STATUS(HIP_FN(svt_crossprod2_mat_SVT)(DATAPTR(x), x_nrow, x_ncol, TYPEOF(x), &yv, tr_x, REAL(ans)), 1,
+		   C_crossprod2_mat_SVT_cpu(x, y_dim, y_type, y_SVT, transpose_x, ans_type, ans_dimnames));
 	UNPROTECT(1);
 	return ans;
 }
@@ -252,8 +267,8 @@ SEXP C_crossprod2_SVT_SVT(SEXP x_dim, SEXP x_type, SEXP x_SVT, SEXP y_dim, SEXP 
 	SEXP ans = PROTECT(_new_Rmatrix0(REALSXP, INTEGER(x_dim)[1], INTEGER(y_dim)[1], ans_dimnames));
 	svt_view xv = make_view(x_dim, x_Rtype, x_SVT, 0);
 	svt_view yv = make_view(y_dim, y_Rtype, y_SVT, 0);
-	if (HIP_FN(svt_crossprod2_SVT_SVT)(&xv, &yv, REAL(ans)) != 0)
-		hip_fail();
+	HIP_STATUS(HIP_FN(svt_crossprod2_SVT_SVT)(&xv, &yv, REAL(ans)), 1,
+		   C_crossprod2_SVT_SVT_cpu(x_dim, x_type, x_SVT, y_dim, y_type, y_SVT, ans_type, ans_dimnames));
 	UNPROTECT(1);
 	return ans;
 }
@@ -269,8 +284,8 @@ SEXP C_crossprod1_SVT(SEXP x_dim, SEXP x_type, SEXP x_SVT, SEXP ans_type, SEXP a
 	int n = INTEGER(x_dim)[1];
 	SEXP ans = PROTECT(_new_Rmatrix0(REALSXP, n, n, ans_dimnames));
 	svt_view xv = make_view(x_dim, Rtype, x_SVT, 0);
-	if (HIP_FN(svt_crossprod1_SVT)(&xv, REAL(ans)) != 0)
-		hip_fail();
+	HIP_STATUS(HIP_FN(svt_crossprod1_SVT)(&xv, REAL(ans)), 1,
+		   C_crossprod1_SVT_cpu(x_dim, x_type, x_SVT, ans_type, ans_dimnames));
 	UNPROTECT(1);
 	return ans;
 }
@@ -326,8 +341,8 @@ SEXP C_colStats_SVT(SEXP x_dim, SEXP x_dimnames, SEXP x_type, SEXP x_SVT, SEXP x
 	   allocation path (alloc_ans() + propagate_colStats_dimnames(), :108-176) */
 	SEXP ans = PROTECT(alloc_colStats_ans(ans_Rtype, x_dim, x_dimnames, d));
 	svt_view xv = make_view(x_dim, Rtype, x_SVT, na_bg);
-	if (HIP_FN(svt_colStats_SVT)(&xv, opcode, LOGICAL(na_rm)[0], REAL(center)[0], d, DATAPTR(ans), &warn) != 0)
-		hip_fail();
+	HIP_STATUS(HIP_FN(svt_colStats_SVT)(&xv, opcode, LOGICAL(na_rm)[0], REAL(center)[0], d, DATAPTR(ans), &warn), 1,
+		   C_colStats_SVT_cpu(x_dim, x_dimnames, x_type, x_SVT, x_na_background, op, na_rm, center, dims));
 	if (warn)
 		warning("NAs introduced by coercion of infinite values to integers");
 	UNPROTECT(1);
@@ -353,14 +368,8 @@ SEXP C_rowStats_SVT(SEXP x_dim, SEXP x_dimnames, SEXP x_type, SEXP x_SVT, SEXP x
 	SEXP ans = PROTECT(alloc_rowStats_ans(ans_Rtype, ans_dim, x_dimnames, ans_ndim));
 	svt_view xv = make_view(x_dim, Rtype, x_SVT, na_bg);
 	/* ops the device does not cover natively for this shape come back as status > 0: CPU body */
-	int rc = HIP_FN(svt_rowStats_SVT)(&xv, opcode, LOGICAL(na_rm)[0], center_p, ans_ndim, DATAPTR(ans), &warn);
-	if (rc > 0) {
-		UNPROTECT(2);
-		return C_rowStats_SVT_cpu(x_dim, x_dimnames, x_type, x_SVT, x_na_background, op, na_rm,
-					  center, dims);
-	}
-	if (rc < 0)
-		hip_fail();
+	HIP_STATUS(HIP_FN(svt_rowStats_SVT)(&xv, opcode, LOGICAL(na_rm)[0], center_p, ans_ndim, DATAPTR(ans), &warn), 2,
+		   C_rowStats_SVT_cpu(x_dim, x_dimnames, x_type, x_SVT, x_na_background, op, na_rm, center, dims));
 	if (warn)
 		warning("NAs introduced by coercion of infinite values to integers");
 	UNPROTECT(2);
@@ -384,9 +393,9 @@ SEXP C_summarize_SVT(SEXP x_dim, SEXP x_type, SEXP x_SVT, SEXP x_na_background,
 	svt_view xv = make_view(x_dim, Rtype, x_SVT, na_bg);
 	double out_d[2] = {0.0, 0.0};
 	int out_i[2] = {0, 0}, out_Rtype = 0, warn = 0;
-	if (HIP_FN(svt_summarize_SVT)(&xv, opcode, LOGICAL(na_rm)[0], REAL(center)[0],
-				      out_d, out_i, &out_Rtype, &warn) != 0)
-		hip_fail();
+	HIP_STATUS(HIP_FN(svt_summarize_SVT)(&xv, opcode, LOGICAL(na_rm)[0], REAL(center)[0],
+					     out_d, out_i, &out_Rtype, &warn), 0,
+		   C_summarize_SVT_cpu(x_dim, x_type, x_SVT, x_na_background, op, na_rm, center));
 	if (warn)
 		warning("NAs introduced by coercion of infinite values to integers");
 	/* The library hands back the post-processed state (value(s) + their type); the R object is made from it
@@ -431,8 +440,8 @@ static SEXP groupsum_SVT(SEXP x_dim, SEXP x_type, SEXP x_SVT, SEXP group, SEXP n
 	int ovflow = 0;
 	int rc = colsum ? HIP_FN(svt_colsum_SVT)(&xv, INTEGER(group), ng, LOGICAL(na_rm)[0], DATAPTR(ans), &ovflow)
 			: HIP_FN(svt_rowsum_SVT)(&xv, INTEGER(group), ng, LOGICAL(na_rm)[0], DATAPTR(ans), &ovflow);
-	if (rc != 0)
-		hip_fail();
+	HIP_STATUS(rc, 1, colsum ? C_colsum_SVT_cpu(x_dim, x_type, x_SVT, group, ngroup, na_rm)
+				 : C_rowsum_SVT_cpu(x_dim, x_type, x_SVT, group, ngroup, na_rm));
 	if (ovflow)
 		warning("NAs produced by integer overflow");
 	UNPROTECT(1);
@@ -471,8 +480,8 @@ static SEXP groupsum_dgCMatrix(SEXP x, SEXP group, SEXP ngroup, SEXP na_rm, int 
 			: HIP_FN(svt_rowsum_dgCMatrix)(x_nrow, x_ncol, REAL(x_slotx), INTEGER(x_sloti),
 						       INTEGER(x_slotp), INTEGER(group), ng,
 						       LOGICAL(na_rm)[0], REAL(ans));
-	if (rc != 0)
-		hip_fail();
+	HIP_STATUS(rc, 1, colsum ? C_colsum_dgCMatrix_cpu(x, group, ngroup, na_rm)
+				 : C_rowsum_dgCMatrix_cpu(x, group, ngroup, na_rm));
 	UNPROTECT(1);
 	return ans;
 }
@@ -495,15 +504,15 @@ SEXP C_colsum_dgCMatrix(SEXP x, SEXP group, SEXP ngroup, SEXP na_rm)
 /* column statistics of a dgCMatrix -- src/sparseMatrix_utils.c:105-223                             */
 /* ------------------------------------------------------------------------------------------------ */
 typedef int (*dgc_colstat_fn)(int, int, const double *, const int *, int, double *);
+typedef SEXP (*dgc_cpu_fn)(SEXP, SEXP);
 
-static SEXP colstat_dgCMatrix(SEXP x, SEXP na_rm, dgc_colstat_fn fn, int is_range)
+static SEXP colstat_dgCMatrix(SEXP x, SEXP na_rm, dgc_colstat_fn fn, int is_range, dgc_cpu_fn cpu)
 {
 	SEXP x_Dim = GET_SLOT(x, install("Dim"));
 	int x_nrow = INTEGER(x_Dim)[0], x_ncol = INTEGER(x_Dim)[1];
 	SEXP x_slotx = GET_SLOT(x, install("x")), x_slotp = GET_SLOT(x, install("p"));
 	SEXP ans = PROTECT(is_range ? allocMatrix(REALSXP, x_ncol, 2) : NEW_NUMERIC(x_ncol));
-	if (fn(x_nrow, x_ncol, REAL(x_slotx), INTEGER(x_slotp), LOGICAL(na_rm)[0], REAL(ans)) != 0)
-		hip_fail();
+	HIP_STATUS(fn(x_nrow, x_ncol, REAL(x_slotx), INTEGER(x_slotp), LOGICAL(na_rm)[0], REAL(ans)), 1, cpu(x, na_rm));
 	UNPROTECT(1);
 	return ans;
 }
@@ -512,28 +521,28 @@ SEXP C_colMins_dgCMatrix(SEXP x, SEXP na_rm)
 {
 	if (!hip_available())
 		return C_colMins_dgCMatrix_cpu(x, na_rm);
-	return colstat_dgCMatrix(x, na_rm, HIP_FN(svt_colMins_dgCMatrix), 0);
+	return colstat_dgCMatrix(x, na_rm, HIP_FN(svt_colMins_dgCMatrix), 0, C_colMins_dgCMatrix_cpu);
 }
 
 SEXP C_colMaxs_dgCMatrix(SEXP x, SEXP na_rm)
 {
 	if (!hip_available())
 		return C_colMaxs_dgCMatrix_cpu(x, na_rm);
-	return colstat_dgCMatrix(x, na_rm, HIP_FN(svt_colMaxs_dgCMatrix), 0);
+	return colstat_dgCMatrix(x, na_rm, HIP_FN(svt_colMaxs_dgCMatrix), 0, C_colMaxs_dgCMatrix_cpu);
 }
 
 SEXP C_colRanges_dgCMatrix(SEXP x, SEXP na_rm)
 {
 	if (!hip_available())
 		return C_colRanges_dgCMatrix_cpu(x, na_rm);
-	return colstat_dgCMatrix(x, na_rm, HIP_FN(svt_colRanges_dgCMatrix), 1);
+	return colstat_dgCMatrix(x, na_rm, HIP_FN(svt_colRanges_dgCMatrix), 1, C_colRanges_dgCMatrix_cpu);
 }
 
 SEXP C_colVars_dgCMatrix(SEXP x, SEXP na_rm)
 {
 	if (!hip_available())
 		return C_colVars_dgCMatrix_cpu(x, na_rm);
-	return colstat_dgCMatrix(x, na_rm, HIP_FN(svt_colVars_dgCMatrix), 0);
+	return colstat_dgCMatrix(x, na_rm, HIP_FN(svt_colVars_dgCMatrix), 0, C_colVars_dgCMatrix_cpu);
 }
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -591,8 +600,7 @@ SEXP C_transpose_2D_SVT(SEXP x_dim, SEXP x_type, SEXP x_SVT)
 	int64_t *cp = (int64_t *) R_alloc((size_t) ans_dim[1] + 1, sizeof(int64_t));
 	int *ri = (int *) R_alloc(nnz > 0 ? (size_t) nnz : 1, sizeof(int));
 	char *vv = (char *) R_alloc(nnz > 0 ? (size_t) nnz : 1, esz);
-	if (HIP_FN(svt_transpose_2D_SVT)(&xv, cp, ri, vv) != 0)
-		hip_fail();
+	HIP_STATUS(HIP_FN(svt_transpose_2D_SVT)(&xv, cp, ri, vv), 0, C_transpose_2D_SVT_cpu(x_dim, x_type, x_SVT));
 	return tree_from_csc(ans_dim, 2, Rtype, cp, ri, vv, esz, 0);
 }
 
@@ -632,8 +640,7 @@ SEXP C_aperm_SVT(SEXP x_dim, SEXP x_type, SEXP x_SVT, SEXP perm)
 	int64_t *cp = (int64_t *) R_alloc((size_t) new_nl + 1, sizeof(int64_t));
 	int *ri = (int *) R_alloc(nnz > 0 ? (size_t) nnz : 1, sizeof(int));
 	char *vv = (char *) R_alloc(nnz > 0 ? (size_t) nnz : 1, esz);
-	if (HIP_FN(svt_aperm_SVT)(&xv, INTEGER(perm), cp, ri, vv) != 0)
-		hip_fail();
+	HIP_STATUS(HIP_FN(svt_aperm_SVT)(&xv, INTEGER(perm), cp, ri, vv), 0, C_aperm_SVT_cpu(x_dim, x_type, x_SVT, perm));
 	return tree_from_csc(ans_dim, ndim, Rtype, cp, ri, vv, esz, 0);
 }
 

@@ -7,7 +7,7 @@ in this package: using any operator without the HIP library raises.
 """
 from .svt import (NA_integer, NA_logical, NA_real, SVT_SparseArray,  # noqa: F401
                   is_NA_real, is_NaN_real)
-from .api import Session, SparseArrayError  # noqa: F401
+from .api import Session, SparseArrayError, SparseArrayUnsupported  # noqa: F401
 
 
 def hip_session():

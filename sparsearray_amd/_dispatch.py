@@ -15,7 +15,7 @@ from ctypes import POINTER, byref, c_char_p, c_double, c_int, c_void_p
 
 import numpy as np
 
-from .api import OPCODES, SparseArrayError, naked_result
+from .api import OPCODES, SparseArrayError, SparseArrayUnsupported, naked_result
 from .svt import (INTSXP, LGLSXP, REALSXP, SVT_SparseArray, make_view,
                   r_type_of, svt_view)
 
@@ -78,7 +78,7 @@ class CAbiDispatcher:
     def _check(self, rc):
         if rc != 0:
             msg = self._fn("last_error")()
-            raise SparseArrayError(msg.decode() if msg else f"error {rc}")
+            raise (SparseArrayUnsupported if rc > 0 else SparseArrayError)(msg.decode() if msg else f"error {rc}")
 
     # -- dispatcher ------------------------------------------------------------
     def __call__(self, name: str, *args):

@@ -34,6 +34,12 @@ class SparseArrayError(RuntimeError):
     """R's error() raised by an entry point."""
 
 
+class SparseArrayUnsupported(SparseArrayError):
+    """Status > 0 of the C ABI (include/svt_hip.h): the device kernels do not take this operand / operation; the R
+    glue runs the reference's CPU body instead (integration/svt_hip_glue.c).  This package has no CPU path: it
+    raises."""
+
+
 _SUPPORTED_MULT_TYPES = ("double", "integer")
 
 

@@ -319,7 +319,7 @@ int launch_gram_mirror(double *out, int64_t n, int64_t ld, hipStream_t s)
 		return 0;
 	const unsigned nt = (unsigned) ((n + 63) / 64);
 	if (nt > 65535)
-		return svt_set_error("sparse crossprod: result too wide to mirror");
+		return svt_set_unsupported("sparse crossprod: result too wide to mirror");
 	hipLaunchKernelGGL(gram_mirror_kernel, dim3(nt, nt), dim3(256), 0, s, out, n, ld);
 	HIP_TRY(hipGetLastError());
 	return 0;
@@ -385,7 +385,7 @@ int launch_gram(GramArgs a, int64_t a_nnz, int64_t b_nnz, void *ws, hipStream_t 
 	}
 	if (a.sym) run *= 0.5;
 	if (nwg >= (int64_t) 2147483647)
-		return svt_set_error("sparse crossprod: too many workgroups for one launch");
+		return svt_set_unsupported("sparse crossprod: too many workgroups for one launch");
 	int G = 64;
 	while (G > 8 && run < 2.0 * G) G >>= 1;
 #ifdef SVT_TUNING

@@ -343,7 +343,7 @@ int launch_colmedians(const int64_t *col_ptr, const void *val, int Rtype, int64_
 	if (ncol <= 0)
 		return 0;
 	if (nnz > 0x7FFFFFFFLL || ncol > 0x7FFFFFFFLL)
-		return svt_set_error("colMedians: more than 2^31-1 nonzeros or columns");
+		return svt_set_unsupported("colMedians: more than 2^31-1 nonzeros or columns");
 	int64_t *cnt_neg = (int64_t *) (((uintptr_t) ws + 255) & ~(uintptr_t) 255);
 	int64_t *cnt_pos = cnt_neg + ncol, *cnt_nan = cnt_pos + ncol;
 	int *todo = (int *) (cnt_nan + ncol);

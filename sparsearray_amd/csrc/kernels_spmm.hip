@@ -314,11 +314,11 @@ int launch_spmm_product(SpmmArgs a, int64_t a_nnz, int64_t b_nnz, const void *ws
 		return 0;
 	// the kernel counts the nonzeros of a workgroup's columns of B in 32 bits
 	if (b_nnz >= (int64_t) 2147483647)
-		return svt_set_error("sparse x sparse product: the second operand holds 2^31 nonzeros or more");
+		return svt_set_unsupported("sparse x sparse product: the second operand holds 2^31 nonzeros or more");
 	int ps, KW; int64_t npan;
 	spmm_shape(a.nrow, a.K, &ps, &npan, &KW);
 	if (npan >= (int64_t) 2147483647)
-		return svt_set_error("sparse x sparse product: too many row panels for one launch");
+		return svt_set_unsupported("sparse x sparse product: too many row panels for one launch");
 	const int64_t P = (int64_t) 1 << ps;
 	a.pt = (const int32_t *) ws; a.npan = npan; a.ps = ps;
 	// lanes per run: the largest power of two <= half its mean length (81 nonzeros at config 3: three trips of
@@ -334,7 +334,7 @@ int launch_spmm_product(SpmmArgs a, int64_t a_nnz, int64_t b_nnz, const void *ws
 	const size_t lds = (size_t) KW * P * 8;
 	const int64_t nkb = (a.K + KW - 1) / KW;
 	if (npan * nkb >= (int64_t) 2147483647)
-		return svt_set_error("sparse x sparse product: too many workgroups for one launch");
+		return svt_set_unsupported("sparse x sparse product: too many workgroups for one launch");
 	dim3 grid((unsigned) (npan * nkb));
 	static int order = -1;
 	if (order < 0) {

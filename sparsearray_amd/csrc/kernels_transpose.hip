@@ -756,7 +756,7 @@ static int launch_transpose_sorted(const int64_t *col_ptr, const int32_t *row_id
 		     void *out_val, void *ws, hipStream_t s)
 {
 	if (nnz >= ((int64_t) 1 << 31))
-		return svt_set_error("svt_dev_transpose: more than 2^31-1 nonzeros");
+		return svt_set_unsupported("svt_dev_transpose: more than 2^31-1 nonzeros");
 	const unsigned nbr = (unsigned) ((nrow + 1 + 255) / 256);
 	if (nnz == 0) {
 		HIP_TRY(hipMemsetAsync(out_ptr, 0, (size_t) (nrow + 1) * 8, s));
@@ -856,7 +856,7 @@ int launch_transpose(const int64_t *col_ptr, const int32_t *row_idx, const void 
 		     void *out_val, void *ws, hipStream_t s)
 {
 	if (nnz >= ((int64_t) 1 << 31))
-		return svt_set_error("svt_dev_transpose: more than 2^31-1 nonzeros");
+		return svt_set_unsupported("svt_dev_transpose: more than 2^31-1 nonzeros");
 	if (nnz == 0) {
 		HIP_TRY(hipMemsetAsync(out_ptr, 0, (size_t) (nrow + 1) * 8, s));
 		return 0;
@@ -1376,7 +1376,7 @@ int launch_aperm(const int64_t *col_ptr, const int32_t *row_idx, const void *val
 	if (ndim < 1 || ndim > 8)
 		return svt_set_error("aperm: between 1 and 8 dimensions are supported");
 	if (nnz >= ((int64_t) 1 << 31))
-		return svt_set_error("aperm: more than 2^31-1 nonzeros");
+		return svt_set_unsupported("aperm: more than 2^31-1 nonzeros");
 	ApermDims d;
 	d.ndim = ndim;
 	bool seen[8] = {false, false, false, false, false, false, false, false};

@@ -103,6 +103,8 @@ __device__ inline double ordered_to_f64(unsigned long long u)
 
 // ---- host-side plumbing (svt_hip.cpp) ----------------------------------------
 int svt_set_error(const char *fmt, ...);
+int svt_set_unsupported(const char *fmt, ...);     // status > 0 at the ABI: the caller runs its CPU body
+void svt_clear_unsupported(void);
 #define HIP_TRY(expr)                                                         \
 	do {                                                                  \
 		hipError_t e__ = (expr);                                      \

@@ -29,6 +29,25 @@ int svt_set_error(const char *fmt, ...)
 	return -1;
 }
 
+// "Not supported here" (include/svt_hip.h: status > 0): inside the library it unwinds like an error (-1, with the
+// message), and the entry point that hands a status to the caller turns it into 1 (svt_status).  A caller inside
+// the library that recovers from it (another route) clears the mark.
+static thread_local int g_unsupported = 0;
+int svt_set_unsupported(const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof(g_err), fmt, ap);
+	va_end(ap);
+	g_unsupported = 1;
+	return -1;
+}
+void svt_clear_unsupported(void) { g_unsupported = 0; }
+static inline int svt_status(int rc)
+{
+	return rc < 0 && g_unsupported ? 1 : rc;
+}
+
 extern "C" const char *svt_last_error(void) { return g_err; }
 extern "C" const char *svt_device_arch(void) { return g_arch; }
 
@@ -695,9 +714,9 @@ static int device_op_supported(int opcode)
 {
 	if (opcode == SVT_OP_RANGE || opcode == SVT_OP_SUM_X_X2 ||
 	    opcode == SVT_OP_VAR2 || opcode == SVT_OP_SD2)
-		return svt_set_error("op code %d is not reachable from the R API for "
-				     "col/row stats and is not implemented on the device",
-				     opcode);
+		return svt_set_unsupported("op code %d is not reachable from the R API for "
+					   "col/row stats and is not implemented on the device",
+					   opcode);
 	return 0;
 }
 
@@ -721,7 +740,8 @@ extern "C" int svt_dev_colstats(const svt_dev_csc *A, int opcode, int na_rm,
 				double center, int64_t inner, void *out,
 				int *warn_flag, void *stream)
 {
-	return dev_colstats_ex(A, opcode, na_rm, center, inner, out, warn_flag, stream, 0);
+	g_unsupported = 0;
+	return svt_status(dev_colstats_ex(A, opcode, na_rm, center, inner, out, warn_flag, stream, 0));
 }
 
 extern "C" size_t svt_dev_colmedians_ws_bytes(int64_t nnz, int64_t ncol)
@@ -729,7 +749,7 @@ extern "C" size_t svt_dev_colmedians_ws_bytes(int64_t nnz, int64_t ncol)
 	return colmedians_ws_bytes(nnz, ncol);
 }
 
-extern "C" int svt_dev_colmedians(const svt_dev_csc *A, int na_rm, double *out, void *ws,
+static int dev_colmedians_impl(const svt_dev_csc *A, int na_rm, double *out, void *ws,
 				  size_t ws_bytes, void *stream)
 {
 	if (A->na_background)
@@ -738,6 +758,12 @@ extern "C" int svt_dev_colmedians(const svt_dev_csc *A, int na_rm, double *out, 
 		return svt_set_error("svt_dev_colmedians: workspace too small");
 	return launch_colmedians(A->col_ptr, A->val, A->Rtype, A->nrow, A->ncol, A->nnz, na_rm, out, ws,
 				 (hipStream_t) stream);
+}
+extern "C" int svt_dev_colmedians(const svt_dev_csc *A, int na_rm, double *out, void *ws,
+				  size_t ws_bytes, void *stream)
+{
+	g_unsupported = 0;
+	return svt_status(dev_colmedians_impl(A, na_rm, out, ws, ws_bytes, stream));
 }
 
 extern "C" size_t svt_dev_rowstats_ws_bytes(int64_t nrow, int64_t ncol)
@@ -789,13 +815,19 @@ extern "C" size_t svt_dev_transpose_ws_bytes(int64_t nrow, int64_t nnz)
 	return transpose_ws_bytes(nrow, nnz);
 }
 
-extern "C" int svt_dev_transpose(const svt_dev_csc *A, int64_t *out_col_ptr, int32_t *out_row_idx,
+static int dev_transpose_impl(const svt_dev_csc *A, int64_t *out_col_ptr, int32_t *out_row_idx,
 				 void *out_val, void *ws, size_t ws_bytes, void *stream)
 {
 	if (ws_bytes < transpose_ws_bytes(A->nrow, A->nnz))
 		return svt_set_error("svt_dev_transpose: workspace too small");
 	return launch_transpose(A->col_ptr, A->row_idx, A->val, A->Rtype, A->nrow, A->ncol, A->nnz,
 				out_col_ptr, out_row_idx, out_val, ws, (hipStream_t) stream);
+}
+extern "C" int svt_dev_transpose(const svt_dev_csc *A, int64_t *out_col_ptr, int32_t *out_row_idx,
+				 void *out_val, void *ws, size_t ws_bytes, void *stream)
+{
+	g_unsupported = 0;
+	return svt_status(dev_transpose_impl(A, out_col_ptr, out_row_idx, out_val, ws, ws_bytes, stream));
 }
 
 // A %*% B, both sparse (kernels_spmm.hip): out[r + k * ldo], r < A->nrow, k < B->ncol.
@@ -827,7 +859,7 @@ extern "C" int svt_dev_matmul_csc_csc_prepare(const svt_dev_csc *A, void *ws, si
 	return launch_spmm_prepare(spmm_args(A, &none, NULL, 0, (int *) ws), A->nnz, (char *) ws + 256, s);
 }
 
-extern "C" int svt_dev_matmul_csc_csc_prepared(const svt_dev_csc *A, const svt_dev_csc *B, double *out, int64_t ldo,
+static int dev_matmul_csc_csc_prepared_impl(const svt_dev_csc *A, const svt_dev_csc *B, double *out, int64_t ldo,
 					       void *ws, size_t ws_bytes, int *not_finite, void *stream)
 {
 	if (A->ncol != B->nrow)
@@ -845,8 +877,14 @@ extern "C" int svt_dev_matmul_csc_csc_prepared(const svt_dev_csc *A, const svt_d
 		HIP_TRY(hipMemcpyAsync(not_finite, flag, 4, hipMemcpyDeviceToDevice, s));
 	return 0;
 }
+extern "C" int svt_dev_matmul_csc_csc_prepared(const svt_dev_csc *A, const svt_dev_csc *B, double *out, int64_t ldo,
+					       void *ws, size_t ws_bytes, int *not_finite, void *stream)
+{
+	g_unsupported = 0;
+	return svt_status(dev_matmul_csc_csc_prepared_impl(A, B, out, ldo, ws, ws_bytes, not_finite, stream));
+}
 
-extern "C" int svt_dev_matmul_csc_csc(const svt_dev_csc *A, const svt_dev_csc *B, double *out, int64_t ldo,
+static int dev_matmul_csc_csc_impl(const svt_dev_csc *A, const svt_dev_csc *B, double *out, int64_t ldo,
 				      void *ws, size_t ws_bytes, int *not_finite, void *stream)
 {
 	if (A->ncol != B->nrow)
@@ -870,6 +908,12 @@ extern "C" int svt_dev_matmul_csc_csc(const svt_dev_csc *A, const svt_dev_csc *B
 		HIP_TRY(hipMemcpyAsync(not_finite, flag, 4, hipMemcpyDeviceToDevice, s));
 	return 0;
 }
+extern "C" int svt_dev_matmul_csc_csc(const svt_dev_csc *A, const svt_dev_csc *B, double *out, int64_t ldo,
+				      void *ws, size_t ws_bytes, int *not_finite, void *stream)
+{
+	g_unsupported = 0;
+	return svt_status(dev_matmul_csc_csc_impl(A, B, out, ldo, ws, ws_bytes, not_finite, stream));
+}
 
 // crossprod(X, Y) of two sparse operands on t(X) and Y (kernels_gram.hip)
 extern "C" size_t svt_dev_crossprod_csc_csc_ws_bytes(const svt_dev_csc *Xt)
@@ -882,7 +926,7 @@ extern "C" void svt_dev_crossprod_csc_csc_set_panel(int one_block_max, int log2_
 	gram_set_panel(one_block_max, log2_panel);
 }
 
-extern "C" int svt_dev_crossprod_csc_csc(const svt_dev_csc *Xt, const svt_dev_csc *Y, int sym, double *out,
+static int dev_crossprod_csc_csc_impl(const svt_dev_csc *Xt, const svt_dev_csc *Y, int sym, double *out,
 					 int64_t ldo, void *ws, size_t ws_bytes, int *not_finite, void *stream)
 {
 	if (Xt->ncol != Y->nrow)
@@ -908,6 +952,12 @@ extern "C" int svt_dev_crossprod_csc_csc(const svt_dev_csc *Xt, const svt_dev_cs
 		HIP_TRY(hipMemcpyAsync(not_finite, ws, 4, hipMemcpyDeviceToDevice, s));
 	return 0;
 }
+extern "C" int svt_dev_crossprod_csc_csc(const svt_dev_csc *Xt, const svt_dev_csc *Y, int sym, double *out,
+					 int64_t ldo, void *ws, size_t ws_bytes, int *not_finite, void *stream)
+{
+	g_unsupported = 0;
+	return svt_status(dev_crossprod_csc_csc_impl(Xt, Y, sym, out, ldo, ws, ws_bytes, not_finite, stream));
+}
 
 static int aperm_args(int ndim, const int *perm, int *perm0)
 {
@@ -926,7 +976,7 @@ extern "C" size_t svt_dev_aperm_ws_bytes(int64_t nnz, int ndim, const int64_t *d
 	return aperm_ws_bytes(nnz, dim, ndim);
 }
 
-extern "C" int svt_dev_aperm(const svt_dev_csc *A, int ndim, const int64_t *dim, const int *perm,
+static int dev_aperm_impl(const svt_dev_csc *A, int ndim, const int64_t *dim, const int *perm,
 			     int64_t *out_col_ptr, int32_t *out_row_idx, void *out_val,
 			     void *ws, size_t ws_bytes, void *stream)
 {
@@ -942,9 +992,16 @@ extern "C" int svt_dev_aperm(const svt_dev_csc *A, int ndim, const int64_t *dim,
 	return launch_aperm(A->col_ptr, A->row_idx, A->val, A->Rtype, A->ncol, A->nnz, dim, ndim,
 			    perm0, out_col_ptr, out_row_idx, out_val, ws, (hipStream_t) stream);
 }
+extern "C" int svt_dev_aperm(const svt_dev_csc *A, int ndim, const int64_t *dim, const int *perm,
+			     int64_t *out_col_ptr, int32_t *out_row_idx, void *out_val,
+			     void *ws, size_t ws_bytes, void *stream)
+{
+	g_unsupported = 0;
+	return svt_status(dev_aperm_impl(A, ndim, dim, perm, out_col_ptr, out_row_idx, out_val, ws, ws_bytes, stream));
+}
 
 // C_aperm_SVT, src/SparseArray_aperm.c:935-970
-extern "C" int svt_aperm_SVT(const svt_view *x, const int *perm, int64_t *out_col_ptr,
+static int aperm_SVT_impl(const svt_view *x, const int *perm, int64_t *out_col_ptr,
 			     int32_t *out_row_idx, void *out_val)
 {
 	if (ensure_init() || check_view(x))
@@ -973,6 +1030,12 @@ extern "C" int svt_aperm_SVT(const svt_view *x, const int *perm, int64_t *out_co
 			return -1;
 	}
 	return 0;
+}
+extern "C" int svt_aperm_SVT(const svt_view *x, const int *perm, int64_t *out_col_ptr,
+			     int32_t *out_row_idx, void *out_val)
+{
+	g_unsupported = 0;
+	return svt_status(aperm_SVT_impl(x, perm, out_col_ptr, out_row_idx, out_val));
 }
 
 extern "C" int svt_dev_rowsum(const svt_dev_csc *A, const int *group, int ngroup,
@@ -1214,7 +1277,7 @@ static bool mult_types_ok(int a, int b)
 }
 
 // C_crossprod2_SVT_mat, src/SparseMatrix_mult.c:931-982
-extern "C" int svt_crossprod2_SVT_mat(const svt_view *x, const void *y, int y_nrow,
+static int crossprod2_SVT_mat_impl(const svt_view *x, const void *y, int y_nrow,
 				      int y_ncol, int y_Rtype, int tr_y, double *out)
 {
 	if (ensure_init() || check_mult_view(x, "input objects"))
@@ -1249,9 +1312,15 @@ extern "C" int svt_crossprod2_SVT_mat(const svt_view *x, const void *y, int y_nr
 	if (staged_download(out, O.p, out_n * 8)) return -1;
 	return 0;
 }
+extern "C" int svt_crossprod2_SVT_mat(const svt_view *x, const void *y, int y_nrow,
+				      int y_ncol, int y_Rtype, int tr_y, double *out)
+{
+	g_unsupported = 0;
+	return svt_status(crossprod2_SVT_mat_impl(x, y, y_nrow, y_ncol, y_Rtype, tr_y, out));
+}
 
 // C_crossprod2_mat_SVT, src/SparseMatrix_mult.c:985-1034
-extern "C" int svt_crossprod2_mat_SVT(const void *x, int x_nrow, int x_ncol,
+static int crossprod2_mat_SVT_impl(const void *x, int x_nrow, int x_ncol,
 				      int x_Rtype, const svt_view *y, int tr_x,
 				      double *out)
 {
@@ -1285,6 +1354,13 @@ extern "C" int svt_crossprod2_mat_SVT(const void *x, int x_nrow, int x_ncol,
 		return -1;
 	if (staged_download(out, O.p, out_n * 8)) return -1;
 	return 0;
+}
+extern "C" int svt_crossprod2_mat_SVT(const void *x, int x_nrow, int x_ncol,
+				      int x_Rtype, const svt_view *y, int tr_x,
+				      double *out)
+{
+	g_unsupported = 0;
+	return svt_status(crossprod2_mat_SVT_impl(x, x_nrow, x_ncol, x_Rtype, y, tr_x, out));
 }
 
 // Densify columns of `pp` chunk by chunk and multiply every chunk with the
@@ -1395,13 +1471,18 @@ static int dev_crossprod_sparse(const CscGuard &X, const svt_dev_csc *Y, bool sy
 	int own_T = 1;
 	svt_dev_csc *T = transposed_for(X, &own_T);
 	OwnedCsc TX = { T, own_T };
-	if (T == NULL) return -1;
+	if (T == NULL) {
+		// an operand the transposition does not take (2^31 nonzeros or more): the dense-buffer route needs no t(x)
+		if (g_unsupported) { g_unsupported = 0; return 1; }
+		return -1;
+	}
 	DevBuf Ws;
 	int bad = 1;
 	if (Ws.alloc(svt_dev_crossprod_csc_csc_ws_bytes(T)))
 		return -1;
-	if (svt_dev_crossprod_csc_csc(T, Y, sym ? 1 : 0, O, ldo, Ws.p, Ws.bytes, NULL, 0))
-		return -1;
+	const int rc = svt_dev_crossprod_csc_csc(T, Y, sym ? 1 : 0, O, ldo, Ws.p, Ws.bytes, NULL, 0);
+	if (rc > 0) { g_unsupported = 0; return 1; }      // a shape this kernel refuses: the other route
+	if (rc < 0) return -1;
 	HIP_TRY(hipMemcpy(&bad, Ws.p, 4, hipMemcpyDeviceToHost));
 	return bad ? 1 : 0;
 }
@@ -1435,7 +1516,7 @@ static int64_t view_nzcount(const svt_view *x)   // _REC_nzcount_SVT, SVT_Sparse
 }
 
 // C_crossprod2_SVT_SVT, src/SparseMatrix_mult.c:1037-1101
-extern "C" int svt_crossprod2_SVT_SVT(const svt_view *x, const svt_view *y, double *out)
+static int crossprod2_SVT_SVT_impl(const svt_view *x, const svt_view *y, double *out)
 {
 	if (ensure_init() || check_mult_view(x, "input objects") ||
 	    check_mult_view(y, "input objects"))
@@ -1477,6 +1558,11 @@ extern "C" int svt_crossprod2_SVT_SVT(const svt_view *x, const svt_view *y, doub
 	if (rc) return -1;
 	if (staged_download(out, O.p, out_n * 8)) return -1;
 	return 0;
+}
+extern "C" int svt_crossprod2_SVT_SVT(const svt_view *x, const svt_view *y, double *out)
+{
+	g_unsupported = 0;
+	return svt_status(crossprod2_SVT_SVT_impl(x, y, out));
 }
 
 // t(A) on the device, as a handle that owns its buffers (A may be released afterwards).
@@ -1531,7 +1617,7 @@ static svt_dev_csc *transposed_for(const CscGuard &A, int *owned)
 }
 
 // C_transpose_2D_SVT, src/SparseArray_aperm.c:395-423
-extern "C" int svt_transpose_2D_SVT(const svt_view *x, int64_t *out_col_ptr,
+static int transpose_2D_SVT_impl(const svt_view *x, int64_t *out_col_ptr,
 				    int32_t *out_row_idx, void *out_val)
 {
 	if (ensure_init() || check_view(x))
@@ -1557,12 +1643,18 @@ extern "C" int svt_transpose_2D_SVT(const svt_view *x, int64_t *out_col_ptr,
 	}
 	return 0;
 }
+extern "C" int svt_transpose_2D_SVT(const svt_view *x, int64_t *out_col_ptr,
+				    int32_t *out_row_idx, void *out_val)
+{
+	g_unsupported = 0;
+	return svt_status(transpose_2D_SVT_impl(x, out_col_ptr, out_row_idx, out_val));
+}
 
 // x %*% y, y an ordinary matrix: the R method (R/SparseMatrix-mult.R:195-215) is
 // .crossprod2_SparseMatrix_matrix(t(x), y), i.e. C_transpose_2D_SVT on the host
 // followed by C_crossprod2_SVT_mat.  Here the transposition happens on the device,
 // between the upload and the product (no second marshalling of a 1e8-nonzero tree).
-extern "C" int svt_matmul_SVT_mat(const svt_view *x, const void *y, int y_nrow,
+static int matmul_SVT_mat_impl(const svt_view *x, const void *y, int y_nrow,
 				  int y_ncol, int y_Rtype, double *out)
 {
 	if (ensure_init() || check_mult_view(x, "input objects"))
@@ -1601,11 +1693,17 @@ extern "C" int svt_matmul_SVT_mat(const svt_view *x, const void *y, int y_nrow,
 	if (staged_download(out, O.p, out_n * 8)) return -1;
 	return 0;
 }
+extern "C" int svt_matmul_SVT_mat(const svt_view *x, const void *y, int y_nrow,
+				  int y_ncol, int y_Rtype, double *out)
+{
+	g_unsupported = 0;
+	return svt_status(matmul_SVT_mat_impl(x, y, y_nrow, y_ncol, y_Rtype, out));
+}
 
 // x %*% y, both SVT_SparseMatrix: .crossprod2_SparseMatrix_SparseMatrix(t(x), y) with
 // the transposition on the device; operand to expand chosen as C_crossprod2_SVT_SVT
 // does (src/SparseMatrix_mult.c:1075-1097; nzcount(t(x)) == nzcount(x)).
-extern "C" int svt_matmul_SVT_SVT(const svt_view *x, const svt_view *y, double *out)
+static int matmul_SVT_SVT_impl(const svt_view *x, const svt_view *y, double *out)
 {
 	if (ensure_init() || check_mult_view(x, "input objects") ||
 	    check_mult_view(y, "input objects"))
@@ -1636,11 +1734,15 @@ extern "C" int svt_matmul_SVT_SVT(const svt_view *x, const svt_view *y, double *
 		int bad = 1;
 		if (Os.alloc(out_n * 8) || Ws.alloc(svt_dev_matmul_csc_csc_ws_bytes(X.h)))
 			return -1;
-		if (svt_dev_matmul_csc_csc(X.h, Y.h, Os.as<double>(), out_nrow, Ws.p, Ws.bytes, NULL, 0))
+		const int rc_s = svt_dev_matmul_csc_csc(X.h, Y.h, Os.as<double>(), out_nrow, Ws.p, Ws.bytes, NULL, 0);
+		if (rc_s < 0)
 			return -1;
-		HIP_TRY(hipMemcpy(&bad, (char *) Ws.p + 4, 4, hipMemcpyDeviceToHost));
-		if (!bad)
-			return staged_download(out, Os.p, out_n * 8) ? -1 : 0;
+		if (rc_s == 0) {
+			HIP_TRY(hipMemcpy(&bad, (char *) Ws.p + 4, 4, hipMemcpyDeviceToHost));
+			if (!bad)
+				return staged_download(out, Os.p, out_n * 8) ? -1 : 0;
+		} else
+			g_unsupported = 0;                // (a shape the row-panel kernel refuses: the route below)
 	}
 	int own_T = 1;
 	svt_dev_csc *T = transposed_for(X, &own_T);
@@ -1659,9 +1761,14 @@ extern "C" int svt_matmul_SVT_SVT(const svt_view *x, const svt_view *y, double *
 	if (staged_download(out, O.p, out_n * 8)) return -1;
 	return 0;
 }
+extern "C" int svt_matmul_SVT_SVT(const svt_view *x, const svt_view *y, double *out)
+{
+	g_unsupported = 0;
+	return svt_status(matmul_SVT_SVT_impl(x, y, out));
+}
 
 // C_crossprod1_SVT, src/SparseMatrix_mult.c:1104-1140
-extern "C" int svt_crossprod1_SVT(const svt_view *x, double *out)
+static int crossprod1_SVT_impl(const svt_view *x, double *out)
 {
 	if (ensure_init() || check_mult_view(x, "'x'"))
 		return -1;
@@ -1690,6 +1797,11 @@ extern "C" int svt_crossprod1_SVT(const svt_view *x, double *out)
 	if (staged_download(out, O.p, out_n * 8)) return -1;
 	return 0;
 }
+extern "C" int svt_crossprod1_SVT(const svt_view *x, double *out)
+{
+	g_unsupported = 0;
+	return svt_status(crossprod1_SVT_impl(x, out));
+}
 
 // ==================================================================================
 // Host level: stats
@@ -1712,7 +1824,7 @@ static int run_colstats(const svt_dev_csc *A, int opcode, int na_rm, double cent
 }
 
 // C_colStats_SVT, src/SparseArray_matrixStats.c:234-284
-extern "C" int svt_colStats_SVT(const svt_view *x, int opcode, int na_rm, double center,
+static int colStats_SVT_impl(const svt_view *x, int opcode, int na_rm, double center,
 				int dims, void *out, int *warn)
 {
 	*warn = 0;
@@ -1741,6 +1853,12 @@ extern "C" int svt_colStats_SVT(const svt_view *x, int opcode, int na_rm, double
 		return run_colstats(&E, opcode, na_rm, center, 1, out, out_Rtype, warn);
 	}
 	return run_colstats(A.h, opcode, na_rm, center, inner, out, out_Rtype, warn);
+}
+extern "C" int svt_colStats_SVT(const svt_view *x, int opcode, int na_rm, double center,
+				int dims, void *out, int *warn)
+{
+	g_unsupported = 0;
+	return svt_status(colStats_SVT_impl(x, opcode, na_rm, center, dims, out, warn));
 }
 
 // colMedians(): .colMedians_SVT_SparseMatrix, R/SparseArray-matrixStats.R:761-784 (pure R in the
@@ -1781,18 +1899,28 @@ static int medians_SVT(const svt_view *x, int na_rm, int by_row, double *out)
 	return staged_download(out, O.p, (size_t) nout * 8);
 }
 
-extern "C" int svt_colMedians_SVT(const svt_view *x, int na_rm, double *out)
+static int colMedians_SVT_impl(const svt_view *x, int na_rm, double *out)
 {
 	return medians_SVT(x, na_rm, 0, out);
 }
+extern "C" int svt_colMedians_SVT(const svt_view *x, int na_rm, double *out)
+{
+	g_unsupported = 0;
+	return svt_status(colMedians_SVT_impl(x, na_rm, out));
+}
 
-extern "C" int svt_rowMedians_SVT(const svt_view *x, int na_rm, double *out)
+static int rowMedians_SVT_impl(const svt_view *x, int na_rm, double *out)
 {
 	return medians_SVT(x, na_rm, 1, out);
 }
+extern "C" int svt_rowMedians_SVT(const svt_view *x, int na_rm, double *out)
+{
+	g_unsupported = 0;
+	return svt_status(rowMedians_SVT_impl(x, na_rm, out));
+}
 
 // C_summarize_SVT, src/SparseArray_summarization.c:112-142
-extern "C" int svt_summarize_SVT(const svt_view *x, int opcode, int na_rm, double center,
+static int summarize_SVT_impl(const svt_view *x, int opcode, int na_rm, double center,
 				 double *out_d, int *out_i, int *out_Rtype, int *warn)
 {
 	*warn = 0;
@@ -1829,9 +1957,15 @@ extern "C" int svt_summarize_SVT(const svt_view *x, int opcode, int na_rm, doubl
 	}
 	return 0;
 }
+extern "C" int svt_summarize_SVT(const svt_view *x, int opcode, int na_rm, double center,
+				 double *out_d, int *out_i, int *out_Rtype, int *warn)
+{
+	g_unsupported = 0;
+	return svt_status(summarize_SVT_impl(x, opcode, na_rm, center, out_d, out_i, out_Rtype, warn));
+}
 
 // C_rowStats_SVT, src/SparseArray_matrixStats.c:1121-1205
-extern "C" int svt_rowStats_SVT(const svt_view *x, int opcode, int na_rm,
+static int rowStats_SVT_impl(const svt_view *x, int opcode, int na_rm,
 				const double *center, int dims, void *out, int *warn)
 {
 	*warn = 0;
@@ -1866,7 +2000,7 @@ extern "C" int svt_rowStats_SVT(const svt_view *x, int opcode, int na_rm,
 		return 0;
 	}
 	if (nstrata > 0xFFFFFFFFLL)
-		return svt_set_error("too many strata for the device coverage counters");
+		return svt_set_unsupported("too many strata for the device coverage counters");
 	CscGuard A(x);
 	if (A.h == NULL) return -1;
 	DevBuf O, C, S, W;
@@ -1885,7 +2019,7 @@ extern "C" int svt_rowStats_SVT(const svt_view *x, int opcode, int na_rm,
 	a.out = O.p; a.scratch = S.p; a.warn_flag = W.as<int>(); a.nnz_hint = A.h->nnz;
 	a.na_bg = x->na_background != 0;
 	if (a.na_bg && inner > 65535)
-		return svt_set_error("row statistics of NaArray objects: more than 65535 output columns");
+		return svt_set_unsupported("row statistics of NaArray objects: more than 65535 output columns");
 	if (inner <= 65535) {
 		DevBuf T;
 		if (T.alloc(rowstats_panel_ws_bytes(a.nrow, a.ncol)) || launch_rowstats_panel(a, T.p, 0))
@@ -1899,6 +2033,12 @@ extern "C" int svt_rowStats_SVT(const svt_view *x, int opcode, int na_rm,
 	HIP_TRY(hipMemcpy(&w, W.p, 4, hipMemcpyDeviceToHost));
 	if (w) *warn = 1;
 	return 0;
+}
+extern "C" int svt_rowStats_SVT(const svt_view *x, int opcode, int na_rm,
+				const double *center, int dims, void *out, int *warn)
+{
+	g_unsupported = 0;
+	return svt_status(rowStats_SVT_impl(x, opcode, na_rm, center, dims, out, warn));
 }
 
 // ==================================================================================
@@ -1981,17 +2121,29 @@ static int xsum_SVT(const svt_view *x, const int *group, int ngroup, int na_rm,
 }
 
 // C_rowsum_SVT, src/rowsum_methods.c:281-325
-extern "C" int svt_rowsum_SVT(const svt_view *x, const int *group, int ngroup,
+static int rowsum_SVT_impl(const svt_view *x, const int *group, int ngroup,
 			      int na_rm, void *out, int *ovflow)
 {
 	return xsum_SVT(x, group, ngroup, na_rm, false, out, ovflow);
 }
+extern "C" int svt_rowsum_SVT(const svt_view *x, const int *group, int ngroup,
+			      int na_rm, void *out, int *ovflow)
+{
+	g_unsupported = 0;
+	return svt_status(rowsum_SVT_impl(x, group, ngroup, na_rm, out, ovflow));
+}
 
 // C_colsum_SVT, src/rowsum_methods.c:363-401
-extern "C" int svt_colsum_SVT(const svt_view *x, const int *group, int ngroup,
+static int colsum_SVT_impl(const svt_view *x, const int *group, int ngroup,
 			      int na_rm, void *out, int *ovflow)
 {
 	return xsum_SVT(x, group, ngroup, na_rm, true, out, ovflow);
+}
+extern "C" int svt_colsum_SVT(const svt_view *x, const int *group, int ngroup,
+			      int na_rm, void *out, int *ovflow)
+{
+	g_unsupported = 0;
+	return svt_status(colsum_SVT_impl(x, group, ngroup, na_rm, out, ovflow));
 }
 
 static int xsum_dgC(int nrow, int ncol, const double *xx, const int *xi, const int *xp,
@@ -2033,17 +2185,31 @@ static int xsum_dgC(int nrow, int ncol, const double *xx, const int *xi, const i
 }
 
 // C_rowsum_dgCMatrix / C_colsum_dgCMatrix, src/rowsum_methods.c:328-356, 404-439
-extern "C" int svt_rowsum_dgCMatrix(int nrow, int ncol, const double *xx, const int *xi,
+static int rowsum_dgCMatrix_impl(int nrow, int ncol, const double *xx, const int *xi,
 				    const int *xp, const int *group, int ngroup,
 				    int na_rm, double *out)
 {
 	return xsum_dgC(nrow, ncol, xx, xi, xp, group, ngroup, na_rm, false, out);
 }
-extern "C" int svt_colsum_dgCMatrix(int nrow, int ncol, const double *xx, const int *xi,
+extern "C" int svt_rowsum_dgCMatrix(int nrow, int ncol, const double *xx, const int *xi,
+				    const int *xp, const int *group, int ngroup,
+				    int na_rm, double *out)
+{
+	g_unsupported = 0;
+	return svt_status(rowsum_dgCMatrix_impl(nrow, ncol, xx, xi, xp, group, ngroup, na_rm, out));
+}
+static int colsum_dgCMatrix_impl(int nrow, int ncol, const double *xx, const int *xi,
 				    const int *xp, const int *group, int ngroup,
 				    int na_rm, double *out)
 {
 	return xsum_dgC(nrow, ncol, xx, xi, xp, group, ngroup, na_rm, true, out);
+}
+extern "C" int svt_colsum_dgCMatrix(int nrow, int ncol, const double *xx, const int *xi,
+				    const int *xp, const int *group, int ngroup,
+				    int na_rm, double *out)
+{
+	g_unsupported = 0;
+	return svt_status(colsum_dgCMatrix_impl(nrow, ncol, xx, xi, xp, group, ngroup, na_rm, out));
 }
 
 // ==================================================================================
@@ -2099,25 +2265,49 @@ static int colstat_dgC(int nrow, int ncol, const double *xx, const int *xp, int 
 }
 
 // C_colMins_dgCMatrix / C_colMaxs_dgCMatrix, src/sparseMatrix_utils.c:128-138
-extern "C" int svt_colMins_dgCMatrix(int nrow, int ncol, const double *xx, const int *xp,
+static int colMins_dgCMatrix_impl(int nrow, int ncol, const double *xx, const int *xp,
 				     int na_rm, double *out)
 {
 	return colstat_dgC(nrow, ncol, xx, xp, na_rm, 0, out);
 }
-extern "C" int svt_colMaxs_dgCMatrix(int nrow, int ncol, const double *xx, const int *xp,
+extern "C" int svt_colMins_dgCMatrix(int nrow, int ncol, const double *xx, const int *xp,
+				     int na_rm, double *out)
+{
+	g_unsupported = 0;
+	return svt_status(colMins_dgCMatrix_impl(nrow, ncol, xx, xp, na_rm, out));
+}
+static int colMaxs_dgCMatrix_impl(int nrow, int ncol, const double *xx, const int *xp,
 				     int na_rm, double *out)
 {
 	return colstat_dgC(nrow, ncol, xx, xp, na_rm, 1, out);
 }
+extern "C" int svt_colMaxs_dgCMatrix(int nrow, int ncol, const double *xx, const int *xp,
+				     int na_rm, double *out)
+{
+	g_unsupported = 0;
+	return svt_status(colMaxs_dgCMatrix_impl(nrow, ncol, xx, xp, na_rm, out));
+}
 // C_colRanges_dgCMatrix, src/sparseMatrix_utils.c:143-166
-extern "C" int svt_colRanges_dgCMatrix(int nrow, int ncol, const double *xx, const int *xp,
+static int colRanges_dgCMatrix_impl(int nrow, int ncol, const double *xx, const int *xp,
 				       int na_rm, double *out)
 {
 	return colstat_dgC(nrow, ncol, xx, xp, na_rm, 2, out);
 }
+extern "C" int svt_colRanges_dgCMatrix(int nrow, int ncol, const double *xx, const int *xp,
+				       int na_rm, double *out)
+{
+	g_unsupported = 0;
+	return svt_status(colRanges_dgCMatrix_impl(nrow, ncol, xx, xp, na_rm, out));
+}
 // C_colVars_dgCMatrix, src/sparseMatrix_utils.c:205-223
-extern "C" int svt_colVars_dgCMatrix(int nrow, int ncol, const double *xx, const int *xp,
+static int colVars_dgCMatrix_impl(int nrow, int ncol, const double *xx, const int *xp,
 				     int na_rm, double *out)
 {
 	return colstat_dgC(nrow, ncol, xx, xp, na_rm, 3, out);
+}
+extern "C" int svt_colVars_dgCMatrix(int nrow, int ncol, const double *xx, const int *xp,
+				     int na_rm, double *out)
+{
+	g_unsupported = 0;
+	return svt_status(colVars_dgCMatrix_impl(nrow, ncol, xx, xp, na_rm, out));
 }

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _hip
-from .api import OPCODES, SparseArrayError
+from .api import OPCODES, SparseArrayError, SparseArrayUnsupported
 from .svt import INTSXP, LGLSXP, REALSXP
 
 _protos_done = False
@@ -96,7 +96,7 @@ def _lib():
 
 def _check(rc):
     if rc != 0:
-        raise SparseArrayError(_lib().svt_last_error().decode())
+        raise (SparseArrayUnsupported if rc > 0 else SparseArrayError)(_lib().svt_last_error().decode())
 
 
 def _stream() -> c_void_p:

@@ -237,7 +237,7 @@ class Glue:
         return SVT_SparseArray(dim, type_, leaves)
 
     # ---- one .Call ---------------------------------------------------------------------------
-    def call(self, name: str, *args):
+    def call(self, name: str, *args, allow_cpu_body: bool = False):
         """Returns the result SEXP; error() -> RError; warning()s are re-issued as Python warnings.  Every call is
         checked for R's protection discipline (depth 0 at exit, never popped below 0) and for R_alloc() overruns."""
         f = ctypes.cast(getattr(self.lib, name), ctypes.c_void_p)
@@ -253,7 +253,7 @@ class Glue:
             self.stats["errors"] += 1
             raise RError(self.lib.sx_error().decode())
         assert self.lib.sx_protect_depth() == 0, f"{name}: returned with {self.lib.sx_protect_depth()} object(s) protected"
-        assert self.lib.env_cpu_body_calls() == 0 or name.endswith("_threads") or name.endswith("_procs"), \
+        assert allow_cpu_body or self.lib.env_cpu_body_calls() == 0 or name.endswith("_threads") or name.endswith("_procs"), \
             f"{name}: fell through to {self.lib.env_cpu_body_last().decode()} with the library available"
         nw = self.lib.sx_nwarnings()
         msgs = self.lib.sx_warnings().decode().split("\x1e") if nw else []

@@ -140,3 +140,66 @@ def test_null_subtrees_and_dimnames(glue):
     s = g.call("C_rowStats_SVT", xd, g.dimnames(dn), xt, xs, g.lgl(False), g.string("sum"), g.lgl(False), g.nil, g.ints(1))
     assert np.array_equal(g.to_numpy(s), a.sum(axis=(1, 2))) and g.names_of(s) == [dn[0]]
     g.reset()
+
+
+def test_status_above_zero_runs_the_cpu_body_and_below_zero_raises(glue):
+    """include/svt_hip.h: a status > 0 means "not supported here" (e.g. 2^31 nonzeros or more in a transposition, an
+    operation the device kernels do not implement) -- every registered compute entry point must then hand the call
+    to the reference's own body (its `_cpu` name) with nothing left protected; a status < 0 is error() with the
+    library's message.  The shim answers every svt_* call with $SVT_SHIM_STATUS here."""
+    from sparsearray_amd import SVT_SparseArray
+    g = glue
+    a = np.zeros((6, 4)); a[1, 0] = 2.5; a[3, 2] = -1.0; a[5, 3] = 4.0
+    x = SVT_SparseArray.from_dense(a)
+    a3 = np.zeros((3, 4, 2)); a3[1, 2, 0] = 2.5; a3[0, 0, 1] = -1.0
+    x3 = SVT_SparseArray.from_dense(a3)
+    y = np.arange(12, dtype=np.float64).reshape(6, 2, order="F")
+
+    def dgc():
+        return g.dgc(((6, 4), np.array([0, 1, 1, 2, 3], dtype=np.int32), np.array([1, 3, 5], dtype=np.int32),
+                      np.array([2.5, -1.0, 4.0])))
+
+    NAMES = ["C_crossprod2_SVT_mat", "C_crossprod2_mat_SVT", "C_crossprod2_SVT_SVT", "C_crossprod1_SVT", "C_colStats_SVT",
+             "C_rowStats_SVT", "C_summarize_SVT", "C_rowsum_SVT", "C_colsum_SVT", "C_rowsum_dgCMatrix", "C_colsum_dgCMatrix",
+             "C_colMins_dgCMatrix", "C_colMaxs_dgCMatrix", "C_colRanges_dgCMatrix", "C_colVars_dgCMatrix",
+             "C_transpose_2D_SVT", "C_aperm_SVT"]
+
+    def args_of(name):          # (fresh SEXPs per call: g.reset() releases them all)
+        xd, xt, xs = g.svt_args(x)
+        xd3, xt3, xs3 = g.svt_args(x3)
+        grp = g.ints(1, 2, 1, 2, 1, 2)
+        grp_c = g.ints(1, 2, 1, 2)
+        F, nan = g.lgl(False), g.real(float("nan"))
+        return {
+            "C_crossprod2_SVT_mat": (xd, xt, xs, g.matrix(y), F, g.string("double"), g.nil),
+            "C_crossprod2_mat_SVT": (g.matrix(y), xd, xt, xs, F, g.string("double"), g.nil),
+            "C_crossprod2_SVT_SVT": (xd, xt, xs, xd, xt, xs, g.string("double"), g.nil),
+            "C_crossprod1_SVT": (xd, xt, xs, g.string("double"), g.nil),
+            "C_colStats_SVT": (xd, g.nil, xt, xs, F, g.string("sum"), F, nan, g.ints(1)),
+            "C_rowStats_SVT": (xd3, g.nil, xt3, xs3, F, g.string("sum"), F, g.nil, g.ints(1)),
+            "C_summarize_SVT": (xd, xt, xs, F, g.string("sum"), F, nan),
+            "C_rowsum_SVT": (xd, xt, xs, grp, g.ints(2), F),
+            "C_colsum_SVT": (xd, xt, xs, grp_c, g.ints(2), F),
+            "C_rowsum_dgCMatrix": (dgc(), grp, g.ints(2), F),
+            "C_colsum_dgCMatrix": (dgc(), grp_c, g.ints(2), F),
+            "C_colMins_dgCMatrix": (dgc(), F), "C_colMaxs_dgCMatrix": (dgc(), F),
+            "C_colRanges_dgCMatrix": (dgc(), F), "C_colVars_dgCMatrix": (dgc(), F),
+            "C_transpose_2D_SVT": (xd, xt, xs),
+            "C_aperm_SVT": (xd3, xt3, xs3, g.ints(2, 1, 3)),
+        }[name]
+    import glue_harness
+    try:
+        os.environ["SVT_SHIM_STATUS"] = "1"
+        for name in NAMES:
+            g.call(name, *args_of(name), allow_cpu_body=True)        # (asserts protection depth 0 and intact R_alloc() guards)
+            assert g.lib.env_cpu_body_calls() == 1, name
+            assert g.lib.env_cpu_body_last().decode() == name + "_cpu", (name, g.lib.env_cpu_body_last())
+            g.reset()
+        os.environ["SVT_SHIM_STATUS"] = "-1"
+        for name in NAMES:
+            with pytest.raises(glue_harness.RError, match="forced status"):
+                g.call(name, *args_of(name))
+            assert g.lib.env_cpu_body_calls() == 0, name
+            g.reset()
+    finally:
+        os.environ.pop("SVT_SHIM_STATUS", None)
