@@ -918,20 +918,6 @@ __global__ void aperm_key_kernel(const int64_t *__restrict__ col_ptr,
 	pos[k] = (uint32_t) k;
 }
 
-__global__ void aperm_bounds_kernel(const unsigned long long *__restrict__ skeys, int64_t nnz,
-				    int64_t nleaves, int64_t dim0, int64_t *__restrict__ out_ptr)
-{
-	const int64_t j = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-	if (j > nleaves) return;
-	const unsigned long long key = (unsigned long long) j * (unsigned long long) dim0;
-	int64_t lo = 0, hi = nnz;
-	while (lo < hi) {
-		const int64_t mid = (lo + hi) >> 1;
-		if (skeys[mid] < key) lo = mid + 1; else hi = mid;
-	}
-	out_ptr[j] = lo;
-}
-
 template <typename T>
 __global__ void aperm_gather_kernel(const unsigned long long *__restrict__ skeys,
 				    const uint32_t *__restrict__ perm, const T *__restrict__ val,
@@ -1049,15 +1035,31 @@ __global__ void aperm_key32_kernel(const int64_t *__restrict__ col_ptr, const in
 }
 
 // out_ptr[j] = first sorted position whose leaf is >= j: every sorted element fills the leaves between its
-// predecessor's and its own (most new leaves are empty when leaves shatter: a search per leaf costs more)
-__global__ void aperm_ptr_fill_kernel(const uint32_t *__restrict__ skeys, int64_t nnz, int64_t nleaves,
-				      int64_t *__restrict__ out_ptr)
+// predecessor's and its own (most new leaves are empty when leaves shatter: a search per leaf costs more -- the
+// 64-bit route did one binary search per NEW LEAF until round 6: 48 of the 81.7 ms of aperm(x, c(3,2,4,1)) of a
+// 2e4 x 2e3 x 10 x 64 array, 4e8 leaves).  The first 16 leaves of a gap by the element's own lane, the rest of a
+// long gap by the whole wavefront.  K = uint32_t: the key is the leaf; unsigned long long: leaf * dim0 + row.
+template <typename K>
+__global__ void __launch_bounds__(256)
+aperm_ptr_fill_kernel(const K *__restrict__ skeys, int64_t nnz, int64_t nleaves, unsigned long long dim0,
+		      int64_t *__restrict__ out_ptr)
 {
 	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-	if (i > nnz) return;
-	const int64_t from = i == 0 ? 0 : (int64_t) skeys[i - 1] + 1;
-	const int64_t to = i == nnz ? nleaves : (int64_t) skeys[i];
-	for (int64_t j = from; j <= to; j++) out_ptr[j] = i;
+	const int lane = threadIdx.x & 63;
+	int64_t from = 1, to = 0;
+	if (i <= nnz) {
+		from = i == 0 ? 0 : (int64_t) ((unsigned long long) skeys[i - 1] / dim0) + 1;
+		to = i == nnz ? nleaves : (int64_t) ((unsigned long long) skeys[i] / dim0);
+	}
+	const int64_t near = to < from + 15 ? to : from + 15;
+	for (int64_t j = from; j <= near; j++) out_ptr[j] = i;
+	unsigned long long mask = __ballot(to > from + 15);
+	while (mask != 0) {
+		const int l = __ffsll((long long) mask) - 1;
+		mask &= mask - 1;
+		const int64_t f = __shfl(from, l, 64) + 16, t = __shfl(to, l, 64), v = __shfl(i, l, 64);
+		for (int64_t j = f + lane; j <= t; j += 64) out_ptr[j] = v;
+	}
 }
 
 template <typename T>
@@ -1369,9 +1371,25 @@ static size_t aperm_ws_core(int64_t nnz, const int64_t *dim, int ndim)
 	return need + scan_b + 256;
 }
 
+// nested != 0: a step of a composed route (the 3-d "via" form, the general form).  Such a call gets what is left of
+// the workspace behind its caller's intermediates, which aperm_ws_bytes() sizes for the forms of aperm_ws_core() only:
+// it must not carve intermediates of its own (a slab form that refuses at run time -- one slab over
+// SLAB_CAP -- used to re-enter the general form inside `sub` and write past the workspace), so it goes from the
+// direct forms (leaf-preserving, first two axes swapped, slab) straight to the key sort.
+static int launch_aperm_n(const int64_t *col_ptr, const int32_t *row_idx, const void *val, int Rtype,
+			  int64_t ncol, int64_t nnz, const int64_t *dim, int ndim, const int *perm,
+			  int64_t *out_ptr, int32_t *out_idx, void *out_val, void *ws, hipStream_t s, int nested);
+
 int launch_aperm(const int64_t *col_ptr, const int32_t *row_idx, const void *val, int Rtype,
 		 int64_t ncol, int64_t nnz, const int64_t *dim, int ndim, const int *perm,
 		 int64_t *out_ptr, int32_t *out_idx, void *out_val, void *ws, hipStream_t s)
+{
+	return launch_aperm_n(col_ptr, row_idx, val, Rtype, ncol, nnz, dim, ndim, perm, out_ptr, out_idx, out_val, ws, s, 0);
+}
+
+static int launch_aperm_n(const int64_t *col_ptr, const int32_t *row_idx, const void *val, int Rtype,
+			  int64_t ncol, int64_t nnz, const int64_t *dim, int ndim, const int *perm,
+			  int64_t *out_ptr, int32_t *out_idx, void *out_val, void *ws, hipStream_t s, int nested)
 {
 	if (ndim < 1 || ndim > 8)
 		return svt_set_error("aperm: between 1 and 8 dimensions are supported");
@@ -1426,7 +1444,7 @@ int launch_aperm(const int64_t *col_ptr, const int32_t *row_idx, const void *val
 		return 0;
 	}
 	// 3-d: c(2,3,1) and c(3,2,1) as c(2,1,3) followed by c(1,3,2) / c(3,1,2) (see aperm_via_bytes)
-	if (ndim == 3 && ((perm[0] == 1 && perm[1] == 2 && perm[2] == 0) ||
+	if (!nested && ndim == 3 && ((perm[0] == 1 && perm[1] == 2 && perm[2] == 0) ||
 			  (perm[0] == 2 && perm[1] == 1 && perm[2] == 0 && dim[2] <= 1024))) {
 		T2Shape sh;
 		size_t reserve = 0;
@@ -1449,8 +1467,8 @@ int launch_aperm(const int64_t *col_ptr, const int32_t *row_idx, const void *val
 				return rc;
 			const int64_t dimy[3] = {dim[1], dim[0], dim[2]};
 			const int p231[3] = {0, 2, 1}, p321[3] = {2, 0, 1};
-			return launch_aperm(ycp, yri, yv, Rtype, nly, nnz, dimy, 3, perm[0] == 1 ? p231 : p321,
-					    out_ptr, out_idx, out_val, sub, s);
+			return launch_aperm_n(ycp, yri, yv, Rtype, nly, nnz, dimy, 3, perm[0] == 1 ? p231 : p321,
+					      out_ptr, out_idx, out_val, sub, s, 1);
 		}
 	}
 	// the first two axes change places, the others stay: one batched bucketed transposition, no sort
@@ -1517,14 +1535,14 @@ int launch_aperm(const int64_t *col_ptr, const int32_t *row_idx, const void *val
 		}
 	}
 	// the general form: leaf-preserving step, first two axes swapped, leaf-preserving step (aperm_general_plan)
-	{
+	if (!nested) {
 		ApermPlan3 pl;
 		if (aperm_general_plan(nnz, dim, ndim, perm, &pl)) {
 			char *p = (char *) ws;
 			const int64_t *cp_a = col_ptr; const int32_t *ri_a = row_idx; const void *v_a = val;
 			int64_t ncol_a = ncol;
 			int64_t *xcp = NULL; int32_t *xri = NULL; void *xv = NULL;
-			if (!pl.a_id) {
+			if (!pl.a_id && !pl.slab_first) {       // (the slab form goes from the operand to y in one step)
 				xcp = (int64_t *) p; p += t2_a((size_t) pl.leaves_a + 1, 8);
 				xri = (int32_t *) p; p += t2_a((size_t) nnz, 4);
 				xv = p;              p += t2_a((size_t) nnz, 8);
@@ -1542,21 +1560,21 @@ int launch_aperm(const int64_t *col_ptr, const int32_t *row_idx, const void *val
 				int p1[8];
 				p1[0] = perm[0]; p1[1] = 0;
 				for (int a = 2; a < ndim; a++) p1[a] = pl.pa[a];
-				int rc = launch_aperm(col_ptr, row_idx, val, Rtype, ncol, nnz, dim, ndim, p1, ycp, yri, yv, sub, s);
+				int rc = launch_aperm_n(col_ptr, row_idx, val, Rtype, ncol, nnz, dim, ndim, p1, ycp, yri, yv, sub, s, 1);
 				if (rc) return rc;
-				return launch_aperm(ycp, yri, yv, Rtype, pl.leaves_b, nnz, pl.dim_b, ndim, pl.pc, out_ptr, out_idx, out_val, sub, s);
+				return launch_aperm_n(ycp, yri, yv, Rtype, pl.leaves_b, nnz, pl.dim_b, ndim, pl.pc, out_ptr, out_idx, out_val, sub, s, 1);
 			}
 			if (!pl.a_id) {
-				const int rc = launch_aperm(col_ptr, row_idx, val, Rtype, ncol, nnz, dim, ndim, pl.pa, xcp, xri, xv, sub, s);
+				const int rc = launch_aperm_n(col_ptr, row_idx, val, Rtype, ncol, nnz, dim, ndim, pl.pa, xcp, xri, xv, sub, s, 1);
 				if (rc) return rc;
 				cp_a = xcp; ri_a = xri; v_a = xv; ncol_a = pl.leaves_a;
 			}
 			int pb[8];
 			for (int a = 0; a < ndim; a++) pb[a] = a == 0 ? 1 : a == 1 ? 0 : a;
-			int rc = launch_aperm(cp_a, ri_a, v_a, Rtype, ncol_a, nnz, pl.dim_a, ndim, pb, ycp, yri, yv, sub, s);
+			int rc = launch_aperm_n(cp_a, ri_a, v_a, Rtype, ncol_a, nnz, pl.dim_a, ndim, pb, ycp, yri, yv, sub, s, 1);
 			if (rc) return rc;
 			if (!pl.c_id)
-				rc = launch_aperm(ycp, yri, yv, Rtype, pl.leaves_b, nnz, pl.dim_b, ndim, pl.pc, out_ptr, out_idx, out_val, sub, s);
+				rc = launch_aperm_n(ycp, yri, yv, Rtype, pl.leaves_b, nnz, pl.dim_b, ndim, pl.pc, out_ptr, out_idx, out_val, sub, s, 1);
 			return rc;
 		}
 	}
@@ -1578,8 +1596,8 @@ int launch_aperm(const int64_t *col_ptr, const int32_t *row_idx, const void *val
 				   keys, pos, newrow);
 		if (svt_sort_pairs<uint32_t>(keys, skeys, ktmp, pos, spos, ptmp, nnz, bits, tmp, s))
 			return -1;
-		hipLaunchKernelGGL(aperm_ptr_fill_kernel, dim3((unsigned) ((nnz + 1 + 255) / 256)), dim3(256), 0, s,
-				   skeys, nnz, new_nleaves, out_ptr);
+		hipLaunchKernelGGL(aperm_ptr_fill_kernel<uint32_t>, dim3((unsigned) ((nnz + 1 + 255) / 256)), dim3(256), 0, s,
+				   skeys, nnz, new_nleaves, 1ULL, out_ptr);
 		if (Rtype == SVT_REALSXP)
 			hipLaunchKernelGGL(aperm_gather32_kernel<double>, dim3(nb8), dim3(256), 0, s, spos, newrow,
 					   (const double *) val, nnz, out_idx, (double *) out_val);
@@ -1604,7 +1622,8 @@ int launch_aperm(const int64_t *col_ptr, const int32_t *row_idx, const void *val
 	hipLaunchKernelGGL(aperm_key_kernel, dim3(nb), dim3(256), 0, s, col_ptr, row_idx, ncol, nnz, d, keys, pos);
 	if (svt_sort_pairs<unsigned long long>(keys, skeys, ktmp, pos, spos, ptmp, nnz, bits, tmp, s))
 		return -1;
-	hipLaunchKernelGGL(aperm_bounds_kernel, dim3(nbl), dim3(256), 0, s, skeys, nnz, new_nleaves, new_dim0, out_ptr);
+	hipLaunchKernelGGL(aperm_ptr_fill_kernel<unsigned long long>, dim3((unsigned) ((nnz + 1 + 255) / 256)), dim3(256), 0, s,
+			   skeys, nnz, new_nleaves, (unsigned long long) (new_dim0 > 0 ? new_dim0 : 1), out_ptr);
 	if (Rtype == SVT_REALSXP)
 		hipLaunchKernelGGL(aperm_gather_kernel<double>, dim3(nb8), dim3(256), 0, s, skeys, spos,
 				   (const double *) val, nnz, new_dim0, out_idx, (double *) out_val);

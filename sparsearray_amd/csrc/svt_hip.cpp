@@ -1458,6 +1458,11 @@ static bool sparse_route_pays(int64_t nnz_x, int64_t nnz_y, int64_t nrow, double
 	if (g_gram_cost < 0.0 || nrow <= 0 || nnz_x <= 0 || nnz_y <= 0)
 		return false;
 	double pairs = (double) nnz_x * (double) nnz_y / (double) nrow;
+	// small products stay with the general kernels of the dense-buffer route: their sums run in the reference's own
+	// ascending order, bit for bit (tests/test_hip_vs_oracle.py); from the size on where that route takes the panel
+	// kernels (pbc_applies) neither route is ordered like the reference and the faster one is taken
+	if (g_gram_cost > 0.0 && dense_ops < 268435456.0)
+		return false;
 	if (sym) { pairs *= 0.5; dense_ops *= 0.5; }
 	const double t_sparse = 0.2e-3 + pairs / 2.6e11 + (double) nnz_x * 2.5e-11;
 	const double t_dense = 1.0e-3 + dense_ops / 3.0e12;

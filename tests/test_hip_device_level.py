@@ -810,3 +810,43 @@ def test_pbc_fixup_on_two_streams_at_once(hip):
         fin = torch.isfinite(want[t])
         assert bool((outs[t][fin] == want[t][fin]).all())
     assert dt < 0.5, f"40 small products took {dt:.2f} s: a grid barrier starved"
+
+
+def test_device_aperm_slab_refused_at_run_time_inside_the_general_form(hip):
+    """aperm(x, c(3, 4, 1, 2)) of a 4-d array takes the general form with the slab kernel for its
+    first step (aperm(x, c(3, 1, ...)) in one go); one skewed slab over the kernel's cap makes that step refuse at
+    run time, INSIDE the part of the workspace behind the general form's intermediates -- it must then go to the key
+    sort (which that part is sized for), not re-enter the general form and carve a second set of intermediates."""
+    dim, perm = (3000, 4, 6, 5), (3, 4, 1, 2)
+    rng = np.random.default_rng(49)
+    a = np.zeros(dim, order="F")
+    # one slab (fixed indices of axes 2 and 4) holds 12 000 of its 18 000 cells, the other 19 share 80 000
+    blk = np.zeros((dim[0], dim[2]))
+    blk.reshape(-1)[rng.choice(blk.size, size=12_000, replace=False)] = rng.normal(size=12_000)
+    a[:, 0, :, 0] = blk
+    mask = np.ones(dim, dtype=bool); mask[:, 0, :, 0] = False
+    rest = np.flatnonzero(mask.reshape(-1, order="F"))
+    idx = rng.choice(rest, size=80_000, replace=False)
+    a.reshape(-1, order="F")[idx] = rng.normal(size=80_000)
+    x = SVT_SparseArray.from_dense(a, "double", lacunar=False)
+    cp, ri, v = x.to_csc()
+    A = _dev(cp, ri, v, dim[0])
+    T, new_dim = A.aperm(dim, perm)
+    torch.cuda.synchronize()
+    want = SVT_SparseArray.from_dense(np.asfortranarray(np.transpose(a, [q - 1 for q in perm])), "double", lacunar=False)
+    wcp, wri, wv = want.to_csc()
+    assert new_dim == want.dim
+    assert np.array_equal(T.col_ptr.cpu().numpy(), wcp)
+    assert np.array_equal(T.row_idx.cpu().numpy(), wri)
+    assert np.array_equal(T.val.cpu().numpy(), wv)
+    # the same array through the 3-d "via" route with a refusing second step: c(3, 2, 1) of (3000, 6, 20)
+    a3 = np.asfortranarray(a.transpose(0, 2, 1, 3).reshape((3000, 6, 20), order="F"))
+    x3 = SVT_SparseArray.from_dense(a3, "double", lacunar=False)
+    cp, ri, v = x3.to_csc()
+    T, new_dim = _dev(cp, ri, v, 3000).aperm((3000, 6, 20), (3, 2, 1))
+    torch.cuda.synchronize()
+    want = SVT_SparseArray.from_dense(np.asfortranarray(np.transpose(a3, (2, 1, 0))), "double", lacunar=False)
+    wcp, wri, wv = want.to_csc()
+    assert np.array_equal(T.col_ptr.cpu().numpy(), wcp)
+    assert np.array_equal(T.row_idx.cpu().numpy(), wri)
+    assert np.array_equal(T.val.cpu().numpy(), wv)
