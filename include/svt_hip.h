@@ -300,7 +300,9 @@ void svt_dev_pbc_release(svt_dev_pbc *P);
    released memory for the next build; svt_dev_pbc_release() frees behind the work of every stream that has run a
    product with the layout (an event recorded on each of them at release time: no device-wide synchronisation, and
    nothing put on the stream per product; a stream destroyed before the handle is released makes the release
-   synchronise the device instead).  svt_dev_pbc_trim() hands everything the pools hold
+   synchronise the device instead -- a stream that has run a product with a layout should outlive the layout's
+   handle, or the handle be released first: the release records on every stream it noted, and a stale
+   hipStream_t is only as safe as the runtime's validation of it).  svt_dev_pbc_trim() hands everything the pools hold
    but no layout uses back to the driver -- e.g. before another allocator of the process needs the memory. */
 void svt_dev_pbc_trim(void);
 /* Device bytes held by a layout (records + tile table + flags). */
@@ -492,6 +494,12 @@ size_t svt_dev_aperm_ws_bytes(int64_t nnz, int ndim, const int64_t *dim);
 int svt_dev_aperm(const svt_dev_csc *A, int ndim, const int64_t *dim, const int *perm,
 		  int64_t *out_col_ptr, int32_t *out_row_idx, void *out_val,
 		  void *ws, size_t ws_bytes, void *stream);
+/* How many transpositions / permutations of this process took which route (diagnostics; the differential fuzzers
+   print it): counts[0] t() bucketed, [1] t() by the key sort, [2] aperm leaf-preserving, [3] first two axes swapped,
+   [4] slab form, [5] 3-d through an intermediate, [6] general (composed), [7] key sort with 32-bit keys, [8] key sort
+   with 64-bit keys, [9] slab form refused at run time.  Steps of composed routes count too.  reset != 0 zeroes them. */
+void svt_dev_aperm_route_counts(int64_t counts[10], int reset);
+
 /* Host level: same, on host buffers (x->nleaves leaves in, out_* as above with
    nnz = sum of x->nzcount). */
 int svt_aperm_SVT(const svt_view *x, const int *perm, int64_t *out_col_ptr,

@@ -32,7 +32,7 @@ EXPORTS = [
     "svt_dev_dense_prepare", "svt_dev_crossprod_prepared",
     "svt_dev_pbc_build", "svt_dev_pbc_release", "svt_dev_pbc_trim",
     "svt_dev_crossprod_pbc_ws_bytes", "svt_dev_crossprod_pbc", "svt_dev_crossprod_pbc_phase", "svt_dev_crossprod_pbc_from",
-    "svt_get_num_procs", "svt_get_max_threads", "svt_set_max_threads", "svt_dev_aperm_ws_bytes", "svt_dev_aperm", "svt_aperm_SVT", "svt_transpose_2D_SVT", "svt_dev_transpose_ws_bytes", "svt_dev_transpose", "svt_dev_colstats", "svt_dev_rowstats_ws_bytes", "svt_dev_rowsums", "svt_dev_rowsum",
+    "svt_get_num_procs", "svt_get_max_threads", "svt_set_max_threads", "svt_dev_aperm_ws_bytes", "svt_dev_aperm", "svt_dev_aperm_route_counts", "svt_aperm_SVT", "svt_transpose_2D_SVT", "svt_dev_transpose_ws_bytes", "svt_dev_transpose", "svt_dev_colstats", "svt_dev_rowstats_ws_bytes", "svt_dev_rowsums", "svt_dev_rowsum",
 ]
 
 

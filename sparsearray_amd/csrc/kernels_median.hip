@@ -253,7 +253,7 @@ median_select_kernel(const int64_t *__restrict__ col_ptr, const T *__restrict__ 
 		     const int64_t *__restrict__ cnt_neg, const int64_t *__restrict__ cnt_pos,
 		     const int64_t *__restrict__ cnt_nan, const int *__restrict__ todo, double *__restrict__ out)
 {
-	__shared__ unsigned hist[MSEL_BINS];
+	__shared__ __attribute__((aligned(16))) unsigned hist[MSEL_BINS];      // (also read as 64-bit words below)
 	__shared__ unsigned wsum[MSEL_NT / 64];
 	__shared__ unsigned found[4];
 	__shared__ unsigned long long red[2 * (MSEL_NT / 64)];

@@ -124,6 +124,16 @@ int launch_exclusive_scan_i64(int64_t *data, int64_t n, void *ws, hipStream_t s)
 // Shapes it does not fit (less than one nonzero per column and coarse bucket) take the key sort of
 // launch_transpose_sorted() below.
 // ---------------------------------------------------------------------------
+// which route the transpositions / permutations of this process took (svt_dev_aperm_route_counts; the fuzzers print it:
+// evidence for what is hot and what is a fallback): 0 t() bucketed, 1 t() key sort, 2 aperm leaf-preserving,
+// 3 first two axes swapped (bucketed), 4 slab form, 5 3-d via an intermediate, 6 general (composed), 7 key sort, 32-bit
+// keys, 8 key sort, 64-bit keys, 9 slab form refused at run time
+static int64_t g_route[10];
+void aperm_route_counts(int64_t *out, int reset)
+{
+	for (int i = 0; i < 10; i++) { if (out != NULL) out[i] = g_route[i]; if (reset) g_route[i] = 0; }
+}
+
 #define T2_NT 256                 // columns per group = threads per workgroup of pass 2
 #define T2_NFINE_MAX 32           // fine buckets per coarse bucket: 16 or 32 (T2Shape::cbits = 4 or 5)
 #define T2_CAP 2048               // nonzeros a pass-2 workgroup assembles in LDS (more: straight to memory)
@@ -757,6 +767,7 @@ static int launch_transpose_sorted(const int64_t *col_ptr, const int32_t *row_id
 {
 	if (nnz >= ((int64_t) 1 << 31))
 		return svt_set_unsupported("svt_dev_transpose: more than 2^31-1 nonzeros");
+	g_route[1]++;
 	const unsigned nbr = (unsigned) ((nrow + 1 + 255) / 256);
 	if (nnz == 0) {
 		HIP_TRY(hipMemsetAsync(out_ptr, 0, (size_t) (nrow + 1) * 8, s));
@@ -871,6 +882,7 @@ int launch_transpose(const int64_t *col_ptr, const int32_t *row_idx, const void 
 	// (one matrix: t2_shape() has left nslab = 1, srow = nrow, scol = ncol)
 	if (!bucketed)
 		return launch_transpose_sorted(col_ptr, row_idx, val, Rtype, nrow, ncol, nnz, out_ptr, out_idx, out_val, ws, s);
+	g_route[0]++;
 	if (Rtype == SVT_REALSXP)
 		return launch_transpose_bucketed<double>(col_ptr, row_idx, (const double *) val, nrow, ncol, nnz, sh, out_ptr,
 							 out_idx, (double *) out_val, ws, reserve, s);
@@ -1430,6 +1442,7 @@ static int launch_aperm_n(const int64_t *col_ptr, const int32_t *row_idx, const 
 		for (int a = 1; a < ndim; a++) { os[a] = st; st *= dim[a]; }      // leaf strides of the old axes
 		for (int a = 1; a < ndim; a++) { lm.new_dim[a] = dim[perm[a]]; lm.old_stride[a] = os[perm[a]]; }
 		// counts into out_ptr, exclusive scan in place (the scan's scratch comes from the workspace)
+		g_route[2]++;
 		hipLaunchKernelGGL(aperm_leaf_count_kernel, dim3(nbl), dim3(256), 0, s, col_ptr, new_nleaves, lm, out_ptr);
 		if (launch_exclusive_scan_i64(out_ptr, new_nleaves + 1, ws, s))
 			return -1;
@@ -1450,6 +1463,7 @@ static int launch_aperm_n(const int64_t *col_ptr, const int32_t *row_idx, const 
 		size_t reserve = 0;
 		const size_t via = aperm_via_bytes(nnz, dim, 3);
 		if (via > 0 && aperm_swap01_bytes(nnz, dim, 3, &sh, &reserve) > 0) {
+			g_route[5]++;
 			const int64_t nly = dim[0] * dim[2];
 			char *p = (char *) ws;
 			int64_t *ycp = (int64_t *) p;         p += t2_a((size_t) nly + 1, 8);
@@ -1478,6 +1492,7 @@ static int launch_aperm_n(const int64_t *col_ptr, const int32_t *row_idx, const 
 		T2Shape sh;
 		size_t reserve = 0;
 		if (swap01 && aperm_swap01_bytes(nnz, dim, ndim, &sh, &reserve) > 0) {
+			g_route[3]++;
 			if (Rtype == SVT_REALSXP)
 				return launch_transpose_bucketed<double>(col_ptr, row_idx, (const double *) val, dim[0], ncol, nnz, sh,
 									 out_ptr, out_idx, (double *) out_val, ws, reserve, s);
@@ -1515,7 +1530,9 @@ static int launch_aperm_n(const int64_t *col_ptr, const int32_t *row_idx, const 
 			unsigned long long mx = 0;
 			HIP_TRY(hipMemcpyAsync(&mx, maxcnt, 8, hipMemcpyDeviceToHost, s));
 			HIP_TRY(hipStreamSynchronize(s));
+			if (mx > SLAB_CAP) g_route[9]++;
 			if (mx <= SLAB_CAP) {
+				g_route[4]++;
 				if (launch_exclusive_scan_i64(base, nslab + 1, scan_tmp, s))
 					return -1;
 				int bits = 1;
@@ -1538,6 +1555,7 @@ static int launch_aperm_n(const int64_t *col_ptr, const int32_t *row_idx, const 
 	if (!nested) {
 		ApermPlan3 pl;
 		if (aperm_general_plan(nnz, dim, ndim, perm, &pl)) {
+			g_route[6]++;
 			char *p = (char *) ws;
 			const int64_t *cp_a = col_ptr; const int32_t *ri_a = row_idx; const void *v_a = val;
 			int64_t ncol_a = ncol;
@@ -1591,6 +1609,7 @@ static int launch_aperm_n(const int64_t *col_ptr, const int32_t *row_idx, const 
 		const unsigned nb = (unsigned) ((nnz + 255) / 256);
 		const unsigned nb8 = (unsigned) (((nnz + 255) / 256 + 7) / 8 * 8);
 		const int64_t nblk = (nnz >> HINT_SHIFT) + 1;
+		g_route[7]++;
 		hipLaunchKernelGGL(col_hint_kernel, dim3((unsigned) ((nblk + 1 + 255) / 256)), dim3(256), 0, s, col_ptr, ncol, nblk, hint);
 		hipLaunchKernelGGL(aperm_key32_kernel, dim3(nb), dim3(256), 0, s, col_ptr, row_idx, hint, ncol, nnz, d,
 				   keys, pos, newrow);
@@ -1619,6 +1638,7 @@ static int launch_aperm_n(const int64_t *col_ptr, const int32_t *row_idx, const 
 	const int bits = aperm_bits(dim, ndim);
 	const unsigned nb = (unsigned) ((nnz + 255) / 256);
 	const unsigned nb8 = (unsigned) (((nnz + 255) / 256 + 7) / 8 * 8);
+	g_route[8]++;
 	hipLaunchKernelGGL(aperm_key_kernel, dim3(nb), dim3(256), 0, s, col_ptr, row_idx, ncol, nnz, d, keys, pos);
 	if (svt_sort_pairs<unsigned long long>(keys, skeys, ktmp, pos, spos, ptmp, nnz, bits, tmp, s))
 		return -1;

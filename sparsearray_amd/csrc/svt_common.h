@@ -199,6 +199,7 @@ int launch_transpose(const int64_t *col_ptr, const int32_t *row_idx, const void 
 		     int64_t nrow, int64_t ncol, int64_t nnz, int64_t *out_ptr, int32_t *out_idx,
 		     void *out_val, void *ws, hipStream_t s);
 
+void aperm_route_counts(int64_t *out, int reset);
 size_t aperm_ws_bytes(int64_t nnz, const int64_t *dim, int ndim);
 int launch_aperm(const int64_t *col_ptr, const int32_t *row_idx, const void *val, int Rtype,
 		 int64_t ncol, int64_t nnz, const int64_t *dim, int ndim, const int *perm,

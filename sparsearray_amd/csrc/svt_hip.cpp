@@ -959,6 +959,11 @@ extern "C" int svt_dev_crossprod_csc_csc(const svt_dev_csc *Xt, const svt_dev_cs
 	return svt_status(dev_crossprod_csc_csc_impl(Xt, Y, sym, out, ldo, ws, ws_bytes, not_finite, stream));
 }
 
+extern "C" void svt_dev_aperm_route_counts(int64_t *counts, int reset)
+{
+	aperm_route_counts(counts, reset);
+}
+
 static int aperm_args(int ndim, const int *perm, int *perm0)
 {
 	if (ndim < 1 || ndim > 8)

@@ -233,6 +233,17 @@ class PbcPlan:
             pass
 
 
+def aperm_route_counts(reset=False) -> dict:
+    """Which route the transpositions / permutations of this process took so far (svt_dev_aperm_route_counts)."""
+    names = ("t_bucketed", "t_key_sort", "leaf_preserving", "first_two_axes_swapped", "slab", "via_intermediate_3d",
+             "general_composed", "key_sort_32", "key_sort_64", "slab_refused_at_run_time")
+    buf = (c_int64 * 10)()
+    _lib().svt_dev_aperm_route_counts.argtypes = [c_void_p, c_int]
+    _lib().svt_dev_aperm_route_counts.restype = None
+    _lib().svt_dev_aperm_route_counts(buf, int(bool(reset)))
+    return dict(zip(names, (int(x) for x in buf)))
+
+
 def trim_layout_pool() -> None:
     """Returns the memory the layout pools keep for the next build to the driver (svt_dev_pbc_trim)."""
     _lib().svt_dev_pbc_trim.restype = None

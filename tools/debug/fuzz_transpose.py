@@ -118,4 +118,9 @@ for case in range(ncases):
         print(f"MISMATCH case {case}: nrow {nrow} ncol {ncol} nnz {lin.numel()} kind {kind} int {is_int}", flush=True)
     del A, T, lin, ri, col, cp, v, order, want_idx, want_val, want_cp
 print(f"{ncases} cases, {bad} mismatches")
+from sparsearray_amd.device import aperm_route_counts
+rc = aperm_route_counts()
+tot = max(1, sum(rc.values()))
+print("routes taken (steps of composed routes included): " + ", ".join(f"{k} {v}" for k, v in rc.items())
+      + f"; key sorts = {100.0 * (rc['t_key_sort'] + rc['key_sort_32'] + rc['key_sort_64']) / tot:.1f} % of {tot} route steps")
 sys.exit(1 if bad else 0)
