@@ -1853,18 +1853,21 @@ pbc_transpose_dense_kernel(const double *__restrict__ Yin, int64_t ldY, int64_t 
 #define PBC_DIRTY_CAP 8192
 #define PBC_DIRTY_COLS 256    // light dense columns that get a slot (hit counters of a wavefront in LDS)
 #define PBC_DIRTY_LIGHT 256     // a dense column lists at most this many of its non-finite entries
+#define PBC_DIRTY_FIRST 4       // rows of a column's first non-finite entries kept apart from the list: a leaf that has no
+                                // nonzero on one of them has its cell decided (NaN) without a walk
 struct DirtyWs {
 	int *flags;          // the flag block: [0] product kernel saw a non-finite y, [2] run the general
 	                     // kernels, [3] number of listed non-finite entries
 	int *col_nf;         // [Kp] non-finite entries per dense column
 	int *has_na;         // [Kp] the column holds an R NA
 	uint2 *list;         // [PBC_DIRTY_CAP] (row, column)
+	int *first;          // [Kp][PBC_DIRTY_FIRST] rows of the first non-finite entries noted in every column (whatever the list holds)
 };
 
 static size_t dirty_ws_bytes(int64_t ncol, int64_t Kp)
 {
 	(void) ncol;
-	return (size_t) Kp * 8 + (size_t) PBC_DIRTY_CAP * 8 + 256;
+	return (size_t) Kp * 8 + (size_t) PBC_DIRTY_CAP * 8 + (size_t) Kp * PBC_DIRTY_FIRST * 4 + 256;
 }
 
 static DirtyWs dirty_ws_of(void *flag_block, void *tail, int64_t ncol, int64_t Kp)
@@ -1878,6 +1881,7 @@ static DirtyWs dirty_ws_of(void *flag_block, void *tail, int64_t ncol, int64_t K
 	d.col_nf = in_block ? (int *) ((char *) flag_block + 256) : (int *) tail;   // then phase 1 clears them with the flags
 	d.has_na = d.col_nf + Kp;
 	d.list = (uint2 *) (((uintptr_t) (in_block ? (char *) tail : (char *) (d.has_na + Kp)) + 15) & ~(uintptr_t) 15);
+	d.first = (int *) (d.list + PBC_DIRTY_CAP);
 	return d;
 }
 
@@ -1903,6 +1907,7 @@ __device__ inline void pbc_dirty_scan(const double *__restrict__ Y, int64_t rs, 
 			return;
 		const int seen = atomicAdd(d.col_nf + k, 1);
 		if (svt_is_na(y)) d.has_na[k] = 1;
+		if (seen < PBC_DIRTY_FIRST) d.first[k * PBC_DIRTY_FIRST + seen] = (int) r;
 		if (seen >= PBC_DIRTY_LIGHT)
 			return;                                 // a heavy column: decided without its entries, or by the general kernels
 		const int at = atomicAdd(d.flags + 3, 1);
@@ -2080,19 +2085,38 @@ pbc_dirty_leaf_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__rest
 		      DirtyWs d, double *__restrict__ out, int64_t sc, int64_t sk, int64_t max_leaf_nnz,
 		      int *__restrict__ gen_counters, int n_gen_counters)
 {
-	extern __shared__ int slot_lds[];                       // [K] + [PBC_DIRTY_WPB][PBC_DIRTY_COLS]
+	extern __shared__ int slot_lds[];                       // [K] + [PBC_DIRTY_WPB][PBC_DIRTY_COLS] + [PBC_DIRTY_WPB][K]
 	if (d.flags[0] == 0)                                    // (the same answer in every workgroup)
 		return;
 	(void) gen_counters; (void) n_gen_counters;
 	const int nslots = pbc_dirty_classes(K, d, slot_lds, max_leaf_nnz);      // (the same answer in every workgroup)
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	int *hits = slot_lds + K + w * PBC_DIRTY_COLS;
+	int *miss = slot_lds + K + PBC_DIRTY_WPB * PBC_DIRTY_COLS + w * K;
 	int n = d.flags[3];
 	if (n > PBC_DIRTY_CAP) n = 0;                            // (the list is incomplete: no column has a slot, all are walked)
 	for (int64_t c = (int64_t) blockIdx.x * PBC_DIRTY_WPB + w; c < ncol; c += (int64_t) gridDim.x * PBC_DIRTY_WPB) {
 		for (int i = lane; i < nslots; i += 64) hits[i] = 0;
+		for (int i = lane; i < K; i += 64) miss[i] = 0;
 		__builtin_amdgcn_wave_barrier();
 		const int64_t beg = col_ptr[c], end = col_ptr[c + 1];
+		// Columns of class -2 (the leaf would be walked for each of them): one of the column's first non-finite entries
+		// on a row where the leaf holds nothing decides the cell -- 0 * Inf, 0 * NaN -- without the walk.  (Round 5
+		// walked always: 1.7 ms per such column at config 2a, 215 ms for 128 of them where the general kernels of
+		// rounds 2-4 took 35 for everything; a leaf of a 1 % operand misses the first entry 99 times in 100.)
+		for (int t = lane; t < K * PBC_DIRTY_FIRST; t += 64) {
+			const int k = t / PBC_DIRTY_FIRST, j = t % PBC_DIRTY_FIRST;
+			if (slot_lds[k] != -2 || j >= d.col_nf[k])
+				continue;
+			const uint32_t r = (uint32_t) d.first[t];
+			int64_t lo = beg, hi = end;
+			while (lo < hi) {
+				const int64_t mid = (lo + hi) >> 1;
+				if ((uint32_t) row_idx[mid] < r) lo = mid + 1; else hi = mid;
+			}
+			if (!(lo < end && (uint32_t) row_idx[lo] == r))
+				miss[k] = 1;                        // (LDS; several lanes may write the same 1)
+		}
 		for (int e = lane; e < n; e += 64) {
 			const uint2 rk = d.list[e];
 			const int sl = slot_lds[rk.y];
@@ -2118,7 +2142,7 @@ pbc_dirty_leaf_kernel(const int64_t *__restrict__ col_ptr, const int32_t *__rest
 			const int cls = slot_lds[k];
 			if (d.has_na[k] || leaf_na) {
 				if (lane == 0) *cell = svt_na_real();
-			} else if (cls == -1 || (cls >= 0 && hits[cls] < nf)) {
+			} else if (cls == -1 || (cls >= 0 && hits[cls] < nf) || (cls == -2 && miss[k] != 0)) {
 				if (lane == 0) *cell = *cell + NAN;
 			} else {
 				// every non-finite entry of the column sits on a nonzero of the leaf (cls >= 0), or that is still to be
@@ -2649,7 +2673,7 @@ static int pbc_phase_impl(const svt_dev_pbc *P, const svt_dev_csc *A,
 		int64_t nwg = (P->ncol + PBC_DIRTY_WPB - 1) / PBC_DIRTY_WPB;
 		if (nwg > 4096) nwg = 4096;
 		hipLaunchKernelGGL(pbc_dirty_leaf_kernel, dim3((unsigned) nwg), dim3(PBC_DIRTY_WPB * 64),
-				   (size_t) (K + PBC_DIRTY_WPB * PBC_DIRTY_COLS) * 4, s,
+				   (size_t) (K + PBC_DIRTY_WPB * PBC_DIRTY_COLS + PBC_DIRTY_WPB * K) * 4, s,
 				   A->col_ptr, A->row_idx, (const double *) A->val, P->col_has_na, Yd, yrs, ycs,
 				   P->ncol, K, dw, out, out_stride_c, out_stride_k, P->max_leaf_nnz,
 				   gen_counters, n_gen_counters);

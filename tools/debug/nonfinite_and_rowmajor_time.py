@@ -37,3 +37,15 @@ t_try = timed(lambda: plan.run(Yrm, K, out, tr_y=True))
 print(f"crossprod(A, Y) config 2a: clean {t_clean:.3f} ms; one Inf in Y {t_inf:.3f} ms ({t_inf / t_clean:.2f}x); "
       f"a whole NaN column {t_col:.3f} ms; Y given by rows (tcrossprod) {t_try:.3f} ms "
       f"({t_try / t_clean:.2f}x)")
+# every dense column in the class the leaf kernel WALKS for (more than 256 non-finite entries but
+# fewer than the longest leaf holds: pbc_dirty_leaf_kernel re-walks each leaf once per such column) -- the worst
+# case of the one-launch fix-up, against the ~35 ms the general kernels of rounds 2-4 took for a whole product
+g = torch.Generator(device=dev); g.manual_seed(9)
+for ncols_dirty in (1, 16, 128):
+    Yw = Y.clone()
+    for k in range(ncols_dirty):
+        rows = torch.randint(0, nrow, (400,), generator=g, device=dev)
+        Yw[k, rows] = float("nan")
+    t_w = timed(lambda: plan.run(Yw, nrow, out), 3)
+    print(f"  {ncols_dirty:3d} dense column(s) with ~400 NaN each (walked per leaf): {t_w:.3f} ms ({t_w / t_clean:.2f}x the clean product)")
+    del Yw
