@@ -178,6 +178,19 @@ template <> struct __attribute__((packed, aligned(4))) GramRec<int, 1> { int c; 
 template <> struct GramRec<double, 0> { int c; double v; };
 template <> struct GramRec<int, 0> { int c; int v; };
 
+// a record as the plain words a load brings in
+template <typename T> struct GramRaw;
+template <> struct GramRaw<double> {
+	struct type { int a, b, c; };
+	__device__ static inline int col(const type &q) { return q.a; }
+	__device__ static inline double val(const type &q) { return __hiloint2double(q.c, q.b); }
+};
+template <> struct GramRaw<int> {
+	struct type { int a, b; };
+	__device__ static inline int col(const type &q) { return q.a; }
+	__device__ static inline int val(const type &q) { return q.b; }
+};
+
 template <typename T, int AOS>
 __global__ void __launch_bounds__(256)
 gram_pack_kernel(const int32_t *__restrict__ idx, const T *__restrict__ val, int64_t n, GramRec<T, AOS> *__restrict__ rec)
@@ -189,7 +202,7 @@ gram_pack_kernel(const int32_t *__restrict__ idx, const T *__restrict__ val, int
 	}
 }
 
-template <typename T, int SU, int AOS, int TT>
+template <typename T, int SU, int AOS>
 __global__ void __launch_bounds__(GRAM_NT)
 gram_sym_kernel(GramArgs a, int G)
 {
@@ -215,8 +228,7 @@ gram_sym_kernel(GramArgs a, int G)
 	const int np2 = k2 != k1 ? (int) (a.b_ptr[k2 + 1] - bb2) : 0;
 	const int nunits = np1 > np2 ? np1 : np2;
 	bool bad = false;
-	// positions inside t(X) in 32 bits (the launcher sends operands with 2^31 nonzeros or more to gram_kernel);
-	// a lane takes TT consecutive entries per trip, a group G * TT
+	// positions inside t(X) in 32 bits (the launcher sends operands with 2^31 nonzeros or more to gram_kernel)
 	for (int t0 = grp; t0 < nunits; t0 += SU * ngrp) {
 		unsigned x[SU], xe[SU], x2[SU], xe2[SU];
 		double b[SU], b2[SU];
@@ -228,51 +240,47 @@ gram_sym_kernel(GramArgs a, int G)
 			if (t < np1) {
 				const int64_t r = a.b_idx[bb1 + t];
 				const T w = bv[bb1 + t];
-				x[u] = (unsigned) a.a_ptr[r] + sl * TT; xe[u] = (unsigned) a.a_ptr[r + 1];
+				x[u] = (unsigned) a.a_ptr[r] + sl; xe[u] = (unsigned) a.a_ptr[r + 1];
 				b[u] = (double) w; bad |= gram_bad<T>(w);
 			}
 			if (t < np2) {
 				const int64_t r = a.b_idx[bb2 + t];
 				const T w = bv[bb2 + t];
-				x2[u] = (unsigned) a.a_ptr[r] + sl * TT; xe2[u] = (unsigned) a.a_ptr[r + 1];
+				x2[u] = (unsigned) a.a_ptr[r] + sl; xe2[u] = (unsigned) a.a_ptr[r + 1];
 				b2[u] = (double) w; bad |= gram_bad<T>(w);
 			}
 		}
 		bool more = true;
 		while (more) {
-			T v[SU][TT];
-			int c[SU][TT];
+			T v[SU];
+			int c[SU];
+			// The loads of all SU slots are issued before any of them is waited for: no branch around a load (a lane
+			// whose walk is over reads record 0 again, one address for the whole wavefront) and the record taken apart
+			// only where it is used -- with the load inside `if (x < xe)` and the 12-byte record unpacked at once the
+			// compiler waits behind every single load and two slots are no faster than one (15.0 against 14.6 ms).
+			typename GramRaw<T>::type raw[SU];
 #pragma unroll
 			for (int u = 0; u < SU; u++) {
 				if (x[u] >= xe[u]) {            // this walk is over: on to the unit's second one (or to nothing)
 					x[u] = x2[u]; xe[u] = xe2[u]; b[u] = b2[u]; second |= 1 << u;
 					x2[u] = xe2[u] = 0;
 				}
-#pragma unroll
-				for (int t = 0; t < TT; t++)
-					if (x[u] + t < xe[u]) {
-						if (AOS) { const GramRec<T, AOS> q = rec[x[u] + t]; c[u][t] = q.c; v[u][t] = q.v; }
-						else { c[u][t] = a.a_idx[x[u] + t]; v[u][t] = av[x[u] + t]; }
-					}
+				const unsigned xi = x[u] < xe[u] ? x[u] : 0u;
+				if (AOS) raw[u] = ((const typename GramRaw<T>::type *) a.a_val)[xi];
+				else { c[u] = a.a_idx[xi]; v[u] = av[xi]; }
 			}
 			more = false;
 #pragma unroll
 			for (int u = 0; u < SU; u++) {
+				if (AOS) { c[u] = GramRaw<T>::col(raw[u]); v[u] = GramRaw<T>::val(raw[u]); }
 				if (x[u] < xe[u]) {
 					const bool sec = (second >> u) & 1;
-					const int hi = sec ? hi2 : hi1;
-					double *__restrict__ cell = acc + (sec ? off2 : 0);
-					bool over = false;      // (ascending columns: past the cut once, past it for good)
-#pragma unroll
-					for (int t = 0; t < TT; t++)
-						if (x[u] + t < xe[u] && !over) {
-							if (c[u][t] < hi) {
-								bad |= gram_bad<T>(v[u][t]);
-								atomicAdd(&cell[c[u][t]], (double) v[u][t] * b[u]);
-							} else
-								over = true;
-						}
-					x[u] = over ? xe[u] : x[u] + G * TT;
+					if (c[u] < (sec ? hi2 : hi1)) {
+						bad |= gram_bad<T>(v[u]);
+						atomicAdd(&acc[(sec ? off2 : 0) + c[u]], (double) v[u] * b[u]);
+						x[u] += G;
+					} else
+						x[u] = xe[u];           // (ascending columns: the lane's later entries are past the cut too)
 				}
 				more |= x[u] < xe[u] || x2[u] < xe2[u];
 			}
@@ -325,7 +333,7 @@ int launch_gram_mirror(double *out, int64_t n, int64_t ld, hipStream_t s)
 	return 0;
 }
 
-static int g_gram_aos = 1, g_gram_su = 1;
+static int g_gram_aos = 1, g_gram_su = 2;
 
 // does the symmetric one-block form (gram_sym_kernel) apply?  (32-bit positions inside t(X))
 static bool gram_sym_one(int64_t nx, int64_t a_nnz)
@@ -407,9 +415,6 @@ int launch_gram(GramArgs a, int64_t a_nnz, int64_t b_nnz, void *ws, hipStream_t 
 	if (getenv("SVT_GRAM_SYMK")) symk = atoi(getenv("SVT_GRAM_SYMK"));
 	if (getenv("SVT_GRAM_AOS")) aos = atoi(getenv("SVT_GRAM_AOS"));
 	if (getenv("SVT_GRAM_SU")) su = atoi(getenv("SVT_GRAM_SU"));
-	int tt = 1;
-	if (getenv("SVT_GRAM_TT")) tt = atoi(getenv("SVT_GRAM_TT"));
-	(void) tt;
 #endif
 	(void) su;
 	if (mode == 1 && symk && a.a_type == a.b_type && gram_sym_one(a.nx, a_nnz)) {
@@ -422,16 +427,15 @@ int launch_gram(GramArgs a, int64_t a_nnz, int64_t b_nnz, void *ws, hipStream_t 
 #undef GRAM_PACK
 			a.a_val = rec; a.a_idx = NULL;
 		}
-#define GRAM_SYM_GO(T, SU, AOS, TT) do { \
-		(void) hipFuncSetAttribute((const void *) gram_sym_kernel<T, SU, AOS, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); \
-		hipLaunchKernelGGL((gram_sym_kernel<T, SU, AOS, TT>), grid, dim3(nt), lds, s, a, G); } while (0)
+#define GRAM_SYM_GO(T, SU, AOS) do { \
+		(void) hipFuncSetAttribute((const void *) gram_sym_kernel<T, SU, AOS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); \
+		hipLaunchKernelGGL((gram_sym_kernel<T, SU, AOS>), grid, dim3(nt), lds, s, a, G); } while (0)
 #ifdef SVT_TUNING
 #define GRAM_SYM_SU(T, AOS) do { \
-		if (su == 4) GRAM_SYM_GO(T, 4, AOS, 1); else if (su == 1 && tt == 2) GRAM_SYM_GO(T, 1, AOS, 2); \
-		else if (su == 1) GRAM_SYM_GO(T, 1, AOS, 1); \
-		else if (tt == 2) GRAM_SYM_GO(T, 2, AOS, 2); else GRAM_SYM_GO(T, 2, AOS, 1); } while (0)
+		if (su == 4) GRAM_SYM_GO(T, 4, AOS); else if (su == 3) GRAM_SYM_GO(T, 3, AOS); \
+		else if (su == 1) GRAM_SYM_GO(T, 1, AOS); else GRAM_SYM_GO(T, 2, AOS); } while (0)
 #else
-#define GRAM_SYM_SU(T, AOS) GRAM_SYM_GO(T, 1, AOS, 1)
+#define GRAM_SYM_SU(T, AOS) GRAM_SYM_GO(T, 2, AOS)
 #endif
 		if (a.a_type == SVT_REALSXP) { if (aos) GRAM_SYM_SU(double, 1); else GRAM_SYM_SU(double, 0); }
 		else { if (aos) GRAM_SYM_SU(int, 1); else GRAM_SYM_SU(int, 0); }
