@@ -163,32 +163,35 @@ gram_kernel(GramArgs a, int G)
 // (first version, one walk per slot: 24.3 ms at config-2 scale where the general form, which reads twice as much,
 // took 22.1).  Here a slot's unit of work is the t-th nonzero of column j TOGETHER with the t-th nonzero of
 // column n - 1 - j: a prefix of one row up to column j and a prefix of another up to column n - 1 - j, about one
-// row's length in all whatever j is: 18.3 ms.  One unit per lane group in flight (more of them, or several entries per
-// lane and trip, only read further past the cuts: 2 units 15.0 ms, 4 units 21.1, two entries per lane 19.5; 32 lanes
-// per group 18.9, 8 lanes 16.3) on 12-byte records: 14.6 ms = 60 GB of prefixes + what the last trip of a walk reads
-// past its cut, at the rate the chip gathers 600-byte runs from HBM.
+// row's length in all whatever j is: 18.3 ms; on 12-byte records (one run of memory per walk instead of two) 14.6;
+// with the loop written as it stands below 13.8.  Lane groups of 16 (32 lanes read further past the cuts: 15.5; 8
+// lanes make twice the trips: 16.5); two consecutive entries per lane and trip 19.5 (twice the over-read).
 // Records of t(X) for the symmetric form: (column, value) side by side, 12 bytes (8 for integer values) -- a
 // prefix of a row is then ONE run of memory instead of two (columns, values), read by one load per lane
 // AOS: 0 = t(X) as it is (two arrays), 1 = records.  (Measured at config-2 scale, symmetric form: two arrays 16.3 ms,
 // 12-byte records 14.6 incl. the 0.45 ms that makes them, 10-byte records with a 16-bit column -- the value at a 2-byte
 // boundary, global_load_dwordx2 at offset 2 -- 15.4.)
 template <typename T, int AOS> struct GramRec;
-template <> struct __attribute__((packed, aligned(4))) GramRec<double, 1> { int c; double v; };
-template <> struct __attribute__((packed, aligned(4))) GramRec<int, 1> { int c; int v; };
+template <> struct __attribute__((packed, aligned(4))) GramRec<double, 1> { double v; int c; };   // (value first: it lands in an even register pair)
+template <> struct __attribute__((packed, aligned(4))) GramRec<int, 1> { int v; int c; };
 template <> struct GramRec<double, 0> { int c; double v; };
 template <> struct GramRec<int, 0> { int c; int v; };
 
 // a record as the plain words a load brings in
 template <typename T> struct GramRaw;
 template <> struct GramRaw<double> {
-	struct type { int a, b, c; };
-	__device__ static inline int col(const type &q) { return q.a; }
-	__device__ static inline double val(const type &q) { return __hiloint2double(q.c, q.b); }
+	struct type { int a, b, c; };           // value (low, high word), column
+	__device__ static inline int col(const type &q) { return q.c; }
+	__device__ static inline double val(const type &q) { return __hiloint2double(q.b, q.a); }
+	// (all three words are wanted HERE: without this the compiler loads the column alone and fetches the value
+	// behind the cut test, a second, dependent trip to memory)
+	__device__ static inline void pin(type &q) { asm volatile("" : "+v"(q.a), "+v"(q.b), "+v"(q.c)); }
 };
 template <> struct GramRaw<int> {
-	struct type { int a, b; };
-	__device__ static inline int col(const type &q) { return q.a; }
-	__device__ static inline int val(const type &q) { return q.b; }
+	struct type { int a, b; };              // value, column
+	__device__ static inline int col(const type &q) { return q.b; }
+	__device__ static inline int val(const type &q) { return q.a; }
+	__device__ static inline void pin(type &q) { asm volatile("" : "+v"(q.a), "+v"(q.b)); }
 };
 
 template <typename T, int AOS>
@@ -202,9 +205,9 @@ gram_pack_kernel(const int32_t *__restrict__ idx, const T *__restrict__ val, int
 	}
 }
 
-template <typename T, int SU, int AOS>
+template <typename T, int SU, int G>
 __global__ void __launch_bounds__(GRAM_NT)
-gram_sym_kernel(GramArgs a, int G)
+gram_sym_kernel(GramArgs a)
 {
 	extern __shared__ double acc[];
 	__shared__ int stop;
@@ -219,24 +222,34 @@ gram_sym_kernel(GramArgs a, int G)
 	if (stop != 0)
 		return;
 	const int grp = tid / G, sl = tid % G, ngrp = NT / G;
-	const T *__restrict__ av = (const T *) a.a_val;
-	const GramRec<T, AOS> *__restrict__ rec = (const GramRec<T, AOS> *) a.a_val;      // (AOS)
+	const typename GramRaw<T>::type *__restrict__ rec = (const typename GramRaw<T>::type *) a.a_val;
 	const T *__restrict__ bv = (const T *) a.b_val;
 	const int64_t bb1 = a.b_ptr[k1];
 	const int np1 = (int) (a.b_ptr[k1 + 1] - bb1);
 	const int64_t bb2 = a.b_ptr[k2];
 	const int np2 = k2 != k1 ? (int) (a.b_ptr[k2 + 1] - bb2) : 0;
 	const int nunits = np1 > np2 ? np1 : np2;
+	// Every stored value of x is the `b` of exactly one walk of some workgroup (Y is X): looking at the b's looks at
+	// all of them, the entries of the walked rows need no look of their own.
 	bool bad = false;
-	// positions inside t(X) in 32 bits (the launcher sends operands with 2^31 nonzeros or more to gram_kernel)
+	// positions inside t(X) in 32 bits (the launcher sends operands with 2^31 nonzeros or more to gram_kernel).
+	// What bounds the loop below (config-2 scale, 13.5-14 ms): memory.  Its first form issued 39 vector + 25 scalar
+	// instructions per LDS add (rocprofv3 SQ_INSTS_*: 4.5e9 / 2.9e9 / 1.15e8 per launch) and waited behind every load;
+	// this one -- selects instead of branches, one exec-masked region, the loads of all slots in flight together --
+	// issues half of that and runs in the same time, with one unit per lane group in flight or two (13.8 / 14.0 ms;
+	// three 15.9, four 17.6: more walks in flight only spread the reads of a row further apart).  The walks move
+	// ~60 GB of row prefixes in 600-byte runs plus what the last trip of a walk reads past its cut; L2 serves 46 %
+	// of the requests (TCC_HIT / TCC_REQ), the rest is the rate at which HBM and the memory-side cache deliver
+	// such runs.  Workgroups deliberately started at different places of their sweeps: 18.0 ms (the ~1000 columns in
+	// flight name every row ~10 times; side by side those reads share the caches).
 	for (int t0 = grp; t0 < nunits; t0 += SU * ngrp) {
 		unsigned x[SU], xe[SU], x2[SU], xe2[SU];
 		double b[SU], b2[SU];
-		int second = 0;                                 // bit u: slot u is on its unit's second walk
+		int hi[SU], off[SU];
 #pragma unroll
 		for (int u = 0; u < SU; u++) {
 			const int t = t0 + u * ngrp;
-			x[u] = xe[u] = x2[u] = xe2[u] = 0; b[u] = b2[u] = 0.0;
+			x[u] = xe[u] = x2[u] = xe2[u] = 0; b[u] = b2[u] = 0.0; hi[u] = hi1; off[u] = 0;
 			if (t < np1) {
 				const int64_t r = a.b_idx[bb1 + t];
 				const T w = bv[bb1 + t];
@@ -252,36 +265,29 @@ gram_sym_kernel(GramArgs a, int G)
 		}
 		bool more = true;
 		while (more) {
-			T v[SU];
-			int c[SU];
-			// The loads of all SU slots are issued before any of them is waited for: no branch around a load (a lane
-			// whose walk is over reads record 0 again, one address for the whole wavefront) and the record taken apart
-			// only where it is used -- with the load inside `if (x < xe)` and the 12-byte record unpacked at once the
-			// compiler waits behind every single load and two slots are no faster than one (15.0 against 14.6 ms).
 			typename GramRaw<T>::type raw[SU];
+			bool act[SU];
+			// all SU loads are issued before any is waited for: no branch around a load (a lane whose walk is over
+			// reads record 0 again, one address for the whole wavefront), the record taken apart only where it is used
 #pragma unroll
 			for (int u = 0; u < SU; u++) {
-				if (x[u] >= xe[u]) {            // this walk is over: on to the unit's second one (or to nothing)
-					x[u] = x2[u]; xe[u] = xe2[u]; b[u] = b2[u]; second |= 1 << u;
-					x2[u] = xe2[u] = 0;
-				}
-				const unsigned xi = x[u] < xe[u] ? x[u] : 0u;
-				if (AOS) raw[u] = ((const typename GramRaw<T>::type *) a.a_val)[xi];
-				else { c[u] = a.a_idx[xi]; v[u] = av[xi]; }
+				const bool sw = x[u] >= xe[u];          // this walk is over: on to the unit's second one (or to nothing)
+				x[u] = sw ? x2[u] : x[u]; xe[u] = sw ? xe2[u] : xe[u]; b[u] = sw ? b2[u] : b[u];
+				hi[u] = sw ? hi2 : hi[u]; off[u] = sw ? off2 : off[u];
+				xe2[u] = sw ? 0u : xe2[u];
+				act[u] = x[u] < xe[u];
+				raw[u] = rec[act[u] ? x[u] : 0u];
 			}
 			more = false;
 #pragma unroll
+			for (int u = 0; u < SU; u++) GramRaw<T>::pin(raw[u]);
+#pragma unroll
 			for (int u = 0; u < SU; u++) {
-				if (AOS) { c[u] = GramRaw<T>::col(raw[u]); v[u] = GramRaw<T>::val(raw[u]); }
-				if (x[u] < xe[u]) {
-					const bool sec = (second >> u) & 1;
-					if (c[u] < (sec ? hi2 : hi1)) {
-						bad |= gram_bad<T>(v[u]);
-						atomicAdd(&acc[(sec ? off2 : 0) + c[u]], (double) v[u] * b[u]);
-						x[u] += G;
-					} else
-						x[u] = xe[u];           // (ascending columns: the lane's later entries are past the cut too)
-				}
+				const int c = GramRaw<T>::col(raw[u]);
+				const double p = (double) GramRaw<T>::val(raw[u]) * b[u];
+				const bool ok = act[u] && c < hi[u];    // (ascending columns: past the cut once, past it for good)
+				if (ok) atomicAdd(&acc[off[u] + c], p);
+				x[u] = ok ? x[u] + G : xe[u];
 				more |= x[u] < xe[u] || x2[u] < xe2[u];
 			}
 		}
@@ -333,7 +339,7 @@ int launch_gram_mirror(double *out, int64_t n, int64_t ld, hipStream_t s)
 	return 0;
 }
 
-static int g_gram_aos = 1, g_gram_su = 2;
+static int g_gram_aos = 1, g_gram_su = 1;
 
 // does the symmetric one-block form (gram_sym_kernel) apply?  (32-bit positions inside t(X))
 static bool gram_sym_one(int64_t nx, int64_t a_nnz)
@@ -417,28 +423,30 @@ int launch_gram(GramArgs a, int64_t a_nnz, int64_t b_nnz, void *ws, hipStream_t 
 	if (getenv("SVT_GRAM_SU")) su = atoi(getenv("SVT_GRAM_SU"));
 #endif
 	(void) su;
-	if (mode == 1 && symk && a.a_type == a.b_type && gram_sym_one(a.nx, a_nnz)) {
-		if (aos && a_nnz > 0) {
+	if (mode == 1 && symk && aos && a.a_type == a.b_type && gram_sym_one(a.nx, a_nnz)) {
+		{
 			void *rec = (char *) ws + 256;
 			int64_t nb = (a_nnz + 255) / 256;
 			if (nb > 256 * 32) nb = 256 * 32;
+			if (nb < 1) nb = 1;
 #define GRAM_PACK(T, W) hipLaunchKernelGGL((gram_pack_kernel<T, W>), dim3((unsigned) nb), dim3(256), 0, s, a.a_idx, (const T *) a.a_val, a_nnz, (GramRec<T, W> *) rec)
 			if (a.a_type == SVT_REALSXP) GRAM_PACK(double, 1); else GRAM_PACK(int, 1);
 #undef GRAM_PACK
 			a.a_val = rec; a.a_idx = NULL;
 		}
-#define GRAM_SYM_GO(T, SU, AOS) do { \
-		(void) hipFuncSetAttribute((const void *) gram_sym_kernel<T, SU, AOS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); \
-		hipLaunchKernelGGL((gram_sym_kernel<T, SU, AOS>), grid, dim3(nt), lds, s, a, G); } while (0)
+#define GRAM_SYM_GO(T, SU, GG) do { \
+		(void) hipFuncSetAttribute((const void *) gram_sym_kernel<T, SU, GG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); \
+		hipLaunchKernelGGL((gram_sym_kernel<T, SU, GG>), grid, dim3(nt), lds, s, a); } while (0)
 #ifdef SVT_TUNING
-#define GRAM_SYM_SU(T, AOS) do { \
-		if (su == 4) GRAM_SYM_GO(T, 4, AOS); else if (su == 3) GRAM_SYM_GO(T, 3, AOS); \
-		else if (su == 1) GRAM_SYM_GO(T, 1, AOS); else GRAM_SYM_GO(T, 2, AOS); } while (0)
+#define GRAM_SYM_G(T, SU) do { if (G >= 32) GRAM_SYM_GO(T, SU, 32); else if (G <= 8) GRAM_SYM_GO(T, SU, 8); else GRAM_SYM_GO(T, SU, 16); } while (0)
+#define GRAM_SYM_SU(T) do { if (su == 4) GRAM_SYM_G(T, 4); else if (su == 3) GRAM_SYM_G(T, 3); else if (su == 2) GRAM_SYM_G(T, 2); else GRAM_SYM_G(T, 1); } while (0)
 #else
-#define GRAM_SYM_SU(T, AOS) GRAM_SYM_GO(T, 2, AOS)
+#define GRAM_SYM_SU(T) do { if (G >= 32) GRAM_SYM_GO(T, 1, 32); else if (G <= 8) GRAM_SYM_GO(T, 1, 8); else GRAM_SYM_GO(T, 1, 16); } while (0)
 #endif
-		if (a.a_type == SVT_REALSXP) { if (aos) GRAM_SYM_SU(double, 1); else GRAM_SYM_SU(double, 0); }
-		else { if (aos) GRAM_SYM_SU(int, 1); else GRAM_SYM_SU(int, 0); }
+		if (a.a_type == SVT_REALSXP) GRAM_SYM_SU(double); else GRAM_SYM_SU(int);
+#ifdef SVT_TUNING
+#undef GRAM_SYM_G
+#endif
 #undef GRAM_SYM_SU
 #undef GRAM_SYM_GO
 	} else
