@@ -544,6 +544,25 @@ def sharded_crossprod_sparse(local_product: Callable, B_block, blocks_B, group=N
     return gather_columns(part.contiguous(), [b[1] - b[0] for b in (blocks_A or blocks_B)], group)
 
 
+def device_sparse_crossprod_block(A_block):
+    """`local_product` for sharded_crossprod_sparse() on the device: the rank's leaf block of A (a DeviceCSC) against
+    the gathered B through the sparse-aware kernel (svt_dev_crossprod_csc_csc on t(A_block), built once here).  The
+    rank's rows of the result come back as the (ncol_A_local, ncol_B) tensor gather_columns() concatenates; the
+    kernel's not-finite flag of the last product is kept in `.flag` (nonzero: that product has to be redone by
+    the dense-buffer route, svt_dev_crossprod_csc_csc_dense_buffer)."""
+    from .device import DeviceCSC, crossprod_csc_csc
+    At = A_block.t()
+
+    def local_product(B_full):
+        cp, ri, v = B_full
+        B = DeviceCSC(A_block.nrow, cp, ri, v)
+        out, flag = crossprod_csc_csc(At, B)          # (ncol_B, ncol_A_local) = column-major ncol_A_local x ncol_B
+        local_product.flag = flag
+        return out.t().contiguous()
+    local_product.flag = None
+    return local_product
+
+
 def sharded_colsum(local_colsum: Callable, group=None) -> torch.Tensor:
     """colsum(A, group) with the leaves sharded: a group of columns spans ranks, so every rank adds the
     leaves it holds into its own nrow x ngroup partial (src/rowsum_methods.c:204-255) and the partials

@@ -286,6 +286,7 @@ def test_two_ranks_same_device_sharded_ops_match_one_rank(hip, tmp_path):
         assert v["crossprod_rel_err"] <= 1e-12, (name, v)
         assert v["crossprod_peer_rel_err"] <= 1e-12, (name, v)        # PeerReducer: peer copies + local sum
         assert v["colsums_rel_err"] <= 1e-12, (name, v)
+        assert v["sparse_crossprod_rel_err"] <= 1e-12, (name, v)  # leaf-sharded unary crossprod, sparse-aware kernel
         assert v["colvars_identical"], name
         assert v["rowsum_rel_err"] <= 1e-12, (name, v)
 

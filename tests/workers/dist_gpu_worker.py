@@ -78,7 +78,23 @@ def main():
         rs_ref = rowsum(A, grp, ng)
         torch.cuda.synchronize()
         err_rs = float((rs - rs_ref).abs().max()) / max(float(rs_ref.abs().max()), 1e-300)
+        # unary crossprod(A) with the LEAVES sharded (last but one row): every rank all-gathers the
+        # other operand and forms its own rows of the ncol x ncol result with the sparse-aware kernel; against the one-rank
+        # symmetric product (config2a slice only: 10^4 columns -- the config-4 slice's result would be 20 GB)
+        err_sp = 0.0
+        if ncol <= 10_000:
+            from sparsearray_amd.device import crossprod_csc_csc
+            lp = par.device_sparse_crossprod_block(Ac)
+            c0, c1 = blocks[rank]
+            k0, k1 = int(cp[c0]), int(cp[c1])
+            got_sp = par.sharded_crossprod_sparse(lp, ((cp[c0:c1 + 1] - k0).contiguous(), ri[k0:k1], v[k0:k1]), blocks)
+            ref_sp, flag_sp = crossprod_csc_csc(A.t(), A, sym=True)
+            torch.cuda.synchronize()
+            assert int(flag_sp.item()) == 0 and int(lp.flag.item()) == 0
+            err_sp = float((got_sp - ref_sp.t()).abs().max()) / float(ref_sp.abs().max())
+            del got_sp, ref_sp, lp
         verdict[name] = {"same_shard": bool(same_shard), "crossprod_rel_err": err_cp, "crossprod_peer_rel_err": err_peer,
+                         "sparse_crossprod_rel_err": err_sp,
                          "colsums_rel_err": err_cs,
                          "colvars_identical": bool(torch.equal(cv, cv_ref)), "rowsum_rel_err": err_rs,
                          "nnz": A.nnz, "rows_rank": r1 - r0, "blocks": blocks}
