@@ -11,6 +11,8 @@ import sys
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 os.environ["LOCAL_RANK"] = "0"
+for k_, v_ in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "30477")):
+    os.environ.setdefault(k_, v_)           # (started by hand, e.g. from tools/debug/r6_profiles.sh)
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
