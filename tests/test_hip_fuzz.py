@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("script,ncases,seed", [("fuzz_pbc.py", 60, 101), ("fuzz_stats.py", 24, 102), ("fuzz_transpose.py", 40, 103), ("fuzz_spmm.py", 40, 104)])
+@pytest.mark.parametrize("script,ncases,seed", [("fuzz_pbc.py", 60, 101), ("fuzz_stats.py", 24, 102), ("fuzz_transpose.py", 40, 103), ("fuzz_spmm.py", 40, 104), ("fuzz_gram.py", 40, 105)])
 def test_fuzzers_find_nothing(hip, script, ncases, seed):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "debug", script), str(ncases), str(seed)],
                        capture_output=True, text=True, timeout=900)
