@@ -304,6 +304,71 @@ gram_sym_kernel(GramArgs a)
 	}
 }
 
+// The general one-block form on records: one result column per workgroup, whole rows of x (no cut), the loop of
+// gram_sym_kernel.  (gram_kernel<.., 0> on the two arrays of t(X): 22.1 ms for the config-2 operand against itself.)
+// The values of x are looked at by the scan in front of the launch, those of y here.
+template <typename TA, typename TB, int SU, int G>
+__global__ void __launch_bounds__(GRAM_NT)
+gram_gen_kernel(GramArgs a)
+{
+	extern __shared__ double acc[];
+	__shared__ int stop;
+	const int tid = threadIdx.x, NT = blockDim.x;
+	const int64_t k = blockIdx.x;
+	const int ncell = (int) a.nx;
+	for (int x = tid; x < ncell; x += NT) acc[x] = 0.0;
+	if (tid == 0)
+		stop = *(volatile const int *) a.flag;
+	__syncthreads();
+	if (stop != 0)
+		return;
+	const int grp = tid / G, sl = tid % G, ngrp = NT / G;
+	const typename GramRaw<TA>::type *__restrict__ rec = (const typename GramRaw<TA>::type *) a.a_val;
+	const TB *__restrict__ bv = (const TB *) a.b_val;
+	const int64_t bb = a.b_ptr[k];
+	const int np = (int) (a.b_ptr[k + 1] - bb);
+	bool bad = false;
+	for (int t0 = grp; t0 < np; t0 += SU * ngrp) {
+		unsigned x[SU], xe[SU];
+		double b[SU];
+#pragma unroll
+		for (int u = 0; u < SU; u++) {
+			const int t = t0 + u * ngrp;
+			x[u] = xe[u] = 0; b[u] = 0.0;
+			if (t < np) {
+				const int64_t r = a.b_idx[bb + t];
+				const TB w = bv[bb + t];
+				x[u] = (unsigned) a.a_ptr[r] + sl; xe[u] = (unsigned) a.a_ptr[r + 1];
+				b[u] = (double) w; bad |= gram_bad<TB>(w);
+			}
+		}
+		bool more = true;
+		while (more) {
+			typename GramRaw<TA>::type raw[SU];
+			bool act[SU];
+#pragma unroll
+			for (int u = 0; u < SU; u++) {
+				act[u] = x[u] < xe[u];
+				raw[u] = rec[act[u] ? x[u] : 0u];
+			}
+			more = false;
+#pragma unroll
+			for (int u = 0; u < SU; u++) GramRaw<TA>::pin(raw[u]);
+#pragma unroll
+			for (int u = 0; u < SU; u++) {
+				const double p = (double) GramRaw<TA>::val(raw[u]) * b[u];
+				if (act[u]) atomicAdd(&acc[GramRaw<TA>::col(raw[u])], p);
+				x[u] += G;
+				more |= x[u] < xe[u];
+			}
+		}
+	}
+	if (__ballot(bad) != 0 && (tid & 63) == 0) *a.flag = 1;
+	__syncthreads();
+	double *__restrict__ dst = a.out + k * a.ldo;
+	for (int x = tid; x < ncell; x += NT) dst[x] = acc[x];
+}
+
 // out[j, i] = out[i, j] for i < j (n x n, column-major, leading dimension ld): 64 x 64 tiles through LDS, both
 // the reads and the writes run along columns
 __global__ void __launch_bounds__(256)
@@ -347,14 +412,14 @@ static bool gram_sym_one(int64_t nx, int64_t a_nnz)
 	return nx <= g_gram_one && a_nnz < (int64_t) 2147483647 - 64;
 }
 
-// [256 bytes: flag words][table of run bounds, wide results only | records of t(X), symmetric one-block form only]
+// [256 bytes: flag words][table of run bounds, wide results only | records of t(X), one-block forms]
 size_t gram_ws_bytes(int64_t nx, int64_t nrow, int64_t a_nnz)
 {
 	size_t n = 256;
 	if (nx > g_gram_one) {
 		const int64_t npan = (nx + ((int64_t) 1 << g_gram_ps) - 1) >> g_gram_ps;
 		n += ((size_t) (nrow > 0 ? nrow : 1) * (size_t) (npan + 1) * 4 + 255) / 256 * 256;
-	} else if (gram_sym_one(nx, a_nnz))
+	} else if (gram_sym_one(nx, a_nnz))             // (records: the symmetric and the general one-block form)
 		n += ((size_t) (a_nnz > 0 ? a_nnz : 1) * 12 + 255) / 256 * 256;
 	return n;
 }
@@ -423,17 +488,30 @@ int launch_gram(GramArgs a, int64_t a_nnz, int64_t b_nnz, void *ws, hipStream_t 
 	if (getenv("SVT_GRAM_SU")) su = atoi(getenv("SVT_GRAM_SU"));
 #endif
 	(void) su;
-	if (mode == 1 && symk && aos && a.a_type == a.b_type && gram_sym_one(a.nx, a_nnz)) {
-		{
-			void *rec = (char *) ws + 256;
-			int64_t nb = (a_nnz + 255) / 256;
-			if (nb > 256 * 32) nb = 256 * 32;
-			if (nb < 1) nb = 1;
+	const bool recs = aos && symk && gram_sym_one(a.nx, a_nnz) && ((mode == 1 && a.a_type == a.b_type) || mode == 0);
+	if (recs) {
+		void *rec = (char *) ws + 256;
+		int64_t nb = (a_nnz + 255) / 256;
+		if (nb > 256 * 32) nb = 256 * 32;
+		if (nb < 1) nb = 1;
 #define GRAM_PACK(T, W) hipLaunchKernelGGL((gram_pack_kernel<T, W>), dim3((unsigned) nb), dim3(256), 0, s, a.a_idx, (const T *) a.a_val, a_nnz, (GramRec<T, W> *) rec)
-			if (a.a_type == SVT_REALSXP) GRAM_PACK(double, 1); else GRAM_PACK(int, 1);
+		if (a.a_type == SVT_REALSXP) GRAM_PACK(double, 1); else GRAM_PACK(int, 1);
 #undef GRAM_PACK
-			a.a_val = rec; a.a_idx = NULL;
-		}
+		a.a_val = rec; a.a_idx = NULL;
+	}
+	if (recs && mode == 0) {
+#define GRAM_GEN_GO(TA, TB, GG) do { \
+		(void) hipFuncSetAttribute((const void *) gram_gen_kernel<TA, TB, 2, GG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); \
+		hipLaunchKernelGGL((gram_gen_kernel<TA, TB, 2, GG>), grid, dim3(nt), lds, s, a); } while (0)
+#define GRAM_GEN_G(TA, TB) do { if (G >= 32) GRAM_GEN_GO(TA, TB, 32); else if (G <= 8) GRAM_GEN_GO(TA, TB, 8); else GRAM_GEN_GO(TA, TB, 16); } while (0)
+		if (a.a_type == SVT_REALSXP && a.b_type == SVT_REALSXP) GRAM_GEN_G(double, double);
+		else if (a.a_type == SVT_INTSXP && a.b_type == SVT_INTSXP) GRAM_GEN_G(int, int);
+		else if (a.a_type == SVT_REALSXP && a.b_type == SVT_INTSXP) GRAM_GEN_G(double, int);
+		else GRAM_GEN_G(int, double);
+#undef GRAM_GEN_G
+#undef GRAM_GEN_GO
+	} else
+	if (recs && mode == 1) {
 #define GRAM_SYM_GO(T, SU, GG) do { \
 		(void) hipFuncSetAttribute((const void *) gram_sym_kernel<T, SU, GG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); \
 		hipLaunchKernelGGL((gram_sym_kernel<T, SU, GG>), grid, dim3(nt), lds, s, a); } while (0)

@@ -30,9 +30,7 @@ def timed(fn, n=reps):
 
 ref = None
 KEYS = ("SVT_GRAM_SYMK", "SVT_GRAM_G", "SVT_GRAM_NT", "SVT_GRAM_SU", "SVT_GRAM_AOS", "SVT_GRAM_TT")
-CASES = [(True, {"SVT_GRAM_SU": "1"}), (True, {"SVT_GRAM_SU": "2"}), (True, {"SVT_GRAM_SU": "3"}), (True, {"SVT_GRAM_SU": "4"}),
-         (True, {"SVT_GRAM_SU": "2", "SVT_GRAM_G": "8"}), (True, {"SVT_GRAM_SU": "3", "SVT_GRAM_G": "8"}),
-         (True, {"SVT_GRAM_SU": "2", "SVT_GRAM_G": "32"}), (True, {"SVT_GRAM_SU": "3", "SVT_GRAM_NT": "512"}), (False, {})]
+CASES = [(True, {}), (False, {}), (False, {"SVT_GRAM_G": "16"}), (False, {"SVT_GRAM_G": "64"}), (False, {"SVT_GRAM_SYMK": "0"})]
 for sym, env in CASES:
     for k in KEYS:
         os.environ.pop(k, None)
