@@ -840,6 +840,22 @@ def main():
                                      "bytes_over_pcie_cold": int(nnz * 12 + lrow * K * 8 + ncol * K * 8),
                                      "GNZ/s_cold": nnz / cold / 1e6, "GNZ/s_resident": nnz / resident / 1e6,
                                      "max_rel_diff_vs_device_level_result": herr}
+        if not a.no_sparse_crossprod and "sparse_crossprod" in ex:
+            # the unary crossprod(A) of the same operand through its .Call-shaped entry point: marshal + 1.2 GB up + t(A) + the
+            # sparse-aware kernel + the 0.8 GB result back (the reference's loop nest needs ~5e11 multiply-adds for it)
+            h1 = hl.svt_crossprod1_SVT
+            h1.restype = ctypes.c_int
+            h1.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+            hsq = np.zeros((ncol, ncol))
+
+            def host_call1():
+                t0_ = time.perf_counter()
+                assert h1(ctypes.addressof(hview), hsq.ctypes.data) == 0
+                return (time.perf_counter() - t0_) * 1e3
+            host_call1()
+            ex["sparse_crossprod"]["crossprod(A)_config2_scale"]["host_entry_point_svt_crossprod1_SVT_ms"] = min(host_call1() for _ in range(2))
+            ex["sparse_crossprod"]["crossprod(A)_config2_scale"]["host_result_bit_symmetric"] = bool(np.array_equal(hsq, hsq.T))
+            del hsq
         del hcp, hri, hv, hy, hout, hview
     if world == 1 and not a.no_cpu_baseline:
         ns = max(1, min(ncol, int(1e8 / max(nnz / ncol, 1))))   # <= 1e8 nz x K: 10-30 core-seconds
