@@ -412,6 +412,32 @@ static bool gram_sym_one(int64_t nx, int64_t a_nnz)
 	return nx <= g_gram_one && a_nnz < (int64_t) 2147483647 - 64;
 }
 
+// *out += sum over the leaves of t(X) of len * (len + 1) / 2: the pairs of nonzeros the symmetric form multiplies, exactly
+// (the entry points' route choice estimates them as nnz^2 / (2 nrow), which rows of very unequal length exceed)
+__global__ void __launch_bounds__(256)
+gram_pairs_kernel(const int64_t *__restrict__ a_ptr, int64_t nrow, double *__restrict__ out)
+{
+	double t = 0.0;
+	for (int64_t r = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; r < nrow; r += (int64_t) gridDim.x * blockDim.x) {
+		const double len = (double) (a_ptr[r + 1] - a_ptr[r]);
+		t += 0.5 * len * (len + 1.0);
+	}
+	t = wave_sum(t);
+	if ((threadIdx.x & 63) == 0 && t != 0.0) atomicAdd(out, t);
+}
+
+int launch_gram_pairs(const int64_t *a_ptr, int64_t nrow, double *out, hipStream_t s)
+{
+	HIP_TRY(hipMemsetAsync(out, 0, 8, s));
+	if (nrow > 0) {
+		int64_t nb = (nrow + 255) / 256;
+		if (nb > 2048) nb = 2048;
+		hipLaunchKernelGGL(gram_pairs_kernel, dim3((unsigned) nb), dim3(256), 0, s, a_ptr, nrow, out);
+	}
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
 // [256 bytes: flag words][table of run bounds, wide results only | records of t(X), one-block forms]
 size_t gram_ws_bytes(int64_t nx, int64_t nrow, int64_t a_nnz)
 {

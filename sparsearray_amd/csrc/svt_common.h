@@ -193,6 +193,7 @@ void gram_set_panel(int one_block_max, int log2_panel);
 size_t gram_ws_bytes(int64_t nx, int64_t nrow, int64_t a_nnz);
 int launch_gram(GramArgs a, int64_t a_nnz, int64_t b_nnz, void *ws, hipStream_t s);
 int launch_gram_mirror(double *out, int64_t n, int64_t ld, hipStream_t s);
+int launch_gram_pairs(const int64_t *a_ptr, int64_t nrow, double *out, hipStream_t s);
 
 size_t transpose_ws_bytes(int64_t nrow, int64_t nnz);
 int launch_transpose(const int64_t *col_ptr, const int32_t *row_idx, const void *val, int Rtype,

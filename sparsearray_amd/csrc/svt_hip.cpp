@@ -1458,6 +1458,9 @@ extern "C" void svt_sparse_crossprod_set_cost(double factor)
 	g_gram_cost = factor;      // the sparse-aware route's estimated time is multiplied by it; < 0: never that route; 0: always
 }
 
+static double dense_route_seconds(double dense_ops) { return 1.0e-3 + dense_ops / 3.0e12; }
+static double sparse_route_seconds(double pairs, int64_t nnz_x) { return 0.2e-3 + pairs / 2.6e11 + (double) nnz_x * 2.5e-11; }
+
 static bool sparse_route_pays(int64_t nnz_x, int64_t nnz_y, int64_t nrow, double dense_ops, bool sym)
 {
 	if (g_gram_cost < 0.0 || nrow <= 0 || nnz_x <= 0 || nnz_y <= 0)
@@ -1469,14 +1472,12 @@ static bool sparse_route_pays(int64_t nnz_x, int64_t nnz_y, int64_t nrow, double
 	if (g_gram_cost > 0.0 && dense_ops < 268435456.0)
 		return false;
 	if (sym) { pairs *= 0.5; dense_ops *= 0.5; }
-	const double t_sparse = 0.2e-3 + pairs / 2.6e11 + (double) nnz_x * 2.5e-11;
-	const double t_dense = 1.0e-3 + dense_ops / 3.0e12;
-	return t_sparse * g_gram_cost < t_dense;
+	return sparse_route_seconds(pairs, nnz_x) * g_gram_cost < dense_route_seconds(dense_ops);
 }
 
 // 0: `O` holds the result; 1: a non-finite value or an NA took part (the caller takes the dense-buffer route, whose
 // dirty-leaf rules are the reference's); -1: error
-static int dev_crossprod_sparse(const CscGuard &X, const svt_dev_csc *Y, bool sym, double *O, int64_t ldo)
+static int dev_crossprod_sparse(const CscGuard &X, const svt_dev_csc *Y, bool sym, double *O, int64_t ldo, double dense_ops)
 {
 	int own_T = 1;
 	svt_dev_csc *T = transposed_for(X, &own_T);
@@ -1490,6 +1491,16 @@ static int dev_crossprod_sparse(const CscGuard &X, const svt_dev_csc *Y, bool sy
 	int bad = 1;
 	if (Ws.alloc(svt_dev_crossprod_csc_csc_ws_bytes(T)))
 		return -1;
+	if (sym && g_gram_cost > 0.0) {
+		// The choice was made on nnz^2 / (2 nrow) pairs; with t(x) at hand they can be counted: rows of very unequal
+		// length hold more (sum of len^2), and an operand whose count says the other route is clearly faster goes there.
+		double pairs = 0.0;
+		if (launch_gram_pairs(T->col_ptr, T->ncol, (double *) Ws.p, 0))
+			return -1;
+		HIP_TRY(hipMemcpy(&pairs, Ws.p, 8, hipMemcpyDeviceToHost));
+		if (sparse_route_seconds(pairs, 0) * g_gram_cost > 1.5 * dense_route_seconds(0.5 * dense_ops))
+			return 1;
+	}
 	const int rc = svt_dev_crossprod_csc_csc(T, Y, sym ? 1 : 0, O, ldo, Ws.p, Ws.bytes, NULL, 0);
 	if (rc > 0) { g_unsupported = 0; return 1; }      // a shape this kernel refuses: the other route
 	if (rc < 0) return -1;
@@ -1553,7 +1564,7 @@ static int crossprod2_SVT_SVT_impl(const svt_view *x, const svt_view *y, double 
 	// anywhere sends the product down the reference's route below
 	if (!x->svt_is_null && !y->svt_is_null &&
 	    sparse_route_pays(X.h->nnz, Y.h->nnz, in_nrow, (double) (Lpp_nops < Rpp_nops ? Lpp_nops : Rpp_nops), false)) {
-		const int st = dev_crossprod_sparse(X, Y.h, false, O.as<double>(), out_nrow);
+		const int st = dev_crossprod_sparse(X, Y.h, false, O.as<double>(), out_nrow, (double) (Lpp_nops < Rpp_nops ? Lpp_nops : Rpp_nops));
 		if (st < 0) return -1;
 		if (st == 0)
 			return staged_download(out, O.p, out_n * 8) ? -1 : 0;
@@ -1793,7 +1804,7 @@ static int crossprod1_SVT_impl(const svt_view *x, double *out)
 	if (O.alloc(out_n * 8))
 		return -1;
 	if (sparse_route_pays(X.h->nnz, X.h->nnz, x->dim[0], (double) X.h->nnz * (double) n, true)) {
-		const int st = dev_crossprod_sparse(X, X.h, true, O.as<double>(), n);
+		const int st = dev_crossprod_sparse(X, X.h, true, O.as<double>(), n, (double) X.h->nnz * (double) n);
 		if (st < 0) return -1;
 		if (st == 0)
 			return staged_download(out, O.p, out_n * 8) ? -1 : 0;

@@ -208,3 +208,25 @@ def test_golden_unary_and_sparse_sparse_products_through_the_sparse_kernel(hip, 
     finally:
         set_sparse_crossprod_cost(1.0)
     assert n >= 200
+
+
+def test_rows_of_very_unequal_length(hip, oracle):
+    """The route choice estimates the pairs of nonzeros that meet in a row as nnz^2 / (2 nrow); an operand with a few
+    hundred nearly full rows holds far more of them.  With t(x) built the symmetric route counts them exactly and
+    hands such an operand to the other route; whichever runs, the reference's cells."""
+    from sparsearray_amd.device import set_sparse_crossprod_cost
+    rng = np.random.default_rng(661)
+    nrow, ncol = 40_000, 900
+    a = (rng.random((nrow, ncol)) < 0.01) * rng.normal(size=(nrow, ncol))
+    heavy = rng.choice(nrow, size=400, replace=False)
+    a[heavy, :] = rng.normal(size=(400, ncol))
+    x = SVT_SparseArray.from_dense(np.asfortranarray(a), "double", lacunar=False)
+    want = np.asarray(oracle.crossprod(x))
+    for route in (1.0, 0.0):
+        try:
+            set_sparse_crossprod_cost(route)
+            got = np.asarray(hip.crossprod(x))
+        finally:
+            set_sparse_crossprod_cost(1.0)
+        assert np.array_equal(got, got.T)
+        assert_equal(got, want, tol=1e-11, atol=1e-11, what=f"route {route}")
