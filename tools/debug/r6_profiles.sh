@@ -20,9 +20,9 @@ echo "==== rocprofv3 --kernel-trace --stats of tools/debug/gram_only.py 5 1 (cro
 bash tools/debug/prof_py.sh tools/debug/gram_only.py 3 "5 1" 2>&1 | grep -v amdgpu.ids | grep -i "gram\|transpose\|scan_"
 echo "==== rocprofv3 --pmc, one pass per line of tools/debug/pmc_sets_gram.txt, kernel gram_sym_kernel (per-launch averages; FETCH_SIZE / WRITE_SIZE in KiB as reported)"
 bash tools/debug/pmc_py.sh tools/debug/gram_only.py gram_sym "2 1" tools/debug/pmc_sets_gram.txt 2>&1 | grep -v amdgpu.ids
-echo "==== the same for the general form (crossprod(x, x) without the symmetry), kernel gram_kernel"
+echo "==== the same for the general form (crossprod(x, x) without the symmetry), kernel gram_gen_kernel"
 printf 'FETCH_SIZE\nTCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum\n' > $O/sets2.txt
-bash tools/debug/pmc_py.sh tools/debug/gram_only.py "gram_kernel" "2 0" gpurun_out/r6/sets2.txt 2>&1 | grep -v amdgpu.ids
+bash tools/debug/pmc_py.sh tools/debug/gram_only.py "gram_gen" "2 0" gpurun_out/r6/sets2.txt 2>&1 | grep -v amdgpu.ids
 } > $O/r06_sparse_crossprod.txt 2>&1
 tail -40 $O/r06_sparse_crossprod.txt
 # 4. other kernels touched this round
