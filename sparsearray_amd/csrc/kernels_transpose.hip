@@ -1046,31 +1046,39 @@ __global__ void aperm_key32_kernel(const int64_t *__restrict__ col_ptr, const in
 	newrow[k] = (int32_t) nr;
 }
 
-// out_ptr[j] = first sorted position whose leaf is >= j: every sorted element fills the leaves between its
-// predecessor's and its own (most new leaves are empty when leaves shatter: a search per leaf costs more -- the
-// 64-bit route did one binary search per NEW LEAF until round 6: 48 of the 81.7 ms of aperm(x, c(3,2,4,1)) of a
-// 2e4 x 2e3 x 10 x 64 array, 4e8 leaves).  The first 16 leaves of a gap by the element's own lane, the rest of a
-// long gap by the whole wavefront.  K = uint32_t: the key is the leaf; unsigned long long: leaf * dim0 + row.
+// out_ptr[j] = first sorted position whose leaf is >= j, j = 0 .. nleaves.  Most new leaves are empty when leaves
+// shatter, so the work is WRITING the pointers (20 GB for the 2.56e9 leaves of aperm(x, c(3,2,4,1)) of a 2e4 x 2e3 x
+// 10 x 64 array), not finding them.  Rounds 1-5: one binary search over the sorted keys per new leaf on the 64-bit
+// route (48 ms there).  Round 6, first form: every sorted element fills the leaves between its predecessor's and its
+// own (9.6 ms: a lane's run of leaves is contiguous, a wavefront's store instruction is not).  Now: a workgroup takes
+// 256 consecutive sorted elements (plus the sentinel "element" nnz with leaf nleaves), keeps their leaves in LDS and
+// fills the range of leaves they cover with consecutive lanes on consecutive leaves -- coalesced stores --, each lane
+// finding its leaf's element by a binary search in LDS.  K = uint32_t: the key is the leaf; unsigned long long:
+// leaf * dim0 + row.
+#define PTRFILL_NT 256
 template <typename K>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(PTRFILL_NT)
 aperm_ptr_fill_kernel(const K *__restrict__ skeys, int64_t nnz, int64_t nleaves, unsigned long long dim0,
 		      int64_t *__restrict__ out_ptr)
 {
-	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-	const int lane = threadIdx.x & 63;
-	int64_t from = 1, to = 0;
-	if (i <= nnz) {
-		from = i == 0 ? 0 : (int64_t) ((unsigned long long) skeys[i - 1] / dim0) + 1;
-		to = i == nnz ? nleaves : (int64_t) ((unsigned long long) skeys[i] / dim0);
-	}
-	const int64_t near = to < from + 15 ? to : from + 15;
-	for (int64_t j = from; j <= near; j++) out_ptr[j] = i;
-	unsigned long long mask = __ballot(to > from + 15);
-	while (mask != 0) {
-		const int l = __ffsll((long long) mask) - 1;
-		mask &= mask - 1;
-		const int64_t f = __shfl(from, l, 64) + 16, t = __shfl(to, l, 64), v = __shfl(i, l, 64);
-		for (int64_t j = f + lane; j <= t; j += 64) out_ptr[j] = v;
+	__shared__ int64_t s_leaf[PTRFILL_NT];
+	__shared__ int64_t s_first;
+	const int tid = threadIdx.x;
+	const int64_t i0 = (int64_t) blockIdx.x * PTRFILL_NT, i = i0 + tid;
+	// element i covers the leaves (leaf(i - 1), leaf(i)]; past the sentinel: nothing (a leaf no search will stop at)
+	s_leaf[tid] = i < nnz ? (int64_t) ((unsigned long long) skeys[i] / dim0) : (i == nnz ? nleaves : nleaves + 1);
+	if (tid == 0)
+		s_first = i0 == 0 ? 0 : (int64_t) ((unsigned long long) skeys[i0 - 1] / dim0) + 1;
+	__syncthreads();
+	const int nvalid = (int) (nnz + 1 - i0 < PTRFILL_NT ? nnz + 1 - i0 : PTRFILL_NT);
+	const int64_t first = s_first, last = s_leaf[nvalid - 1];
+	for (int64_t j = first + tid; j <= last; j += PTRFILL_NT) {
+		int lo = 0, hi = nvalid - 1;                    // smallest t with s_leaf[t] >= j (exists: s_leaf[nvalid - 1] = last >= j)
+		while (lo < hi) {
+			const int mid = (lo + hi) >> 1;
+			if (s_leaf[mid] < j) lo = mid + 1; else hi = mid;
+		}
+		out_ptr[j] = i0 + lo;
 	}
 }
 
@@ -1615,7 +1623,7 @@ static int launch_aperm_n(const int64_t *col_ptr, const int32_t *row_idx, const 
 				   keys, pos, newrow);
 		if (svt_sort_pairs<uint32_t>(keys, skeys, ktmp, pos, spos, ptmp, nnz, bits, tmp, s))
 			return -1;
-		hipLaunchKernelGGL(aperm_ptr_fill_kernel<uint32_t>, dim3((unsigned) ((nnz + 1 + 255) / 256)), dim3(256), 0, s,
+		hipLaunchKernelGGL(aperm_ptr_fill_kernel<uint32_t>, dim3((unsigned) ((nnz + 1 + PTRFILL_NT - 1) / PTRFILL_NT)), dim3(PTRFILL_NT), 0, s,
 				   skeys, nnz, new_nleaves, 1ULL, out_ptr);
 		if (Rtype == SVT_REALSXP)
 			hipLaunchKernelGGL(aperm_gather32_kernel<double>, dim3(nb8), dim3(256), 0, s, spos, newrow,
@@ -1642,7 +1650,7 @@ static int launch_aperm_n(const int64_t *col_ptr, const int32_t *row_idx, const 
 	hipLaunchKernelGGL(aperm_key_kernel, dim3(nb), dim3(256), 0, s, col_ptr, row_idx, ncol, nnz, d, keys, pos);
 	if (svt_sort_pairs<unsigned long long>(keys, skeys, ktmp, pos, spos, ptmp, nnz, bits, tmp, s))
 		return -1;
-	hipLaunchKernelGGL(aperm_ptr_fill_kernel<unsigned long long>, dim3((unsigned) ((nnz + 1 + 255) / 256)), dim3(256), 0, s,
+	hipLaunchKernelGGL(aperm_ptr_fill_kernel<unsigned long long>, dim3((unsigned) ((nnz + 1 + PTRFILL_NT - 1) / PTRFILL_NT)), dim3(PTRFILL_NT), 0, s,
 			   skeys, nnz, new_nleaves, (unsigned long long) (new_dim0 > 0 ? new_dim0 : 1), out_ptr);
 	if (Rtype == SVT_REALSXP)
 		hipLaunchKernelGGL(aperm_gather_kernel<double>, dim3(nb8), dim3(256), 0, s, skeys, spos,
