@@ -168,14 +168,12 @@ gram_kernel(GramArgs a, int G)
 // lanes make twice the trips: 16.5); two consecutive entries per lane and trip 19.5 (twice the over-read).
 // Records of t(X) for the symmetric form: (column, value) side by side, 12 bytes (8 for integer values) -- a
 // prefix of a row is then ONE run of memory instead of two (columns, values), read by one load per lane
-// AOS: 0 = t(X) as it is (two arrays), 1 = records.  (Measured at config-2 scale, symmetric form: two arrays 16.3 ms,
-// 12-byte records 14.6 incl. the 0.45 ms that makes them, 10-byte records with a 16-bit column -- the value at a 2-byte
-// boundary, global_load_dwordx2 at offset 2 -- 15.4.)
+// (Measured at config-2 scale, symmetric form: t(X) as it is, two arrays, 16.3 ms; 12-byte records 14.6 incl. the 0.45 ms
+// that makes them; 10-byte records with a 16-bit column -- the value at a 2-byte boundary, global_load_dwordx2 at
+// offset 2 -- 15.4.)
 template <typename T, int AOS> struct GramRec;
 template <> struct __attribute__((packed, aligned(4))) GramRec<double, 1> { double v; int c; };   // (value first: it lands in an even register pair)
 template <> struct __attribute__((packed, aligned(4))) GramRec<int, 1> { int v; int c; };
-template <> struct GramRec<double, 0> { int c; double v; };
-template <> struct GramRec<int, 0> { int c; int v; };
 
 // a record as the plain words a load brings in
 template <typename T> struct GramRaw;
@@ -507,10 +505,9 @@ int launch_gram(GramArgs a, int64_t a_nnz, int64_t b_nnz, void *ws, hipStream_t 
 #define GRAM_MODES(TA, TB) do { \
 		if (mode == 0) GRAM_GO(TA, TB, 0); else if (mode == 1) GRAM_GO(TA, TB, 1); \
 		else if (mode == 2) GRAM_GO(TA, TB, 2); else GRAM_GO(TA, TB, 3); } while (0)
-	int symk = 1, aos = g_gram_aos, su = g_gram_su;  // (tuning build: SVT_GRAM_SYMK=0 = the first, one-walk-per-slot form)
+	int symk = 1, aos = g_gram_aos, su = g_gram_su;  // (tuning build: SVT_GRAM_SYMK=0 = the first forms, on t(X)'s two arrays)
 #ifdef SVT_TUNING
 	if (getenv("SVT_GRAM_SYMK")) symk = atoi(getenv("SVT_GRAM_SYMK"));
-	if (getenv("SVT_GRAM_AOS")) aos = atoi(getenv("SVT_GRAM_AOS"));
 	if (getenv("SVT_GRAM_SU")) su = atoi(getenv("SVT_GRAM_SU"));
 #endif
 	(void) su;

@@ -29,8 +29,10 @@ def timed(fn, n=reps):
 
 
 ref = None
-KEYS = ("SVT_GRAM_SYMK", "SVT_GRAM_G", "SVT_GRAM_NT", "SVT_GRAM_SU", "SVT_GRAM_AOS", "SVT_GRAM_TT")
-CASES = [(True, {}), (False, {}), (False, {"SVT_GRAM_G": "16"}), (False, {"SVT_GRAM_G": "64"}), (False, {"SVT_GRAM_SYMK": "0"})]
+KEYS = ("SVT_GRAM_SYMK", "SVT_GRAM_G", "SVT_GRAM_NT", "SVT_GRAM_SU", "SVT_GRAM_GRID")
+CASES = [(True, {}), (True, {"SVT_GRAM_SU": "2"}), (True, {"SVT_GRAM_SU": "4"}), (True, {"SVT_GRAM_G": "8"}), (True, {"SVT_GRAM_G": "32"}),
+         (True, {"SVT_GRAM_NT": "512"}), (True, {"SVT_GRAM_SYMK": "0"}), (True, {"SVT_GRAM_GRID": "512"}), (True, {"SVT_GRAM_GRID": "513"}),
+         (False, {}), (False, {"SVT_GRAM_SYMK": "0"})]
 for sym, env in CASES:
     for k in KEYS:
         os.environ.pop(k, None)
@@ -39,4 +41,4 @@ for sym, env in CASES:
     if ref is None:
         ref = out.clone()
     d = float((out - ref).abs().max())
-    print(f"sym={int(sym)} {str(env):70s} {ms:8.3f} ms   max |diff to first| {d:.2e}", flush=True)
+    print(f"sym={int(sym)} {str(env):50s} {ms:8.3f} ms   max |diff to first| {d:.2e}" + ("   (a clamped grid: timing only)" if "SVT_GRAM_GRID" in env else ""), flush=True)
