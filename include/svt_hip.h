@@ -157,6 +157,16 @@ int svt_matmul_SVT_mat(const svt_view *x, const void *y, int y_nrow, int y_ncol,
 		       int y_Rtype, double *out);
 int svt_matmul_SVT_SVT(const svt_view *x, const svt_view *y, double *out);
 
+/* tcrossprod(x) and tcrossprod(x, y) of SVT_SparseMatrix objects in one call (round 6).  The R methods
+   (R/SparseMatrix-mult.R:165-193) are crossprod(t(x)) / crossprod(t(x), t(y)) with t() on the host
+   (C_transpose_2D_SVT, then a second marshalling of the transposed trees); here x (and y) are uploaded as they are and
+   transposed on the device -- and the sparse-aware kernel of svt_dev_crossprod_csc_csc wants the ROWS of t(x), i.e. x
+   itself, so its side needs no transposition at all.  Same checks, messages, route choice and NA / NaN rules as
+   svt_crossprod1_SVT / svt_crossprod2_SVT_SVT on the transposed operands.
+   out: nrow(x) x nrow(x) resp. nrow(x) x nrow(y) doubles, column-major. */
+int svt_tcrossprod1_SVT(const svt_view *x, double *out);
+int svt_tcrossprod2_SVT_SVT(const svt_view *x, const svt_view *y, double *out);
+
 /* colMedians(x, na.rm) of a 2-D SVT: .colMedians_SVT_SparseMatrix / .padded_median,
    R/SparseArray-matrixStats.R:690-784 -- pure R in the reference (one sort per leaf; its TODO
    at :690-691 asks for a .Call version).  Median of each column's nrow values, the implicit

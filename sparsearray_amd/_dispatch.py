@@ -67,7 +67,9 @@ class CAbiDispatcher:
             protos["rowMedians_SVT"] = (I, [V, I, P])
         # x %*% y in one call (device-side transposition): HIP library only
         for name, sig in (("matmul_SVT_mat", (I, [V, P, I, I, I, P])),
-                          ("matmul_SVT_SVT", (I, [V, V, P]))):
+                          ("matmul_SVT_SVT", (I, [V, V, P])),
+                          ("tcrossprod1_SVT", (I, [V, P])),
+                          ("tcrossprod2_SVT_SVT", (I, [V, V, P]))):
             if hasattr(self.lib, self.prefix + name):
                 protos[name] = sig
         for name, (res, args) in protos.items():
@@ -179,6 +181,18 @@ class CAbiDispatcher:
         out = np.zeros((x.dim[0], y.dim[1]), dtype=np.float64, order="F")
         xv, yv = make_view(x), make_view(y)
         self._check(self._fn("matmul_SVT_SVT")(byref(xv), byref(yv), _ptr(out)))
+        return out
+
+    def C_tcrossprod1_SVT(self, x: SVT_SparseArray):
+        out = np.zeros((x.dim[0], x.dim[0]), dtype=np.float64, order="F")
+        xv = make_view(x)
+        self._check(self._fn("tcrossprod1_SVT")(byref(xv), _ptr(out)))
+        return out
+
+    def C_tcrossprod2_SVT_SVT(self, x: SVT_SparseArray, y: SVT_SparseArray):
+        out = np.zeros((x.dim[0], y.dim[0]), dtype=np.float64, order="F")
+        xv, yv = make_view(x), make_view(y)
+        self._check(self._fn("tcrossprod2_SVT_SVT")(byref(xv), byref(yv), _ptr(out)))
         return out
 
     def C_crossprod1_SVT(self, x: SVT_SparseArray):

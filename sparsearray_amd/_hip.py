@@ -19,7 +19,7 @@ EXPORTS = [
     "svt_init", "svt_last_error", "svt_device_arch",
     "svt_crossprod2_SVT_mat", "svt_crossprod2_mat_SVT",
     "svt_crossprod2_SVT_SVT", "svt_crossprod1_SVT",
-    "svt_matmul_SVT_mat", "svt_matmul_SVT_SVT",
+    "svt_matmul_SVT_mat", "svt_matmul_SVT_SVT", "svt_tcrossprod1_SVT", "svt_tcrossprod2_SVT_SVT",
     "svt_colMedians_SVT", "svt_rowMedians_SVT", "svt_dev_colmedians_ws_bytes", "svt_dev_colmedians",
     "svt_resident_set_limit", "svt_resident_clear", "svt_resident_stats", "svt_dev_pbc_bytes", "svt_dev_pbc_set_spare_cus", "svt_dev_pbc_spare_cus", "svt_dev_pbc_set_gather_pacing", "svt_dev_pbc_set_round_launches", "svt_dev_matmul_csc_csc_ws_bytes", "svt_dev_matmul_csc_csc", "svt_dev_rowsums_prepare", "svt_dev_rowsums_prepared", "svt_dev_rowsum_gid_bytes", "svt_dev_rowsum_prepare", "svt_dev_rowsum_prepared", "svt_dev_matmul_csc_csc_prepare", "svt_dev_matmul_csc_csc_prepared",
     "svt_dev_crossprod_csc_csc_ws_bytes", "svt_dev_crossprod_csc_csc", "svt_dev_crossprod_csc_csc_set_panel", "svt_sparse_crossprod_set_cost", "svt_dev_crossprod_csc_csc_dense_buffer",

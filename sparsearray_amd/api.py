@@ -224,9 +224,26 @@ class Session:
     def tcrossprod(self, x, y=None):
         self._no_NaArray("tcrossprod", x, y)
         xs, ys = isinstance(x, SVT_SparseArray), isinstance(y, SVT_SparseArray)
+        # The R methods transpose first (t() = C_transpose_2D_SVT on the host, R/SparseMatrix-mult.R:165-193).  The HIP
+        # library offers both sparse forms in one call with the transpositions on the device (svt_tcrossprod*_SVT*,
+        # include/svt_hip.h); same checks, same coercions, applied to the transposed operands.
+        has = getattr(self._call, "has_entry", lambda name: False)
         if xs and y is None:
+            if has("C_tcrossprod1_SVT") and x.ndim == 2:
+                _check_crossprod_input_type(x.type)
+                return self.SparseArray_Call("C_tcrossprod1_SVT", x)
             return self._crossprod1_SparseMatrix(self.t(x))
         if xs and ys:
+            if has("C_tcrossprod2_SVT_SVT") and x.ndim == 2 and y.ndim == 2:
+                if x.dim[1] != y.dim[1]:
+                    raise SparseArrayError("non-conformable arguments")
+                if x.type == y.type:
+                    _check_crossprod_input_type(x.type)
+                else:
+                    xy = _common_type(x.type, y.type)
+                    _check_crossprod_input_type(xy)
+                    x, y = x.with_type(xy), y.with_type(xy)
+                return self.SparseArray_Call("C_tcrossprod2_SVT_SVT", x, y)
             return self._crossprod2_SparseMatrix_SparseMatrix(self.t(x), self.t(y))
         if xs:
             return self._crossprod2_SparseMatrix_matrix(self.t(x), y, True)

@@ -1477,16 +1477,8 @@ static bool sparse_route_pays(int64_t nnz_x, int64_t nnz_y, int64_t nrow, double
 
 // 0: `O` holds the result; 1: a non-finite value or an NA took part (the caller takes the dense-buffer route, whose
 // dirty-leaf rules are the reference's); -1: error
-static int dev_crossprod_sparse(const CscGuard &X, const svt_dev_csc *Y, bool sym, double *O, int64_t ldo, double dense_ops)
+static int dev_crossprod_sparse_on(const svt_dev_csc *T, const svt_dev_csc *Y, bool sym, double *O, int64_t ldo, double dense_ops)
 {
-	int own_T = 1;
-	svt_dev_csc *T = transposed_for(X, &own_T);
-	OwnedCsc TX = { T, own_T };
-	if (T == NULL) {
-		// an operand the transposition does not take (2^31 nonzeros or more): the dense-buffer route needs no t(x)
-		if (g_unsupported) { g_unsupported = 0; return 1; }
-		return -1;
-	}
 	DevBuf Ws;
 	int bad = 1;
 	if (Ws.alloc(svt_dev_crossprod_csc_csc_ws_bytes(T)))
@@ -1506,6 +1498,19 @@ static int dev_crossprod_sparse(const CscGuard &X, const svt_dev_csc *Y, bool sy
 	if (rc < 0) return -1;
 	HIP_TRY(hipMemcpy(&bad, Ws.p, 4, hipMemcpyDeviceToHost));
 	return bad ? 1 : 0;
+}
+
+static int dev_crossprod_sparse(const CscGuard &X, const svt_dev_csc *Y, bool sym, double *O, int64_t ldo, double dense_ops)
+{
+	int own_T = 1;
+	svt_dev_csc *T = transposed_for(X, &own_T);
+	OwnedCsc TX = { T, own_T };
+	if (T == NULL) {
+		// an operand the transposition does not take (2^31 nonzeros or more): the dense-buffer route needs no t(x)
+		if (g_unsupported) { g_unsupported = 0; return 1; }
+		return -1;
+	}
+	return dev_crossprod_sparse_on(T, Y, sym, O, ldo, dense_ops);
 }
 
 // The dense-buffer route on resident operands (what the entry points below fall back to, and the yardstick of
@@ -1822,6 +1827,108 @@ extern "C" int svt_crossprod1_SVT(const svt_view *x, double *out)
 {
 	g_unsupported = 0;
 	return svt_status(crossprod1_SVT_impl(x, out));
+}
+
+// tcrossprod(x) = crossprod(t(x)) and tcrossprod(x, y) = crossprod(t(x), t(y)) of SVT_SparseMatrix objects in one call.
+// The R methods (R/SparseMatrix-mult.R:165-193) take t() on the host first (C_transpose_2D_SVT: the transposed tree comes
+// back as R leaves and is marshalled again by C_crossprod1_SVT / C_crossprod2_SVT_SVT).  Here the operands are uploaded as
+// they are and transposed on the device; the sparse-aware kernel needs the ROWS of its first operand t(x), i.e. x itself --
+// no transposition at all on that side.  Checks, messages and the route choice are those of the crossprod entry points
+// applied to the transposed operands; a non-finite value or an NA anywhere takes the dense-buffer route (the reference's
+// dirty-leaf rules).  out: nrow(x) x nrow(x) / nrow(x) x nrow(y) doubles, column-major.
+static int tcrossprod1_SVT_impl(const svt_view *x, double *out)
+{
+	if (ensure_init() || check_mult_view(x, "'x'"))
+		return -1;
+	const int n = x->dim[0];
+	const size_t out_n = (size_t) n * n;
+	memset(out, 0, out_n * sizeof(double));
+	if (x->svt_is_null || out_n == 0 || x->dim[1] == 0)      // (t(x)@SVT is NULL: src/SparseMatrix_mult.c:880-881)
+		return 0;
+	CscGuard X(x);
+	if (X.h == NULL) return -1;
+	int own_T = 1;
+	svt_dev_csc *M = transposed_for(X, &own_T);             // M = t(x): ncol(x) rows, nrow(x) leaves
+	OwnedCsc TM = { M, own_T };
+	if (M == NULL) return -1;
+	DevBuf O;
+	if (O.alloc(out_n * 8))
+		return -1;
+	const double dense_ops = (double) M->nnz * (double) n;
+	if (sparse_route_pays(M->nnz, M->nnz, M->nrow, dense_ops, true)) {
+		const int st = dev_crossprod_sparse_on(X.h, M, true, O.as<double>(), n, dense_ops);     // t(M) is x
+		if (st < 0) return -1;
+		if (st == 0)
+			return staged_download(out, O.p, out_n * 8) ? -1 : 0;
+	}
+	if (O.zero())
+		return -1;
+	if (dev_crossprod_pp(M, M, O.as<double>(), 1, n))
+		return -1;
+	if (launch_mirror_lower(O.as<double>(), n, 0))
+		return -1;
+	if (staged_download(out, O.p, out_n * 8)) return -1;
+	return 0;
+}
+extern "C" int svt_tcrossprod1_SVT(const svt_view *x, double *out)
+{
+	g_unsupported = 0;
+	return svt_status(tcrossprod1_SVT_impl(x, out));
+}
+
+static int tcrossprod2_SVT_SVT_impl(const svt_view *x, const svt_view *y, double *out)
+{
+	if (ensure_init() || check_mult_view(x, "input objects") ||
+	    check_mult_view(y, "input objects"))
+		return -1;
+	if (x->dim[1] != y->dim[1])
+		return svt_set_error("input SVT_SparseMatrix objects are non-conformable");
+	if (x->Rtype != y->Rtype)
+		return svt_set_error("input SVT_SparseMatrix objects must have the "
+				     "same type() for now");
+	const int out_nrow = x->dim[0], out_ncol = y->dim[0];
+	const size_t out_n = (size_t) out_nrow * out_ncol;
+	memset(out, 0, out_n * sizeof(double));
+	if (out_n == 0)
+		return 0;
+	const int64_t Lpp_nops = view_nzcount(y) * out_nrow;
+	const int64_t Rpp_nops = view_nzcount(x) * out_ncol;
+	CscGuard X(x), Y(y);
+	if (X.h == NULL || Y.h == NULL) return -1;
+	int own_Ty = 1;
+	svt_dev_csc *Ty = transposed_for(Y, &own_Ty);
+	OwnedCsc TY = { Ty, own_Ty };
+	if (Ty == NULL) return -1;
+	DevBuf O;
+	if (O.alloc(out_n * 8))
+		return -1;
+	const double dense_ops = (double) (Lpp_nops < Rpp_nops ? Lpp_nops : Rpp_nops);
+	if (!x->svt_is_null && !y->svt_is_null && x->dim[1] > 0 &&
+	    sparse_route_pays(X.h->nnz, Y.h->nnz, x->dim[1], dense_ops, false)) {
+		const int st = dev_crossprod_sparse_on(X.h, Ty, false, O.as<double>(), out_nrow, dense_ops);   // t(t(x)) is x
+		if (st < 0) return -1;
+		if (st == 0)
+			return staged_download(out, O.p, out_n * 8) ? -1 : 0;
+	}
+	int own_Tx = 1;
+	svt_dev_csc *Tx = transposed_for(X, &own_Tx);
+	OwnedCsc TXg = { Tx, own_Tx };
+	if (Tx == NULL) return -1;
+	if (O.zero())
+		return -1;
+	int rc;
+	if (Lpp_nops < Rpp_nops)
+		rc = dev_crossprod_pp(Ty, Tx, O.as<double>(), out_nrow, 1);
+	else
+		rc = dev_crossprod_pp(Tx, Ty, O.as<double>(), 1, out_nrow);
+	if (rc) return -1;
+	if (staged_download(out, O.p, out_n * 8)) return -1;
+	return 0;
+}
+extern "C" int svt_tcrossprod2_SVT_SVT(const svt_view *x, const svt_view *y, double *out)
+{
+	g_unsupported = 0;
+	return svt_status(tcrossprod2_SVT_SVT_impl(x, y, out));
 }
 
 // ==================================================================================

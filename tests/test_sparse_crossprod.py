@@ -230,3 +230,36 @@ def test_rows_of_very_unequal_length(hip, oracle):
             set_sparse_crossprod_cost(1.0)
         assert np.array_equal(got, got.T)
         assert_equal(got, want, tol=1e-11, atol=1e-11, what=f"route {route}")
+
+
+@pytest.mark.parametrize("shape", [(400, 25_000, 0.07), (700, 3000, 0.05), (60, 100, 0.2), (1, 64, 0.5), (9, 1, 0.7)])
+@pytest.mark.parametrize("route", [1.0, 0.0, -1.0])
+def test_tcrossprod_in_one_call(hip, oracle, shape, route):
+    """tcrossprod(x) / tcrossprod(x, y) through svt_tcrossprod1_SVT / svt_tcrossprod2_SVT_SVT (operands transposed on the
+    device; the sparse-aware kernel walks x itself) against the oracle's reference flow t() + C_crossprod1_SVT /
+    C_crossprod2_SVT_SVT (R/SparseMatrix-mult.R:165-193), each route forced and the model's choice; NA / Inf operands
+    follow the reference's dirty-leaf rules."""
+    from sparsearray_amd.device import set_sparse_crossprod_cost
+    nrow, ncol, d = shape
+    cp, ri, v = random_csc(nrow, ncol, d, seed=671)
+    x = SVT_SparseArray.from_csc((nrow, ncol), "double", cp, ri, v)
+    ny = max(1, nrow // 3)
+    cp2, ri2, v2 = random_csc(ny, ncol, min(1.0, d * 2), seed=672)
+    y = SVT_SparseArray.from_csc((ny, ncol), "double", cp2, ri2, v2)
+    vbad = v.copy()
+    if len(vbad) > 3:
+        vbad[3] = np.inf
+    xbad = SVT_SparseArray.from_csc((nrow, ncol), "double", cp, ri, vbad)
+    try:
+        set_sparse_crossprod_cost(route)
+        got1, got2, got3 = hip.tcrossprod(x), hip.tcrossprod(x, y), hip.tcrossprod(y, x)
+        gotb = hip.tcrossprod(xbad)
+    finally:
+        set_sparse_crossprod_cost(1.0)
+    g1 = np.asarray(got1)
+    assert np.array_equal(g1, g1.T)
+    assert_equal(got1, oracle.tcrossprod(x), tol=1e-11, atol=1e-12, what="tcrossprod(x)")
+    want2 = np.asarray(oracle.tcrossprod(x, y))
+    assert_equal(got2, want2, tol=1e-11, atol=1e-12, what="tcrossprod(x, y)")
+    assert_equal(got3, want2.T, tol=1e-11, atol=1e-12, what="tcrossprod(y, x)")
+    assert_equal(gotb, oracle.tcrossprod(xbad), tol=1e-11, atol=1e-12, strict_na=True, what="tcrossprod(x with Inf)")
