@@ -13,12 +13,14 @@
 // and, for every nonzero (r, v) of Y[:, j], adds v * X[r, .] -- row r of X, i.e. LEAF r of t(X), a contiguous run
 // of (column, value) pairs -- into them (ds_add_f64; two rows can meet in a cell).  A group of G lanes takes one
 // nonzero of Y at a time.  t(X) is the caller's (svt_dev_transpose; for x %*% y the operand itself).
-//   * nx = ncol(X) <= 10200: all cells of a result column fit one workgroup's LDS (two workgroups per CU).
+//   * nx = ncol(X) <= 20400: all cells of a result column fit one workgroup's LDS (two workgroups per CU up to 10200
+//     cells, one beyond -- still faster than the panels below: 8.2 vs 9.6 ms for x 1e5 x 2e4 @ 1 %, 1.8 vs 4.4 for
+//     2e5 x 1.2e4 @ 0.5 %).
 //     Symmetric case (Y is X): only the cells c <= j are formed -- row r's pairs come in ascending column order,
 //     a lane stops at its first column > j, so the prefix needs no search -- and columns j and nx - 1 - j share a
 //     workgroup: nx + 1 cells, the same work for every workgroup (which keeps the workgroups in flight walking
 //     the same stretch of rows: the runs several of them name can then come from the memory-side cache).
-//   * wider results: panels of 8192 cells; the part of leaf r inside a panel comes from the table of run bounds
+//   * wider results (> 20400 columns): panels of 8192 cells; the part of leaf r inside a panel comes from the table of run bounds
 //     that the row-panel kernels use (launch_rowpanel_table, kernels_rowstats.hip); symmetric: panels above the
 //     diagonal cell are skipped, the diagonal panel is cut as above.
 // The lower triangle of a symmetric result is the mirror image of the upper one (gram_mirror_kernel, 64 x 64
@@ -35,11 +37,11 @@
 #define GRAM_NT 1024
 #define GRAM_U 4
 
-static int g_gram_one = 10200, g_gram_ps = 13;
+static int g_gram_one = 20400, g_gram_ps = 13;
 
 void gram_set_panel(int one_block_max, int log2_panel)
 {
-	g_gram_one = one_block_max < 0 ? 10200 : (one_block_max > 10200 ? 10200 : one_block_max);
+	g_gram_one = one_block_max < 0 ? 20400 : (one_block_max > 20400 ? 20400 : one_block_max);   // (> 10200: one workgroup per CU)
 	g_gram_ps = log2_panel < 4 || log2_panel > 13 ? 13 : log2_panel;
 }
 

@@ -85,7 +85,7 @@ def test_binary_crossprod_device_level(hip, oracle, shape, types):
 @pytest.mark.parametrize("panel", [(0, 6), (0, 9), (100, 8), (0, 13)])
 def test_wide_results_go_by_cell_panels(oracle, panel):
     """Results taller than one workgroup's LDS: panels of cells + the table of run bounds (forced here on small
-    operands by shrinking the panel; the default is one block up to 10200 cells, panels of 8192 beyond)."""
+    operands by shrinking the panel; the default is one block up to 20400 cells, panels of 8192 beyond)."""
     from sparsearray_amd.device import crossprod_csc_csc, set_sparse_crossprod_panel
     nrow, nx, ny = 4000, 777, 333
     cpx, rix, vx = random_csc(nrow, nx, 0.03, seed=621)
@@ -108,7 +108,9 @@ def test_wide_results_go_by_cell_panels(oracle, panel):
 
 
 def test_really_wide_result(oracle):
-    """12 000 result cells per column: two panels of 8192 with the default settings; against scipy."""
+    """12 000 result cells per column: past what two workgroups per CU hold (10 200), one block of 96 KB of LDS, one
+    workgroup per CU (the default up to 20 400 columns; the cell-panel form beyond is forced on small operands by
+    test_wide_results_go_by_cell_panels and the fuzzer); against scipy."""
     import scipy.sparse as sp
     from sparsearray_amd.device import crossprod_csc_csc
     nrow, ncol = 3000, 12_000

@@ -5,5 +5,9 @@ ROOT0 = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__
 sys.path.insert(0, ROOT0)
 sys.argv = ["x", "none"]
 exec(open(os.path.join(ROOT0, "tools", "debug", "sparse_crossprod_time.py")).read().split('if what in ("small", "all"):')[0])
-unary(100_000, 20_000, 0.01, 21, with_dense=True, with_spmm=False, tag=" [wide result: cell panels]")
-unary(200_000, 12_000, 0.005, 22, with_dense=True, with_spmm=False, tag=" [wide result: cell panels]")
+from sparsearray_amd.device import set_sparse_crossprod_panel
+for n_, r_, d_, seed_ in ((20_000, 100_000, 0.01, 21), (12_000, 200_000, 0.005, 22)):
+    unary(r_, n_, d_, seed_, with_dense=True, with_spmm=False, tag=" [one block, one workgroup per CU: the default up to 20 400 columns]")
+    set_sparse_crossprod_panel(10200, 13)
+    unary(r_, n_, d_, seed_, with_dense=False, with_spmm=False, tag=" [the same by panels of 8192 cells]")
+    set_sparse_crossprod_panel(-1, -1)
