@@ -20,7 +20,8 @@
 //     a lane stops at its first column > j, so the prefix needs no search -- and columns j and nx - 1 - j share a
 //     workgroup: nx + 1 cells, the same work for every workgroup (which keeps the workgroups in flight walking
 //     the same stretch of rows: the runs several of them name can then come from the memory-side cache).
-//   * wider results (> 20400 columns): panels of 8192 cells; the part of leaf r inside a panel comes from the table of run bounds
+//   * wider results (> 20400 columns): panels of 16384 cells (128 KB, one workgroup per CU; 8.8 against 12.6 ms with
+//     panels of 8192 for x 1e5 x 3e4 @ 0.5 %); the part of leaf r inside a panel comes from the table of run bounds
 //     that the row-panel kernels use (launch_rowpanel_table, kernels_rowstats.hip); symmetric: panels above the
 //     diagonal cell are skipped, the diagonal panel is cut as above.
 // The lower triangle of a symmetric result is the mirror image of the upper one (gram_mirror_kernel, 64 x 64
@@ -37,12 +38,12 @@
 #define GRAM_NT 1024
 #define GRAM_U 4
 
-static int g_gram_one = 20400, g_gram_ps = 13;
+static int g_gram_one = 20400, g_gram_ps = 14;
 
 void gram_set_panel(int one_block_max, int log2_panel)
 {
 	g_gram_one = one_block_max < 0 ? 20400 : (one_block_max > 20400 ? 20400 : one_block_max);   // (> 10200: one workgroup per CU)
-	g_gram_ps = log2_panel < 4 || log2_panel > 13 ? 13 : log2_panel;
+	g_gram_ps = log2_panel < 4 || log2_panel > 14 ? 14 : log2_panel;
 }
 
 template <typename T> __device__ inline bool gram_bad(T v);

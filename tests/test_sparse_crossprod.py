@@ -82,10 +82,10 @@ def test_binary_crossprod_device_level(hip, oracle, shape, types):
     assert_equal(hip.crossprod(y, x), want.T, tol=1e-12, atol=1e-13, what="host crossprod(y, x)")
 
 
-@pytest.mark.parametrize("panel", [(0, 6), (0, 9), (100, 8), (0, 13)])
+@pytest.mark.parametrize("panel", [(0, 6), (0, 9), (100, 8), (0, 13), (300, 14)])
 def test_wide_results_go_by_cell_panels(oracle, panel):
     """Results taller than one workgroup's LDS: panels of cells + the table of run bounds (forced here on small
-    operands by shrinking the panel; the default is one block up to 20400 cells, panels of 8192 beyond)."""
+    operands by shrinking the panel; the default is one block up to 20400 cells, panels of 16384 beyond)."""
     from sparsearray_amd.device import crossprod_csc_csc, set_sparse_crossprod_panel
     nrow, nx, ny = 4000, 777, 333
     cpx, rix, vx = random_csc(nrow, nx, 0.03, seed=621)

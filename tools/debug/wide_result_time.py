@@ -11,3 +11,7 @@ for n_, r_, d_, seed_ in ((20_000, 100_000, 0.01, 21), (12_000, 200_000, 0.005, 
     set_sparse_crossprod_panel(10200, 13)
     unary(r_, n_, d_, seed_, with_dense=False, with_spmm=False, tag=" [the same by panels of 8192 cells]")
     set_sparse_crossprod_panel(-1, -1)
+for ps_ in (13, 14):
+    set_sparse_crossprod_panel(-1, ps_)
+    unary(100_000, 30_000, 0.005, 23, with_dense=(ps_ == 13), with_spmm=False, tag=f" [30 000 columns: panels of {1 << ps_} cells]")
+set_sparse_crossprod_panel(-1, -1)
