@@ -471,11 +471,10 @@ int svt_dev_matmul_csc_csc_prepared(const svt_dev_csc *A, const svt_dev_csc *B, 
 size_t svt_dev_crossprod_csc_csc_ws_bytes(const svt_dev_csc *Xt);
 int svt_dev_crossprod_csc_csc(const svt_dev_csc *Xt, const svt_dev_csc *Y, int sym, double *out, int64_t ldo,
 			      void *ws, size_t ws_bytes, int *not_finite, void *stream);
-/* Results up to `one_block_max` (<= 20400, the default: 160 KB of LDS; two workgroups per CU up to 10200 cells)
-   cells tall keep a whole result column in one workgroup's LDS; taller ones are cut into panels of
-   2^log2_panel (<= 14, the default) cells.  Negative /
-   out-of-range arguments restore the defaults.  Process-wide; tests and tuning (workspaces sized before a change
-   may be too small after it). */
+/* Results up to `one_block_max` cells tall (<= 20400, the default: 160 KB of LDS; two workgroups per CU up to 10200
+   cells; the symmetric form stops at 16384) keep a whole result column in one workgroup's LDS; taller ones are
+   cut into panels of 2^log2_panel (<= 14; default 13) cells.  Negative / out-of-range arguments restore the
+   defaults.  Process-wide; tests and tuning (workspaces sized before a change may be too small after it). */
 void svt_dev_crossprod_csc_csc_set_panel(int one_block_max, int log2_panel);
 
 /* The dense-buffer route of the same product on resident operands -- the reference's own form (one operand

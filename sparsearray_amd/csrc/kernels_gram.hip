@@ -13,15 +13,13 @@
 // and, for every nonzero (r, v) of Y[:, j], adds v * X[r, .] -- row r of X, i.e. LEAF r of t(X), a contiguous run
 // of (column, value) pairs -- into them (ds_add_f64; two rows can meet in a cell).  A group of G lanes takes one
 // nonzero of Y at a time.  t(X) is the caller's (svt_dev_transpose; for x %*% y the operand itself).
-//   * nx = ncol(X) <= 20400: all cells of a result column fit one workgroup's LDS (two workgroups per CU up to 10200
-//     cells, one beyond -- still faster than the panels below: 8.2 vs 9.6 ms for x 1e5 x 2e4 @ 1 %, 1.8 vs 4.4 for
-//     2e5 x 1.2e4 @ 0.5 %).
+//   * nx = ncol(X) <= 20400 (symmetric form: 16384): all cells of a result column fit one workgroup's LDS (two
+//     workgroups per CU up to 10200 cells, one beyond; gram_one_block() has the measurements).
 //     Symmetric case (Y is X): only the cells c <= j are formed -- row r's pairs come in ascending column order,
 //     a lane stops at its first column > j, so the prefix needs no search -- and columns j and nx - 1 - j share a
 //     workgroup: nx + 1 cells, the same work for every workgroup (which keeps the workgroups in flight walking
 //     the same stretch of rows: the runs several of them name can then come from the memory-side cache).
-//   * wider results (> 20400 columns): panels of 16384 cells (128 KB, one workgroup per CU; 8.8 against 12.6 ms with
-//     panels of 8192 for x 1e5 x 3e4 @ 0.5 %); the part of leaf r inside a panel comes from the table of run bounds
+//   * wider results: panels of 8192 cells; the part of leaf r inside a panel comes from the table of run bounds
 //     that the row-panel kernels use (launch_rowpanel_table, kernels_rowstats.hip); symmetric: panels above the
 //     diagonal cell are skipped, the diagonal panel is cut as above.
 // The lower triangle of a symmetric result is the mirror image of the upper one (gram_mirror_kernel, 64 x 64
@@ -38,12 +36,13 @@
 #define GRAM_NT 1024
 #define GRAM_U 4
 
-static int g_gram_one = 20400, g_gram_ps = 14;
+static int g_gram_one = 20400, g_gram_ps = 13;
+#define GRAM_SYM_ONE_MAX 16384          // the symmetric form keeps one block up to here (see gram_one_block)
 
 void gram_set_panel(int one_block_max, int log2_panel)
 {
 	g_gram_one = one_block_max < 0 ? 20400 : (one_block_max > 20400 ? 20400 : one_block_max);   // (> 10200: one workgroup per CU)
-	g_gram_ps = log2_panel < 4 || log2_panel > 14 ? 14 : log2_panel;
+	g_gram_ps = log2_panel < 4 || log2_panel > 14 ? 13 : log2_panel;
 }
 
 template <typename T> __device__ inline bool gram_bad(T v);
@@ -370,6 +369,82 @@ gram_gen_kernel(GramArgs a)
 	for (int x = tid; x < ncell; x += NT) dst[x] = acc[x];
 }
 
+// The panel form on records (results wider than one block): workgroup = (panel of 2^ps cells, result column), the
+// part of row r inside the panel from the table of run bounds, CUT: the symmetric product's cells c <= column only
+// (panels above the diagonal cell leave at once).  The loop of gram_gen_kernel.
+template <typename TA, typename TB, bool CUT, int SU, int G>
+__global__ void __launch_bounds__(GRAM_NT)
+gram_pan_kernel(GramArgs a)
+{
+	extern __shared__ double acc[];
+	__shared__ int stop;
+	const int tid = threadIdx.x, NT = blockDim.x;
+	const int64_t L = blockIdx.x;
+	const int64_t q = L % a.npan, k = L / a.npan;
+	const int64_t c0 = q << a.ps;
+	int64_t c1 = c0 + ((int64_t) 1 << a.ps);
+	if (c1 > a.nx) c1 = a.nx;
+	if (CUT && c1 > k + 1) c1 = k + 1;
+	if (c1 <= c0)
+		return;                                         // (a panel above the diagonal cell: the whole workgroup leaves)
+	const int ncell = (int) (c1 - c0), lo = (int) c0, hi = (int) c1;
+	for (int x = tid; x < ncell; x += NT) acc[x] = 0.0;
+	if (tid == 0)
+		stop = *(volatile const int *) a.flag;
+	__syncthreads();
+	if (stop != 0)
+		return;
+	const int grp = tid / G, sl = tid % G, ngrp = NT / G;
+	const typename GramRaw<TA>::type *__restrict__ rec = (const typename GramRaw<TA>::type *) a.a_val;
+	const TB *__restrict__ bv = (const TB *) a.b_val;
+	const int32_t *__restrict__ pt0 = a.pt + q * a.nrow, *__restrict__ pt1 = pt0 + a.nrow;
+	const int64_t bb = a.b_ptr[k];
+	const int np = (int) (a.b_ptr[k + 1] - bb);
+	bool bad = false;
+	for (int t0 = grp; t0 < np; t0 += SU * ngrp) {
+		unsigned x[SU], xe[SU];
+		double b[SU];
+#pragma unroll
+		for (int u = 0; u < SU; u++) {
+			const int t = t0 + u * ngrp;
+			x[u] = xe[u] = 0; b[u] = 0.0;
+			if (t < np) {
+				const int64_t r = a.b_idx[bb + t];
+				const TB w = bv[bb + t];
+				const unsigned base = (unsigned) a.a_ptr[r];
+				x[u] = base + (unsigned) pt0[r] + sl; xe[u] = base + (unsigned) pt1[r];
+				b[u] = (double) w; bad |= gram_bad<TB>(w);
+			}
+		}
+		bool more = true;
+		while (more) {
+			typename GramRaw<TA>::type raw[SU];
+			bool act[SU];
+#pragma unroll
+			for (int u = 0; u < SU; u++) {
+				act[u] = x[u] < xe[u];
+				raw[u] = rec[act[u] ? x[u] : 0u];
+			}
+			more = false;
+#pragma unroll
+			for (int u = 0; u < SU; u++) GramRaw<TA>::pin(raw[u]);
+#pragma unroll
+			for (int u = 0; u < SU; u++) {
+				const int c = GramRaw<TA>::col(raw[u]);
+				const double p = (double) GramRaw<TA>::val(raw[u]) * b[u];
+				const bool ok = act[u] && (!CUT || c < hi);
+				if (ok) atomicAdd(&acc[c - lo], p);
+				x[u] = ok ? x[u] + G : xe[u];
+				more |= x[u] < xe[u];
+			}
+		}
+	}
+	if (__ballot(bad) != 0 && (tid & 63) == 0) *a.flag = 1;
+	__syncthreads();
+	double *__restrict__ dst = a.out + k * a.ldo + c0;
+	for (int x = tid; x < ncell; x += NT) dst[x] = acc[x];
+}
+
 // out[j, i] = out[i, j] for i < j (n x n, column-major, leading dimension ld): 64 x 64 tiles through LDS, both
 // the reads and the writes run along columns
 __global__ void __launch_bounds__(256)
@@ -440,15 +515,29 @@ int launch_gram_pairs(const int64_t *a_ptr, int64_t nrow, double *out, hipStream
 }
 
 // [256 bytes: flag words][table of run bounds, wide results only | records of t(X), one-block forms]
+// One block of cells per result column, or panels?  Measured (x 2e5 x 1.2e4 @ 0.5 % / 1e5 x 2e4 @ 1 % / 1e5 x 3e4 @ 0.5 %, ms):
+//   symmetric: one block (one workgroup per CU past 10200 cells) 1.8 / 8.2 / -, panels of 8192 2.3 / 6.1 / 7.4, of 16384 - / - / 7.0
+//   general:   one block 1.9 / 7.6 / -, panels of 8192 2.6 / 9.4 / 6.9, of 16384 - / - / 7.8
+// (the symmetric form skips the panels above the diagonal cell, whose work a single block only cuts short).
+static bool gram_one_block(int64_t nx, bool sym)
+{
+	const int64_t lim = sym && g_gram_one > GRAM_SYM_ONE_MAX ? GRAM_SYM_ONE_MAX : g_gram_one;
+	return nx <= lim;
+}
+
 size_t gram_ws_bytes(int64_t nx, int64_t nrow, int64_t a_nnz)
 {
-	size_t n = 256;
-	if (nx > g_gram_one) {
+	const bool small = a_nnz < (int64_t) 2147483647 - 64;
+	const size_t recs = small ? ((size_t) (a_nnz > 0 ? a_nnz : 1) * 12 + 255) / 256 * 256 : 0;
+	size_t need = 0;
+	if (gram_one_block(nx, false) || gram_one_block(nx, true))              // (either form may be asked for)
+		need = gram_sym_one(nx, a_nnz) ? recs : 0;
+	if (!gram_one_block(nx, false) || !gram_one_block(nx, true)) {
 		const int64_t npan = (nx + ((int64_t) 1 << g_gram_ps) - 1) >> g_gram_ps;
-		n += ((size_t) (nrow > 0 ? nrow : 1) * (size_t) (npan + 1) * 4 + 255) / 256 * 256;
-	} else if (gram_sym_one(nx, a_nnz))             // (records: the symmetric and the general one-block form)
-		n += ((size_t) (a_nnz > 0 ? a_nnz : 1) * 12 + 255) / 256 * 256;
-	return n;
+		const size_t pan = ((size_t) (nrow > 0 ? nrow : 1) * (size_t) (npan + 1) * 4 + 255) / 256 * 256 + recs;
+		if (pan > need) need = pan;
+	}
+	return 256 + need;
 }
 
 int launch_gram(GramArgs a, int64_t a_nnz, int64_t b_nnz, void *ws, hipStream_t s)
@@ -469,7 +558,7 @@ int launch_gram(GramArgs a, int64_t a_nnz, int64_t b_nnz, void *ws, hipStream_t 
 			hipLaunchKernelGGL(gram_scan_values_kernel<int>, dim3((unsigned) nb), dim3(256), 0, s,
 					   (const int *) a.a_val, a_nnz, flag);
 	}
-	const bool one = a.nx <= g_gram_one;
+	const bool one = gram_one_block(a.nx, a.sym != 0);
 	int mode;
 	size_t lds;
 	int64_t nwg;
@@ -525,6 +614,29 @@ int launch_gram(GramArgs a, int64_t a_nnz, int64_t b_nnz, void *ws, hipStream_t 
 #undef GRAM_PACK
 		a.a_val = rec; a.a_idx = NULL;
 	}
+	if (!one && aos && symk && a_nnz < (int64_t) 2147483647 - 64 && (mode == 2 || a.a_type == a.b_type)) {
+		void *rec = (char *) ws + 256 + ((size_t) (a.nrow > 0 ? a.nrow : 1) * (size_t) (a.npan + 1) * 4 + 255) / 256 * 256;
+		int64_t nb = (a_nnz + 255) / 256;
+		if (nb > 256 * 32) nb = 256 * 32;
+		if (nb < 1) nb = 1;
+		if (a.a_type == SVT_REALSXP)
+			hipLaunchKernelGGL((gram_pack_kernel<double, 1>), dim3((unsigned) nb), dim3(256), 0, s, a.a_idx, (const double *) a.a_val, a_nnz, (GramRec<double, 1> *) rec);
+		else
+			hipLaunchKernelGGL((gram_pack_kernel<int, 1>), dim3((unsigned) nb), dim3(256), 0, s, a.a_idx, (const int *) a.a_val, a_nnz, (GramRec<int, 1> *) rec);
+		a.a_val = rec; a.a_idx = NULL;
+#define GRAM_PAN_GO(TA, TB, CUT, GG) do { \
+		(void) hipFuncSetAttribute((const void *) gram_pan_kernel<TA, TB, CUT, 2, GG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); \
+		hipLaunchKernelGGL((gram_pan_kernel<TA, TB, CUT, 2, GG>), grid, dim3(nt), lds, s, a); } while (0)
+#define GRAM_PAN_G(TA, TB, CUT) do { if (G >= 32) GRAM_PAN_GO(TA, TB, CUT, 32); else if (G <= 8) GRAM_PAN_GO(TA, TB, CUT, 8); else GRAM_PAN_GO(TA, TB, CUT, 16); } while (0)
+#define GRAM_PAN_T(TA, TB) do { if (mode == 3) GRAM_PAN_G(TA, TB, true); else GRAM_PAN_G(TA, TB, false); } while (0)
+		if (a.a_type == SVT_REALSXP && a.b_type == SVT_REALSXP) GRAM_PAN_T(double, double);
+		else if (a.a_type == SVT_INTSXP && a.b_type == SVT_INTSXP) GRAM_PAN_T(int, int);
+		else if (a.a_type == SVT_REALSXP && a.b_type == SVT_INTSXP) GRAM_PAN_T(double, int);
+		else GRAM_PAN_T(int, double);
+#undef GRAM_PAN_T
+#undef GRAM_PAN_G
+#undef GRAM_PAN_GO
+	} else
 	if (recs && mode == 0) {
 #define GRAM_GEN_GO(TA, TB, GG) do { \
 		(void) hipFuncSetAttribute((const void *) gram_gen_kernel<TA, TB, 2, GG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); \

@@ -85,7 +85,7 @@ def test_binary_crossprod_device_level(hip, oracle, shape, types):
 @pytest.mark.parametrize("panel", [(0, 6), (0, 9), (100, 8), (0, 13), (300, 14)])
 def test_wide_results_go_by_cell_panels(oracle, panel):
     """Results taller than one workgroup's LDS: panels of cells + the table of run bounds (forced here on small
-    operands by shrinking the panel; the default is one block up to 20400 cells, panels of 16384 beyond)."""
+    operands by shrinking the panel; the default is one block up to 16384 / 20400 cells, panels of 8192 beyond)."""
     from sparsearray_amd.device import crossprod_csc_csc, set_sparse_crossprod_panel
     nrow, nx, ny = 4000, 777, 333
     cpx, rix, vx = random_csc(nrow, nx, 0.03, seed=621)
@@ -109,8 +109,9 @@ def test_wide_results_go_by_cell_panels(oracle, panel):
 
 def test_really_wide_result(oracle):
     """12 000 result cells per column: past what two workgroups per CU hold (10 200), one block of 96 KB of LDS, one
-    workgroup per CU (the default up to 20 400 columns; the cell-panel form beyond is forced on small operands by
-    test_wide_results_go_by_cell_panels and the fuzzer); against scipy."""
+    workgroup per CU (the default up to 16 384 columns for the symmetric form; the cell-panel form beyond is forced on
+    small operands by test_wide_results_go_by_cell_panels and the fuzzer, and runs at its default on 17 000 columns
+    below); against scipy."""
     import scipy.sparse as sp
     from sparsearray_amd.device import crossprod_csc_csc
     nrow, ncol = 3000, 12_000
@@ -124,6 +125,21 @@ def test_really_wide_result(oracle):
     want = (m.T @ m).toarray()
     assert np.array_equal(got, got.T)
     assert np.allclose(got, want, rtol=1e-12, atol=1e-12)
+    # 17 000 columns: the symmetric form goes by panels of 8192 cells at its defaults, the general form in one block
+    nrow, ncol = 2500, 17_000
+    cp, ri, v = random_csc(nrow, ncol, 0.004, seed=632)
+    A = _dev(cp, ri, v, nrow)
+    At = A.t()
+    out, flag = crossprod_csc_csc(At, A, sym=True)
+    out2, flag2 = crossprod_csc_csc(At, A, sym=False)
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0 and int(flag2.item()) == 0
+    m = sp.csc_matrix((v, ri, cp), shape=(nrow, ncol))
+    want = (m.T @ m).toarray()
+    got = out.cpu().numpy()
+    assert np.array_equal(got, got.T)
+    assert np.allclose(got, want, rtol=1e-12, atol=1e-12)
+    assert np.allclose(out2.cpu().numpy(), want, rtol=1e-12, atol=1e-12)
 
 
 def test_not_finite_raises_the_flag_and_the_entry_points_follow_the_reference(hip, oracle):
